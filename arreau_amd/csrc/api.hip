@@ -1,0 +1,148 @@
+// arreau_predict_scores: one evaluation of the score network on the current sampler state, plus the
+// workspace carve-up and the hipEvent timing hook for the dominant (edge) kernel.
+#include <mutex>
+#include <vector>
+
+#include "internal.h"
+
+namespace {
+struct Carver {
+    char* base;
+    size_t off = 0, cap;
+    Carver(void* p, size_t c) : base((char*)p), cap(c) {}
+    template <typename T>
+    T* take(size_t n) {
+        off = (off + 255) & ~(size_t)255;
+        T* r = (T*)(base ? base + off : nullptr);
+        off += n * sizeof(T);
+        return r;
+    }
+};
+
+struct Workspace {
+    float *lattice, *cart, *cvec, *dir, *dist, *kbuf, *xa, *xb, *xbar, *vsum;
+    int32_t *batch, *deg, *src, *cell;
+    size_t bytes;
+};
+
+Workspace carve(const arreau_config* cfg, int64_t N, int64_t B, void* base, size_t cap) {
+    Carver c(base, cap);
+    Workspace w;
+    const size_t C = cfg->hidden_dim, L = cfg->num_layers, k = cfg->max_neighbors, O = cfg->num_ori;
+    w.lattice = c.take<float>(B * 9);
+    w.cart = c.take<float>(N * 3);
+    w.cvec = c.take<float>(B * C);
+    w.batch = c.take<int32_t>(N);
+    w.deg = c.take<int32_t>(N);
+    w.src = c.take<int32_t>(N * k);
+    w.cell = c.take<int32_t>(N * k);
+    w.dir = c.take<float>(N * k * 3);
+    w.dist = c.take<float>(N * k);
+    w.kbuf = c.take<float>(L * N * k * O * C);
+    w.xa = c.take<float>(N * O * C);
+    w.xb = c.take<float>(N * O * C);
+    w.xbar = c.take<float>(L * N * C);
+    w.vsum = c.take<float>(N * O);
+    w.bytes = (c.off + 255) & ~(size_t)255;
+    return w;
+}
+
+// hipEvent pairs around the edge kernel, on the stream it is launched on
+struct EdgeProfile {
+    std::mutex mu;
+    bool enabled = false;
+    std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
+} g_prof;
+}  // namespace
+
+extern "C" size_t arreau_workspace_bytes(const arreau_config* cfg, int64_t max_atoms, int64_t max_crystals) {
+    if (!cfg || max_atoms < 0 || max_crystals < 0) return 0;
+    return carve(cfg, max_atoms, max_crystals, nullptr, 0).bytes;
+}
+
+extern "C" int arreau_profile_edge_kernel(int32_t enable) {
+    std::lock_guard<std::mutex> lock(g_prof.mu);
+    for (auto& ev : g_prof.events) {
+        (void)hipEventDestroy(ev.first);
+        (void)hipEventDestroy(ev.second);
+    }
+    g_prof.events.clear();
+    g_prof.enabled = enable != 0;
+    return ARREAU_OK;
+}
+
+extern "C" int arreau_edge_kernel_time_ms(double* mean_ms, int64_t* launches) {
+    ARREAU_REQUIRE(mean_ms && launches, "arreau_edge_kernel_time_ms: null pointer");
+    std::lock_guard<std::mutex> lock(g_prof.mu);
+    double tot = 0.0;
+    int64_t n = 0;
+    for (auto& ev : g_prof.events) {
+        ARREAU_CHECK_HIP(hipEventSynchronize(ev.second));
+        float ms = 0.f;
+        ARREAU_CHECK_HIP(hipEventElapsedTime(&ms, ev.first, ev.second));
+        tot += ms;
+        ++n;
+    }
+    *mean_ms = n ? tot / (double)n : 0.0;
+    *launches = n;
+    return ARREAU_OK;
+}
+
+extern "C" int arreau_predict_scores(const arreau_model* m, const float* d_frac, const int32_t* d_types,
+                                     const float* d_lengths, const float* d_angles, const int32_t* d_t,
+                                     const int32_t* d_off, int32_t B, int32_t N, int32_t use_given_edges,
+                                     int32_t* d_deg, int32_t* d_src, float* d_dir, float* d_dist, float* d_eps,
+                                     float* d_logits, float* d_len0, void* d_workspace, size_t workspace_bytes,
+                                     void* stream) {
+    ARREAU_REQUIRE(m && d_frac && d_types && d_lengths && d_angles && d_t && d_off && d_eps && d_logits && d_len0,
+                   "arreau_predict_scores: null pointer");
+    ARREAU_REQUIRE(B >= 1 && N >= 0, "arreau_predict_scores: bad size");
+    ARREAU_REQUIRE(d_workspace != nullptr, "arreau_predict_scores: null workspace");
+    Workspace w = carve(&m->cfg, N, B, d_workspace, workspace_bytes);
+    if (w.bytes > workspace_bytes) {
+        arreau_set_error("arreau_predict_scores: workspace too small");
+        return ARREAU_ECAPACITY;
+    }
+    if (use_given_edges) {
+        ARREAU_REQUIRE(d_deg && d_src && d_dir && d_dist, "arreau_predict_scores: teacher-forced edges missing");
+    }
+    int32_t* deg = d_deg ? d_deg : w.deg;
+    int32_t* src = d_src ? d_src : w.src;
+    float* dir = d_dir ? d_dir : w.dir;
+    float* dist = d_dist ? d_dist : w.dist;
+    hipStream_t s = (hipStream_t)stream;
+    int rc;
+    if ((rc = arreau_launch_prep(m, d_frac, d_lengths, d_angles, d_t, d_off, B, N, w.lattice, w.cart, w.batch, w.cvec, s)))
+        return rc;
+    if (!use_given_edges) {
+        if ((rc = arreau_launch_neighbor(w.cart, w.lattice, d_off, B, N, m->cfg.radius, m->k, deg, src, w.cell, dir,
+                                         dist, s)))
+            return rc;
+    }
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    bool prof = false;
+    {
+        std::lock_guard<std::mutex> lock(g_prof.mu);
+        prof = g_prof.enabled;
+    }
+    if (prof) {
+        ARREAU_CHECK_HIP(hipEventCreate(&e0));
+        ARREAU_CHECK_HIP(hipEventCreate(&e1));
+        ARREAU_CHECK_HIP(hipEventRecord(e0, s));
+    }
+    rc = arreau_launch_edge(m, dir, dist, deg, w.batch, w.lattice, N, w.kbuf, s);
+    if (prof) {
+        ARREAU_CHECK_HIP(hipEventRecord(e1, s));
+        std::lock_guard<std::mutex> lock(g_prof.mu);
+        g_prof.events.emplace_back(e0, e1);
+    }
+    if (rc) return rc;
+    if ((rc = arreau_launch_embed(m, d_frac, d_types, w.lattice, w.batch, w.cvec, N, w.xa, s))) return rc;
+    float* xin = w.xa;
+    float* xout = w.xb;
+    for (int l = 0; l < m->L; ++l) {
+        if ((rc = arreau_launch_node_layer(m, l, w.kbuf, deg, src, xin, xout, w.xbar, w.vsum, N, s))) return rc;
+        float* tmp = xin; xin = xout; xout = tmp;
+    }
+    return arreau_launch_readout(m, w.xbar, w.vsum, d_off, B, N, d_eps, d_logits, d_len0, s);
+}

@@ -1,0 +1,294 @@
+// Model construction: weight folding / MFMA packing (host), upload, one-time fiber-kernel
+// evaluation on the GPU.  Replaces PonitaFiberBundle.__init__ + load_state_dict
+// (ponita/models/ponita.py:31-86) for the sampling path.
+#include <string.h>
+
+#include <vector>
+
+#include "internal.h"
+
+static thread_local std::string g_last_error;
+void arreau_set_error(const std::string& msg) { g_last_error = msg; }
+extern "C" const char* arreau_last_error(void) { return g_last_error.c_str(); }
+extern "C" const char* arreau_version(void) { return "arreau_hip 0.1 (gfx950)"; }
+
+// P[u][t][q][lane][m] = W[out = 32u + (lane&31)][in = 32t + 8q + 4*(lane>>5) + m]; W is row-major
+// [out_dim][in_stride] (torch Linear layout); entries beyond (out_dim, in_dim) are zero.
+static void pack_linear(const float* W, int out_dim, int in_dim, int in_stride, int out_pad, int in_pad,
+                        float* P) {
+    const int U = out_pad / 32, Tn = in_pad / 32;
+    for (int u = 0; u < U; ++u)
+        for (int t = 0; t < Tn; ++t)
+            for (int q = 0; q < 4; ++q)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int m = 0; m < 4; ++m) {
+                        int out = 32 * u + (lane & 31);
+                        int in = 32 * t + 8 * q + 4 * (lane >> 5) + m;
+                        float v = (out < out_dim && in < in_dim) ? W[(size_t)out * in_stride + in] : 0.0f;
+                        P[((((size_t)u * Tn + t) * 4 + q) * 64 + lane) * 4 + m] = v;
+                    }
+}
+
+// Monomial table: distinct monomials of degree 1..3 in 6 variables in the canonical order
+// (i), (i<=j), (i<=j<=k), each lexicographic.  The device code (edge.hip) generates them in the
+// same order.
+struct Mono { int n; int idx[3]; };
+static std::vector<Mono> monomials() {
+    std::vector<Mono> v;
+    for (int i = 0; i < 6; ++i) v.push_back({1, {i, 0, 0}});
+    for (int i = 0; i < 6; ++i)
+        for (int j = i; j < 6; ++j) v.push_back({2, {i, j, 0}});
+    for (int i = 0; i < 6; ++i)
+        for (int j = i; j < 6; ++j)
+            for (int k = j; k < 6; ++k) v.push_back({3, {i, j, k}});
+    return v;
+}
+
+// Fold basis_fn.1.weight [C][258] onto the 83 distinct monomials: the reference's feature vector
+// (nn/embedding.py:10-14) holds x_i at column i, x_i x_j at 6 + 6i + j and x_i x_j x_k at
+// 42 + 36i + 6j + k, so every permutation of a multiset is a separate column with its own weight;
+// the sum of those weights (accumulated in double) multiplies the single monomial.
+static void fold_poly_weight(const float* W, int C, std::vector<float>& Wf /*[C][96]*/) {
+    auto mons = monomials();
+    Wf.assign((size_t)C * ARREAU_MONO_PAD, 0.0f);
+    for (int c = 0; c < C; ++c) {
+        const float* row = W + (size_t)c * ARREAU_POLY_COLS;
+        for (size_t mi = 0; mi < mons.size(); ++mi) {
+            const Mono& mo = mons[mi];
+            double acc = 0.0;
+            if (mo.n == 1) {
+                acc = row[mo.idx[0]];
+            } else if (mo.n == 2) {
+                int i = mo.idx[0], j = mo.idx[1];
+                acc = row[6 + 6 * i + j];
+                if (i != j) acc += row[6 + 6 * j + i];
+            } else {
+                int a[3] = {mo.idx[0], mo.idx[1], mo.idx[2]};
+                // all distinct permutations of (a0,a1,a2)
+                int perms[6][3] = {{0, 1, 2}, {0, 2, 1}, {1, 0, 2}, {1, 2, 0}, {2, 0, 1}, {2, 1, 0}};
+                int seen[6][3];
+                int ns = 0;
+                for (auto& p : perms) {
+                    int t3[3] = {a[p[0]], a[p[1]], a[p[2]]};
+                    bool dup = false;
+                    for (int s = 0; s < ns; ++s)
+                        if (seen[s][0] == t3[0] && seen[s][1] == t3[1] && seen[s][2] == t3[2]) dup = true;
+                    if (dup) continue;
+                    seen[ns][0] = t3[0]; seen[ns][1] = t3[1]; seen[ns][2] = t3[2];
+                    ++ns;
+                    acc += row[42 + 36 * t3[0] + 6 * t3[1] + t3[2]];
+                }
+            }
+            Wf[(size_t)c * ARREAU_MONO_PAD + mi] = (float)acc;
+        }
+    }
+}
+
+struct BlobBuilder {
+    std::vector<float> data;
+    // every region starts 64-float (256 B) aligned so 16-byte vector loads are always aligned
+    size_t reserve(size_t n) {
+        size_t off = (data.size() + 63) / 64 * 64;
+        data.resize(off + n, 0.0f);
+        return off;
+    }
+    size_t put(const float* src, size_t n) {
+        size_t off = reserve(n);
+        memcpy(data.data() + off, src, n * sizeof(float));
+        return off;
+    }
+};
+
+extern "C" int arreau_model_create(const arreau_config* cfg, const arreau_state_dict* sd, void* stream,
+                                   arreau_model** out_model) {
+    ARREAU_REQUIRE(cfg && sd && out_model, "arreau_model_create: null argument");
+    const int S = cfg->num_atomic_states, C = cfg->hidden_dim, D = cfg->basis_dim, L = cfg->num_layers;
+    const int O = cfg->num_ori, W = cfg->widening_factor, T = cfg->num_timesteps, k = cfg->max_neighbors;
+    const int H = W * C;
+    ARREAU_REQUIRE(O == ARREAU_ORI, "unsupported num_ori (this build handles num_ori = 16)");
+    ARREAU_REQUIRE(cfg->degree == 3, "unsupported polynomial degree (this build handles degree = 3)");
+    ARREAU_REQUIRE(C == 128 && D == 256, "unsupported hidden_dim/basis_dim (this build instantiates C=128, D=256)");
+    ARREAU_REQUIRE(W == 4, "unsupported widening_factor (this build handles 4)");
+    ARREAU_REQUIRE(k >= 1 && k <= ARREAU_MAX_K, "max_neighbors must be in 1..8");
+    ARREAU_REQUIRE(S >= 2 && S <= 128, "num_atomic_states must be in 2..128");
+    ARREAU_REQUIRE(L >= 1 && L <= 16 && T >= 2, "bad num_layers / num_timesteps");
+    const float* need[] = {sd->basis_w1, sd->basis_b1, sd->basis_w2, sd->basis_b2, sd->fiber_w1, sd->fiber_b1,
+                           sd->fiber_w2, sd->fiber_b2, sd->x_embedder_w, sd->conv_kernel_w, sd->conv_fiber_w,
+                           sd->conv_bias, sd->norm_w, sd->norm_b, sd->linear1_w, sd->linear1_b, sd->linear2_w,
+                           sd->linear2_b, sd->readout_w, sd->readout_b, sd->ori_grid, sd->t_emb_w, sd->ve_sigmas,
+                           sd->vp_alpha_bars, sd->vp_betas, sd->q_one_step_transposed, sd->q_mats};
+    for (const float* p : need) ARREAU_REQUIRE(p != nullptr, "arreau_model_create: missing state_dict entry");
+
+    BlobBuilder bb;
+    std::vector<float> tmp;
+    const size_t off_ori = bb.put(sd->ori_grid, (size_t)O * 3);
+
+    std::vector<float> w1f;
+    fold_poly_weight(sd->basis_w1, C, w1f);
+    tmp.assign((size_t)(C / 32) * (ARREAU_MONO_PAD / 32) * ARREAU_PACK_TILE_FLOATS, 0.f);
+    pack_linear(w1f.data(), C, ARREAU_MONO_PAD, ARREAU_MONO_PAD, C, ARREAU_MONO_PAD, tmp.data());
+    const size_t off_w1p = bb.put(tmp.data(), tmp.size());
+    const size_t off_b1 = bb.put(sd->basis_b1, C);
+
+    tmp.assign((size_t)(D / 32) * (C / 32) * ARREAU_PACK_TILE_FLOATS, 0.f);
+    pack_linear(sd->basis_w2, D, C, C, D, C, tmp.data());
+    const size_t off_w2p = bb.put(tmp.data(), tmp.size());
+    const size_t off_b2 = bb.put(sd->basis_b2, D);
+
+    const size_t wk_tile = (size_t)(C / 32) * (D / 32) * ARREAU_PACK_TILE_FLOATS;
+    const size_t off_wkp = bb.reserve(wk_tile * L);
+    for (int l = 0; l < L; ++l)
+        pack_linear(sd->conv_kernel_w + (size_t)l * C * D, C, D, D, C, D, bb.data.data() + off_wkp + l * wk_tile);
+
+    const size_t off_fk = bb.reserve((size_t)L * O * O * C);
+    const size_t off_conv_bias = bb.put(sd->conv_bias, (size_t)L * C);
+    const size_t off_ln_w = bb.put(sd->norm_w, (size_t)L * C);
+    const size_t off_ln_b = bb.put(sd->norm_b, (size_t)L * C);
+
+    const size_t m1_tile = (size_t)(H / 32) * (C / 32) * ARREAU_PACK_TILE_FLOATS;
+    const size_t off_m1p = bb.reserve(m1_tile * L);
+    for (int l = 0; l < L; ++l)
+        pack_linear(sd->linear1_w + (size_t)l * H * C, H, C, C, H, C, bb.data.data() + off_m1p + l * m1_tile);
+    const size_t off_mb1 = bb.put(sd->linear1_b, (size_t)L * H);
+    const size_t m2_tile = (size_t)(C / 32) * (H / 32) * ARREAU_PACK_TILE_FLOATS;
+    const size_t off_m2p = bb.reserve(m2_tile * L);
+    for (int l = 0; l < L; ++l)
+        pack_linear(sd->linear2_w + (size_t)l * C * H, C, H, H, C, H, bb.data.data() + off_m2p + l * m2_tile);
+    const size_t off_mb2 = bb.put(sd->linear2_b, (size_t)L * C);
+
+    tmp.assign((size_t)L * C, 1.0f);
+    if (cfg->has_layer_scale && sd->layer_scale) memcpy(tmp.data(), sd->layer_scale, tmp.size() * sizeof(float));
+    const size_t off_ls = bb.put(tmp.data(), tmp.size());
+
+    const int IN = S + 78;
+    tmp.assign((size_t)IN * C, 0.f);
+    for (int c = 0; c < C; ++c)
+        for (int i = 0; i < IN; ++i) tmp[(size_t)i * C + c] = sd->x_embedder_w[(size_t)c * IN + i];
+    const size_t off_embT = bb.put(tmp.data(), tmp.size());
+
+    const int RO = S + 4;
+    tmp.assign((size_t)L * C * RO, 0.f);
+    for (int l = 0; l < L; ++l)
+        for (int s = 0; s < RO; ++s)
+            for (int c = 0; c < C; ++c)
+                tmp[((size_t)l * C + c) * RO + s] = sd->readout_w[((size_t)l * RO + s) * C + c];
+    const size_t off_ro_wT = bb.put(tmp.data(), tmp.size());
+    const size_t off_ro_b = bb.put(sd->readout_b, (size_t)L * RO);
+
+    const size_t off_temb = bb.put(sd->t_emb_w, ARREAU_T_EMB_DIM / 2);
+    const size_t off_ve = bb.put(sd->ve_sigmas, (size_t)T + 1);
+    const size_t off_ab = bb.put(sd->vp_alpha_bars, (size_t)T + 1);
+    const size_t off_be = bb.put(sd->vp_betas, (size_t)T + 1);
+    const size_t off_q1t = bb.put(sd->q_one_step_transposed, (size_t)T * S * S);
+    const size_t off_qm = bb.put(sd->q_mats, (size_t)T * S * S);
+
+    const size_t off_fw1 = bb.put(sd->fiber_w1, (size_t)C * 3);
+    const size_t off_fb1 = bb.put(sd->fiber_b1, C);
+    const size_t off_fw2 = bb.put(sd->fiber_w2, (size_t)D * C);
+    const size_t off_fb2 = bb.put(sd->fiber_b2, D);
+    const size_t off_fwk = bb.put(sd->conv_fiber_w, (size_t)L * C * D);
+
+    arreau_model* m = new arreau_model();
+    memset(m, 0, sizeof(*m));
+    m->cfg = *cfg;
+    m->S = S; m->C = C; m->D = D; m->L = L; m->O = O; m->W = W; m->H = H; m->k = k; m->T = T;
+    m->blob_floats = bb.data.size();
+    hipError_t e = hipMalloc((void**)&m->blob, m->blob_floats * sizeof(float));
+    if (e != hipSuccess) {
+        delete m;
+        arreau_set_error(std::string("hipMalloc(model blob): ") + hipGetErrorString(e));
+        return ARREAU_EHIP;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    e = hipMemcpyAsync(m->blob, bb.data.data(), m->blob_floats * sizeof(float), hipMemcpyHostToDevice, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);  // host staging buffer dies at scope exit
+    if (e != hipSuccess) {
+        (void)hipFree(m->blob);
+        delete m;
+        arreau_set_error(std::string("model upload: ") + hipGetErrorString(e));
+        return ARREAU_EHIP;
+    }
+    float* b = m->blob;
+    m->ori = b + off_ori; m->w1p = b + off_w1p; m->b1 = b + off_b1; m->w2p = b + off_w2p; m->b2 = b + off_b2;
+    m->wkp = b + off_wkp; m->fk = b + off_fk; m->conv_bias = b + off_conv_bias; m->ln_w = b + off_ln_w;
+    m->ln_b = b + off_ln_b; m->m1p = b + off_m1p; m->mb1 = b + off_mb1; m->m2p = b + off_m2p; m->mb2 = b + off_mb2;
+    m->ls = b + off_ls; m->embT = b + off_embT; m->ro_wT = b + off_ro_wT; m->ro_b = b + off_ro_b;
+    m->t_emb_w = b + off_temb; m->ve_sigmas = b + off_ve; m->vp_alpha_bars = b + off_ab; m->vp_betas = b + off_be;
+    m->q1t = b + off_q1t; m->qmats = b + off_qm;
+    m->fiber_w1 = b + off_fw1; m->fiber_b1 = b + off_fb1; m->fiber_w2 = b + off_fw2; m->fiber_b2 = b + off_fb2;
+    m->fiber_wk = b + off_fwk;
+
+    int rc = arreau_launch_fiber_precompute(m, s);
+    if (rc == ARREAU_OK) {
+        e = hipStreamSynchronize(s);
+        if (e != hipSuccess) {
+            arreau_set_error(std::string("fiber precompute: ") + hipGetErrorString(e));
+            rc = ARREAU_EHIP;
+        }
+    }
+    if (rc != ARREAU_OK) {
+        (void)hipFree(m->blob);
+        delete m;
+        return rc;
+    }
+    *out_model = m;
+    return ARREAU_OK;
+}
+
+extern "C" void arreau_model_destroy(arreau_model* model) {
+    if (!model) return;
+    if (model->blob) (void)hipFree(model->blob);
+    delete model;
+}
+
+extern "C" int arreau_model_config(const arreau_model* model, arreau_config* out_cfg) {
+    ARREAU_REQUIRE(model && out_cfg, "arreau_model_config: null argument");
+    *out_cfg = model->cfg;
+    return ARREAU_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// One-time fiber kernels.  fiber_attr[o][p] = ori_o . ori_p (geometry/invariants.py:24);
+// fiber_kernel_basis = fiber_basis_fn(fiber_attr) (ponita.py:66,95: PolynomialFeatures(3) ->
+// Linear(3->C) -> GELU -> Linear(C->D) -> GELU); per layer fiber_kernel = Linear_{D->C}
+// (conv.py:113) and the spherical conv divides by O (conv.py:115) -- folded in here.
+// One workgroup per (o,p); runs once per model load, so it is written for clarity, not speed.
+// ---------------------------------------------------------------------------------------------
+__global__ void fiber_precompute_kernel(const float* __restrict__ ori, const float* __restrict__ w1,
+                                        const float* __restrict__ b1, const float* __restrict__ w2,
+                                        const float* __restrict__ b2, const float* __restrict__ wk,
+                                        float* __restrict__ fk, int C, int D, int L, int O) {
+    extern __shared__ float sm[];  // h1[C] then basis[D]
+    float* h1 = sm;
+    float* basis = sm + C;
+    const int o = blockIdx.x / O, p = blockIdx.x % O;
+    const float a = ori[o * 3 + 0] * ori[p * 3 + 0] + ori[o * 3 + 1] * ori[p * 3 + 1] + ori[o * 3 + 2] * ori[p * 3 + 2];
+    const float poly[3] = {a, a * a, (a * a) * a};
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        float v = b1[c];
+        for (int i = 0; i < 3; ++i) v += w1[c * 3 + i] * poly[i];
+        h1[c] = arreau_gelu(v);
+    }
+    __syncthreads();
+    for (int d = threadIdx.x; d < D; d += blockDim.x) {
+        float v = b2[d];
+        for (int c = 0; c < C; ++c) v += w2[(size_t)d * C + c] * h1[c];
+        basis[d] = arreau_gelu(v);
+    }
+    __syncthreads();
+    for (int idx = threadIdx.x; idx < L * C; idx += blockDim.x) {
+        const int l = idx / C, c = idx % C;
+        const float* wrow = wk + ((size_t)l * C + c) * D;
+        float v = 0.f;
+        for (int d = 0; d < D; ++d) v += wrow[d] * basis[d];
+        fk[(((size_t)l * O + o) * O + p) * C + c] = v / (float)O;
+    }
+}
+
+int arreau_launch_fiber_precompute(arreau_model* m, hipStream_t s) {
+    const size_t smem = (size_t)(m->C + m->D) * sizeof(float);
+    hipLaunchKernelGGL(fiber_precompute_kernel, dim3(m->O * m->O), dim3(256), smem, s, m->ori, m->fiber_w1,
+                       m->fiber_b1, m->fiber_w2, m->fiber_b2, m->fiber_wk, m->fk, m->C, m->D, m->L, m->O);
+    ARREAU_CHECK_HIP(hipGetLastError());
+    return ARREAU_OK;
+}

@@ -1,0 +1,157 @@
+// K6: the reverse updates of one denoising step (diffusion/diffusion_loss.py:338-347).
+#include "internal.h"
+
+#define D3PM_EPS 1e-6f  // d3pm.py:23
+
+// VP_lattice.reverse_given_x0 (diffusion_helpers.py:185-199) on lengths, then lattice_from_params.
+// Note the reference adds `variance * z` (not sqrt(variance)) and zeroes z when t <= 1.
+__global__ void reverse_lattice_kernel(float* __restrict__ lengths, const float* __restrict__ angles,
+                                       const int32_t* __restrict__ tstep, const int32_t* __restrict__ offsets,
+                                       const float* __restrict__ len0, const float* __restrict__ z,
+                                       const float* __restrict__ alpha_bars, const float* __restrict__ betas, int B,
+                                       int T, float* __restrict__ lattice) {
+    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+    if (b >= B) return;
+    int t = tstep[b];
+    t = t < 1 ? 1 : (t > T ? T : t);
+    const float n = (float)(offsets[b + 1] - offsets[b]);
+    const float ab_t = alpha_bars[t], ab_p = alpha_bars[t - 1], beta = betas[t];
+    const float denom = 1.0f - ab_t;
+    const float alpha_t = 1.0f - beta;
+    const float c0 = sqrtf(ab_p) * beta;
+    const float c1 = sqrtf(alpha_t) * (1.0f - ab_p);
+    const float variance = (1.0f - ab_p) * beta / denom;
+    float newlen[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const float x0 = len0[3 * b + i] * n;  // pred_lengths_0 * num_atoms (diffusion_loss.py:338)
+        const float xt = lengths[3 * b + i];
+        const float mean = (c0 * x0 + c1 * xt) / denom;
+        const float zz = t > 1 ? z[3 * b + i] : 0.0f;
+        newlen[i] = mean + variance * zz;
+        lengths[3 * b + i] = newlen[i];
+    }
+    // lattice_from_params (lattice_helpers.py:55-105)
+    const float* ang = angles + 3 * b;
+    const float ca = cosf(ang[0]), cb = cosf(ang[1]), cg = cosf(ang[2]);
+    const float sa = sinf(ang[0]), sb = sinf(ang[1]);
+    float val = (ca * cb - cg) / (sa * sb);
+    val = fminf(fmaxf(val, -1.0f), 1.0f);
+    const float gs = acosf(val);
+    float* Lm = lattice + 9 * b;
+    Lm[0] = newlen[0] * sb;             Lm[1] = 0.0f;                      Lm[2] = newlen[0] * cb;
+    Lm[3] = -newlen[1] * sa * cosf(gs); Lm[4] = newlen[1] * sa * sinf(gs); Lm[5] = newlen[1] * ca;
+    Lm[6] = 0.0f;                       Lm[7] = 0.0f;                      Lm[8] = newlen[2];
+}
+
+// torch.remainder(x, 1) for floats: fmod, then shift negatives up by one (can return exactly 1.0f
+// for tiny negative x, like the reference's `% 1`).
+__device__ __forceinline__ float remainder_one(float x) {
+    float m = fmodf(x, 1.0f);
+    if (m != 0.0f && m < 0.0f) m += 1.0f;
+    return m;
+}
+
+// One wave per atom: VE_pbc.reverse on the fractional coordinates (diffusion_helpers.py:65-81) and
+// D3PM.reverse on the atom type (d3pm.py:74-110, 198-215).  Lanes span the S classes (2 per lane).
+__global__ __launch_bounds__(256) void reverse_atoms_kernel(
+    float* __restrict__ frac, int32_t* __restrict__ types, const int32_t* __restrict__ tstep,
+    const int32_t* __restrict__ offsets, int B, int N, const float* __restrict__ eps,
+    const float* __restrict__ logits, const float* __restrict__ z_frac, const float* __restrict__ u_types,
+    const float* __restrict__ ve_sigmas, const float* __restrict__ q1t, const float* __restrict__ qmats, int S,
+    int T) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int i = blockIdx.x * 4 + wave;
+    if (i >= N) return;  // wave-uniform; no block-level barrier below
+    // crystal of this atom
+    int lo = 0, hi = B;
+    while (hi - lo > 1) {
+        const int mid = (lo + hi) >> 1;
+        if (offsets[mid] <= i) lo = mid; else hi = mid;
+    }
+    int t = tstep[lo];
+    t = t < 1 ? 1 : (t > T ? T : t);
+
+    if (lane < 3) {
+        const float s = ve_sigmas[t];
+        const float sp = ve_sigmas[t - 1];  // t >= 1 here; the reference's t == 0 branch is unreachable in sampling
+        const float s2 = s * s, sp2 = sp * sp;
+        const size_t g = 3 * (size_t)i + lane;
+        const float mean = frac[g] - eps[g] * (s2 - sp2);
+        const float stdv = sqrtf((sp2 * (s2 - sp2)) / s2);
+        frac[g] = remainder_one(mean + stdv * z_frac[g]);
+    }
+
+    // ---- D3PM posterior logits ------------------------------------------------------------------
+    const int s0 = lane, s1 = lane + 64;
+    const bool v0 = s0 < S, v1 = s1 < S;
+    const float* lg = logits + (size_t)i * S;
+    const float l0 = v0 ? lg[s0] : -INFINITY, l1 = v1 ? lg[s1] : -INFINITY;
+    float post0, post1;
+    if (t == 1) {
+        post0 = l0; post1 = l1;  // raw x0 logits at the last step (d3pm.py:106-108)
+    } else {
+        float mx = fmaxf(l0, l1);
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+        const float e0 = v0 ? expf(l0 - mx) : 0.f, e1 = v1 ? expf(l1 - mx) : 0.f;
+        float sum = e0 + e1;
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) sum += __shfl_xor(sum, off, 64);
+        const float p0 = e0 / sum, p1 = e1 / sum;  // softmax of the x0 logits; lane holds classes s0, s1
+        int xt = types[i];
+        xt = xt < 0 ? 0 : (xt >= S ? S - 1 : xt);
+        const float* q1row = q1t + ((size_t)(t - 1) * S + xt) * S;  // fact1 = Q_t^T[x_t, :]
+        const float* qm = qmats + (size_t)(t - 2) * S * S;          // Qbar_{t-1} (reference index t-2)
+        float f2a = 0.f, f2b = 0.f;
+        for (int c = 0; c < S; ++c) {
+            const float sc = c < 64 ? __shfl(p0, c, 64) : __shfl(p1, c - 64, 64);  // c is wave-uniform
+            if (v0) f2a += sc * qm[(size_t)c * S + s0];
+            if (v1) f2b += sc * qm[(size_t)c * S + s1];
+        }
+        post0 = v0 ? logf(q1row[s0] + D3PM_EPS) + logf(f2a + D3PM_EPS) : -INFINITY;
+        post1 = v1 ? logf(q1row[s1] + D3PM_EPS) + logf(f2b + D3PM_EPS) : -INFINITY;
+    }
+    // ---- Gumbel arg-max (d3pm.py:206-214) ----------------------------------------------------------
+    const float scale = (t != 1) ? 1.0f : 0.2f;
+    const float* un = u_types + (size_t)i * S;
+    float best = -INFINITY;
+    int besti = 0x7fffffff;
+    if (v0) {
+        const float u = fminf(fmaxf(un[s0], D3PM_EPS), 1.0f);
+        best = post0 + (-logf(-logf(u))) * scale;
+        besti = s0;
+    }
+    if (v1) {
+        const float u = fminf(fmaxf(un[s1], D3PM_EPS), 1.0f);
+        const float val = post1 + (-logf(-logf(u))) * scale;
+        if (val > best) { best = val; besti = s1; }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        const float ob = __shfl_xor(best, off, 64);
+        const int oi = __shfl_xor(besti, off, 64);
+        if (ob > best || (ob == best && oi < besti)) { best = ob; besti = oi; }  // first index wins ties
+    }
+    if (lane == 0) types[i] = besti;
+}
+
+extern "C" int arreau_reverse_step(const arreau_model* m, float* d_frac, int32_t* d_types, float* d_lengths,
+                                   const float* d_angles, const int32_t* d_t, const int32_t* d_off, int32_t B,
+                                   int32_t N, const float* d_eps, const float* d_logits, const float* d_len0,
+                                   const float* d_z_lattice, const float* d_z_frac, const float* d_u_types,
+                                   float* d_lattice, void* stream) {
+    ARREAU_REQUIRE(m && d_frac && d_types && d_lengths && d_angles && d_t && d_off && d_eps && d_logits && d_len0 &&
+                       d_z_lattice && d_z_frac && d_u_types && d_lattice, "arreau_reverse_step: null pointer");
+    ARREAU_REQUIRE(B >= 1 && N >= 0, "arreau_reverse_step: bad size");
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(reverse_lattice_kernel, dim3((B + 127) / 128), dim3(128), 0, s, d_lengths, d_angles, d_t, d_off,
+                       d_len0, d_z_lattice, m->vp_alpha_bars, m->vp_betas, B, m->T, d_lattice);
+    ARREAU_CHECK_HIP(hipGetLastError());
+    if (N > 0) {
+        hipLaunchKernelGGL(reverse_atoms_kernel, dim3((N + 3) / 4), dim3(256), 0, s, d_frac, d_types, d_t, d_off, B, N,
+                           d_eps, d_logits, d_z_frac, d_u_types, m->ve_sigmas, m->q1t, m->qmats, m->S, m->T);
+        ARREAU_CHECK_HIP(hipGetLastError());
+    }
+    return ARREAU_OK;
+}

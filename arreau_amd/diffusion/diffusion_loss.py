@@ -1,0 +1,133 @@
+"""DiffusionLoss: the sampling loop of the reference (diffusion/diffusion_loss.py:276-377) driving
+the HIP engine.  Training (`__call__`) is out of this build's scope and raises."""
+from dataclasses import dataclass
+from typing import Optional
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from .d3pm import D3PM
+from .diffusion_helpers import VE_pbc, VP_lattice, crystal_offsets, sample_bravais_angles
+from .inference.visualize_crystal import VisualizationSetting
+from .tools.atomic_number_table import AtomicNumberTable, atomic_number_indexes_to_atomic_numbers
+
+pos_sigma_min = 0.001
+pos_sigma_max = 1.0
+type_power = 2
+lattice_power = 2
+type_clipmax = 0.999
+lattice_clipmax = 0.999
+
+
+@dataclass
+class SampleResult:
+    """Same fields as the reference (diffusion_loss.py:39-49)."""
+    frac_x: Optional[np.ndarray] = None
+    atomic_numbers: Optional[np.ndarray] = None
+    lattice: Optional[np.ndarray] = None
+    idx_start: Optional[np.ndarray] = None
+    num_atoms: Optional[np.ndarray] = None
+
+
+class DiffusionLoss(nn.Module):
+    def __init__(self, args, num_atomic_states: int):
+        super().__init__()
+        self.cutoff = args.radius
+        self.max_neighbors = args.max_neighbors
+        self.T = args.num_timesteps
+        self.pos_diffusion = VE_pbc(self.T, sigma_min=pos_sigma_min, sigma_max=pos_sigma_max)
+        self.d3pm = D3PM(x0_model=None, n_T=args.num_timesteps, num_classes=num_atomic_states, forward_type="mask")
+        self.lattice_diffusion = VP_lattice(num_steps=self.T, power=lattice_power, clipmax=lattice_clipmax)
+        self.num_atomic_states = num_atomic_states
+
+    def __call__(self, *a, **kw):
+        raise NotImplementedError("score-matching training is not part of this build (sampling path only)")
+
+    # ------------------------------------------------------------------------------------------
+    def predict_scores(self, noisy_frac_x, noisy_atom_types, t_feat, num_atoms, noisy_lengths, angles, model,
+                       batch=None, t_emb_weights=None, edges=None):
+        """diffusion_loss.py:112-197.  `noisy_atom_types` may be class indices [N] or one-hot [N,S]
+        (the reference passes the one-hot); `t_feat` is the per-atom timestep [N] (or per-crystal [B]).
+        Returns (pred_frac_eps_x [N,3], logits [N,S], pred_lengths_0 [B,3]) on the GPU."""
+        eng = model.engine()
+        dev = eng.device
+        frac = noisy_frac_x.to(device=dev, dtype=torch.float32).contiguous()
+        ty = noisy_atom_types
+        if ty.dim() == 2:
+            ty = ty.argmax(dim=1)
+        ty = ty.to(device=dev, dtype=torch.int32).contiguous()
+        lengths = noisy_lengths.to(device=dev, dtype=torch.float32).contiguous()
+        ang = angles.to(device=dev, dtype=torch.float32).contiguous()
+        n_cpu = torch.as_tensor(num_atoms).to("cpu", torch.int64)
+        off = crystal_offsets(n_cpu, dev)
+        t_feat = torch.as_tensor(t_feat)
+        if t_feat.numel() == n_cpu.numel():
+            t_c = t_feat.reshape(-1)
+        else:  # per-atom timestep: constant inside a crystal, take each crystal's first atom
+            first = (torch.cumsum(n_cpu, 0) - n_cpu).clamp(max=max(int(t_feat.numel()) - 1, 0))
+            t_c = t_feat.reshape(-1).to("cpu")[first]
+        t_c = t_c.to(device=dev, dtype=torch.int32).contiguous()
+        return eng.predict_scores(frac, ty, lengths, ang, t_c, off, edges=edges)
+
+    @torch.no_grad()
+    def sample(self, *, model, z_table: AtomicNumberTable, t_emb_weights=None, num_atoms_per_sample: int,
+               num_samples_in_batch: int, vis_name: str = "", visualization_setting=VisualizationSetting.NONE,
+               show_bonds: bool = False, constant_atoms: Optional[torch.Tensor] = None, noise: str = "device",
+               max_steps: Optional[int] = None) -> SampleResult:
+        """diffusion_loss.py:276-377.  The initial state is drawn on the host exactly like the
+        reference (numpy uniforms for the angles, then randn lengths, randn fractional coordinates
+        from torch's global CPU generator).  Per-step noise: `noise="device"` draws on the GPU
+        (fast path); `noise="reference"` draws randn[B,3], randn[N,3], rand[N,S] from the global
+        CPU generator in the reference's order and uploads it."""
+        if visualization_setting != VisualizationSetting.NONE:
+            raise NotImplementedError("per-step visualisation is outside this build; use VisualizationSetting.NONE")
+        if noise not in ("device", "reference"):
+            raise ValueError("noise must be 'device' or 'reference'")
+        eng = model.engine()
+        dev = eng.device
+        S = len(z_table)
+        B, n = int(num_samples_in_batch), int(num_atoms_per_sample)
+        N = B * n
+        dt = torch.get_default_dtype()
+        angles = torch.tensor(np.array([sample_bravais_angles("monoclinic") for _ in range(B)]))
+        lengths = torch.randn([B, 3])
+        frac_x = torch.randn([N, 3], dtype=dt) * pos_sigma_max
+        num_atoms = torch.full((B,), n)
+        if constant_atoms is not None:
+            atom_types = torch.as_tensor(constant_atoms).reshape(-1).long()
+            if atom_types.numel() != N:
+                raise ValueError("constant_atoms must hold one class index per atom")
+        else:
+            atom_types = torch.full((N,), S - 1)
+
+        f32 = dict(device=dev, dtype=torch.float32)
+        frac_d = frac_x.to(**f32).contiguous()
+        len_d = lengths.to(**f32).contiguous()
+        ang_d = angles.to(**f32).contiguous()
+        types_d = atom_types.to(device=dev, dtype=torch.int32).contiguous()
+        const_d = types_d.clone() if constant_atoms is not None else None
+        off_d = crystal_offsets(num_atoms, dev)
+        lattice_d = torch.zeros((B, 3, 3), **f32)
+        t_d = torch.empty(B, device=dev, dtype=torch.int32)
+        done = 0
+        for timestep in reversed(range(1, self.T)):
+            t_d.fill_(timestep)
+            eps, logits, len0 = eng.predict_scores(frac_d, types_d, len_d, ang_d, t_d, off_d)
+            if noise == "device":
+                z_l = torch.randn((B, 3), **f32)
+                z_f = torch.randn((N, 3), **f32)
+                u_t = torch.rand((N, S), **f32)
+            else:
+                z_l = torch.randn([B, 3]).to(**f32)
+                z_f = torch.randn([N, 3], dtype=dt).to(**f32)
+                u_t = torch.rand([N, S]).to(**f32)
+            eng.reverse_step(frac_d, types_d, len_d, ang_d, t_d, off_d, eps, logits, len0, z_l, z_f, u_t, lattice_d)
+            if const_d is not None:
+                types_d.copy_(const_d)
+            done += 1
+            if max_steps is not None and done >= max_steps:
+                break
+        atomic_numbers = atomic_number_indexes_to_atomic_numbers(z_table, types_d.cpu().numpy())
+        return SampleResult(num_atoms=num_atoms.numpy(), frac_x=frac_d.cpu().numpy().astype(np.float64),
+                            atomic_numbers=atomic_numbers, lattice=lattice_d.cpu().numpy().astype(np.float64))

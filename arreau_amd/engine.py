@@ -1,0 +1,156 @@
+"""HipEngine: owns the arreau_model handle (packed weights in HBM) and the step workspace.
+
+Host-side plumbing only: tensors are allocated with torch, every arithmetic step on the sampler
+state runs in libarreau_hip.so.
+"""
+import ctypes
+
+import torch
+
+from . import _hip
+
+
+def _f32(t):
+    return t.detach().to("cpu", torch.float32).contiguous()
+
+
+class HipEngine:
+    def __init__(self, module, device):
+        """module: a PONITA_DIFFUSION (state_dict layout of the reference); device: cuda device."""
+        _hip.require_gpu()
+        self.device = torch.device(device)
+        net = module.model
+        sd = module.state_dict()
+        L = net.num_layers
+        S = module.num_atomic_states
+        cfg = _hip.Config(
+            num_atomic_states=S, hidden_dim=net.hidden_dim, basis_dim=net.basis_dim, num_layers=L,
+            num_ori=net.num_ori, widening_factor=net.widening_factor, degree=net.degree,
+            max_neighbors=int(module.diffusion_loss.max_neighbors), num_timesteps=int(module.diffusion_loss.T),
+            radius=float(module.diffusion_loss.cutoff),
+            has_layer_scale=int(f"model.interaction_layers.0.layer_scale" in sd and
+                                sd["model.interaction_layers.0.layer_scale"] is not None))
+        self.cfg = cfg
+        il = "model.interaction_layers.{}."
+        stack = lambda fmt: torch.stack([_f32(sd[fmt.format(i)]) for i in range(L)], 0).contiguous()
+        host = {
+            "basis_w1": _f32(sd["model.basis_fn.1.weight"]), "basis_b1": _f32(sd["model.basis_fn.1.bias"]),
+            "basis_w2": _f32(sd["model.basis_fn.3.weight"]), "basis_b2": _f32(sd["model.basis_fn.3.bias"]),
+            "fiber_w1": _f32(sd["model.fiber_basis_fn.1.weight"]), "fiber_b1": _f32(sd["model.fiber_basis_fn.1.bias"]),
+            "fiber_w2": _f32(sd["model.fiber_basis_fn.3.weight"]), "fiber_b2": _f32(sd["model.fiber_basis_fn.3.bias"]),
+            "x_embedder_w": _f32(sd["model.x_embedder.weight"]),
+            "conv_kernel_w": stack(il + "conv.kernel.weight"), "conv_fiber_w": stack(il + "conv.fiber_kernel.weight"),
+            "conv_bias": stack(il + "conv.bias"), "norm_w": stack(il + "norm.weight"), "norm_b": stack(il + "norm.bias"),
+            "linear1_w": stack(il + "linear_1.weight"), "linear1_b": stack(il + "linear_1.bias"),
+            "linear2_w": stack(il + "linear_2.weight"), "linear2_b": stack(il + "linear_2.bias"),
+            "readout_w": stack("model.read_out_layers.{}.weight"), "readout_b": stack("model.read_out_layers.{}.bias"),
+            "ori_grid": _f32(net.ori_grid), "t_emb_w": _f32(sd["t_emb.gaussian_fourier_proj_w"]),
+            "ve_sigmas": _f32(sd["diffusion_loss.pos_diffusion.sigmas"]),
+            "vp_alpha_bars": _f32(sd["diffusion_loss.lattice_diffusion.alpha_bars"]),
+            "vp_betas": _f32(sd["diffusion_loss.lattice_diffusion.betas"]),
+            "q_one_step_transposed": _f32(sd["diffusion_loss.d3pm.q_one_step_transposed"]),
+            "q_mats": _f32(sd["diffusion_loss.d3pm.q_mats"]),
+        }
+        if cfg.has_layer_scale:
+            host["layer_scale"] = stack(il + "layer_scale")
+        expect = {"basis_w1": (net.hidden_dim, 258), "x_embedder_w": (net.hidden_dim, S + 78),
+                  "readout_w": (L, S + 4, net.hidden_dim), "ori_grid": (net.num_ori, 3),
+                  "q_mats": (cfg.num_timesteps, S, S), "ve_sigmas": (cfg.num_timesteps + 1,)}
+        for k, shp in expect.items():
+            if tuple(host[k].shape) != shp:
+                raise ValueError(f"state_dict entry for {k} has shape {tuple(host[k].shape)}, expected {shp}")
+        csd = _hip.StateDict()
+        for name in _hip._SD_FIELDS:
+            t = host.get(name)
+            setattr(csd, name, t.data_ptr() if t is not None else None)
+        self._handle = ctypes.c_void_p()
+        with torch.cuda.device(self.device):
+            _hip.check(_hip.lib().arreau_model_create(ctypes.byref(cfg), ctypes.byref(csd),
+                                                      _hip.stream_ptr(self.device), ctypes.byref(self._handle)),
+                       "arreau_model_create")
+        self._host_keepalive = host
+        self._ws = None
+        self._ws_cap = (0, 0)
+        self.S, self.k = S, cfg.max_neighbors
+
+    def close(self):
+        if getattr(self, "_handle", None) is not None and self._handle.value:
+            _hip.lib().arreau_model_destroy(self._handle)
+            self._handle = ctypes.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ------------------------------------------------------------------------------------------
+    def workspace(self, N, B):
+        if self._ws is None or N > self._ws_cap[0] or B > self._ws_cap[1]:
+            capN, capB = max(N, self._ws_cap[0]), max(B, self._ws_cap[1])
+            nbytes = _hip.lib().arreau_workspace_bytes(ctypes.byref(self.cfg), capN, capB)
+            self._ws = None
+            self._ws = torch.empty(nbytes, dtype=torch.uint8, device=self.device)
+            self._ws_cap = (capN, capB)
+        return self._ws
+
+    def predict_scores(self, frac, types, lengths, angles, t_crystal, offsets, edges=None, return_edges=False):
+        """frac [N,3] f32, types [N] i32, lengths/angles [B,3] f32, t_crystal [B] i32, offsets [B+1] i32 (device).
+        edges = (deg [N] i32, src [N,k] i32, dir [N,k,3] f32, dist [N,k] f32) teacher-forces the graph.
+        Returns (eps [N,3], logits [N,S], len0 [B,3]) [+ edges]."""
+        dev = self.device
+        N, B = frac.shape[0], lengths.shape[0]
+        eps = torch.empty((N, 3), device=dev, dtype=torch.float32)
+        logits = torch.empty((N, self.S), device=dev, dtype=torch.float32)
+        len0 = torch.empty((B, 3), device=dev, dtype=torch.float32)
+        ws = self.workspace(N, B)
+        if edges is not None:
+            deg, src, direction, dist = edges
+            given = 1
+        elif return_edges:
+            k = self.k
+            deg = torch.empty(N, device=dev, dtype=torch.int32)
+            src = torch.empty((N, k), device=dev, dtype=torch.int32)
+            direction = torch.empty((N, k, 3), device=dev, dtype=torch.float32)
+            dist = torch.empty((N, k), device=dev, dtype=torch.float32)
+            given = 0
+        else:
+            deg = src = direction = dist = None
+            given = 0
+        _hip.check(_hip.lib().arreau_predict_scores(
+            self._handle, _hip.ptr(frac), _hip.ptr(types), _hip.ptr(lengths), _hip.ptr(angles), _hip.ptr(t_crystal),
+            _hip.ptr(offsets), B, N, given, _hip.ptr(deg), _hip.ptr(src), _hip.ptr(direction), _hip.ptr(dist),
+            _hip.ptr(eps), _hip.ptr(logits), _hip.ptr(len0), _hip.ptr(ws), ws.numel(), _hip.stream_ptr(dev)),
+            "arreau_predict_scores")
+        if return_edges:
+            return eps, logits, len0, (deg, src, direction, dist)
+        return eps, logits, len0
+
+    def reverse_step(self, frac, types, lengths, angles, t_crystal, offsets, eps, logits, len0, z_lattice, z_frac,
+                     u_types, lattice_out):
+        """In-place update of (frac, types, lengths); lattice_out [B,3,3] receives the new cell."""
+        B, N = lengths.shape[0], frac.shape[0]
+        _hip.check(_hip.lib().arreau_reverse_step(
+            self._handle, _hip.ptr(frac), _hip.ptr(types), _hip.ptr(lengths), _hip.ptr(angles), _hip.ptr(t_crystal),
+            _hip.ptr(offsets), B, N, _hip.ptr(eps), _hip.ptr(logits), _hip.ptr(len0), _hip.ptr(z_lattice),
+            _hip.ptr(z_frac), _hip.ptr(u_types), _hip.ptr(lattice_out), _hip.stream_ptr(self.device)),
+            "arreau_reverse_step")
+
+    def edges_to_slots(self, edge_index, dists, direction, N):
+        """Receiver-sorted COO edges -> slot form (deg, src, dir, dist)."""
+        dev, k = self.device, self.k
+        ei = edge_index.to(device=dev, dtype=torch.int64).contiguous()
+        E = ei.shape[1]
+        d = dists.to(device=dev, dtype=torch.float32).contiguous()
+        dr = direction.to(device=dev, dtype=torch.float32).contiguous()
+        deg = torch.empty(N, device=dev, dtype=torch.int32)
+        src = torch.empty((N, k), device=dev, dtype=torch.int32)
+        sdir = torch.empty((N, k, 3), device=dev, dtype=torch.float32)
+        sdist = torch.empty((N, k), device=dev, dtype=torch.float32)
+        status = torch.zeros(1, device=dev, dtype=torch.int32)
+        _hip.check(_hip.lib().arreau_edges_to_slots(_hip.ptr(ei), _hip.ptr(d), _hip.ptr(dr), E, N, k, _hip.ptr(deg),
+                                                     _hip.ptr(src), _hip.ptr(sdir), _hip.ptr(sdist), _hip.ptr(status),
+                                                     _hip.stream_ptr(dev)), "arreau_edges_to_slots")
+        if int(status.item()) != 0:
+            raise ValueError(f"edge list must be receiver-sorted with at most {k} in-edges per node")
+        return deg, src, sdir, sdist

@@ -1,0 +1,143 @@
+"""PONITA_DIFFUSION: the module surface of lightning_wrappers/diffusion.py:29-253 of the reference
+(constructor arguments, attributes, state_dict keys, `load_from_checkpoint`, `forward`, `sample`)
+with the per-step work running in libarreau_hip.so.  pytorch_lightning is not required; the class
+is a plain nn.Module that reads and writes Lightning-format checkpoint dicts."""
+import os
+import pathlib
+from types import SimpleNamespace
+from typing import Optional
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from ..diffusion.diffusion_helpers import GaussianFourierProjection, crystal_offsets
+from ..diffusion.diffusion_loss import DiffusionLoss, SampleResult
+from ..diffusion.inference.visualize_crystal import VisualizationSetting
+from ..diffusion.tools.atomic_number_table import AtomicNumberTable, atomic_symbols_to_indices
+from ..ponita.models.ponita import PonitaFiberBundle
+
+fourier_scale = 16
+t_emb_dim = 64
+OUT_DIR = f"{pathlib.Path(__file__).parent.resolve()}/../out"
+DIFFUSION_DIR = f"{OUT_DIR}/diffusion"
+
+ORI_GRID_KEY = "arreau_amd.ori_grid"  # optional extra checkpoint entry (the reference does not persist the grid)
+
+
+class PONITA_DIFFUSION(nn.Module):
+    def __init__(self, args, z_table: AtomicNumberTable, ori_grid=None):
+        super().__init__()
+        self.hparams = SimpleNamespace(args=args, z_table=z_table)
+        self.register_buffer("z_table_zs", torch.tensor(list(z_table.zs), dtype=torch.int64))
+        self.dataset = getattr(args, "dataset", "alexandria")
+        num_atomic_states = len(z_table)
+        self.num_atomic_states = num_atomic_states
+        self.lr = getattr(args, "lr", 1e-3)
+        self.weight_decay = getattr(args, "weight_decay", 1e-10)
+        self.epochs = getattr(args, "epochs", 0)
+        self.warmup = getattr(args, "warmup", 0)
+        if args.layer_scale == 0.0:
+            args.layer_scale = None
+        self.train_augm = getattr(args, "train_augm", False)
+
+        self.t_emb = GaussianFourierProjection(t_emb_dim // 2, fourier_scale)
+        self.diffusion_loss = DiffusionLoss(args, num_atomic_states)
+
+        in_channels_scalar = num_atomic_states + 64 + 1 + 3 + 3 + 3
+        in_channels_vec = 1 + 3
+        self.model = PonitaFiberBundle(
+            in_channels_scalar + in_channels_vec, args.hidden_dim, num_atomic_states, 3, 0, 0, args.layers,
+            output_dim_vec=1, radius=args.radius, num_ori=args.num_ori, basis_dim=args.basis_dim,
+            degree=args.degree, widening_factor=args.widening_factor, layer_scale=args.layer_scale,
+            multiple_readouts=args.multiple_readouts, ori_grid=ori_grid)
+        self._engine = None
+        self._device = torch.device("cpu")
+
+    # ---- device / engine management --------------------------------------------------------------
+    def _apply(self, fn, *a, **kw):
+        out = super()._apply(fn, *a, **kw)
+        self._engine = None  # parameters moved or changed dtype: repack on next use
+        self._device = self.z_table_zs.device
+        return out
+
+    def load_state_dict(self, state_dict, strict: bool = True, **kw):
+        state_dict = dict(state_dict)
+        grid = state_dict.pop(ORI_GRID_KEY, None)
+        if grid is not None:
+            self.model.ori_grid = torch.as_tensor(grid).detach().cpu().clone()
+        out = super().load_state_dict(state_dict, strict=strict, **kw)
+        self._engine = None
+        return out
+
+    def engine(self):
+        """The HIP engine for the module's current (cuda) device; packs the weights on first use."""
+        if self._engine is None:
+            from ..engine import HipEngine
+            dev = self._device if self._device.type == "cuda" else torch.device("cuda", 0)
+            self._engine = HipEngine(self, dev)
+        return self._engine
+
+    # ---- checkpoint I/O (Lightning dict format) --------------------------------------------------
+    @classmethod
+    def load_from_checkpoint(cls, checkpoint_path, map_location=None, strict: bool = False, **kwargs):
+        from ..checkpoint import load_lightning_checkpoint
+        ckpt = load_lightning_checkpoint(checkpoint_path)
+        hp = ckpt["hyper_parameters"]
+        model = cls(hp["args"], hp["z_table"], ori_grid=ckpt["state_dict"].get(ORI_GRID_KEY))
+        model.load_state_dict(ckpt["state_dict"], strict=strict)
+        if torch.cuda.is_available():
+            model = model.to(map_location if map_location is not None else "cuda")
+        return model
+
+    # ---- operator seam ----------------------------------------------------------------------------
+    def forward(self, graph):
+        """model(batch) of diffusion_loss.py:183-189 / PonitaFiberBundle.forward (ponita.py:88-123).
+        `graph` carries x [N,S+74], vec [N,4,3], edge_index [2,E] (sender, receiver; receiver-sorted),
+        dists [E], inter_atom_direction [E,3], lattice [B,3,3], batch [N], num_atoms [B].  Returns the
+        reference's 5-tuple (logits [N,S], vec [N,1,3], global_scalar [B,3], None, [None]*L).
+
+        The engine consumes the sampler state, so the node features are decoded back to it: class index
+        = argmax of the one-hot block, per-crystal features from the first atom of each crystal."""
+        eng = self.engine()
+        S = self.num_atomic_states
+        x = graph.x
+        n_cpu = torch.as_tensor(graph.num_atoms).to("cpu", torch.int64)
+        first = (torch.cumsum(n_cpu, 0) - n_cpu).to(x.device)
+        types = x[:, :S].argmax(dim=1)
+        t_emb = x[first, S:S + 64]
+        lengths = x[first, S + 65:S + 68]
+        angles = x[first, S + 68:S + 71]
+        frac = graph.vec[:, 0, :]
+        # the time feature is a function of betas[t]; recover t by matching the embedding
+        betas = self.diffusion_loss.lattice_diffusion.betas.to(x.device, torch.float64)
+        w = self.t_emb.gaussian_fourier_proj_w.to(x.device, torch.float64)
+        table = torch.sin(betas[:, None] * w[None, :] * 2 * np.pi)
+        t_c = torch.cdist(t_emb[:, :32].to(torch.float64), table).argmin(dim=1)
+        dev = eng.device
+        edges = eng.edges_to_slots(graph.edge_index, graph.dists, graph.inter_atom_direction, x.shape[0])
+        eps, logits, len0 = eng.predict_scores(
+            frac.to(dev, torch.float32).contiguous(), types.to(dev, torch.int32).contiguous(),
+            lengths.to(dev, torch.float32).contiguous(), angles.to(dev, torch.float32).contiguous(),
+            t_c.to(dev, torch.int32).contiguous(), crystal_offsets(n_cpu, dev), edges=edges)
+        return logits, eps.unsqueeze(1), len0, None, [None] * self.model.num_layers
+
+    @torch.no_grad()
+    def sample(self, num_atoms_per_sample: int, num_samples_in_batch: int,
+               visualization_setting: VisualizationSetting = VisualizationSetting.NONE, show_bonds: bool = False,
+               use_constant_atomic_symbols: Optional[list] = None, noise: str = "device",
+               max_steps: Optional[int] = None) -> SampleResult:
+        """lightning_wrappers/diffusion.py:220-253."""
+        z_table = AtomicNumberTable(self.z_table_zs.tolist())
+        if use_constant_atomic_symbols is not None:
+            # one index per atom of a crystal, tiled over the batch (the reference's np.repeat at :236
+            # interleaves instead of tiling and only works for single-species lists; tiling is the intent)
+            idx = atomic_symbols_to_indices(z_table, use_constant_atomic_symbols)
+            constant_atoms = torch.as_tensor(np.tile(idx, num_samples_in_batch))
+        else:
+            constant_atoms = None
+        return self.diffusion_loss.sample(
+            model=self, z_table=z_table, t_emb_weights=self.t_emb, num_atoms_per_sample=num_atoms_per_sample,
+            num_samples_in_batch=num_samples_in_batch, vis_name=f"{DIFFUSION_DIR}/step",
+            visualization_setting=visualization_setting, show_bonds=show_bonds, constant_atoms=constant_atoms,
+            noise=noise, max_steps=max_steps)

@@ -1,0 +1,199 @@
+/*
+ * arreau_hip.h -- C ABI of libarreau_hip.so: the MI355X (gfx950) implementation of
+ * arreau's reverse-diffusion sampling step.
+ *
+ * The reference (curtischong/arreau) is pure Python; its seams for this path are
+ * Python calls.  Each entry point below names the reference interface it replaces
+ * (paths relative to the reference checkout).  Conventions:
+ *
+ *   - all pointers named d_* are DEVICE pointers (HBM), contiguous row-major;
+ *     h_* are HOST pointers.  float = fp32, index arrays = int32.
+ *   - every launch function enqueues on `stream` (a hipStream_t passed as void*)
+ *     and never synchronises, allocates or frees; scratch memory comes from a
+ *     caller-owned workspace (arreau_workspace_bytes).
+ *   - return value: 0 on success, a negative ARREAU_E* code otherwise;
+ *     arreau_last_error() gives a message for the calling thread.
+ *   - crystals are described CSR-style by d_crystal_offsets[B+1] (first atom of
+ *     each crystal; atoms of one crystal are contiguous, as in the reference's
+ *     `num_atoms` convention, diffusion/diffusion_loss.py:308,330-335).
+ *   - the neighbour list is kept receiver-major in fixed-width slots:
+ *     slot (i, s), s < deg[i] <= k, holds the s-th in-edge of receiver atom i in
+ *     the reference's enumeration order (sender, image).  Unused slots hold
+ *     src = -1, dir = 0, dist = 0.
+ */
+#ifndef ARREAU_HIP_H
+#define ARREAU_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ARREAU_OK 0
+#define ARREAU_EINVAL (-1)      /* bad argument / unsupported hyper-parameter */
+#define ARREAU_EHIP (-2)        /* a HIP runtime call failed */
+#define ARREAU_ECAPACITY (-3)   /* workspace too small / slot overflow */
+
+/* Hyper-parameters read from the checkpoint's `args` (lightning_wrappers/diffusion.py:42-54,
+ * 86-102; diffusion/diffusion_loss.py:70-72) plus S = len(z_table). */
+typedef struct arreau_config {
+    int32_t num_atomic_states;  /* S, including the mask state (last class)          */
+    int32_t hidden_dim;         /* C  (args.hidden_dim)                              */
+    int32_t basis_dim;          /* D  (args.basis_dim)                               */
+    int32_t num_layers;         /* L  (args.layers)                                  */
+    int32_t num_ori;            /* O  (args.num_ori), must be 16                     */
+    int32_t widening_factor;    /* W  (args.widening_factor)                         */
+    int32_t degree;             /* polynomial degree (args.degree), must be 3        */
+    int32_t max_neighbors;      /* k  (args.max_neighbors), <= ARREAU_MAX_K          */
+    int32_t num_timesteps;      /* T  (args.num_timesteps)                           */
+    float radius;               /* R  (args.radius)                                  */
+    int32_t has_layer_scale;    /* 0 when args.layer_scale == 0 (convnext.py:14-17)  */
+} arreau_config;
+
+#define ARREAU_MAX_K 8
+#define ARREAU_T_EMB_DIM 64      /* lightning_wrappers/diffusion.py:23 */
+#define ARREAU_N_CRYSTAL_FEATS 10 /* n, lengths(3), angles(3), |lengths/n|(3): diffusion_loss.py:139-149 */
+
+/* The network's parameters and the diffusion buffers in the reference's state_dict
+ * layout, as HOST fp32 arrays (SURVEY.md section 5 lists the keys).  Per-layer
+ * tensors are stacked along a leading L axis. */
+typedef struct arreau_state_dict {
+    const float* basis_w1;      /* model.basis_fn.1.weight            [C, 258]      */
+    const float* basis_b1;      /* model.basis_fn.1.bias              [C]           */
+    const float* basis_w2;      /* model.basis_fn.3.weight            [D, C]        */
+    const float* basis_b2;      /* model.basis_fn.3.bias              [D]           */
+    const float* fiber_w1;      /* model.fiber_basis_fn.1.weight      [C, 3]        */
+    const float* fiber_b1;      /* model.fiber_basis_fn.1.bias        [C]           */
+    const float* fiber_w2;      /* model.fiber_basis_fn.3.weight      [D, C]        */
+    const float* fiber_b2;      /* model.fiber_basis_fn.3.bias        [D]           */
+    const float* x_embedder_w;  /* model.x_embedder.weight            [C, S+78]     */
+    const float* conv_kernel_w; /* ...interaction_layers.i.conv.kernel.weight        [L, C, D] */
+    const float* conv_fiber_w;  /* ...interaction_layers.i.conv.fiber_kernel.weight  [L, C, D] */
+    const float* conv_bias;     /* ...interaction_layers.i.conv.bias                 [L, C]    */
+    const float* norm_w;        /* ...interaction_layers.i.norm.weight               [L, C]    */
+    const float* norm_b;        /* ...interaction_layers.i.norm.bias                 [L, C]    */
+    const float* linear1_w;     /* ...interaction_layers.i.linear_1.weight           [L, W*C, C] */
+    const float* linear1_b;     /* ...interaction_layers.i.linear_1.bias             [L, W*C]  */
+    const float* linear2_w;     /* ...interaction_layers.i.linear_2.weight           [L, C, W*C] */
+    const float* linear2_b;     /* ...interaction_layers.i.linear_2.bias             [L, C]    */
+    const float* layer_scale;   /* ...interaction_layers.i.layer_scale               [L, C] (NULL if absent) */
+    const float* readout_w;     /* model.read_out_layers.i.weight                    [L, S+4, C] */
+    const float* readout_b;     /* model.read_out_layers.i.bias                      [L, S+4]  */
+    const float* ori_grid;      /* PositionOrientationGraph.ori_grid_s2 (not in the state_dict) [O, 3] */
+    const float* t_emb_w;       /* t_emb.gaussian_fourier_proj_w                     [32]      */
+    const float* ve_sigmas;     /* diffusion_loss.pos_diffusion.sigmas               [T+1]     */
+    const float* vp_alpha_bars; /* diffusion_loss.lattice_diffusion.alpha_bars       [T+1]     */
+    const float* vp_betas;      /* diffusion_loss.lattice_diffusion.betas            [T+1]     */
+    const float* q_one_step_transposed; /* diffusion_loss.d3pm.q_one_step_transposed [T, S, S] */
+    const float* q_mats;        /* diffusion_loss.d3pm.q_mats                        [T, S, S] */
+} arreau_state_dict;
+
+typedef struct arreau_model arreau_model; /* opaque: packed weights resident in HBM */
+
+const char* arreau_last_error(void);
+const char* arreau_version(void);
+
+/* Replaces PonitaFiberBundle.__init__ + load_state_dict (ponita/models/ponita.py:31-86) and the
+ * buffer set-up of DiffusionLoss.__init__ (diffusion/diffusion_loss.py:68-93): folds the 258
+ * polynomial columns onto their 83 distinct monomials, repacks every Linear for the MFMA
+ * fragment order, uploads, and evaluates the input-independent fiber kernels
+ * fiber_kernel(fiber_basis_fn(o_a . o_b)) (ponita.py:95, conv.py:113) once on the GPU.
+ * Allocates device memory (the only entry point besides arreau_model_destroy that does). */
+int arreau_model_create(const arreau_config* cfg, const arreau_state_dict* h_sd, void* stream,
+                        arreau_model** out_model);
+void arreau_model_destroy(arreau_model* model);
+int arreau_model_config(const arreau_model* model, arreau_config* out_cfg);
+
+/* Scratch for one step over at most max_atoms atoms / max_crystals crystals. */
+size_t arreau_workspace_bytes(const arreau_config* cfg, int64_t max_atoms, int64_t max_crystals);
+
+/* ---- small geometric operators ------------------------------------------------------------ */
+
+/* lattice_from_params, diffusion/lattice_helpers.py:55-105.  d_lengths[B,3], d_angles[B,3]
+ * (consumed as radians) -> d_lattice[B,3,3]. */
+int arreau_lattice_from_params(const float* d_lengths, const float* d_angles, int32_t B,
+                               float* d_lattice, void* stream);
+
+/* frac_to_cart_coords, diffusion/diffusion_helpers.py:223-230. */
+int arreau_frac_to_cart(const float* d_frac, const float* d_lattice, const int32_t* d_crystal_offsets,
+                        int32_t B, int32_t N, float* d_cart, void* stream);
+
+/* radius_graph_pbc(cart, lattice, num_atoms, radius, max_num_neighbors_threshold,
+ * remove_self_edges=True), diffusion/diffusion_helpers.py:328-564, in slot form.
+ * Outputs: d_deg[N]; d_src[N,k] (global sender index, -1 when unused); d_cell[N,k] image code
+ * 0..26 in the reference's SUPERCELLS order (diffusion_helpers.py:10), -1 when unused;
+ * d_dir[N,k,3] = pos_sender + image_offset - pos_receiver; d_dist[N,k].
+ * Tie rule (the reference leaves it to an unstable sort): smaller d^2 first, then smaller
+ * enumeration index (sender, image). */
+int arreau_radius_graph_pbc(const float* d_cart, const float* d_lattice,
+                            const int32_t* d_crystal_offsets, int32_t B, int32_t N,
+                            float radius, int32_t k,
+                            int32_t* d_deg, int32_t* d_src, int32_t* d_cell, float* d_dir,
+                            float* d_dist, void* stream);
+
+/* Slot form -> the reference's return tuple (edge_index[2,E] as (sender, receiver),
+ * -unit_cell[E,3], dist[E], direction[E,3]; diffusion_helpers.py:548-555).
+ * d_edge_offsets[N+1] is written (exclusive scan of deg); E = d_edge_offsets[N]. Outputs must
+ * hold N*k entries. */
+int arreau_compact_edges(const int32_t* d_deg, const int32_t* d_src, const int32_t* d_cell,
+                         const float* d_dir, const float* d_dist, int32_t N, int32_t k,
+                         int32_t* d_edge_offsets, int64_t* d_edge_index /*[2, N*k]*/,
+                         float* d_cell_offsets /*[N*k,3]*/, float* d_out_dist, float* d_out_dir,
+                         void* stream);
+
+/* Receiver-sorted COO edges (edge_index[1] non-decreasing) -> slot form, for callers that bring
+ * their own graph (PonitaFiberBundle.forward takes graph.edge_index, ponita.py:88-106).
+ * d_status (int32, device) receives 1 when a receiver has more than k in-edges or the list is
+ * not receiver-sorted. */
+int arreau_edges_to_slots(const int64_t* d_edge_index /*[2,E]*/, const float* d_dist,
+                          const float* d_dir, int64_t E, int32_t N, int32_t k,
+                          int32_t* d_deg, int32_t* d_src, float* d_slot_dir, float* d_slot_dist,
+                          int32_t* d_status, void* stream);
+
+/* ---- the score network ---------------------------------------------------------------------- */
+
+/* One evaluation of DiffusionLoss.predict_scores (diffusion/diffusion_loss.py:112-197):
+ * feature assembly (:124-158), PBC neighbour list (:164-180) unless `use_given_edges`, and
+ * PonitaFiberBundle.forward (ponita/models/ponita.py:88-123) with the read-outs of :126-155.
+ *   d_frac[N,3], d_types[N] (class index), d_lengths[B,3], d_angles[B,3],
+ *   d_t[B] timestep per crystal (the time feature is betas[t], diffusion_loss.py:126).
+ * Outputs: d_eps[N,3] (pred_frac_eps_x), d_logits[N,S], d_len0[B,3] (pred_lengths_0).
+ * When use_given_edges != 0 the slot arrays d_deg/d_src/d_dir/d_dist are inputs (teacher-forced
+ * graph); otherwise they are outputs of the internal neighbour search and may be NULL to use
+ * workspace storage. */
+int arreau_predict_scores(const arreau_model* model,
+                          const float* d_frac, const int32_t* d_types, const float* d_lengths,
+                          const float* d_angles, const int32_t* d_t,
+                          const int32_t* d_crystal_offsets, int32_t B, int32_t N,
+                          int32_t use_given_edges,
+                          int32_t* d_deg, int32_t* d_src, float* d_dir, float* d_dist,
+                          float* d_eps, float* d_logits, float* d_len0,
+                          void* d_workspace, size_t workspace_bytes, void* stream);
+
+/* The four state updates of one loop iteration (diffusion/diffusion_loss.py:338-347):
+ * VP_lattice.reverse_given_x0 on lengths with pred_lengths_0 * num_atoms
+ * (diffusion_helpers.py:185-199), lattice_from_params, VE_pbc.reverse on the fractional
+ * coordinates (diffusion_helpers.py:65-81) and D3PM.reverse on the atom types (d3pm.py:198-215).
+ * Noise is supplied by the caller in the reference's draw order: d_z_lattice[B,3] ~ N(0,1),
+ * d_z_frac[N,3] ~ N(0,1), d_u_types[N,S] ~ U[0,1).  State is updated in place; d_lattice[B,3,3]
+ * receives the new cell. */
+int arreau_reverse_step(const arreau_model* model,
+                        float* d_frac, int32_t* d_types, float* d_lengths, const float* d_angles,
+                        const int32_t* d_t, const int32_t* d_crystal_offsets, int32_t B, int32_t N,
+                        const float* d_eps, const float* d_logits, const float* d_len0,
+                        const float* d_z_lattice, const float* d_z_frac, const float* d_u_types,
+                        float* d_lattice, void* stream);
+
+/* Timing hook used by bench.py: records hipEvents around the dominant kernel of
+ * arreau_predict_scores (the edge kernel) on the stream it is launched on.
+ * enable=1 starts collecting; arreau_edge_kernel_time_ms returns the mean over the launches
+ * recorded since then (synchronises the events) and the count. */
+int arreau_profile_edge_kernel(int32_t enable);
+int arreau_edge_kernel_time_ms(double* mean_ms, int64_t* launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ARREAU_HIP_H */

@@ -1,0 +1,334 @@
+"""Parity of the HIP path (through the C ABI) against the CPU oracle and the committed golden
+fixtures.  Needs an MI355X: run with `-m gpu`.
+
+Tolerances (north_star: per-step scores, lattice updates and type logits match the reference CPU
+path to 1e-5 in fp32): fp32 HIP vs the fp32 oracle, 1e-5 absolute on values of order one, with the
+edge list teacher-forced where the test is about the network and not about tie-breaking.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from oracle import diffusion as OD
+from oracle import geometry as OG
+from oracle import sampler as OS
+from tests.helpers import oracle_from_module, random_state, slots_from_edges
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+TOL = 1e-5
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need a GPU"
+    return torch.device("cuda", 0)
+
+
+@pytest.fixture(scope="module")
+def small_model(dev):
+    """S=12, T=100 synthetic 'trained-like' checkpoint in the reference layout (C=128, D=256, L=5)."""
+    from arreau_amd.checkpoint import make_synthetic_model
+    m = make_synthetic_model(S=12, seed=1234, num_timesteps=100).to(dev)
+    return m, oracle_from_module(m, torch.float32), oracle_from_module(m, torch.float64)
+
+
+@pytest.fixture(scope="module")
+def full_model(dev):
+    """S=90, T=1000: the architecture of the shipped 1.1M-parameter model."""
+    from arreau_amd.checkpoint import make_synthetic_model
+    m = make_synthetic_model(S=90, seed=1234).to(dev)
+    return m, oracle_from_module(m, torch.float32)
+
+
+def test_native_library_is_loaded():
+    from arreau_amd import _hip
+    assert _hip.lib().arreau_version().decode().startswith("arreau_hip")
+    with open("/proc/self/maps") as fh:
+        assert "libarreau_hip.so" in fh.read()
+
+
+# ------------------------------------------------------------------------------------------- geometry
+def test_lattice_from_params_and_frac_to_cart(dev):
+    from arreau_amd.diffusion.diffusion_helpers import frac_to_cart_coords
+    from arreau_amd.diffusion.lattice_helpers import lattice_from_params
+    z = np.load(os.path.join(GOLDEN, "lattice.npz"))
+    lengths = torch.tensor(z["lengths"], dtype=torch.float32)
+    for key, cell_key in (("ang_rad", "cell_rad"), ("ang_deg", "cell_deg")):
+        ang = torch.tensor(z[key], dtype=torch.float32)
+        got = lattice_from_params(lengths.to(dev), ang.to(dev)).cpu()
+        ref32 = OG.lattice_from_params(lengths, ang)
+        np.testing.assert_allclose(got.numpy(), ref32.numpy(), atol=2e-6, rtol=0)
+        # against the reference's own float64 output: limited by rounding the angles to float32
+        np.testing.assert_allclose(got.numpy(), z[cell_key], atol=5e-5, rtol=0)
+    na = torch.tensor(z["num_atoms"])
+    cell = torch.tensor(z["cell_rad"], dtype=torch.float32)
+    frac = torch.tensor(z["frac"], dtype=torch.float32)
+    got = frac_to_cart_coords(frac.to(dev), cell.to(dev), na).cpu()
+    np.testing.assert_allclose(got.numpy(), z["cart"], atol=2e-6, rtol=0)
+
+
+def _golden_radius_cases():
+    z = np.load(os.path.join(GOLDEN, "radius_graph.npz"))
+    return [i for i in range(int(z["n_cases"])) if str(z[f"c{i}_dtype"]) == "f32"]
+
+
+@pytest.mark.parametrize("i", _golden_radius_cases())
+def test_radius_graph_matches_reference_fixture(dev, i):
+    """fp32 fixtures produced by the reference's radius_graph_pbc: same edges in the same order,
+    same image cells; distances and directions to float32 rounding."""
+    from arreau_amd.diffusion.diffusion_helpers import radius_graph_pbc
+    z = np.load(os.path.join(GOLDEN, "radius_graph.npz"))
+    p = f"c{i}_"
+    flag = str(z[p + "flag"])
+    cart, lattice, na = (torch.tensor(z[p + k]) for k in ("cart", "lattice", "num_atoms"))
+    ei, cells, cnt, dist, direction = radius_graph_pbc(cart.to(dev), lattice.to(dev), na, float(z[p + "radius"]),
+                                                       int(z[p + "k"]))
+    assert cnt.cpu().tolist() == z[p + "count"].tolist()
+    if flag.startswith("ties"):
+        # exactly tied images: the reference's unstable sort picks a build-dependent subset
+        np.testing.assert_allclose(np.sort(dist.cpu().numpy()), np.sort(z[p + "dist"]), atol=1e-6, rtol=0)
+        return
+    assert torch.equal(ei.cpu(), torch.tensor(z[p + "edge_index"]))
+    assert torch.equal(cells.cpu(), torch.tensor(z[p + "cells"]))
+    np.testing.assert_allclose(dist.cpu().numpy(), z[p + "dist"], atol=1e-6, rtol=0)
+    np.testing.assert_allclose(direction.cpu().numpy(), z[p + "dir"], atol=1e-6, rtol=0)
+
+
+@pytest.mark.parametrize("num_atoms,cell,seed", [
+    ([20] * 16, (4.0, 8.0), 0), ([1, 2, 3, 5, 8, 13, 20, 7], (3.0, 6.0), 1), ([64, 64], (6.0, 9.0), 2),
+    ([2] * 5, (9.0, 12.0), 3), ([33], (2.5, 4.0), 4)])
+def test_radius_graph_vs_oracle_random(dev, num_atoms, cell, seed):
+    """Larger ragged / dense / sparse cases against the oracle's radius_graph_pbc (fp32).  Edges whose
+    d^2 is within 1e-5 (relative) of the receiver's selection threshold may legitimately differ; none do
+    for these seeds, so equality is asserted outright."""
+    from arreau_amd.diffusion.diffusion_helpers import frac_to_cart_coords, radius_graph_pbc
+    from arreau_amd.diffusion.lattice_helpers import lattice_from_params
+    frac, _, lengths, angles, na = random_state(12, num_atoms, seed, cell=cell)
+    lattice = lattice_from_params(lengths.to(dev), angles.to(dev))
+    cart = frac_to_cart_coords(frac.to(dev), lattice, na)
+    ei, cells, cnt, dist, direction = radius_graph_pbc(cart, lattice, na, 5.0, 8)
+    o_ei, o_cells, o_cnt, o_dist, o_dir = OG.radius_graph_pbc(cart.cpu(), lattice.cpu(), na, 5.0, 8)
+    assert cnt.cpu().tolist() == o_cnt.tolist()
+    assert torch.equal(ei.cpu(), o_ei)
+    assert torch.equal(cells.cpu(), o_cells)
+    np.testing.assert_allclose(dist.cpu().numpy(), o_dist.numpy(), atol=1e-6, rtol=0)
+    np.testing.assert_allclose(direction.cpu().numpy(), o_dir.numpy(), atol=1e-6, rtol=0)
+
+
+def test_empty_and_isolated_atoms(dev):
+    """A lone atom in a 12 A cell has no neighbour inside 5 A: deg 0, conv output is the bias path."""
+    from arreau_amd.diffusion.diffusion_helpers import radius_graph_pbc
+    lattice = (torch.eye(3) * 12.0).unsqueeze(0)
+    cart = torch.tensor([[1.0, 2.0, 3.0]])
+    ei, cells, cnt, dist, direction = radius_graph_pbc(cart.to(dev), lattice.to(dev), torch.tensor([1]), 5.0, 8)
+    assert ei.shape == (2, 0) and cnt.cpu().tolist() == [0] and dist.numel() == 0
+
+
+# ------------------------------------------------------------------------------------------- network
+def _to_dev(dev, frac, types, lengths, angles, na):
+    from arreau_amd.diffusion.diffusion_helpers import crystal_offsets
+    return (frac.to(dev).contiguous(), types.to(dev, torch.int32).contiguous(), lengths.to(dev).contiguous(),
+            angles.to(dev).contiguous(), crystal_offsets(na, dev))
+
+
+def _oracle_scores(om, frac, types, lengths, angles, na, t, edges=None, dtype=torch.float32):
+    S = om.hp["S"]
+    B, N = len(na), frac.shape[0]
+    batch = torch.arange(B).repeat_interleave(na)
+    c = lambda v: v.to(dtype)
+    return OS.predict_scores(om, c(frac), F.one_hot(types, S), torch.full((N,), t), na, c(lengths), c(angles),
+                             batch, edges=edges, return_graph=True)
+
+
+@pytest.mark.parametrize("num_atoms,sampler_like,seed,t", [
+    ([8, 8], False, 0, 50), ([4, 1, 6, 3], False, 1, 99), ([20] * 4, False, 2, 2), ([5, 7], True, 3, 75),
+    ([20] * 8, True, 4, 1)])
+def test_predict_scores_teacher_forced_edges(dev, small_model, num_atoms, sampler_like, seed, t):
+    """Network parity with the oracle's edge list teacher-forced: |delta| <= 1e-5 on eps, logits, len0."""
+    m, om32, om64 = small_model
+    state = random_state(12, num_atoms, seed, sampler_like=sampler_like)
+    frac, types, lengths, angles, na = state
+    eps_o, logits_o, len0_o, (ei, dists, direction, _cart, _lat) = _oracle_scores(om32, *state, t)
+    eng = m.engine()
+    N, B = frac.shape[0], len(num_atoms)
+    deg, src, sdir, sdist = slots_from_edges(ei, dists, direction, N, 8)
+    f, ty, le, an, off = _to_dev(dev, *state)
+    edges = tuple(x.to(dev).contiguous() for x in (deg, src, sdir, sdist))
+    t_c = torch.full((B,), t, device=dev, dtype=torch.int32)
+    eps, logits, len0 = eng.predict_scores(f, ty, le, an, t_c, off, edges=edges)
+    scale = max(1.0, float(logits_o.abs().max()), float(len0_o.abs().max()))
+    assert (eps.cpu() - eps_o).abs().max() <= TOL * scale
+    assert (logits.cpu() - logits_o).abs().max() <= TOL * scale
+    assert (len0.cpu() - len0_o).abs().max() <= TOL * scale * max(num_atoms)
+    # informational: distance to the float64 reference path (same edges)
+    e64 = (ei, dists.double(), direction.double())
+    eps64, logits64, len064, _ = _oracle_scores(om64, *state, t, edges=e64, dtype=torch.float64)
+    print(f"\n[fp64 ref] max|d eps|={float((eps.cpu().double() - eps64).abs().max()):.2e} "
+          f"max|d logits|={float((logits.cpu().double() - logits64).abs().max()):.2e} "
+          f"max|d len0|={float((len0.cpu().double() - len064).abs().max()):.2e} ; "
+          f"fp32 oracle vs fp64: {float((logits_o.double() - logits64).abs().max()):.2e}")
+
+
+def test_edges_to_slots_kernel_matches_host_reference(dev, small_model):
+    m, om32, _ = small_model
+    state = random_state(12, [6, 9, 2], 11)
+    _, _, _, (ei, dists, direction, _c, _l) = _oracle_scores(om32, *state, 10)
+    N = state[0].shape[0]
+    deg, src, sdir, sdist = slots_from_edges(ei, dists, direction, N, 8)
+    g = m.engine().edges_to_slots(ei, dists, direction, N)
+    assert torch.equal(g[0].cpu(), deg) and torch.equal(g[1].cpu(), src)
+    assert torch.equal(g[2].cpu(), sdir) and torch.equal(g[3].cpu(), sdist)
+
+
+@pytest.mark.parametrize("num_atoms,sampler_like,seed,t", [([8, 8, 8], False, 5, 60), ([20] * 4, True, 6, 99)])
+def test_predict_scores_own_neighbor_list(dev, small_model, num_atoms, sampler_like, seed, t):
+    """Whole predict_scores (HIP neighbour list included) vs the oracle end to end."""
+    m, om32, _ = small_model
+    state = random_state(12, num_atoms, seed, sampler_like=sampler_like)
+    eps_o, logits_o, len0_o, _ = _oracle_scores(om32, *state, t)
+    f, ty, le, an, off = _to_dev(dev, *state)
+    t_c = torch.full((len(num_atoms),), t, device=dev, dtype=torch.int32)
+    eps, logits, len0 = m.engine().predict_scores(f, ty, le, an, t_c, off)
+    scale = max(1.0, float(logits_o.abs().max()), float(len0_o.abs().max()))
+    assert (eps.cpu() - eps_o).abs().max() <= TOL * scale
+    assert (logits.cpu() - logits_o).abs().max() <= TOL * scale
+    assert (len0.cpu() - len0_o).abs().max() <= TOL * scale * max(num_atoms)
+
+
+def test_forward_operator_seam(dev, small_model):
+    """PONITA_DIFFUSION.forward(graph) with the reference's batch attributes (diffusion_loss.py:156-189)."""
+    from types import SimpleNamespace
+    m, om32, _ = small_model
+    frac, types, lengths, angles, na = state = random_state(12, [5, 6], 21)
+    t = 33
+    x, cart, vec, lattice = OS.assemble_features(om32, frac, F.one_hot(types, 12), torch.full((11,), t), na, lengths,
+                                                 angles)
+    eps_o, logits_o, len0_o, (ei, dists, direction, _c, _l) = _oracle_scores(om32, *state, t)
+    graph = SimpleNamespace(x=x.float().to(dev), vec=vec.to(dev), edge_index=ei.to(dev), dists=dists.to(dev),
+                            inter_atom_direction=direction.to(dev), lattice=lattice.to(dev), num_atoms=na,
+                            batch=torch.arange(2).repeat_interleave(na).to(dev))
+    logits, vec_out, gscalar, gvec, edge_out = m(graph)
+    assert vec_out.shape == (11, 1, 3) and gvec is None and edge_out == [None] * 5
+    assert (logits.cpu() - logits_o).abs().max() <= TOL * max(1.0, float(logits_o.abs().max()))
+    assert (vec_out.squeeze(1).cpu() - eps_o).abs().max() <= TOL
+    assert (gscalar.cpu() - len0_o).abs().max() <= TOL * 6 * max(1.0, float(len0_o.abs().max()))
+
+
+def test_full_size_architecture_parity(dev, full_model):
+    """S=90 / T=1000 (the 1.1M-parameter configuration), 2 crystals of 20 atoms, sampler-like state."""
+    m, om32 = full_model
+    state = random_state(90, [20, 20], 7, sampler_like=True)
+    t = 999
+    eps_o, logits_o, len0_o, (ei, dists, direction, _c, _l) = _oracle_scores(om32, *state, t)
+    deg, src, sdir, sdist = slots_from_edges(ei, dists, direction, 40, 8)
+    f, ty, le, an, off = _to_dev(dev, *state)
+    edges = tuple(x.to(dev).contiguous() for x in (deg, src, sdir, sdist))
+    t_c = torch.full((2,), t, device=dev, dtype=torch.int32)
+    eps, logits, len0 = m.engine().predict_scores(f, ty, le, an, t_c, off, edges=edges)
+    scale = max(1.0, float(logits_o.abs().max()), float(len0_o.abs().max()))
+    assert (eps.cpu() - eps_o).abs().max() <= TOL * scale
+    assert (logits.cpu() - logits_o).abs().max() <= TOL * scale
+    assert (len0.cpu() - len0_o).abs().max() <= TOL * scale * 20
+
+
+# ------------------------------------------------------------------------------------------- reverse updates
+@pytest.mark.parametrize("t", [99, 50, 2, 1])
+def test_reverse_step_matches_oracle(dev, small_model, t):
+    m, om32, _ = small_model
+    S = 12
+    frac, types, lengths, angles, na = random_state(S, [4, 7, 1], 30 + t, sampler_like=True)
+    frac = frac % 1
+    N, B = frac.shape[0], 3
+    g = torch.Generator().manual_seed(t)
+    eps = torch.randn(N, 3, generator=g)
+    logits = torch.randn(N, S, generator=g) * 2
+    len0 = torch.randn(B, 3, generator=g)
+    noise = OS.StepNoise(torch.randn(B, 3, generator=g), torch.randn(N, 3, generator=g), torch.rand(N, S, generator=g))
+    f_o, ty_o, len_o, lat_o = OS.reverse_step(om32, frac, types, lengths, angles, na, (eps, logits, len0), t, noise)
+    tt = torch.full((N,), t)
+    post_o = OD.d3pm_q_posterior_logits(om32.q_one_step_transposed, om32.q_mats, logits, types, tt)
+    from arreau_amd.diffusion.diffusion_helpers import crystal_offsets
+    d = lambda v: v.to(dev).contiguous()
+    f, ty, le, an = d(frac.clone()), d(types.to(torch.int32)), d(lengths.clone()), d(angles)
+    lat = torch.zeros(B, 3, 3, device=dev)
+    t_c = torch.full((B,), t, device=dev, dtype=torch.int32)
+    m.engine().reverse_step(f, ty, le, an, t_c, crystal_offsets(na, dev), d(eps), d(logits), d(len0),
+                            d(noise.z_lattice), d(noise.z_frac), d(noise.u_types), lat)
+    np.testing.assert_allclose(le.cpu().numpy(), len_o.numpy(), atol=TOL * max(1.0, float(len_o.abs().max())), rtol=0)
+    np.testing.assert_allclose(lat.cpu().numpy(), lat_o.numpy(), atol=TOL * max(1.0, float(lat_o.abs().max())), rtol=0)
+    # wrap-around: a value within rounding of 0 or 1 may land on the other side of the seam
+    df = (f.cpu() - f_o).abs()
+    df = torch.minimum(df, 1 - df)
+    assert df.max() <= TOL
+    # discrete update: identical unless the two best classes are closer than the float32 noise floor
+    scale = 0.2 if t == 1 else 1.0
+    u = torch.clip(noise.u_types, 1e-6, 1.0)
+    val = post_o + (-torch.log(-torch.log(u))) * scale
+    top2 = val.topk(2, dim=-1).values
+    decided = (top2[:, 0] - top2[:, 1]) > 1e-4
+    assert decided.float().mean() > 0.9
+    assert torch.equal(ty.cpu().long()[decided], ty_o[decided])
+
+
+# ------------------------------------------------------------------------------------------- sampler
+def test_teacher_forced_trajectory(dev, small_model):
+    """Per-step parity along a real sampler trajectory (T=100): at t in {99, 75, 50, 25, 2, 1} feed the
+    oracle's state and noise to the HIP path and compare scores and updated state."""
+    m, om32, _ = small_model
+    torch.manual_seed(0)
+    np.random.seed(0)
+    trace = OS.SampleTrace()
+    n_per, B, S = 6, 3, 12
+    OS.sample(om32, n_per, B, torch.float32, trace=trace)
+    assert len(trace.steps) == 99  # T-1 iterations (diffusion_loss.py:318)
+    from arreau_amd.diffusion.diffusion_helpers import crystal_offsets
+    na = torch.full((B,), n_per)
+    off = crystal_offsets(na, dev)
+    angles = None
+    torch.manual_seed(0)
+    np.random.seed(0)
+    _, _, _, angles, _ = OS.init_state(om32, n_per, B, torch.float32)
+    eng = m.engine()
+    d = lambda v: v.to(dev).contiguous()
+    for rec in trace.steps:
+        t = rec["t"]
+        if t not in (99, 75, 50, 25, 2, 1):
+            continue
+        eps_o, logits_o, len0_o = rec["scores"]
+        t_c = torch.full((B,), t, device=dev, dtype=torch.int32)
+        f, ty, le, an = d(rec["frac"]), d(rec["types"].to(torch.int32)), d(rec["lengths"]), d(angles)
+        eps, logits, len0 = eng.predict_scores(f, ty, le, an, t_c, off)
+        scale = max(1.0, float(logits_o.abs().max()), float(len0_o.abs().max()))
+        assert (eps.cpu() - eps_o).abs().max() <= TOL * scale, t
+        assert (logits.cpu() - logits_o).abs().max() <= TOL * scale, t
+        assert (len0.cpu() - len0_o).abs().max() <= TOL * scale * n_per, t
+
+
+def test_sample_end_to_end_properties(dev, small_model):
+    """PONITA_DIFFUSION.sample: shapes, dtypes and invariants of SampleResult after the full T-1 steps."""
+    from arreau_amd.diffusion.inference.visualize_crystal import VisualizationSetting
+    m, _, _ = small_model
+    torch.manual_seed(3)
+    np.random.seed(3)
+    res = m.sample(num_atoms_per_sample=5, num_samples_in_batch=4, visualization_setting=VisualizationSetting.NONE,
+                   show_bonds=False)
+    assert res.frac_x.shape == (20, 3) and res.lattice.shape == (4, 3, 3) and res.atomic_numbers.shape == (20,)
+    assert res.num_atoms.tolist() == [5] * 4
+    assert np.isfinite(res.frac_x).all() and np.isfinite(res.lattice).all()
+    assert (res.frac_x >= 0).all() and (res.frac_x <= 1).all()
+    zs = set(m.z_table_zs.tolist())
+    assert set(res.atomic_numbers.tolist()) <= zs
+    # reference-order host noise gives the same kind of result
+    res2 = m.sample(5, 4, VisualizationSetting.NONE, False, noise="reference", max_steps=5)
+    assert np.isfinite(res2.frac_x).all()
+
+
+def test_constant_atomic_symbols(dev, small_model):
+    from arreau_amd.diffusion.inference.visualize_crystal import VisualizationSetting
+    m, _, _ = small_model  # z table = 1..11 + mask
+    res = m.sample(3, 2, VisualizationSetting.NONE, False, use_constant_atomic_symbols=["C", "H", "O"], max_steps=4)
+    assert res.atomic_numbers.tolist() == [6, 1, 8, 6, 1, 8]
