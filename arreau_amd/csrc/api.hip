@@ -20,7 +20,7 @@ struct Carver {
 };
 
 struct Workspace {
-    float *lattice, *cart, *cvec, *dir, *dist, *kbuf, *xa, *xb, *xbar, *vsum;
+    float *lattice, *cart, *cvec, *dir, *dist, *kbuf, *xa, *xb, *xbar, *vsum, *gs;
     int32_t *batch, *deg, *src, *cell;
     size_t bytes;
 };
@@ -43,6 +43,7 @@ Workspace carve(const arreau_config* cfg, int64_t N, int64_t B, void* base, size
     w.xb = c.take<float>(N * O * C);
     w.xbar = c.take<float>(L * N * C);
     w.vsum = c.take<float>(N * O);
+    w.gs = c.take<float>(N * 3);
     w.bytes = (c.off + 255) & ~(size_t)255;
     return w;
 }
@@ -144,5 +145,5 @@ extern "C" int arreau_predict_scores(const arreau_model* m, const float* d_frac,
         if ((rc = arreau_launch_node_layer(m, l, w.kbuf, deg, src, xin, xout, w.xbar, w.vsum, N, s))) return rc;
         float* tmp = xin; xin = xout; xout = tmp;
     }
-    return arreau_launch_readout(m, w.xbar, w.vsum, d_off, B, N, d_eps, d_logits, d_len0, s);
+    return arreau_launch_readout(m, w.xbar, w.vsum, d_off, B, N, w.gs, d_eps, d_logits, d_len0, s);
 }

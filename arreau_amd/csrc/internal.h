@@ -154,4 +154,4 @@ int arreau_launch_node_layer(const arreau_model* m, int layer, const float* kbuf
                              const int32_t* src, const float* x_in, float* x_out, float* xbar, float* vsum,
                              int N, hipStream_t s);
 int arreau_launch_readout(const arreau_model* m, const float* xbar, const float* vsum, const int32_t* offsets,
-                          int B, int N, float* eps, float* logits, float* len0, hipStream_t s);
+                          int B, int N, float* gs, float* eps, float* logits, float* len0, hipStream_t s);

@@ -371,60 +371,105 @@ int arreau_launch_node_layer(const arreau_model* m, int layer, const float* kbuf
 }
 
 // ---------------------------------------------------------------------------------------------
-// K5 read-outs (ponita.py:105-117,126-155), one workgroup per crystal:
-//   logits[n][s] = (1/L) sum_l (W_l[s,:] . xbar_l[n] + b_l[s])          (sphere_to_scalar commutes with Linear)
+// K5 read-outs (ponita.py:105-117,126-155).  sphere_to_scalar (mean over orientations) commutes
+// with the per-layer Linear, so the scalar / global read-outs are taken of xbar_l = mean_o x_l:
+//   logits[n][s] = (1/L) sum_l (W_l[s,:] . xbar_l[n] + b_l[s])
+//   gs[n][g]     = (1/L) sum_l (W_l[S+1+g,:] . xbar_l[n] + b_l[S+1+g])
 //   eps[n][d]    = (1/(L*O)) sum_o vsum[n][o] * ori[o][d]               (sphere_to_vec of the vector channel)
-//   len0[b][g]   = sum_{n in b} (1/L) sum_l (W_l[S+1+g,:] . xbar_l[n] + b_l[S+1+g])   (global_add_pool)
+//   len0[b][g]   = sum_{n in b} gs[n][g]                                  (global_add_pool, atom order)
+// Kernel 1: 8 atoms per workgroup, thread = output column, weights read once per 8 atoms (coalesced
+// over columns).  Kernel 2: one thread per (crystal, g) sums its atoms in order (deterministic).
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void readout_kernel(
+#define RO_ATOMS 8
+
+__global__ __launch_bounds__(128) void readout_nodes_kernel(
     const float* __restrict__ xbar,   // [L][N][C]
     const float* __restrict__ vsum,   // [N][16]
-    const int32_t* __restrict__ offsets, const float* __restrict__ ro_wT, const float* __restrict__ ro_b,
-    const float* __restrict__ ori, int S, int C, int L, int N, float* __restrict__ eps, float* __restrict__ logits,
-    float* __restrict__ len0) {
-    extern __shared__ float xs[];  // [L*C] xbar of the current atom
-    const int b = blockIdx.x;
-    const int first = offsets[b], n_at = offsets[b + 1] - first;
-    const int RO = S + 4;
-    const int s_out = threadIdx.x;  // output column handled by this thread (0..S-1 scalars, S vec, S+1.. globals)
+    const float* __restrict__ ro_wT,  // [L][C][S+4]
+    const float* __restrict__ ro_b,   // [L][S+4]
+    const float* __restrict__ ori, int S, int C, int L, int N, float* __restrict__ eps,
+    float* __restrict__ logits, float* __restrict__ gs /*[N][3]*/) {
+    extern __shared__ __attribute__((aligned(16))) float xs[];  // [RO_ATOMS][L*C]
+    const int n0 = blockIdx.x * RO_ATOMS;
+    const int RO = S + 4, LC = L * C;
+    for (int i = threadIdx.x; i < RO_ATOMS * LC; i += blockDim.x) {
+        const int a = i / LC, r = i - a * LC;
+        const int l = r / C, c = r - l * C;
+        const int n = n0 + a;
+        xs[i] = n < N ? xbar[((size_t)l * N + n) * C + c] : 0.f;
+    }
+    __syncthreads();
     const float invL = 1.0f / (float)L;
-    float gsum = 0.f;
-    for (int a = 0; a < n_at; ++a) {
-        const size_t n = (size_t)first + a;
-        __syncthreads();
-        for (int i = threadIdx.x; i < L * C; i += blockDim.x) {
-            const int l = i / C, c = i - l * C;
-            xs[i] = xbar[((size_t)l * N + n) * C + c];
-        }
-        __syncthreads();
-        if (s_out < RO && s_out != S) {
-            float tot = 0.f;
-            for (int l = 0; l < L; ++l) {
-                const float* w = ro_wT + (size_t)l * C * RO + s_out;
-                float acc = 0.f;
-                for (int c = 0; c < C; ++c) acc += xs[l * C + c] * w[(size_t)c * RO];
-                tot += acc + ro_b[l * RO + s_out];
+    for (int s_out = threadIdx.x; s_out < RO; s_out += blockDim.x) {
+        if (s_out == S) {
+            // vector channel: eps for the tile's atoms
+            for (int a = 0; a < RO_ATOMS; ++a) {
+                const size_t n = (size_t)n0 + a;
+                if (n >= (size_t)N) break;
+                for (int d = 0; d < 3; ++d) {
+                    float acc = 0.f;
+                    for (int o = 0; o < 16; ++o) acc += (vsum[n * 16 + o] * invL) * ori[3 * o + d];
+                    eps[n * 3 + d] = acc * (1.0f / 16.0f);
+                }
             }
-            tot *= invL;
-            if (s_out < S) logits[n * S + s_out] = tot;
-            else gsum += tot;
+            continue;
         }
-        if (threadIdx.x < 3) {
-            float acc = 0.f;
-            for (int o = 0; o < 16; ++o) acc += (vsum[n * 16 + o] * invL) * ori[3 * o + threadIdx.x];
-            eps[n * 3 + threadIdx.x] = acc * (1.0f / 16.0f);
+        float tot[RO_ATOMS];
+#pragma unroll
+        for (int a = 0; a < RO_ATOMS; ++a) tot[a] = 0.f;
+        for (int l = 0; l < L; ++l) {
+            float acc[RO_ATOMS];
+#pragma unroll
+            for (int a = 0; a < RO_ATOMS; ++a) acc[a] = 0.f;
+            const float* w = ro_wT + (size_t)l * C * RO + s_out;
+            for (int c = 0; c < C; c += 4) {
+                const float w0 = w[(size_t)c * RO], w1 = w[(size_t)(c + 1) * RO], w2 = w[(size_t)(c + 2) * RO],
+                            w3 = w[(size_t)(c + 3) * RO];
+#pragma unroll
+                for (int a = 0; a < RO_ATOMS; ++a) {
+                    const f32x4 x = *reinterpret_cast<const f32x4*>(&xs[a * LC + l * C + c]);
+                    acc[a] += x[0] * w0;
+                    acc[a] += x[1] * w1;
+                    acc[a] += x[2] * w2;
+                    acc[a] += x[3] * w3;
+                }
+            }
+            const float bias = ro_b[l * RO + s_out];
+#pragma unroll
+            for (int a = 0; a < RO_ATOMS; ++a) tot[a] += acc[a] + bias;
+        }
+#pragma unroll
+        for (int a = 0; a < RO_ATOMS; ++a) {
+            const size_t n = (size_t)n0 + a;
+            if (n < (size_t)N) {
+                const float v = tot[a] * invL;
+                if (s_out < S) logits[n * S + s_out] = v;
+                else gs[n * 3 + (s_out - S - 1)] = v;
+            }
         }
     }
-    if (s_out > S && s_out < RO) len0[(size_t)b * 3 + (s_out - S - 1)] = gsum;
+}
+
+__global__ void readout_crystals_kernel(const float* __restrict__ gs, const int32_t* __restrict__ offsets, int B,
+                                        float* __restrict__ len0) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= 3 * B) return;
+    const int b = idx / 3, g = idx - 3 * b;
+    float acc = 0.f;
+    for (int n = offsets[b]; n < offsets[b + 1]; ++n) acc += gs[(size_t)n * 3 + g];
+    len0[idx] = acc;
 }
 
 int arreau_launch_readout(const arreau_model* m, const float* xbar, const float* vsum, const int32_t* offsets, int B,
-                          int N, float* eps, float* logits, float* len0, hipStream_t s) {
+                          int N, float* gs, float* eps, float* logits, float* len0, hipStream_t s) {
     if (B == 0) return ARREAU_OK;
-    const int RO = m->S + 4;
-    const int threads = ((RO + 63) / 64) * 64;
-    hipLaunchKernelGGL(readout_kernel, dim3(B), dim3(threads), (size_t)m->L * m->C * sizeof(float), s, xbar, vsum,
-                       offsets, m->ro_wT, m->ro_b, m->ori, m->S, m->C, m->L, N, eps, logits, len0);
+    if (N > 0) {
+        const size_t smem = (size_t)RO_ATOMS * m->L * m->C * sizeof(float);
+        hipLaunchKernelGGL(readout_nodes_kernel, dim3((N + RO_ATOMS - 1) / RO_ATOMS), dim3(128), smem, s, xbar, vsum,
+                           m->ro_wT, m->ro_b, m->ori, m->S, m->C, m->L, N, eps, logits, gs);
+        ARREAU_CHECK_HIP(hipGetLastError());
+    }
+    hipLaunchKernelGGL(readout_crystals_kernel, dim3((3 * B + 127) / 128), dim3(128), 0, s, gs, offsets, B, len0);
     ARREAU_CHECK_HIP(hipGetLastError());
     return ARREAU_OK;
 }
