@@ -1,0 +1,76 @@
+"""The N>1 path on CPU: world_size-2 gloo processes shard the crystal index, sample their slices with a
+stand-in sampler (the real one needs a GPU) and rank 0 gathers the results in crystal order."""
+import os
+import socket
+import tempfile
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from arreau_amd.diffusion.diffusion_loss import SampleResult
+from arreau_amd.generate import concat_results, generate_n_crystals, save_sample_results, shard_range
+
+
+def test_shard_range_partitions_exactly():
+    for total in (0, 1, 7, 10, 256, 8192):
+        for world in (1, 2, 3, 8):
+            spans = [shard_range(total, world, r) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == total
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def _fake_sampler(tag_base):
+    """Crystal c gets lattice = c * I and atomic number 1 + (c % 5): results are checkable after the gather."""
+    counter = {"next": tag_base}
+
+    def sample(n_atoms, n_crystals):
+        ids = np.arange(counter["next"], counter["next"] + n_crystals)
+        counter["next"] += n_crystals
+        return SampleResult(
+            frac_x=np.repeat(ids, n_atoms)[:, None] * np.ones((1, 3)) / 1e4,
+            atomic_numbers=np.repeat(1 + ids % 5, n_atoms), lattice=ids[:, None, None] * np.eye(3)[None],
+            num_atoms=np.full(n_crystals, n_atoms))
+    return sample
+
+
+def _worker(rank, world, port, total, n_atoms, batch, outfile):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    start, _ = shard_range(total, world, rank)
+    res = generate_n_crystals(_fake_sampler(start), total, n_atoms, batch, rank, world)
+    if rank == 0:
+        save_sample_results(res, outfile)
+    else:
+        assert res is None
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("total,batch", [(10, 4), (7, 16)])
+def test_two_rank_gloo_generate(total, batch):
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    n_atoms = 3
+    with tempfile.TemporaryDirectory() as d:
+        out = os.path.join(d, "crystals.npz")
+        mp.spawn(_worker, args=(2, port, total, n_atoms, batch, out), nprocs=2, join=True)
+        z = np.load(out)
+        assert z["lattice"].shape == (total, 3, 3)
+        assert np.allclose(z["lattice"][:, 0, 0], np.arange(total))  # crystal order preserved across ranks
+        assert z["num_atoms"].tolist() == [n_atoms] * total
+        assert z["idx_start"].tolist() == list(range(0, total * n_atoms, n_atoms))
+        assert z["atomic_numbers"].tolist() == np.repeat(1 + np.arange(total) % 5, n_atoms).tolist()
+        assert z["frac_x"].shape == (total * n_atoms, 3)
+
+
+def test_concat_results_single_rank_matches_reference_layout():
+    res = generate_n_crystals(_fake_sampler(0), 5, 2, num_crystals_per_batch=2)
+    assert res.idx_start.tolist() == [0, 2, 4, 6, 8] and res.lattice.shape == (5, 3, 3)
+    assert concat_results([]).frac_x.shape == (0, 3)
