@@ -111,25 +111,17 @@ __global__ __launch_bounds__(256, 1) void edge_kernel(
     arreau_bias_tiles<TC>(acc1, b1, h);
     static_assert(TM == 3, "three monomial tiles");
     {
-        const f32x16 bt = mono_tile<0>(a, h, std::make_integer_sequence<int, 16>{});
-        arreau_gemm_intile<TC>(acc1, w1p + 0 * ARREAU_PACK_TILE_FLOATS, TM * ARREAU_PACK_TILE_FLOATS, bt, lane);
-    }
-    {
-        const f32x16 bt = mono_tile<1>(a, h, std::make_integer_sequence<int, 16>{});
-        arreau_gemm_intile<TC>(acc1, w1p + 1 * ARREAU_PACK_TILE_FLOATS, TM * ARREAU_PACK_TILE_FLOATS, bt, lane);
-    }
-    {
-        const f32x16 bt = mono_tile<2>(a, h, std::make_integer_sequence<int, 16>{});
-        arreau_gemm_intile<TC>(acc1, w1p + 2 * ARREAU_PACK_TILE_FLOATS, TM * ARREAU_PACK_TILE_FLOATS, bt, lane);
+        const f32x16 bm[TM] = {mono_tile<0>(a, h, std::make_integer_sequence<int, 16>{}),
+                               mono_tile<1>(a, h, std::make_integer_sequence<int, 16>{}),
+                               mono_tile<2>(a, h, std::make_integer_sequence<int, 16>{})};
+        arreau_gemm_chain<TC, TM>(acc1, w1p, TM * ARREAU_PACK_TILE_FLOATS, bm, lane);
     }
     arreau_gelu_tiles<TC>(acc1);
 
     // ---- layer 2: basis = GELU(W2 . h + b2) * window   [D x 32 rows] ----------------------------
     f32x16 acc2[TD];
     arreau_bias_tiles<TD>(acc2, b2, h);
-#pragma unroll
-    for (int t = 0; t < TC; ++t)
-        arreau_gemm_intile<TD>(acc2, w2p + (size_t)t * ARREAU_PACK_TILE_FLOATS, TC * ARREAU_PACK_TILE_FLOATS, acc1[t], lane);
+    arreau_gemm_chain<TD, TC>(acc2, w2p, TC * ARREAU_PACK_TILE_FLOATS, acc1, lane);
 #pragma unroll
     for (int u = 0; u < TD; ++u)
 #pragma unroll
@@ -146,9 +138,7 @@ __global__ __launch_bounds__(256, 1) void edge_kernel(
         for (int u = 0; u < TC; ++u)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc3[u][r] = 0.0f;
-#pragma unroll
-        for (int t = 0; t < TD; ++t)
-            arreau_gemm_intile<TC>(acc3, wl + (size_t)t * ARREAU_PACK_TILE_FLOATS, TD * ARREAU_PACK_TILE_FLOATS, acc2[t], lane);
+        arreau_gemm_chain<TC, TD>(acc3, wl, TD * ARREAU_PACK_TILE_FLOATS, acc2, lane);
         if (live) {
             float* dst = kbuf + (size_t)l * layer_stride + row * C;
 #pragma unroll

@@ -110,6 +110,34 @@ __device__ __forceinline__ void arreau_gemm_intile(f32x16 (&acc)[NT], const floa
     }
 }
 
+// Software-pipelined chain over NIN input tiles: the fragments of k-group g+1 are requested before the
+// MFMAs of group g issue, so the L2 latency of the weight stream hides behind 4*NT MFMAs (64 cycles each).
+// wp points at P[u0][0]; groups are contiguous (256 floats apart) because t*1024 + q*256 = g*256.
+template <int NT, int NIN>
+__device__ __forceinline__ void arreau_gemm_chain(f32x16 (&acc)[NT], const float* __restrict__ wp, int u_stride,
+                                                  const f32x16 (&b)[NIN], int lane) {
+    constexpr int G = NIN * 4;
+    const float* base = wp + lane * 4;
+    f32x4 cur[NT], nxt[NT];
+#pragma unroll
+    for (int u = 0; u < NT; ++u) cur[u] = *reinterpret_cast<const f32x4*>(base + (size_t)u * u_stride);
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        if (g + 1 < G) {
+#pragma unroll
+            for (int u = 0; u < NT; ++u)
+                nxt[u] = *reinterpret_cast<const f32x4*>(base + (size_t)u * u_stride + (g + 1) * 256);
+        }
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+#pragma unroll
+            for (int u = 0; u < NT; ++u) acc[u] = arreau_mfma(cur[u][m], b[g >> 2][4 * (g & 3) + m], acc[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < NT; ++u) cur[u] = nxt[u];
+    }
+}
+
 // exact (erf) GELU, torch.nn.GELU() default
 __device__ __forceinline__ float arreau_gelu(float x) {
     return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
