@@ -138,9 +138,35 @@ __device__ __forceinline__ void arreau_gemm_chain(f32x16 (&acc)[NT], const float
     }
 }
 
+// Branch-free erf (two polynomial pieces, both evaluated, one selected): the library erff branches on
+// |x|, which splits the fully unrolled MFMA chains into hundreds of basic blocks and wrecks register
+// allocation.  Coefficients: N. Juffa's single-precision erf (max error < 1 ulp with an accurate exp);
+// v_exp_f32 adds about 2e-7 relative on the exp term, far inside the 1e-5 parity budget.
+__device__ __forceinline__ float arreau_erf(float a) {
+    const float t = fabsf(a);
+    const float s = a * a;
+    float r = fmaf(-1.72853470e-5f, t, 3.83197126e-4f);
+    const float u = fmaf(-3.88396438e-3f, t, 2.42546219e-2f);
+    r = fmaf(r, s, u);
+    r = fmaf(r, t, -1.06777877e-1f);
+    r = fmaf(r, t, -6.34846687e-1f);
+    r = fmaf(r, t, -1.28717512e-1f);
+    r = fmaf(r, t, -t);
+    r = 1.0f - __builtin_amdgcn_exp2f(r * 1.44269504088896341f);
+    r = copysignf(r, a);
+    float p = -5.96761703e-4f;
+    p = fmaf(p, s, 4.99119423e-3f);
+    p = fmaf(p, s, -2.67681349e-2f);
+    p = fmaf(p, s, 1.12819925e-1f);
+    p = fmaf(p, s, -3.76125336e-1f);
+    p = fmaf(p, s, 1.28379166e-1f);
+    p = fmaf(p, a, a);
+    return t > 0.927734375f ? r : p;
+}
+
 // exact (erf) GELU, torch.nn.GELU() default
 __device__ __forceinline__ float arreau_gelu(float x) {
-    return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+    return 0.5f * x * (1.0f + arreau_erf(x * 0.70710678118654752440f));
 }
 
 template <int NT>

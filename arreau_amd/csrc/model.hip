@@ -123,22 +123,23 @@ extern "C" int arreau_model_create(const arreau_config* cfg, const arreau_state_
     std::vector<float> tmp;
     const size_t off_ori = bb.put(sd->ori_grid, (size_t)O * 3);
 
+    // Edge-kernel weight stream: w1 (folded, out C, in 96) | w2 (out D, in C) | wk_0..L-1 (out C, in D),
+    // contiguous, followed by a pad the prefetch ring may read (never used).
     std::vector<float> w1f;
     fold_poly_weight(sd->basis_w1, C, w1f);
-    tmp.assign((size_t)(C / 32) * (ARREAU_MONO_PAD / 32) * ARREAU_PACK_TILE_FLOATS, 0.f);
-    pack_linear(w1f.data(), C, ARREAU_MONO_PAD, ARREAU_MONO_PAD, C, ARREAU_MONO_PAD, tmp.data());
-    const size_t off_w1p = bb.put(tmp.data(), tmp.size());
-    const size_t off_b1 = bb.put(sd->basis_b1, C);
-
-    tmp.assign((size_t)(D / 32) * (C / 32) * ARREAU_PACK_TILE_FLOATS, 0.f);
-    pack_linear(sd->basis_w2, D, C, C, D, C, tmp.data());
-    const size_t off_w2p = bb.put(tmp.data(), tmp.size());
-    const size_t off_b2 = bb.put(sd->basis_b2, D);
-
+    const size_t n_w1 = (size_t)(C / 32) * (ARREAU_MONO_PAD / 32) * ARREAU_PACK_TILE_FLOATS;
+    const size_t n_w2 = (size_t)(D / 32) * (C / 32) * ARREAU_PACK_TILE_FLOATS;
     const size_t wk_tile = (size_t)(C / 32) * (D / 32) * ARREAU_PACK_TILE_FLOATS;
-    const size_t off_wkp = bb.reserve(wk_tile * L);
+    const size_t stream_pad = 16 * 256;
+    const size_t off_w1p = bb.reserve(n_w1 + n_w2 + wk_tile * L + stream_pad);
+    const size_t off_w2p = off_w1p + n_w1;
+    const size_t off_wkp = off_w2p + n_w2;
+    pack_linear(w1f.data(), C, ARREAU_MONO_PAD, ARREAU_MONO_PAD, C, ARREAU_MONO_PAD, bb.data.data() + off_w1p);
+    pack_linear(sd->basis_w2, D, C, C, D, C, bb.data.data() + off_w2p);
     for (int l = 0; l < L; ++l)
         pack_linear(sd->conv_kernel_w + (size_t)l * C * D, C, D, D, C, D, bb.data.data() + off_wkp + l * wk_tile);
+    const size_t off_b1 = bb.put(sd->basis_b1, C);
+    const size_t off_b2 = bb.put(sd->basis_b2, D);
 
     const size_t off_fk = bb.reserve((size_t)L * O * O * C);
     const size_t off_conv_bias = bb.put(sd->conv_bias, (size_t)L * C);
