@@ -20,7 +20,7 @@ struct Carver {
 };
 
 struct Workspace {
-    float *lattice, *cart, *cvec, *dir, *dist, *kbuf, *xa, *xb, *xbar, *vsum, *gs;
+    float *lattice, *cart, *cvec, *dir, *dist, *kbuf, *xa, *xb, *xc, *xbar, *vsum, *gs;
     int32_t *batch, *deg, *src, *cell;
     size_t bytes;
 };
@@ -41,6 +41,7 @@ Workspace carve(const arreau_config* cfg, int64_t N, int64_t B, void* base, size
     w.kbuf = c.take<float>(L * N * k * O * C);
     w.xa = c.take<float>(N * O * C);
     w.xb = c.take<float>(N * O * C);
+    w.xc = c.take<float>(N * O * C);
     w.xbar = c.take<float>(L * N * C);
     w.vsum = c.take<float>(N * O);
     w.gs = c.take<float>(N * 3);
@@ -142,7 +143,7 @@ extern "C" int arreau_predict_scores(const arreau_model* m, const float* d_frac,
     float* xin = w.xa;
     float* xout = w.xb;
     for (int l = 0; l < m->L; ++l) {
-        if ((rc = arreau_launch_node_layer(m, l, w.kbuf, deg, src, xin, xout, w.xbar, w.vsum, N, s))) return rc;
+        if ((rc = arreau_launch_node_layer(m, l, w.kbuf, deg, src, xin, w.xc, xout, w.xbar, w.vsum, N, s))) return rc;
         float* tmp = xin; xin = xout; xout = tmp;
     }
     return arreau_launch_readout(m, w.xbar, w.vsum, d_off, B, N, w.gs, d_eps, d_logits, d_len0, s);

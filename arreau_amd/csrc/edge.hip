@@ -54,41 +54,6 @@ __device__ __forceinline__ f32x16 mono_tile(const float (&a)[6], int h, std::int
 // GEMM and the three weight matrices become ONE linear stream of 16-byte fragments (w1 | w2 | wk_0..L-1,
 // 1 KiB per wave-load, each fragment feeding 8 MFMAs).  The stream is prefetched PF groups ahead through
 // a register ring, so L2 latency hides behind PF * 8 MFMAs (= 4096 cycles at PF = 8); no LDS, no barrier.
-#define EDGE_PF 8
-
-template <int G, int NIN, int NCB>
-__device__ __forceinline__ void stream_tile(f32x16 (&acc)[NCB], f32x4 (&ring)[EDGE_PF], const float* __restrict__ region,
-                                            const int f0, const f32x16 (&b)[NIN][NCB]) {
-#pragma unroll
-    for (int g = 0; g < G; ++g) {
-        const int f = f0 + g;
-        const f32x4 a = ring[f % EDGE_PF];
-        ring[f % EDGE_PF] = *reinterpret_cast<const f32x4*>(region + (size_t)(f + EDGE_PF) * 256);
-#pragma unroll
-        for (int m = 0; m < 4; ++m) {
-#pragma unroll
-            for (int cb = 0; cb < NCB; ++cb) acc[cb] = arreau_mfma(a[m], b[g >> 2][cb][4 * (g & 3) + m], acc[cb]);
-        }
-    }
-    // pin the issue order inside this scheduling region: one fragment prefetch, then its 4*NCB MFMAs
-    // (without this hipcc clusters the whole tile's loads up front and runs out of registers)
-#pragma unroll
-    for (int g = 0; g < G; ++g) {
-        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);        // VMEM read
-        __builtin_amdgcn_sched_group_barrier(0x008, 4 * NCB, 0);  // MFMA
-    }
-}
-
-__device__ __forceinline__ f32x16 bias_tile(const float* __restrict__ bias, int u, int h) {
-    f32x16 r;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const f32x4 v = *reinterpret_cast<const f32x4*>(bias + 32 * u + 8 * q + 4 * h);
-        r[4 * q] = v[0]; r[4 * q + 1] = v[1]; r[4 * q + 2] = v[2]; r[4 * q + 3] = v[3];
-    }
-    return r;
-}
-
 struct EdgeRow { float a[6]; float window; };
 
 // attributes of one (edge slot, orientation) row  (transforms/invariants.py:82-88)
@@ -135,7 +100,7 @@ __global__ __launch_bounds__(256, OCC) void edge_kernel(
     constexpr int TC = C / 32, TD = D / 32, TM = ARREAU_MONO_PAD / 32;
     constexpr int G1 = TM * 4, G2 = TC * 4, G3 = TD * 4;          // k-groups per output tile
     constexpr int F1 = TC * G1, F2 = TD * G2, F3 = TC * G3;       // groups per matrix
-    static_assert(F1 % EDGE_PF == 0 && F2 % EDGE_PF == 0 && F3 % EDGE_PF == 0, "ring phase must repeat");
+    static_assert(F1 % ARREAU_PF == 0 && F2 % ARREAU_PF == 0 && F3 % ARREAU_PF == 0, "ring phase must repeat");
     const int lane = threadIdx.x & 63;
     const int h = lane >> 5, j = lane & 31;
     constexpr int SLOTS = 2 * NCB;  // edge slots per wave
@@ -150,9 +115,9 @@ __global__ __launch_bounds__(256, OCC) void edge_kernel(
 
     // start the weight stream before anything else
     const float* sp = stream + lane * 4;
-    f32x4 ring[EDGE_PF];
+    f32x4 ring[ARREAU_PF];
 #pragma unroll
-    for (int i = 0; i < EDGE_PF; ++i) ring[i] = *reinterpret_cast<const f32x4*>(sp + (size_t)i * 256);
+    for (int i = 0; i < ARREAU_PF; ++i) ring[i] = *reinterpret_cast<const f32x4*>(sp + (size_t)i * 256);
 
     const float* Lm = lattice + 9 * (size_t)batch[node];
     int slot[NCB];
@@ -181,9 +146,9 @@ __global__ __launch_bounds__(256, OCC) void edge_kernel(
         for (int u = 0; u < TC; ++u) {
             f32x16 acc[NCB];
 #pragma unroll
-            for (int cb = 0; cb < NCB; ++cb) acc[cb] = bias_tile(b1, u, h);
+            for (int cb = 0; cb < NCB; ++cb) acc[cb] = arreau_bias_tile(b1, u, h);
             __builtin_amdgcn_sched_barrier(0);
-            stream_tile<G1, TM, NCB>(acc, ring, sp, u * G1, bm);
+            arreau_stream_tile<G1, TM, NCB>(acc, ring, sp, u * G1, bm);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int cb = 0; cb < NCB; ++cb)
@@ -200,9 +165,9 @@ __global__ __launch_bounds__(256, OCC) void edge_kernel(
         for (int u = 0; u < TD; ++u) {
             f32x16 acc[NCB];
 #pragma unroll
-            for (int cb = 0; cb < NCB; ++cb) acc[cb] = bias_tile(b2, u, h);
+            for (int cb = 0; cb < NCB; ++cb) acc[cb] = arreau_bias_tile(b2, u, h);
             __builtin_amdgcn_sched_barrier(0);
-            stream_tile<G2, TC, NCB>(acc, ring, region, u * G2, acc1);
+            arreau_stream_tile<G2, TC, NCB>(acc, ring, region, u * G2, acc1);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int cb = 0; cb < NCB; ++cb)
@@ -223,7 +188,7 @@ __global__ __launch_bounds__(256, OCC) void edge_kernel(
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[cb][r] = 0.0f;
             __builtin_amdgcn_sched_barrier(0);
-            stream_tile<G3, TD, NCB>(acc, ring, region, u * G3, acc2);
+            arreau_stream_tile<G3, TD, NCB>(acc, ring, region, u * G3, acc2);
             __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int cb = 0; cb < NCB; ++cb) {

@@ -51,9 +51,9 @@ struct arreau_model {
     const float* conv_bias;  // [L][C]
     const float* ln_w;       // [L][C]
     const float* ln_b;       // [L][C]
-    const float* m1p;        // [L] linear_1, MFMA-packed                             out H, in C
+    const float* mlp;        // [L][4 quarters][ linear_1 rows of the quarter (out H/4, in C) | linear_2 columns of the
+                             //  quarter (out C, in H/4) ], MFMA-packed: one linear stream per (layer, quarter)
     const float* mb1;        // [L][H]
-    const float* m2p;        // [L] linear_2, MFMA-packed                             out C, in H
     const float* mb2;        // [L][C]
     const float* ls;         // [L][C] layer_scale (ones when absent)
     const float* embT;       // [S+78][C] x_embedder.weight transposed
@@ -92,50 +92,46 @@ __device__ __forceinline__ f32x16 arreau_mfma(float a, float b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
 }
 
-// acc[u] += W(out tile u0+u, in tile t) * b   for u < NT;  wp points at P[u0][t]; u_stride in floats.
-template <int NT>
-__device__ __forceinline__ void arreau_gemm_intile(f32x16 (&acc)[NT], const float* __restrict__ wp,
-                                                   int u_stride, const f32x16& b, int lane) {
+// Weights are consumed as ONE linear stream of 16-byte fragments per wave (1 KiB per wave-load).  Output
+// tiles are produced one at a time (out-tile-major): for output tile u the k-groups g = 0..G-1 (G = 4 * input
+// tiles) are contiguous, 256 floats apart, and tile u+1 follows.  The stream is prefetched ARREAU_PF groups
+// ahead through a register ring, so L2 latency hides behind ARREAU_PF * 4 * NCB MFMAs (64 cycles each).
+// NCB = 32-row column blocks sharing each fragment.  f0 (first group of this tile within `region`) must be a
+// compile-time constant after unrolling so that ring slots are static registers.
+#define ARREAU_PF 8
+
+template <int G, int NIN, int NCB>
+__device__ __forceinline__ void arreau_stream_tile(f32x16 (&acc)[NCB], f32x4 (&ring)[ARREAU_PF],
+                                                   const float* __restrict__ region, const int f0,
+                                                   const f32x16 (&b)[NIN][NCB]) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        f32x4 a[NT];
-#pragma unroll
-        for (int u = 0; u < NT; ++u)
-            a[u] = *reinterpret_cast<const f32x4*>(wp + (size_t)u * u_stride + q * 256 + lane * 4);
+    for (int g = 0; g < G; ++g) {
+        const int f = f0 + g;
+        const f32x4 a = ring[f % ARREAU_PF];
+        ring[f % ARREAU_PF] = *reinterpret_cast<const f32x4*>(region + (size_t)(f + ARREAU_PF) * 256);
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
 #pragma unroll
-            for (int u = 0; u < NT; ++u) acc[u] = arreau_mfma(a[u][m], b[4 * q + m], acc[u]);
+            for (int cb = 0; cb < NCB; ++cb) acc[cb] = arreau_mfma(a[m], b[g >> 2][cb][4 * (g & 3) + m], acc[cb]);
         }
+    }
+    // pin the issue order inside this scheduling region: one fragment prefetch, then its 4*NCB MFMAs
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);        // VMEM read
+        __builtin_amdgcn_sched_group_barrier(0x008, 4 * NCB, 0);  // MFMA
     }
 }
 
-// Software-pipelined chain over NIN input tiles: the fragments of k-group g+1 are requested before the
-// MFMAs of group g issue, so the L2 latency of the weight stream hides behind 4*NT MFMAs (64 cycles each).
-// wp points at P[u0][0]; groups are contiguous (256 floats apart) because t*1024 + q*256 = g*256.
-template <int NT, int NIN>
-__device__ __forceinline__ void arreau_gemm_chain(f32x16 (&acc)[NT], const float* __restrict__ wp, int u_stride,
-                                                  const f32x16 (&b)[NIN], int lane) {
-    constexpr int G = NIN * 4;
-    const float* base = wp + lane * 4;
-    f32x4 cur[NT], nxt[NT];
+// accumulator tile initialised with a bias: register r gets bias[32u + rho(r,h)]
+__device__ __forceinline__ f32x16 arreau_bias_tile(const float* __restrict__ bias, int u, int h) {
+    f32x16 r;
 #pragma unroll
-    for (int u = 0; u < NT; ++u) cur[u] = *reinterpret_cast<const f32x4*>(base + (size_t)u * u_stride);
-#pragma unroll
-    for (int g = 0; g < G; ++g) {
-        if (g + 1 < G) {
-#pragma unroll
-            for (int u = 0; u < NT; ++u)
-                nxt[u] = *reinterpret_cast<const f32x4*>(base + (size_t)u * u_stride + (g + 1) * 256);
-        }
-#pragma unroll
-        for (int m = 0; m < 4; ++m) {
-#pragma unroll
-            for (int u = 0; u < NT; ++u) acc[u] = arreau_mfma(cur[u][m], b[g >> 2][4 * (g & 3) + m], acc[u]);
-        }
-#pragma unroll
-        for (int u = 0; u < NT; ++u) cur[u] = nxt[u];
+    for (int q = 0; q < 4; ++q) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(bias + 32 * u + 8 * q + 4 * h);
+        r[4 * q] = v[0]; r[4 * q + 1] = v[1]; r[4 * q + 2] = v[2]; r[4 * q + 3] = v[3];
     }
+    return r;
 }
 
 // Branch-free erf (two polynomial pieces, both evaluated, one selected): the library erff branches on
@@ -169,29 +165,6 @@ __device__ __forceinline__ float arreau_gelu(float x) {
     return 0.5f * x * (1.0f + arreau_erf(x * 0.70710678118654752440f));
 }
 
-template <int NT>
-__device__ __forceinline__ void arreau_gelu_tiles(f32x16 (&acc)[NT]) {
-#pragma unroll
-    for (int u = 0; u < NT; ++u)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[u][r] = arreau_gelu(acc[u][r]);
-}
-
-// initialise accumulator tiles with a bias vector: register r of tile u gets bias[32u + rho(r,h)]
-template <int NT>
-__device__ __forceinline__ void arreau_bias_tiles(f32x16 (&acc)[NT], const float* __restrict__ bias, int h) {
-#pragma unroll
-    for (int u = 0; u < NT; ++u)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            f32x4 v = *reinterpret_cast<const f32x4*>(bias + 32 * u + 8 * q + 4 * h);
-            acc[u][4 * q + 0] = v[0];
-            acc[u][4 * q + 1] = v[1];
-            acc[u][4 * q + 2] = v[2];
-            acc[u][4 * q + 3] = v[3];
-        }
-}
-
 // launchers implemented in the other translation units ------------------------------------------
 int arreau_launch_fiber_precompute(arreau_model* m, hipStream_t s);
 int arreau_launch_neighbor(const float* cart, const float* lattice, const int32_t* offsets, int B, int N,
@@ -205,7 +178,7 @@ int arreau_launch_edge(const arreau_model* m, const float* dir, const float* dis
 int arreau_launch_embed(const arreau_model* m, const float* frac, const int32_t* types, const float* lattice,
                         const int32_t* batch, const float* cvec, int N, float* x0, hipStream_t s);
 int arreau_launch_node_layer(const arreau_model* m, int layer, const float* kbuf, const int32_t* deg,
-                             const int32_t* src, const float* x_in, float* x_out, float* xbar, float* vsum,
-                             int N, hipStream_t s);
+                             const int32_t* src, const float* x_in, float* x_conv, float* x_out, float* xbar,
+                             float* vsum, int N, hipStream_t s);
 int arreau_launch_readout(const arreau_model* m, const float* xbar, const float* vsum, const int32_t* offsets,
                           int B, int N, float* gs, float* eps, float* logits, float* len0, hipStream_t s);

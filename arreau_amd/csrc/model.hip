@@ -146,15 +146,19 @@ extern "C" int arreau_model_create(const arreau_config* cfg, const arreau_state_
     const size_t off_ln_w = bb.put(sd->norm_w, (size_t)L * C);
     const size_t off_ln_b = bb.put(sd->norm_b, (size_t)L * C);
 
-    const size_t m1_tile = (size_t)(H / 32) * (C / 32) * ARREAU_PACK_TILE_FLOATS;
-    const size_t off_m1p = bb.reserve(m1_tile * L);
+    // ConvNext MLP stream: per layer and per hidden quarter w, linear_1 rows [w*H/4, (w+1)*H/4) (out H/4, in C)
+    // followed by linear_2 columns of the same quarter (out C, in H/4); + ring pad at the very end.
+    const int HQ = H / 4;
+    const size_t q1 = (size_t)(HQ / 32) * (C / 32) * ARREAU_PACK_TILE_FLOATS;
+    const size_t q2 = (size_t)(C / 32) * (HQ / 32) * ARREAU_PACK_TILE_FLOATS;
+    const size_t off_mlp = bb.reserve((q1 + q2) * 4 * L + stream_pad);
     for (int l = 0; l < L; ++l)
-        pack_linear(sd->linear1_w + (size_t)l * H * C, H, C, C, H, C, bb.data.data() + off_m1p + l * m1_tile);
+        for (int w = 0; w < 4; ++w) {
+            float* dst = bb.data.data() + off_mlp + ((size_t)l * 4 + w) * (q1 + q2);
+            pack_linear(sd->linear1_w + ((size_t)l * H + (size_t)w * HQ) * C, HQ, C, C, HQ, C, dst);
+            pack_linear(sd->linear2_w + (size_t)l * C * H + (size_t)w * HQ, C, HQ, H, C, HQ, dst + q1);
+        }
     const size_t off_mb1 = bb.put(sd->linear1_b, (size_t)L * H);
-    const size_t m2_tile = (size_t)(C / 32) * (H / 32) * ARREAU_PACK_TILE_FLOATS;
-    const size_t off_m2p = bb.reserve(m2_tile * L);
-    for (int l = 0; l < L; ++l)
-        pack_linear(sd->linear2_w + (size_t)l * C * H, C, H, H, C, H, bb.data.data() + off_m2p + l * m2_tile);
     const size_t off_mb2 = bb.put(sd->linear2_b, (size_t)L * C);
 
     tmp.assign((size_t)L * C, 1.0f);
@@ -212,7 +216,7 @@ extern "C" int arreau_model_create(const arreau_config* cfg, const arreau_state_
     float* b = m->blob;
     m->ori = b + off_ori; m->w1p = b + off_w1p; m->b1 = b + off_b1; m->w2p = b + off_w2p; m->b2 = b + off_b2;
     m->wkp = b + off_wkp; m->fk = b + off_fk; m->conv_bias = b + off_conv_bias; m->ln_w = b + off_ln_w;
-    m->ln_b = b + off_ln_b; m->m1p = b + off_m1p; m->mb1 = b + off_mb1; m->m2p = b + off_m2p; m->mb2 = b + off_mb2;
+    m->ln_b = b + off_ln_b; m->mlp = b + off_mlp; m->mb1 = b + off_mb1; m->mb2 = b + off_mb2;
     m->ls = b + off_ls; m->embT = b + off_embT; m->ro_wT = b + off_ro_wT; m->ro_b = b + off_ro_b;
     m->t_emb_w = b + off_temb; m->ve_sigmas = b + off_ve; m->vp_alpha_bars = b + off_ab; m->vp_betas = b + off_be;
     m->q1t = b + off_q1t; m->qmats = b + off_qm;

@@ -122,32 +122,108 @@ int arreau_launch_embed(const arreau_model* m, const float* frac, const int32_t*
 }
 
 // ---------------------------------------------------------------------------------------------
-// K4: one interaction layer for a tile of 2 nodes (32 (node, orientation) rows), 4 waves.
-//   A  message + aggregate:  x1[n,o,c] = sum_{slots s<deg[n]} K_l[(n,s),o,c] * x[src(n,s),o,c]
-//                            (conv.py:111,131-133 + PyG sum aggregation onto the receiver)
-//   B  spherical conv:       x2[n,p,c] = sum_o x1[n,o,c] * FK_l[o,p,c] + bias[c]   (FK holds the /O; conv.py:113-127)
-//   C  LayerNorm over c (eps 1e-5)                                                 (convnext.py:25)
-//   D  MLP on MFMA: each wave owns one quarter of the hidden units:
-//          hid = GELU(W1[quarter] . xn + b1[quarter]);  part = W2[:, quarter] . hid  (convnext.py:26-28)
-//   E  deterministic cross-wave sum of the 4 partial outputs through LDS
-//   F  x_out = (sum + b2) * layer_scale + x_in ; per-layer read-out partials:
-//          xbar_l[n][c] = mean_o x_out ;  vsum[n][o] (+)= w_vec_l . x_out[n,o,:] + b_vec_l   (ponita.py:105-117)
+// K4a: message passing + spherical convolution of one layer (HBM-bound; no MFMA).
+//   x1[n,o,c] = sum_{slots s<deg[n]} K_l[(n,s),o,c] * x[src(n,s),o,c]      (conv.py:111,131-133 + PyG sum
+//                                                                            aggregation onto the receiver)
+//   x2[n,p,c] = sum_o x1[n,o,c] * FK_l[o,p,c] + bias[c]                     (FK holds the /O; conv.py:113-127)
+// Persistent workgroups of 512 threads walk the nodes.  Thread (c, pq) keeps its slice of the layer's fiber
+// kernel FK_l[0..15][4pq..4pq+3][c] in 64 registers for the whole launch, so FK (128 KB per layer) is read
+// once per workgroup instead of once per node.  Per node: 16 rows x 32 float4-columns gather the k in-edge
+// kernels (streamed from HBM, 64 KB per node) and the senders' features (L2 / Infinity Cache), products are
+// rounded and summed in slot order like messages -> index_add_, the 16 x C tile goes through LDS for the
+// depth-wise 16x16 orientation mix.  Two LDS tiles alternate so there is one barrier per node.
 // ---------------------------------------------------------------------------------------------
-#define NODE_TILE_ROWS 32
-#define NODE_LDS_STRIDE 132  // C + 4 floats: 16-byte aligned rows, conflict-free ds_read_b128 of 4 k-steps
+#define CONV_LDS_STRIDE 132
 
-template <int C, int H>
-__global__ __launch_bounds__(256, 2) void node_layer_kernel(
+template <int C>
+__global__ __launch_bounds__(512, 4) void conv_kernel(
     const float* __restrict__ kl,        // this layer's kernels [N*k*16][C]
     const int32_t* __restrict__ deg, const int32_t* __restrict__ src,
-    const float* __restrict__ x_in, float* __restrict__ x_out,
+    const float* __restrict__ x_in,      // [N][16][C]
     const float* __restrict__ fk,        // [16(o)][16(p)][C]
-    const float* __restrict__ conv_bias, const float* __restrict__ ln_w, const float* __restrict__ ln_b,
-    const float* __restrict__ m1p, const float* __restrict__ mb1, const float* __restrict__ m2p,
-    const float* __restrict__ mb2, const float* __restrict__ ls,
+    const float* __restrict__ conv_bias, int N, int k,
+    float* __restrict__ x_conv)          // [N][16][C]
+{
+    static_assert(C == 128, "thread mapping assumes C = 128");
+    __shared__ __attribute__((aligned(16))) float tile[2][16 * CONV_LDS_STRIDE];
+    const int tid = threadIdx.x;
+    const int c = tid & 127, pq = tid >> 7;  // conv role: channel, quarter of the output orientations
+    const int c4 = tid & 31, o_row = tid >> 5;  // gather role: float4 column, orientation row
+    float fkr[16][4];
+#pragma unroll
+    for (int o = 0; o < 16; ++o)
+#pragma unroll
+        for (int p = 0; p < 4; ++p) fkr[o][p] = fk[((size_t)o * 16 + (4 * pq + p)) * C + c];
+    const float bias = conv_bias[c];
+
+    int buf = 0;
+    for (int n = blockIdx.x; n < N; n += gridDim.x, buf ^= 1) {
+        // ---- gather . multiply . ordered sum over the in-edges -------------------------------------
+        const int nd = min(deg[n], k);
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        const size_t kbase = ((size_t)n * k * 16 + o_row) * C + 4 * c4;
+        const int32_t* srow = src + (size_t)n * k;
+#pragma unroll 1
+        for (int s0 = 0; s0 < nd; s0 += 4) {
+            // unconditional loads (unused slots are clamped to a valid address and dropped by the select below:
+            // their kernel rows may be uninitialised, so they must not be multiplied in)
+            f32x4 kv[4], xv[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int s = min(s0 + i, k - 1);
+                const int sn = max(srow[s], 0);
+                kv[i] = *reinterpret_cast<const f32x4*>(kl + kbase + (size_t)s * 16 * C);
+                xv[i] = *reinterpret_cast<const f32x4*>(x_in + ((size_t)sn * 16 + o_row) * C + 4 * c4);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const bool on = s0 + i < nd;  // product rounded, then added in edge order (messages -> index_add_)
+                acc[0] = on ? __fadd_rn(acc[0], __fmul_rn(kv[i][0], xv[i][0])) : acc[0];
+                acc[1] = on ? __fadd_rn(acc[1], __fmul_rn(kv[i][1], xv[i][1])) : acc[1];
+                acc[2] = on ? __fadd_rn(acc[2], __fmul_rn(kv[i][2], xv[i][2])) : acc[2];
+                acc[3] = on ? __fadd_rn(acc[3], __fmul_rn(kv[i][3], xv[i][3])) : acc[3];
+            }
+        }
+        *reinterpret_cast<f32x4*>(&tile[buf][o_row * CONV_LDS_STRIDE + 4 * c4]) = acc;
+        __syncthreads();  // tile[buf] complete; the previous node's readers of tile[buf^1] are long done
+        // ---- depth-wise orientation mix ------------------------------------------------------------
+        float out[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int o = 0; o < 16; ++o) {
+            const float xv = tile[buf][o * CONV_LDS_STRIDE + c];
+#pragma unroll
+            for (int p = 0; p < 4; ++p) out[p] += xv * fkr[o][p];
+        }
+#pragma unroll
+        for (int p = 0; p < 4; ++p) x_conv[((size_t)n * 16 + (4 * pq + p)) * C + c] = out[p] + bias;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// K4b: ConvNext block of one layer on MFMA (convnext.py:25-32) + read-out partials (ponita.py:105-117).
+// Workgroup = 4 waves = one 32-row tile (2 nodes x 16 orientations); wave w owns hidden units
+// [w*H/4, (w+1)*H/4).  Every wave loads the tile's conv output straight into the B-operand register
+// layout (lane (h, j): row j, channels 32t + 8q + 4h + m), applies LayerNorm in registers (a row lives in
+// lanes j and j+32), then runs
+//     hid  = GELU(W1[quarter] . xn + b1[quarter])      out-tile-major, weights streamed through the ring
+//     part = W2[:, quarter] . hid
+// The four partial outputs are summed through LDS in a fixed order, then
+//     x_out = (sum + b2) * layer_scale + x_in ;  xbar_l[n][c] = mean_o x_out ;
+//     vsum[n][o] (+)= w_vec_l . x_out[n,o,:] + b_vec_l
+// ---------------------------------------------------------------------------------------------
+#define NODE_TILE_ROWS 32
+#define NODE_LDS_STRIDE 132
+
+template <int C, int H>
+__global__ __launch_bounds__(256, 2) void mlp_kernel(
+    const float* __restrict__ x_conv,    // [N][16][C]  conv output (pre-LayerNorm)
+    const float* __restrict__ x_in, float* __restrict__ x_out,
+    const float* __restrict__ ln_w, const float* __restrict__ ln_b,
+    const float* __restrict__ mlp,       // this layer's stream: [4 quarters][W1 quarter | W2 quarter]
+    const float* __restrict__ mb1, const float* __restrict__ mb2, const float* __restrict__ ls,
     const float* __restrict__ ro_wT,     // [C][S+4] this layer
     const float* __restrict__ ro_b,      // [S+4]
-    int S, int N, int k, int first_layer,
+    int S, int N, int first_layer,
     float* __restrict__ xbar,            // [N][C] this layer
     float* __restrict__ vsum)            // [N][16]
 {
@@ -155,119 +231,90 @@ __global__ __launch_bounds__(256, 2) void node_layer_kernel(
     constexpr int TC = C / 32;          // in/out tiles of C
     constexpr int HQ = H / 4;           // hidden units per wave
     constexpr int THQ = HQ / 32;        // hidden tiles per wave
+    constexpr int GA = TC * 4, GB = THQ * 4;
+    constexpr int FA = THQ * GA, FB = TC * GB;  // groups in the W1 / W2 quarter
+    static_assert(FA % ARREAU_PF == 0 && FB % ARREAU_PF == 0, "ring phase must repeat");
     __shared__ __attribute__((aligned(16))) float xt[NODE_TILE_ROWS * NODE_LDS_STRIDE];
     __shared__ __attribute__((aligned(16))) float red[NODE_TILE_ROWS * NODE_LDS_STRIDE];
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int h = lane >> 5, j = lane & 31;
     const int n0 = 2 * blockIdx.x;
 
-    // ---- A: gather + multiply + segmented sum (4 rows per thread, 4 channels per thread) --------
-    {
-        const int c4 = tid & 31, rr = tid >> 5;
+    // weight stream of this (layer, quarter): start it first
+    const float* sp = mlp + (size_t)wave * (FA + FB) * 256 + lane * 4;
+    f32x4 ring[ARREAU_PF];
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int r = rr + 8 * i;
-            const int n = n0 + (r >> 4), o = r & 15;
-            f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-            if (n < N) {
-                const int nd = min(deg[n], k);
-                for (int s = 0; s < nd; ++s) {
-                    const int sn = src[(size_t)n * k + s];
-                    const f32x4 kv = *reinterpret_cast<const f32x4*>(kl + (((size_t)n * k + s) * 16 + o) * C + 4 * c4);
-                    const f32x4 xv = *reinterpret_cast<const f32x4*>(x_in + ((size_t)sn * 16 + o) * C + 4 * c4);
-                    // product rounded, then added in edge order, like messages -> index_add_
-                    acc[0] = __fadd_rn(acc[0], __fmul_rn(kv[0], xv[0]));
-                    acc[1] = __fadd_rn(acc[1], __fmul_rn(kv[1], xv[1]));
-                    acc[2] = __fadd_rn(acc[2], __fmul_rn(kv[2], xv[2]));
-                    acc[3] = __fadd_rn(acc[3], __fmul_rn(kv[3], xv[3]));
-                }
-            }
-            *reinterpret_cast<f32x4*>(&xt[r * NODE_LDS_STRIDE + 4 * c4]) = acc;
-        }
-    }
-    __syncthreads();
+    for (int i = 0; i < ARREAU_PF; ++i) ring[i] = *reinterpret_cast<const f32x4*>(sp + (size_t)i * 256);
 
-    // ---- B: depth-wise spherical convolution ------------------------------------------------------
+    // ---- load the row in B-operand layout and LayerNorm it (eps 1e-5, biased variance) ---------------
+    f32x16 bx[TC][1];
     {
-        const int c = tid & 127, ph = tid >> 7;  // channel, half of the output orientations
-        float acc[2][8];
-#pragma unroll
-        for (int n2 = 0; n2 < 2; ++n2)
-#pragma unroll
-            for (int p = 0; p < 8; ++p) acc[n2][p] = 0.f;
-#pragma unroll 4
-        for (int o = 0; o < 16; ++o) {
-            const float xa = xt[o * NODE_LDS_STRIDE + c];
-            const float xb = xt[(16 + o) * NODE_LDS_STRIDE + c];
-#pragma unroll
-            for (int p = 0; p < 8; ++p) {
-                const float f = fk[((size_t)o * 16 + (8 * ph + p)) * C + c];
-                acc[0][p] += xa * f;
-                acc[1][p] += xb * f;
-            }
-        }
-        const float bias = conv_bias[c];
-        __syncthreads();  // every read of x1 is done before it is overwritten with x2
-#pragma unroll
-        for (int n2 = 0; n2 < 2; ++n2)
-#pragma unroll
-            for (int p = 0; p < 8; ++p) xt[(16 * n2 + 8 * ph + p) * NODE_LDS_STRIDE + c] = acc[n2][p] + bias;
-    }
-    __syncthreads();
-
-    // ---- C: LayerNorm over channels, 8 rows per wave, 2 channels per lane --------------------------
-    {
-        const float g0 = ln_w[lane], g1 = ln_w[lane + 64], be0 = ln_b[lane], be1 = ln_b[lane + 64];
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            float* rowp = xt + (8 * wave + i) * NODE_LDS_STRIDE;
-            const float v0 = rowp[lane], v1 = rowp[lane + 64];
-            float sum = v0 + v1;
-#pragma unroll
-            for (int off = 32; off >= 1; off >>= 1) sum += __shfl_xor(sum, off, 64);
-            const float mean = sum * (1.0f / C);
-            const float d0 = v0 - mean, d1 = v1 - mean;
-            float sq = d0 * d0 + d1 * d1;
-#pragma unroll
-            for (int off = 32; off >= 1; off >>= 1) sq += __shfl_xor(sq, off, 64);
-            const float rstd = 1.0f / sqrtf(sq * (1.0f / C) + 1e-5f);
-            rowp[lane] = d0 * rstd * g0 + be0;
-            rowp[lane + 64] = d1 * rstd * g1 + be1;
-        }
-    }
-    __syncthreads();
-
-    // ---- D: MLP, wave `wave` owns hidden units [wave*HQ, (wave+1)*HQ) ---------------------------------
-    const int h = lane >> 5, j = lane & 31;
-    f32x16 acc_o[TC];
-    {
-        f32x16 bx[TC];
+        const int n = n0 + (j >> 4), o = j & 15;
+        const bool valid = n < N;
+        const float* rowp = x_conv + ((size_t)(valid ? n : 0) * 16 + o) * C + 4 * h;
+        float sum = 0.f;
 #pragma unroll
         for (int t = 0; t < TC; ++t)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                const f32x4 v = *reinterpret_cast<const f32x4*>(&xt[j * NODE_LDS_STRIDE + 32 * t + 8 * q + 4 * h]);
-                bx[t][4 * q] = v[0]; bx[t][4 * q + 1] = v[1]; bx[t][4 * q + 2] = v[2]; bx[t][4 * q + 3] = v[3];
+                f32x4 v = *reinterpret_cast<const f32x4*>(rowp + 32 * t + 8 * q);
+                if (!valid) v = f32x4{0.f, 0.f, 0.f, 0.f};
+                bx[t][0][4 * q] = v[0]; bx[t][0][4 * q + 1] = v[1]; bx[t][0][4 * q + 2] = v[2]; bx[t][0][4 * q + 3] = v[3];
+                sum += (v[0] + v[1]) + (v[2] + v[3]);
             }
-        f32x16 acc_h[THQ];
-        arreau_bias_tiles<THQ>(acc_h, mb1 + wave * HQ, h);
-        const float* w1 = m1p + (size_t)(wave * THQ) * TC * ARREAU_PACK_TILE_FLOATS;  // out tiles of this quarter
+        sum += __shfl_xor(sum, 32, 64);
+        const float mean = sum * (1.0f / C);
+        float sq = 0.f;
 #pragma unroll
         for (int t = 0; t < TC; ++t)
-            arreau_gemm_intile<THQ>(acc_h, w1 + (size_t)t * ARREAU_PACK_TILE_FLOATS, TC * ARREAU_PACK_TILE_FLOATS, bx[t], lane);
-        arreau_gelu_tiles<THQ>(acc_h);
 #pragma unroll
-        for (int u = 0; u < TC; ++u)
+            for (int r = 0; r < 16; ++r) {
+                const float d = bx[t][0][r] - mean;
+                bx[t][0][r] = d;
+                sq += d * d;
+            }
+        sq += __shfl_xor(sq, 32, 64);
+        const float rstd = 1.0f / sqrtf(sq * (1.0f / C) + 1e-5f);
 #pragma unroll
-            for (int r = 0; r < 16; ++r) acc_o[u][r] = 0.f;
-        constexpr int TH = H / 32;
-        const float* w2 = m2p + (size_t)(wave * THQ) * ARREAU_PACK_TILE_FLOATS;  // in tiles of this quarter
+        for (int t = 0; t < TC; ++t)
 #pragma unroll
-        for (int t = 0; t < THQ; ++t)
-            arreau_gemm_intile<TC>(acc_o, w2 + (size_t)t * ARREAU_PACK_TILE_FLOATS, TH * ARREAU_PACK_TILE_FLOATS, acc_h[t], lane);
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 g = *reinterpret_cast<const f32x4*>(ln_w + 32 * t + 8 * q + 4 * h);
+                const f32x4 be = *reinterpret_cast<const f32x4*>(ln_b + 32 * t + 8 * q + 4 * h);
+#pragma unroll
+                for (int m = 0; m < 4; ++m) bx[t][0][4 * q + m] = bx[t][0][4 * q + m] * rstd * g[m] + be[m];
+            }
     }
-    __syncthreads();  // all waves have read xn; xt and red are free
 
-    // ---- E: (w0 + w2) -> red, (w1 + w3) -> xt, fixed order ------------------------------------------
+    // ---- hidden quarter: hid = GELU(W1q . xn + b1q) ----------------------------------------------------
+    f32x16 acc_h[THQ][1];
+#pragma unroll
+    for (int u = 0; u < THQ; ++u) {
+        f32x16 acc[1];
+        acc[0] = arreau_bias_tile(mb1 + wave * HQ, u, h);
+        __builtin_amdgcn_sched_barrier(0);
+        arreau_stream_tile<GA, TC, 1>(acc, ring, sp, u * GA, bx);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc_h[u][0][r] = arreau_gelu(acc[0][r]);
+    }
+    // ---- partial output: part = W2[:, quarter] . hid ----------------------------------------------------
+    f32x16 acc_o[TC];
+    {
+        const float* region = sp + (size_t)FA * 256;
+#pragma unroll
+        for (int u = 0; u < TC; ++u) {
+            f32x16 acc[1];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[0][r] = 0.f;
+            __builtin_amdgcn_sched_barrier(0);
+            arreau_stream_tile<GB, THQ, 1>(acc, ring, region, u * GB, acc_h);
+            __builtin_amdgcn_sched_barrier(0);
+            acc_o[u] = acc[0];
+        }
+    }
+
+    // ---- (w0 + w2) -> red, (w1 + w3) -> xt, fixed order ------------------------------------------------
     {
         float* buf = (wave & 1) ? xt : red;
         if (wave < 2) {
@@ -294,7 +341,7 @@ __global__ __launch_bounds__(256, 2) void node_layer_kernel(
         __syncthreads();
     }
 
-    // ---- F: bias, layer scale, residual; write x_out; read-out partials ----------------------------
+    // ---- bias, layer scale, residual; write x_out; read-out partials -------------------------------------
     {
         const int c4 = tid & 31, rr = tid >> 5;
         const f32x4 b2v = *reinterpret_cast<const f32x4*>(mb2 + 4 * c4);
@@ -345,27 +392,25 @@ __global__ __launch_bounds__(256, 2) void node_layer_kernel(
 }
 
 int arreau_launch_node_layer(const arreau_model* m, int layer, const float* kbuf, const int32_t* deg,
-                             const int32_t* src, const float* x_in, float* x_out, float* xbar, float* vsum, int N,
-                             hipStream_t s) {
+                             const int32_t* src, const float* x_in, float* x_conv, float* x_out, float* xbar,
+                             float* vsum, int N, hipStream_t s) {
     if (N == 0) return ARREAU_OK;
-    const int C = m->C, H = m->H, L = m->L, S = m->S;
-    (void)L;
-    const size_t layer_stride = (size_t)N * m->k * 16 * C;
-    const size_t m1_tile = (size_t)(H / 32) * (C / 32) * ARREAU_PACK_TILE_FLOATS;
-    const size_t m2_tile = (size_t)(C / 32) * (H / 32) * ARREAU_PACK_TILE_FLOATS;
-    if (C == 128 && H == 512) {
-        hipLaunchKernelGGL((node_layer_kernel<128, 512>), dim3((N + 1) / 2), dim3(256), 0, s,
-                           kbuf + (size_t)layer * layer_stride, deg, src, x_in, x_out,
-                           m->fk + (size_t)layer * 16 * 16 * C, m->conv_bias + (size_t)layer * C,
-                           m->ln_w + (size_t)layer * C, m->ln_b + (size_t)layer * C, m->m1p + layer * m1_tile,
-                           m->mb1 + (size_t)layer * H, m->m2p + layer * m2_tile, m->mb2 + (size_t)layer * C,
-                           m->ls + (size_t)layer * C, m->ro_wT + (size_t)layer * C * (S + 4),
-                           m->ro_b + (size_t)layer * (S + 4), S, N, m->k, layer == 0 ? 1 : 0,
-                           xbar + (size_t)layer * N * C, vsum);
-    } else {
-        arreau_set_error("node kernel: unsupported (hidden_dim, widening_factor)");
+    const int C = m->C, H = m->H, S = m->S;
+    if (!(C == 128 && H == 512)) {
+        arreau_set_error("node kernels: unsupported (hidden_dim, widening_factor)");
         return ARREAU_EINVAL;
     }
+    const size_t layer_stride = (size_t)N * m->k * 16 * C;
+    const size_t mlp_layer = (size_t)2 * H * C;  // floats of W1 + W2, packed
+    const int conv_blocks = N < 512 ? N : 512;   // persistent: 2 workgroups of 512 threads per CU
+    hipLaunchKernelGGL((conv_kernel<128>), dim3(conv_blocks), dim3(512), 0, s, kbuf + (size_t)layer * layer_stride, deg,
+                       src, x_in, m->fk + (size_t)layer * 16 * 16 * C, m->conv_bias + (size_t)layer * C, N, m->k, x_conv);
+    ARREAU_CHECK_HIP(hipGetLastError());
+    hipLaunchKernelGGL((mlp_kernel<128, 512>), dim3((N + 1) / 2), dim3(256), 0, s, x_conv, x_in, x_out,
+                       m->ln_w + (size_t)layer * C, m->ln_b + (size_t)layer * C, m->mlp + (size_t)layer * mlp_layer,
+                       m->mb1 + (size_t)layer * H, m->mb2 + (size_t)layer * C, m->ls + (size_t)layer * C,
+                       m->ro_wT + (size_t)layer * C * (S + 4), m->ro_b + (size_t)layer * (S + 4), S, N,
+                       layer == 0 ? 1 : 0, xbar + (size_t)layer * N * C, vsum);
     ARREAU_CHECK_HIP(hipGetLastError());
     return ARREAU_OK;
 }
