@@ -201,19 +201,18 @@ __global__ __launch_bounds__(512, 4) void conv_kernel(
 
 // ---------------------------------------------------------------------------------------------
 // K4b: ConvNext block of one layer on MFMA (convnext.py:25-32) + read-out partials (ponita.py:105-117).
-// Workgroup = 4 waves = one 32-row tile (2 nodes x 16 orientations); wave w owns hidden units
-// [w*H/4, (w+1)*H/4).  Every wave loads the tile's conv output straight into the B-operand register
-// layout (lane (h, j): row j, channels 32t + 8q + 4h + m), applies LayerNorm in registers (a row lives in
-// lanes j and j+32), then runs
-//     hid  = GELU(W1[quarter] . xn + b1[quarter])      out-tile-major, weights streamed through the ring
-//     part = W2[:, quarter] . hid
-// The four partial outputs are summed through LDS in a fixed order, then
-//     x_out = (sum + b2) * layer_scale + x_in ;  xbar_l[n][c] = mean_o x_out ;
+// A 32-row tile (2 nodes x 16 orientations) is shared by a PAIR of waves, each owning half of the hidden
+// units (finer tasks balance the 1024 SIMDs at small batches); the pair meets once, through LDS, to add
+// the two partial outputs in a fixed order.  Each wave loads the rows of
+// the conv output straight into the B-operand register layout (lane (h, j): row j, channels
+// 32t + 8q + 4h + m), applies LayerNorm in registers (a row lives in lanes j and j+32), then walks the
+// layer's weight stream quarter by quarter (quarter = 128 hidden units):
+//     hid  = GELU(W1[quarter] . xn + b1[quarter])      out-tile-major, fragments prefetched through the ring
+//     out += W2[:, quarter] . hid
+// and finishes in registers:
+//     x_out = (out + b2) * layer_scale + x_in ;  xbar_l[n][c] = mean_o x_out (16-lane butterfly) ;
 //     vsum[n][o] (+)= w_vec_l . x_out[n,o,:] + b_vec_l
 // ---------------------------------------------------------------------------------------------
-#define NODE_TILE_ROWS 32
-#define NODE_LDS_STRIDE 132
-
 template <int C, int H>
 __global__ __launch_bounds__(256, 2) void mlp_kernel(
     const float* __restrict__ x_conv,    // [N][16][C]  conv output (pre-LayerNorm)
@@ -227,38 +226,42 @@ __global__ __launch_bounds__(256, 2) void mlp_kernel(
     float* __restrict__ xbar,            // [N][C] this layer
     float* __restrict__ vsum)            // [N][16]
 {
-    static_assert(C == 128, "tile mapping below assumes C = 128");
     constexpr int TC = C / 32;          // in/out tiles of C
-    constexpr int HQ = H / 4;           // hidden units per wave
-    constexpr int THQ = HQ / 32;        // hidden tiles per wave
+    constexpr int HQ = H / 4;           // hidden units per quarter
+    constexpr int THQ = HQ / 32;        // hidden tiles per quarter
     constexpr int GA = TC * 4, GB = THQ * 4;
-    constexpr int FA = THQ * GA, FB = TC * GB;  // groups in the W1 / W2 quarter
+    constexpr int FA = THQ * GA, FB = TC * GB;  // groups in the W1 / W2 part of a quarter
     static_assert(FA % ARREAU_PF == 0 && FB % ARREAU_PF == 0, "ring phase must repeat");
-    __shared__ __attribute__((aligned(16))) float xt[NODE_TILE_ROWS * NODE_LDS_STRIDE];
-    __shared__ __attribute__((aligned(16))) float red[NODE_TILE_ROWS * NODE_LDS_STRIDE];
-    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    __shared__ __attribute__((aligned(16))) float part[2][32 * 132];
+    const int lane = threadIdx.x & 63;
     const int h = lane >> 5, j = lane & 31;
-    const int n0 = 2 * blockIdx.x;
+    const int wave = threadIdx.x >> 6;
+    const int tw = wave >> 1, half = wave & 1;  // tile within the workgroup, hidden half
+    const long long tile = (long long)blockIdx.x * 2 + tw;
+    const long long n_ll = 2 * tile + (j >> 4);
+    const bool tile_live = 2 * tile < N;  // both waves of a pair agree; dead pairs still reach the barrier
+    const bool valid = n_ll < N;
+    const int n = valid ? (int)n_ll : N - 1;  // padding rows / dead tiles read a valid row and write nothing
+    const int o = j & 15;
 
-    // weight stream of this (layer, quarter): start it first
-    const float* sp = mlp + (size_t)wave * (FA + FB) * 256 + lane * 4;
+    // weight stream of this layer (this wave starts at its first quarter): start it first
+    const float* sp0 = mlp + lane * 4;
+    const float* sp = sp0 + (size_t)(2 * half) * (FA + FB) * 256;
     f32x4 ring[ARREAU_PF];
 #pragma unroll
     for (int i = 0; i < ARREAU_PF; ++i) ring[i] = *reinterpret_cast<const f32x4*>(sp + (size_t)i * 256);
 
     // ---- load the row in B-operand layout and LayerNorm it (eps 1e-5, biased variance) ---------------
+    const size_t rowoff = ((size_t)n * 16 + o) * C + 4 * h;
     f32x16 bx[TC][1];
     {
-        const int n = n0 + (j >> 4), o = j & 15;
-        const bool valid = n < N;
-        const float* rowp = x_conv + ((size_t)(valid ? n : 0) * 16 + o) * C + 4 * h;
+        const float* rowp = x_conv + rowoff;
         float sum = 0.f;
 #pragma unroll
         for (int t = 0; t < TC; ++t)
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                f32x4 v = *reinterpret_cast<const f32x4*>(rowp + 32 * t + 8 * q);
-                if (!valid) v = f32x4{0.f, 0.f, 0.f, 0.f};
+                const f32x4 v = *reinterpret_cast<const f32x4*>(rowp + 32 * t + 8 * q);
                 bx[t][0][4 * q] = v[0]; bx[t][0][4 * q + 1] = v[1]; bx[t][0][4 * q + 2] = v[2]; bx[t][0][4 * q + 3] = v[3];
                 sum += (v[0] + v[1]) + (v[2] + v[3]);
             }
@@ -286,108 +289,93 @@ __global__ __launch_bounds__(256, 2) void mlp_kernel(
             }
     }
 
-    // ---- hidden quarter: hid = GELU(W1q . xn + b1q) ----------------------------------------------------
-    f32x16 acc_h[THQ][1];
+    f32x16 acc_o[TC][1];
 #pragma unroll
-    for (int u = 0; u < THQ; ++u) {
-        f32x16 acc[1];
-        acc[0] = arreau_bias_tile(mb1 + wave * HQ, u, h);
-        __builtin_amdgcn_sched_barrier(0);
-        arreau_stream_tile<GA, TC, 1>(acc, ring, sp, u * GA, bx);
-        __builtin_amdgcn_sched_barrier(0);
+    for (int u = 0; u < TC; ++u)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc_h[u][0][r] = arreau_gelu(acc[0][r]);
-    }
-    // ---- partial output: part = W2[:, quarter] . hid ----------------------------------------------------
-    f32x16 acc_o[TC];
-    {
-        const float* region = sp + (size_t)FA * 256;
+        for (int r = 0; r < 16; ++r) acc_o[u][0][r] = 0.f;
+
+#pragma unroll 1
+    for (int w = 2 * half; w < 2 * half + 2; ++w) {
+        if (!tile_live) break;
+        const float* region_a = sp0 + (size_t)w * (FA + FB) * 256;
+        const float* region_b = region_a + (size_t)FA * 256;
+        // ---- hid = GELU(W1q . xn + b1q) ---------------------------------------------------------------
+        f32x16 acc_h[THQ][1];
+#pragma unroll
+        for (int u = 0; u < THQ; ++u) {
+            f32x16 acc[1];
+            acc[0] = arreau_bias_tile(mb1 + w * HQ, u, h);
+            __builtin_amdgcn_sched_barrier(0);
+            arreau_stream_tile<GA, TC, 1>(acc, ring, region_a, u * GA, bx);
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc_h[u][0][r] = arreau_gelu(acc[0][r]);
+        }
+        // ---- out += W2[:, quarter] . hid ----------------------------------------------------------------
 #pragma unroll
         for (int u = 0; u < TC; ++u) {
-            f32x16 acc[1];
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[0][r] = 0.f;
             __builtin_amdgcn_sched_barrier(0);
-            arreau_stream_tile<GB, THQ, 1>(acc, ring, region, u * GB, acc_h);
+            arreau_stream_tile<GB, THQ, 1>(acc_o[u], ring, region_b, u * GB, acc_h);
             __builtin_amdgcn_sched_barrier(0);
-            acc_o[u] = acc[0];
         }
     }
 
-    // ---- (w0 + w2) -> red, (w1 + w3) -> xt, fixed order ------------------------------------------------
-    {
-        float* buf = (wave & 1) ? xt : red;
-        if (wave < 2) {
+    // ---- the upper-half wave hands its partial sum to its partner and retires ----------------------------
+    if (half == 1) {
 #pragma unroll
-            for (int u = 0; u < TC; ++u)
+        for (int u = 0; u < TC; ++u)
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    f32x4 v = {acc_o[u][4 * q], acc_o[u][4 * q + 1], acc_o[u][4 * q + 2], acc_o[u][4 * q + 3]};
-                    *reinterpret_cast<f32x4*>(&buf[j * NODE_LDS_STRIDE + 32 * u + 8 * q + 4 * h]) = v;
-                }
-        }
-        __syncthreads();
-        if (wave >= 2) {
-#pragma unroll
-            for (int u = 0; u < TC; ++u)
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    f32x4* p = reinterpret_cast<f32x4*>(&buf[j * NODE_LDS_STRIDE + 32 * u + 8 * q + 4 * h]);
-                    f32x4 v = *p;
-                    v[0] += acc_o[u][4 * q]; v[1] += acc_o[u][4 * q + 1]; v[2] += acc_o[u][4 * q + 2]; v[3] += acc_o[u][4 * q + 3];
-                    *p = v;
-                }
-        }
-        __syncthreads();
-    }
-
-    // ---- bias, layer scale, residual; write x_out; read-out partials -------------------------------------
-    {
-        const int c4 = tid & 31, rr = tid >> 5;
-        const f32x4 b2v = *reinterpret_cast<const f32x4*>(mb2 + 4 * c4);
-        const f32x4 lsv = *reinterpret_cast<const f32x4*>(ls + 4 * c4);
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int r = rr + 8 * i;
-            const int n = n0 + (r >> 4), o = r & 15;
-            f32x4 v = *reinterpret_cast<const f32x4*>(&red[r * NODE_LDS_STRIDE + 4 * c4]) +
-                      *reinterpret_cast<const f32x4*>(&xt[r * NODE_LDS_STRIDE + 4 * c4]);
-            f32x4 xo = {0.f, 0.f, 0.f, 0.f};
-            if (n < N) {
-                const size_t g = ((size_t)n * 16 + o) * C + 4 * c4;
-                const f32x4 xi = *reinterpret_cast<const f32x4*>(x_in + g);
-                xo = (v + b2v) * lsv + xi;
-                *reinterpret_cast<f32x4*>(x_out + g) = xo;
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 v = {acc_o[u][0][4 * q], acc_o[u][0][4 * q + 1], acc_o[u][0][4 * q + 2], acc_o[u][0][4 * q + 3]};
+                *reinterpret_cast<f32x4*>(&part[tw][j * 132 + 32 * u + 8 * q + 4 * h]) = v;
             }
-            *reinterpret_cast<f32x4*>(&red[r * NODE_LDS_STRIDE + 4 * c4]) = xo;  // same thread read it above
-        }
     }
     __syncthreads();
-    {
-        // mean over orientations (feeds the scalar / global read-outs, which commute with the mean)
-        const int c = tid & 127, n2 = tid >> 7;
-        const int n = n0 + n2;
-        if (n < N) {
-            float sum = 0.f;
+    if (half == 1 || !tile_live) return;
 #pragma unroll
-            for (int o = 0; o < 16; ++o) sum += red[(16 * n2 + o) * NODE_LDS_STRIDE + c];
-            xbar[(size_t)n * C + c] = sum * (1.0f / 16.0f);
+    for (int u = 0; u < TC; ++u)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(&part[tw][j * 132 + 32 * u + 8 * q + 4 * h]);
+#pragma unroll
+            for (int m = 0; m < 4; ++m) acc_o[u][0][4 * q + m] += v[m];  // (quarters 0+1) + (quarters 2+3)
         }
-        // vector read-out channel (column S of read_out_layers): one dot product per (node, orientation)
-        const float wv0 = ro_wT[(size_t)lane * (S + 4) + S], wv1 = ro_wT[(size_t)(lane + 64) * (S + 4) + S];
-        const float bv = ro_b[S];
+
+    // ---- bias, layer scale, residual; write x_out; read-out partials (all in registers) ------------------
+    float vdot = 0.f;
+    const float inv16 = 1.0f / 16.0f;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int r = 8 * wave + i;
-            const int nn = n0 + (r >> 4), o = r & 15;
-            float d = red[r * NODE_LDS_STRIDE + lane] * wv0 + red[r * NODE_LDS_STRIDE + lane + 64] * wv1;
+    for (int u = 0; u < TC; ++u)
 #pragma unroll
-            for (int off = 32; off >= 1; off >>= 1) d += __shfl_xor(d, off, 64);
-            if (lane == 0 && nn < N) {
-                const size_t g = (size_t)nn * 16 + o;
-                vsum[g] = (first_layer ? 0.0f : vsum[g]) + (d + bv);
+        for (int q = 0; q < 4; ++q) {
+            const int c0 = 32 * u + 8 * q + 4 * h;
+            const f32x4 b2v = *reinterpret_cast<const f32x4*>(mb2 + c0);
+            const f32x4 lsv = *reinterpret_cast<const f32x4*>(ls + c0);
+            const f32x4 xi = *reinterpret_cast<const f32x4*>(x_in + rowoff + 32 * u + 8 * q);
+            f32x4 xo;
+#pragma unroll
+            for (int m = 0; m < 4; ++m) xo[m] = (acc_o[u][0][4 * q + m] + b2v[m]) * lsv[m] + xi[m];
+            if (valid) *reinterpret_cast<f32x4*>(x_out + rowoff + 32 * u + 8 * q) = xo;
+            // vector read-out channel (column S of read_out_layers)
+#pragma unroll
+            for (int m = 0; m < 4; ++m) vdot += xo[m] * ro_wT[(size_t)(c0 + m) * (S + 4) + S];
+            // mean over the node's 16 orientations: butterfly over lanes j&15 (same h, same node)
+            f32x4 sum = xo;
+#pragma unroll
+            for (int off = 1; off < 16; off <<= 1) {
+#pragma unroll
+                for (int m = 0; m < 4; ++m) sum[m] += __shfl_xor(sum[m], off, 64);
+            }
+            if (valid && o == 0) {
+                const f32x4 mean = {sum[0] * inv16, sum[1] * inv16, sum[2] * inv16, sum[3] * inv16};
+                *reinterpret_cast<f32x4*>(xbar + (size_t)n * C + c0) = mean;
             }
         }
+    vdot += __shfl_xor(vdot, 32, 64);
+    if (valid && h == 0) {
+        const size_t g = (size_t)n * 16 + o;
+        vsum[g] = (first_layer ? 0.0f : vsum[g]) + (vdot + ro_b[S]);
     }
 }
 
@@ -406,7 +394,7 @@ int arreau_launch_node_layer(const arreau_model* m, int layer, const float* kbuf
     hipLaunchKernelGGL((conv_kernel<128>), dim3(conv_blocks), dim3(512), 0, s, kbuf + (size_t)layer * layer_stride, deg,
                        src, x_in, m->fk + (size_t)layer * 16 * 16 * C, m->conv_bias + (size_t)layer * C, N, m->k, x_conv);
     ARREAU_CHECK_HIP(hipGetLastError());
-    hipLaunchKernelGGL((mlp_kernel<128, 512>), dim3((N + 1) / 2), dim3(256), 0, s, x_conv, x_in, x_out,
+    hipLaunchKernelGGL((mlp_kernel<128, 512>), dim3((N + 3) / 4), dim3(256), 0, s, x_conv, x_in, x_out,
                        m->ln_w + (size_t)layer * C, m->ln_b + (size_t)layer * C, m->mlp + (size_t)layer * mlp_layer,
                        m->mb1 + (size_t)layer * H, m->mb2 + (size_t)layer * C, m->ls + (size_t)layer * C,
                        m->ro_wT + (size_t)layer * C * (S + 4), m->ro_b + (size_t)layer * (S + 4), S, N,
