@@ -47,6 +47,7 @@ struct arreau_model {
     const float* w2p;        // basis layer 2, MFMA-packed                            out D, in C
     const float* b2;         // [D]
     const float* wkp;        // [L] conv.kernel.weight, MFMA-packed                   out C, in D
+    const float* edge_bf16;  // w1 | w2 | wk_l as bf16x3 chunks (uint16 data), one chunk per output tile
     float* fk;               // [L][O(o)][O(p)][C] fiber kernels / O (written once by the precompute kernel)
     const float* conv_bias;  // [L][C]
     const float* ln_w;       // [L][C]
@@ -175,6 +176,8 @@ int arreau_launch_prep(const arreau_model* m, const float* frac, const float* le
                        int32_t* batch, float* cvec, hipStream_t s);
 int arreau_launch_edge(const arreau_model* m, const float* dir, const float* dist, const int32_t* deg,
                        const int32_t* batch, const float* lattice, int N, float* kbuf, hipStream_t s);
+int arreau_launch_edge_bf16x6(const arreau_model* m, const float* dir, const float* dist, const int32_t* deg,
+                              const int32_t* batch, const float* lattice, int N, float* kbuf, hipStream_t s);
 int arreau_launch_embed(const arreau_model* m, const float* frac, const int32_t* types, const float* lattice,
                         const int32_t* batch, const float* cvec, int N, float* x0, hipStream_t s);
 int arreau_launch_node_layer(const arreau_model* m, int layer, const float* kbuf, const int32_t* deg,

@@ -29,6 +29,49 @@ static void pack_linear(const float* W, int out_dim, int in_dim, int in_stride, 
                     }
 }
 
+// bf16x3 planes for the split-precision MFMA path.  Truncation split: w = w1 + w2 + w3 EXACTLY, each term
+// holding 8 significant bits (bf16), so six bf16 products (a1b1, a1b2, a2b1, a1b3, a2b2, a3b1) reproduce the
+// fp32 product to ~3 * 2^-24 relative while running on the 16x faster bf16 matrix pipe.
+static inline uint16_t bf16_trunc_bits(float x) {
+    uint32_t u;
+    memcpy(&u, &x, 4);
+    return (uint16_t)(u >> 16);
+}
+static inline float bf16_bits_to_float(uint16_t b) {
+    uint32_t u = (uint32_t)b << 16;
+    float x;
+    memcpy(&x, &u, 4);
+    return x;
+}
+
+// Chunked bf16x3 packing for v_mfma_f32_32x32x16_bf16.  One chunk = one 32-row output tile u:
+//   Q[u][t][s][plane][lane][jj] = plane( W[out = 32u + (lane&31)][in = 32t + 16s + 8(jj>>2) + 4(lane>>5) + (jj&3)] )
+// (t: 32-wide input tile, s: 16-deep k-step, jj = 0..7).  The k permutation is the one under which the
+// previous layer's fp32 accumulator registers 8s..8s+7, converted pairwise to bf16, ARE the B fragment of
+// k-step s (cdna_hip_programming.md, "An accumulator tile as the next MFMA's operand").
+// 1 KiB per (u, t, s, plane) fragment; a chunk is 6 * (in_pad / 32) KiB.
+static void pack_linear_bf16x3(const float* W, int out_dim, int in_dim, int in_stride, int out_pad, int in_pad,
+                               uint16_t* Q) {
+    const int U = out_pad / 32, Tn = in_pad / 32;
+    for (int u = 0; u < U; ++u)
+        for (int t = 0; t < Tn; ++t)
+            for (int s = 0; s < 2; ++s)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int jj = 0; jj < 8; ++jj) {
+                        const int out = 32 * u + (lane & 31);
+                        const int in = 32 * t + 16 * s + 8 * (jj >> 2) + 4 * (lane >> 5) + (jj & 3);
+                        const float w = (out < out_dim && in < in_dim) ? W[(size_t)out * in_stride + in] : 0.0f;
+                        const uint16_t b1 = bf16_trunc_bits(w);
+                        const float r1 = w - bf16_bits_to_float(b1);
+                        const uint16_t b2 = bf16_trunc_bits(r1);
+                        const float r2 = r1 - bf16_bits_to_float(b2);
+                        const uint16_t b3 = bf16_trunc_bits(r2);
+                        const uint16_t pl[3] = {b1, b2, b3};
+                        for (int p = 0; p < 3; ++p)
+                            Q[((((((size_t)u * Tn + t) * 2 + s) * 3 + p) * 64) + lane) * 8 + jj] = pl[p];
+                    }
+}
+
 // Monomial table: distinct monomials of degree 1..3 in 6 variables in the canonical order
 // (i), (i<=j), (i<=j<=k), each lexicographic.  The device code (edge.hip) generates them in the
 // same order.
@@ -140,6 +183,18 @@ extern "C" int arreau_model_create(const arreau_config* cfg, const arreau_state_
         pack_linear(sd->conv_kernel_w + (size_t)l * C * D, C, D, D, C, D, bb.data.data() + off_wkp + l * wk_tile);
     const size_t off_b1 = bb.put(sd->basis_b1, C);
     const size_t off_b2 = bb.put(sd->basis_b2, D);
+    // the same three matrices as bf16x3 chunks (one chunk per output tile): w1 | w2 | wk_0..L-1
+    const size_t h_w1 = (size_t)(C / 32) * (ARREAU_MONO_PAD / 32) * 6 * 512;   // uint16 count
+    const size_t h_w2 = (size_t)(D / 32) * (C / 32) * 6 * 512;
+    const size_t h_wk = (size_t)(C / 32) * (D / 32) * 6 * 512;
+    const size_t off_es16 = bb.reserve((h_w1 + h_w2 + h_wk * L) / 2 + 64);
+    {
+        uint16_t* q = reinterpret_cast<uint16_t*>(bb.data.data() + off_es16);
+        pack_linear_bf16x3(w1f.data(), C, ARREAU_MONO_PAD, ARREAU_MONO_PAD, C, ARREAU_MONO_PAD, q);
+        pack_linear_bf16x3(sd->basis_w2, D, C, C, D, C, q + h_w1);
+        for (int l = 0; l < L; ++l)
+            pack_linear_bf16x3(sd->conv_kernel_w + (size_t)l * C * D, C, D, D, C, D, q + h_w1 + h_w2 + l * h_wk);
+    }
 
     const size_t off_fk = bb.reserve((size_t)L * O * O * C);
     const size_t off_conv_bias = bb.put(sd->conv_bias, (size_t)L * C);
@@ -215,7 +270,7 @@ extern "C" int arreau_model_create(const arreau_config* cfg, const arreau_state_
     }
     float* b = m->blob;
     m->ori = b + off_ori; m->w1p = b + off_w1p; m->b1 = b + off_b1; m->w2p = b + off_w2p; m->b2 = b + off_b2;
-    m->wkp = b + off_wkp; m->fk = b + off_fk; m->conv_bias = b + off_conv_bias; m->ln_w = b + off_ln_w;
+    m->wkp = b + off_wkp; m->edge_bf16 = b + off_es16; m->fk = b + off_fk; m->conv_bias = b + off_conv_bias; m->ln_w = b + off_ln_w;
     m->ln_b = b + off_ln_b; m->mlp = b + off_mlp; m->mb1 = b + off_mb1; m->mb2 = b + off_mb2;
     m->ls = b + off_ls; m->embT = b + off_embT; m->ro_wT = b + off_ro_wT; m->ro_b = b + off_ro_b;
     m->t_emb_w = b + off_temb; m->ve_sigmas = b + off_ve; m->vp_alpha_bars = b + off_ab; m->vp_betas = b + off_be;

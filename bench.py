@@ -25,6 +25,10 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
 MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32-input MFMA = vector peak
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA (spec)
+# The edge kernel evaluates every fp32 product as six bf16 MFMA products (exact 8+8+8-bit operand splits,
+# fp32 accumulation), so its matrix-pipe roof in fp32-equivalent FLOP/s is the bf16 peak / 6.
+BF16X6_EQUIV_PEAK_TFLOPS = MFMA_BF16_PEAK_TFLOPS / 6.0
 
 
 def edge_kernel_flops_per_row(C=128, D=256, L=5):
@@ -39,6 +43,20 @@ def step_flops_per_atom(k=8, S=90, C=128, D=256, L=5, O=16, W=4):
     per_row = 2 * (258 * C + C * D) + 2 * L * D * C + 2 * L * C
     per_node_ori = L * (2 * O * C + 4 * W * C * C) + 2 * (S + 78) * C + 2 * L * C * (S + 4)
     return k * O * per_row + O * per_node_ori
+
+
+def measured_traffic(B, n):
+    """HBM bytes per launch of the edge kernel from the committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE,
+    separate runs, gfx950 FETCH correction applied) -- only valid for the workload they were taken on."""
+    path = os.path.join(ROOT, "profiles", "hbm_traffic_pmc.json")
+    try:
+        with open(path) as fh:
+            d = json.load(fh)
+        if d.get("crystals_per_gpu") == B and d.get("atoms_per_crystal") == n:
+            return d["edge_kernel_hbm_bytes_per_launch"]
+    except (OSError, ValueError, KeyError):
+        pass
+    return None
 
 
 def log(msg):
@@ -174,6 +192,17 @@ def main():
         edge_flops = e_mean * 16 * edge_kernel_flops_per_row()
         edge_tflops = edge_flops / (mean_ms.value * 1e-3) / 1e12 if mean_ms.value > 0 else 0.0
         step_flops = step_flops_per_atom() * N * (e_mean / (8.0 * N))  # scaled by the edge density actually seen
+        variant = int(os.environ.get("ARREAU_EDGE_VARIANT", "3"))
+        if variant == 3:
+            edge_kernel_name = ("edge_kernel_bf16x6<128,256> (pair invariants + basis MLP + 5 kernel projections; "
+                                "fp32 products as 6 bf16 MFMA products, fp32 accumulate)")
+            edge_peak = BF16X6_EQUIV_PEAK_TFLOPS
+            edge_peak_note = "fp32-equivalent roof of the split scheme: dense bf16 MFMA 2500 TFLOP/s / 6 products"
+        else:
+            edge_kernel_name = "edge_kernel<128,256> (v_mfma_f32_32x32x2_f32)"
+            edge_peak = MFMA_F32_PEAK_TFLOPS
+            edge_peak_note = "fp32-input MFMA peak"
+        edge_traffic = measured_traffic(B, n)
         out = {
             "metric": "denoising steps/sec (crystal-steps, whole node)",
             "value": crystal_steps_per_s,
@@ -199,9 +228,10 @@ def main():
             "crystals_per_min": 60.0 * crystal_steps_per_s / (T - 1),
             "step_tflops_algorithmic": world * step_flops / (ms_per_step * 1e-3) / 1e12,
             "roofline": {
-                "kernel": "edge_kernel<128,256> (pair invariants + basis MLP + 5 kernel projections)",
-                "bound": "mfma", "achieved": edge_tflops, "peak": MFMA_F32_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": edge_tflops / MFMA_F32_PEAK_TFLOPS, "traffic": None,
+                "kernel": edge_kernel_name,
+                "bound": "mfma", "achieved": edge_tflops, "peak": edge_peak, "unit": "TFLOP/s",
+                "frac": edge_tflops / edge_peak, "traffic": edge_traffic,
+                "peak_note": edge_peak_note, "frac_of_fp32_mfma_peak": edge_tflops / MFMA_F32_PEAK_TFLOPS,
                 "avg_launch_ms": mean_ms.value, "launches_timed": int(launches.value),
                 "algorithmic_flops_per_launch": edge_flops,
             },
