@@ -54,6 +54,7 @@ struct arreau_model {
     const float* ln_b;       // [L][C]
     const float* mlp;        // [L][4 quarters][ linear_1 rows of the quarter (out H/4, in C) | linear_2 columns of the
                              //  quarter (out C, in H/4) ], MFMA-packed: one linear stream per (layer, quarter)
+    const float* mlp_bf16;   // the same stream as bf16x3 chunks (uint16 data), 24 KiB per output tile
     const float* mb1;        // [L][H]
     const float* mb2;        // [L][C]
     const float* ls;         // [L][C] layer_scale (ones when absent)
@@ -183,5 +184,7 @@ int arreau_launch_embed(const arreau_model* m, const float* frac, const int32_t*
 int arreau_launch_node_layer(const arreau_model* m, int layer, const float* kbuf, const int32_t* deg,
                              const int32_t* src, const float* x_in, float* x_conv, float* x_out, float* xbar,
                              float* vsum, int N, hipStream_t s);
+int arreau_launch_mlp_bf16x6(const arreau_model* m, int layer, const float* x_conv, const float* x_in, float* x_out,
+                             float* xbar, float* vsum, int N, hipStream_t s);
 int arreau_launch_readout(const arreau_model* m, const float* xbar, const float* vsum, const int32_t* offsets,
                           int B, int N, float* gs, float* eps, float* logits, float* len0, hipStream_t s);

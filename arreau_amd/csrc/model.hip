@@ -213,6 +213,16 @@ extern "C" int arreau_model_create(const arreau_config* cfg, const arreau_state_
             pack_linear(sd->linear1_w + ((size_t)l * H + (size_t)w * HQ) * C, HQ, C, C, HQ, C, dst);
             pack_linear(sd->linear2_w + (size_t)l * C * H + (size_t)w * HQ, C, HQ, H, C, HQ, dst + q1);
         }
+    // the same per-quarter layout as bf16x3 chunks (one 24 KiB block per output tile; the kernel takes two per chunk)
+    const size_t hq1 = (size_t)(HQ / 32) * (C / 32) * 6 * 512;   // uint16 count of W1 quarter
+    const size_t hq2 = (size_t)(C / 32) * (HQ / 32) * 6 * 512;   // uint16 count of W2 quarter
+    const size_t off_mlp16 = bb.reserve((hq1 + hq2) * 4 * L / 2 + 64);
+    for (int l = 0; l < L; ++l)
+        for (int w = 0; w < 4; ++w) {
+            uint16_t* dst = reinterpret_cast<uint16_t*>(bb.data.data() + off_mlp16) + ((size_t)l * 4 + w) * (hq1 + hq2);
+            pack_linear_bf16x3(sd->linear1_w + ((size_t)l * H + (size_t)w * HQ) * C, HQ, C, C, HQ, C, dst);
+            pack_linear_bf16x3(sd->linear2_w + (size_t)l * C * H + (size_t)w * HQ, C, HQ, H, C, HQ, dst + hq1);
+        }
     const size_t off_mb1 = bb.put(sd->linear1_b, (size_t)L * H);
     const size_t off_mb2 = bb.put(sd->linear2_b, (size_t)L * C);
 
@@ -271,7 +281,7 @@ extern "C" int arreau_model_create(const arreau_config* cfg, const arreau_state_
     float* b = m->blob;
     m->ori = b + off_ori; m->w1p = b + off_w1p; m->b1 = b + off_b1; m->w2p = b + off_w2p; m->b2 = b + off_b2;
     m->wkp = b + off_wkp; m->edge_bf16 = b + off_es16; m->fk = b + off_fk; m->conv_bias = b + off_conv_bias; m->ln_w = b + off_ln_w;
-    m->ln_b = b + off_ln_b; m->mlp = b + off_mlp; m->mb1 = b + off_mb1; m->mb2 = b + off_mb2;
+    m->ln_b = b + off_ln_b; m->mlp = b + off_mlp; m->mlp_bf16 = b + off_mlp16; m->mb1 = b + off_mb1; m->mb2 = b + off_mb2;
     m->ls = b + off_ls; m->embT = b + off_embT; m->ro_wT = b + off_ro_wT; m->ro_b = b + off_ro_b;
     m->t_emb_w = b + off_temb; m->ve_sigmas = b + off_ve; m->vp_alpha_bars = b + off_ab; m->vp_betas = b + off_be;
     m->q1t = b + off_q1t; m->qmats = b + off_qm;
