@@ -98,13 +98,19 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
-    dev = torch.device("cuda", local_rank)
+    # ARREAU_BENCH_BACKEND=gloo + ARREAU_BENCH_ONE_DEVICE=1 rehearse the multi-rank path on a one-GPU box
+    backend = os.environ.get("ARREAU_BENCH_BACKEND", "nccl")
+    one_device = os.environ.get("ARREAU_BENCH_ONE_DEVICE", "0") == "1"
+    dev = torch.device("cuda", 0 if one_device else local_rank)
     torch.cuda.set_device(dev)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from arreau_amd import _hip, build
     build.build(verbose=False)
@@ -180,7 +186,7 @@ def main():
     e_end = degree_sum()
 
     if dist is not None:
-        tt = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        tt = torch.tensor([elapsed], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
 
