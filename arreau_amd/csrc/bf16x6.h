@@ -112,3 +112,19 @@ __device__ __forceinline__ void stage_store(const u32x4 (&st)[EB_STAGE], u32x4* 
     }
 }
 
+
+// LDS-DMA staging: fragment f = 4 i + wave of the next chunk goes straight from L2 into the idle LDS buffer
+// (global_load_lds_dwordx4: 1 KiB per wave-instruction, destination = wave-uniform base + lane * 16), no VGPR
+// staging and no ds_write burst.  The data is ordered for the readers by the issuing wave's vmcnt(0) followed by
+// the workgroup barrier (__syncthreads() emits both while a DMA is in flight).
+template <int NF>
+__device__ __forceinline__ void stage_dma(const u32x4* __restrict__ chunk, u32x4* __restrict__ buf, int wave, int lane) {
+#pragma unroll
+    for (int i = 0; i < (NF + 3) / 4; ++i) {
+        const int f = 4 * i + wave;
+        if (NF % 4 == 0 || f < NF)
+            __builtin_amdgcn_global_load_lds(
+                (const __attribute__((address_space(1))) void*)(chunk + (size_t)f * 64 + lane),
+                (__attribute__((address_space(3))) void*)(buf + (size_t)f * 64), 16, 0, 0);
+    }
+}

@@ -27,7 +27,7 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel_bf16x6(
     const float* __restrict__ ro_b,      // [S+4]
     int S, int N, int first_layer,
     float* __restrict__ xbar,            // [N][C] this layer
-    float* __restrict__ vsum)            // [N][16]
+    float* __restrict__ vsum, int dbg)   // [N][16]
 {
     static_assert(C == 128 && H == 512, "chunking below assumes C = 128, H = 512");
     constexpr int TC = C / 32;
@@ -107,15 +107,17 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel_bf16x6(
         for (int ch = 0; ch < 2; ++ch) {  // ---- hid tiles 2ch, 2ch+1 ----
             const int cur = ch & 1;
             chunk += (size_t)MLP_FRAGS * 64;
-            stage_load<MLP_FRAGS>(st, chunk, wave, lane);  // always another chunk after a W1 chunk
+            if (!(dbg & 4)) stage_load<MLP_FRAGS>(st, chunk, wave, lane);  // always another chunk after a W1 chunk
             f32x16 a0 = arreau_bias_tile(mb1 + w * HQ, 2 * ch, h);
             f32x16 a1 = arreau_bias_tile(mb1 + w * HQ, 2 * ch + 1, h);
-            if (active) mma_range<TC, 0, 2 * TC>(a0, lds[cur], xn, lane);
-            stage_store<MLP_FRAGS>(st, lds[cur ^ 1], wave, lane);
+            if (active && !(dbg & 2)) mma_range<TC, 0, 2 * TC>(a0, lds[cur], xn, lane);
+            if (!(dbg & 4)) stage_store<MLP_FRAGS>(st, lds[cur ^ 1], wave, lane);
             if (active) {
-                mma_range<TC, 0, 2 * TC>(a1, lds[cur] + (size_t)TILE_FRAGS * 64, xn, lane);
+                if (!(dbg & 2)) mma_range<TC, 0, 2 * TC>(a1, lds[cur] + (size_t)TILE_FRAGS * 64, xn, lane);
+                if (!(dbg & 1)) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) { a0[r] = gelu_fast(a0[r]); a1[r] = gelu_fast(a1[r]); }
+                }
                 hid[2 * ch] = split_tile(a0);
                 hid[2 * ch + 1] = split_tile(a1);
             }
@@ -126,14 +128,14 @@ __global__ __launch_bounds__(256, 1) void mlp_kernel_bf16x6(
             const int cur = ch & 1;
             chunk += (size_t)MLP_FRAGS * 64;
             const bool more = !(w == 3 && ch == 1);  // workgroup-uniform
-            if (more) stage_load<MLP_FRAGS>(st, chunk, wave, lane);
-            if (active) mma_range<THQ, 0, 2 * THQ>(acc_o[2 * ch], lds[cur], hid, lane);
-            if (more) stage_store<MLP_FRAGS>(st, lds[cur ^ 1], wave, lane);
-            if (active) mma_range<THQ, 0, 2 * THQ>(acc_o[2 * ch + 1], lds[cur] + (size_t)TILE_FRAGS * 64, hid, lane);
+            if (more && !(dbg & 4)) stage_load<MLP_FRAGS>(st, chunk, wave, lane);
+            if (active && !(dbg & 2)) mma_range<THQ, 0, 2 * THQ>(acc_o[2 * ch], lds[cur], hid, lane);
+            if (more && !(dbg & 4)) stage_store<MLP_FRAGS>(st, lds[cur ^ 1], wave, lane);
+            if (active && !(dbg & 2)) mma_range<THQ, 0, 2 * THQ>(acc_o[2 * ch + 1], lds[cur] + (size_t)TILE_FRAGS * 64, hid, lane);
             __syncthreads();
         }
     }
-    if (!active) return;
+    if (!active || (dbg & 8)) return;
 
     // ---- bias, layer scale, residual; write x_out; read-out partials (all in registers) ------------------
     float vdot = 0.f;
@@ -179,12 +181,13 @@ int arreau_launch_mlp_bf16x6(const arreau_model* m, int layer, const float* x_co
         return ARREAU_EINVAL;
     }
     const size_t layer_u32x4 = (size_t)2 * H * C * 3 * 2 / 16;  // bytes of W1 + W2 as 3 bf16 planes, in 16-byte units
+    static const int dbg = [] { const char* e = getenv("ARREAU_MLP_DBG"); return e ? atoi(e) : 0; }();
     hipLaunchKernelGGL((mlp_kernel_bf16x6<128, 512>), dim3((N + 7) / 8), dim3(256), 0, s, x_conv, x_in, x_out,
                        m->ln_w + (size_t)layer * C, m->ln_b + (size_t)layer * C,
                        reinterpret_cast<const u32x4*>(m->mlp_bf16) + (size_t)layer * layer_u32x4,
                        m->mb1 + (size_t)layer * H, m->mb2 + (size_t)layer * C, m->ls + (size_t)layer * C,
                        m->ro_wT + (size_t)layer * C * (S + 4), m->ro_b + (size_t)layer * (S + 4), S, N,
-                       layer == 0 ? 1 : 0, xbar + (size_t)layer * N * C, vsum);
+                       layer == 0 ? 1 : 0, xbar + (size_t)layer * N * C, vsum, dbg);
     ARREAU_CHECK_HIP(hipGetLastError());
     return ARREAU_OK;
 }
