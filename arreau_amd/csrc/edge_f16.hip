@@ -1,0 +1,220 @@
+// K2+K3, fp16x3 split-precision variant (default): the fused edge pipeline (pair invariants -> monomials ->
+// basis MLP -> window -> L kernel projections, activations in registers) with every fp32 product evaluated
+// as three fp16 MFMA products (f16x3.h): half the matrix-pipe work and two thirds of the operand bytes of
+// the bf16x6 kernel (edge_bf16.hip), 16 registers per activation tile instead of 24 -- which is what lets
+// two waves share a SIMD (256 registers each), so one wave's VALU phases (GELU, splits, attribute set-up),
+// LDS hand-overs and store traffic overlap the partner's MFMA stream.
+//
+// Workgroup = 8 waves = the 16 edge slots of two receivers (2 waves per SIMD).  Weight chunks (one 32-row
+// output tile: 12 / 16 / 32 KiB) are shared through a double-buffered LDS ring: each wave fetches 1/8 of
+// the next chunk into registers at the top of a chunk and writes it to the idle buffer in the middle of the
+// chunk's MFMA stream; one barrier per chunk.
+#include <stdlib.h>
+#include <utility>
+
+#include "f16x3.h"
+#include "internal.h"
+
+// ---- compile-time monomial table (same canonical order as fold_poly_weight in model.hip) -------------
+struct MonoIdxH { int n, i, j, k; };
+__host__ __device__ constexpr MonoIdxH mono_idx_h(int f) {
+    int p = 0;
+    for (int i = 0; i < 6; ++i, ++p)
+        if (p == f) return {1, i, 0, 0};
+    for (int i = 0; i < 6; ++i)
+        for (int j = i; j < 6; ++j, ++p)
+            if (p == f) return {2, i, j, 0};
+    for (int i = 0; i < 6; ++i)
+        for (int j = i; j < 6; ++j)
+            for (int k = j; k < 6; ++k, ++p)
+                if (p == f) return {3, i, j, k};
+    return {0, 0, 0, 0};
+}
+template <int F>
+__device__ __forceinline__ float mono_at_h(const float (&a)[6]) {
+    constexpr MonoIdxH m = mono_idx_h(F);
+    if constexpr (m.n == 1) return a[m.i];
+    else if constexpr (m.n == 2) return a[m.i] * a[m.j];
+    else if constexpr (m.n == 3) return (a[m.i] * a[m.j]) * a[m.k];
+    else return 0.0f;
+}
+// "accumulator-layout" tile of monomials: register r of tile T holds feature 32T + (r&3) + 8(r>>2) + 4h
+template <int T, int... R>
+__device__ __forceinline__ f32x16 mono_tile_h(const float (&a)[6], int h, std::integer_sequence<int, R...>) {
+    f32x16 v;
+    ((v[R] = h ? mono_at_h<32 * T + 8 * (R >> 2) + (R & 3) + 4>(a) : mono_at_h<32 * T + 8 * (R >> 2) + (R & 3)>(a)), ...);
+    return v;
+}
+
+
+#define EH_WAVES 8
+
+template <int C, int D>
+__global__ __launch_bounds__(512, 2) void edge_kernel_f16x3(
+    const float* __restrict__ nbr_dir,   // [N][k][3]
+    const float* __restrict__ nbr_dist,  // [N][k]
+    const int32_t* __restrict__ deg,     // [N]
+    const int32_t* __restrict__ batch,   // [N] crystal of node
+    const float* __restrict__ lattice,   // [B][9]
+    const float* __restrict__ ori,       // [16][3]
+    const u32x4* __restrict__ stream,    // fp16x3 chunks: w1 (C/32 chunks) | w2 (D/32) | wk_l (L * C/32)
+    const float* __restrict__ b1, const float* __restrict__ b2, float r_max, int N, int k, int L,
+    float* __restrict__ kbuf)            // [L][N*k*16][C]
+{
+    constexpr int TC = C / 32, TD = D / 32, TM = ARREAU_MONO_PAD / 32;
+    constexpr int NF1 = TM * 4, NF2 = TC * 4, NF3 = TD * 4;  // 1 KiB fragments per chunk: 12, 16, 32
+    constexpr int NST = (NF3 + EH_WAVES - 1) / EH_WAVES;     // fragments a wave stages per chunk (4)
+    static_assert(TM == 3 && ((TC + TD) & 1) == 0, "chunk geometry / buffer parity");
+    __shared__ u32x4 lds[2][NF3 * 64];                                        // 2 x 32 KiB
+    __shared__ __attribute__((aligned(16))) float otile[EH_WAVES][32 * 36];   // per-wave transpose pad for the stores
+
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int h = lane >> 5, j = lane & 31;
+    const int node_raw = 2 * blockIdx.x + (wave >> 2);
+    const int node = min(node_raw, N - 1);
+    const int wn = wave & 3;                       // wave within its node: slots 2wn, 2wn+1
+    const int nd = node_raw < N ? min(deg[node], k) : 0;
+    const bool active = 2 * wn < nd;               // wave-uniform; idle waves still stage weights and meet the barriers
+    const int slot = 2 * wn + (j >> 4);
+    const int o = j & 15;
+    const int slot_c = min(slot, k - 1);
+
+    u32x4 st[NST];
+    const u32x4* chunk = stream;
+    stage_load2<NF1, EH_WAVES>(reinterpret_cast<u32x4(&)[(NF1 + EH_WAVES - 1) / EH_WAVES]>(st), chunk, wave, lane);
+
+    // ---- per-row attributes (transforms/invariants.py:82-88) ------------------------------------------
+    float a[6], window;
+    {
+        const size_t e = (size_t)node * k + slot_c;
+        const float dx = nbr_dir[3 * e + 0], dy = nbr_dir[3 * e + 1], dz = nbr_dir[3 * e + 2];
+        const float dist = nbr_dist[e];
+        const float ox = ori[3 * o + 0], oy = ori[3 * o + 1], oz = ori[3 * o + 2];
+        a[0] = (dx * ox + dy * oy) + dz * oz;
+        const float rx = dx - a[0] * ox, ry = dy - a[0] * oy, rz = dz - a[0] * oz;
+        a[1] = sqrtf((rx * rx + ry * ry) + rz * rz);
+        a[2] = dist;
+        const float* Lm = lattice + 9 * (size_t)batch[node];
+        const float dn = fmaxf(sqrtf((dx * dx + dy * dy) + dz * dz), 1e-8f);
+        const float ux = dx / dn, uy = dy / dn, uz = dz / dn;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const float lx = Lm[3 * i], ly = Lm[3 * i + 1], lz = Lm[3 * i + 2];
+            const float ln = fmaxf(sqrtf((lx * lx + ly * ly) + lz * lz), 1e-8f);
+            a[3 + i] = (ux * (lx / ln) + uy * (ly / ln)) + uz * (lz / ln);
+        }
+        const float u = dist / r_max;
+        const float u2 = u * u, u6 = u2 * u2 * u2;
+        const float w = 1.0f - 28.0f * u6 + 48.0f * u6 * u - 21.0f * u6 * u2;
+        window = (slot < nd && dist < r_max) ? w : 0.0f;
+    }
+    Planes2 bm[TM];
+    bm[0] = split_tile2(mono_tile_h<0>(a, h, std::make_integer_sequence<int, 16>{}));
+    bm[1] = split_tile2(mono_tile_h<1>(a, h, std::make_integer_sequence<int, 16>{}));
+    bm[2] = split_tile2(mono_tile_h<2>(a, h, std::make_integer_sequence<int, 16>{}));
+
+    stage_store2<NF1, EH_WAVES>(reinterpret_cast<u32x4(&)[(NF1 + EH_WAVES - 1) / EH_WAVES]>(st), lds[0], wave, lane);
+    __syncthreads();
+
+    // ---- layer 1: h = GELU(W1f . mono + b1) -------------------------------------------------------------
+    Planes2 h1[TC];
+#pragma unroll
+    for (int u = 0; u < TC; ++u) {
+        const int cur = u & 1;
+        chunk += (size_t)NF1 * 64;
+        if (u + 1 < TC) stage_load2<NF1, EH_WAVES>(reinterpret_cast<u32x4(&)[(NF1 + EH_WAVES - 1) / EH_WAVES]>(st), chunk, wave, lane);
+        else stage_load2<NF2, EH_WAVES>(reinterpret_cast<u32x4(&)[(NF2 + EH_WAVES - 1) / EH_WAVES]>(st), chunk, wave, lane);
+        if (active) {
+            f32x16 acc = arreau_bias_tile(b1, u, h), cross;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) cross[r] = 0.f;
+            mma_range2<TM, 0, 2 * TM>(acc, cross, lds[cur], bm, lane);
+            acc = fold_cross(acc, cross);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = gelu_fast(acc[r]);
+            h1[u] = split_tile2(acc);
+        }
+        if (u + 1 < TC) stage_store2<NF1, EH_WAVES>(reinterpret_cast<u32x4(&)[(NF1 + EH_WAVES - 1) / EH_WAVES]>(st), lds[cur ^ 1], wave, lane);
+        else stage_store2<NF2, EH_WAVES>(reinterpret_cast<u32x4(&)[(NF2 + EH_WAVES - 1) / EH_WAVES]>(st), lds[cur ^ 1], wave, lane);
+        __syncthreads();
+    }
+    // ---- layer 2: basis = GELU(W2 . h + b2) * window ------------------------------------------------------
+    Planes2 basis[TD];
+#pragma unroll
+    for (int u = 0; u < TD; ++u) {
+        const int cur = (TC + u) & 1;
+        chunk += (size_t)NF2 * 64;
+        if (u + 1 < TD) stage_load2<NF2, EH_WAVES>(reinterpret_cast<u32x4(&)[(NF2 + EH_WAVES - 1) / EH_WAVES]>(st), chunk, wave, lane);
+        else stage_load2<NF3, EH_WAVES>(st, chunk, wave, lane);
+        if (active) {
+            f32x16 acc = arreau_bias_tile(b2, u, h), cross;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) cross[r] = 0.f;
+            mma_range2<TC, 0, 2 * TC>(acc, cross, lds[cur], h1, lane);
+            acc = fold_cross(acc, cross);
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] = gelu_fast(acc[r]) * window;
+            basis[u] = split_tile2(acc);
+        }
+        if (u + 1 < TD) stage_store2<NF2, EH_WAVES>(reinterpret_cast<u32x4(&)[(NF2 + EH_WAVES - 1) / EH_WAVES]>(st), lds[cur ^ 1], wave, lane);
+        else stage_store2<NF3, EH_WAVES>(st, lds[cur ^ 1], wave, lane);
+        __syncthreads();
+    }
+    // ---- per layer: kernel_l = Wk_l . basis  (conv.py:110), one output tile per chunk ---------------------
+    const size_t layer_stride = (size_t)N * k * 16 * C;
+    const size_t row0 = ((size_t)node * k + 2 * wn) * 16;  // first K row of this wave's 32-row tile
+    const int nchunks = L * TC;
+    int cur = 0;  // (TC + TD) is even
+    f32x16 done;  // finished tile of the previous chunk, stored one chunk late (see below)
+    float* pad = otile[wave];
+    // Transpose a finished 32x32 tile through a wave-private LDS pad so that every store instruction writes
+    // whole 128-byte lines (8 lanes per row) instead of 64 scattered 16-byte pieces.
+    auto store_tile = [&](const f32x16& t, int cidx_done) {
+        const int l = cidx_done / TC, u = cidx_done - l * TC;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 v = {t[4 * q], t[4 * q + 1], t[4 * q + 2], t[4 * q + 3]};
+            *reinterpret_cast<f32x4*>(&pad[j * 36 + 8 * q + 4 * h]) = v;
+        }
+        float* dst = kbuf + (size_t)l * layer_stride + row0 * C + 32 * u + 4 * (lane & 7);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = 8 * i + (lane >> 3);  // row of the wave tile: slot 2*wn + (r >> 4), orientation r & 15
+            const f32x4 v = *reinterpret_cast<const f32x4*>(&pad[r * 36 + 4 * (lane & 7)]);
+            if (2 * wn + (r >> 4) < nd) *reinterpret_cast<f32x4*>(dst + (size_t)r * C) = v;
+        }
+    };
+#pragma unroll 1
+    for (int cidx = 0; cidx < nchunks; ++cidx) {
+        chunk += (size_t)NF3 * 64;
+        const bool more = cidx + 1 < nchunks;  // workgroup-uniform
+        // vmcnt retires in order: the next chunk's fragment loads are issued BEFORE the previous tile's stores,
+        // so waiting for the fragments (mid-chunk) never waits for the stores' HBM round trip.
+        if (more) stage_load2<NF3, EH_WAVES>(st, chunk, wave, lane);
+        if (active && cidx > 0) store_tile(done, cidx - 1);
+        f32x16 acc, cross;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc[r] = 0.0f; cross[r] = 0.0f; }
+        if (active) mma_range2<TD, 0, TD>(acc, cross, lds[cur], basis, lane);
+        if (more) stage_store2<NF3, EH_WAVES>(st, lds[cur ^ 1], wave, lane);
+        if (active) mma_range2<TD, TD, 2 * TD>(acc, cross, lds[cur], basis, lane);
+        __syncthreads();
+        done = fold_cross(acc, cross);
+        cur ^= 1;
+    }
+    if (active) store_tile(done, nchunks - 1);
+}
+
+int arreau_launch_edge_f16x3(const arreau_model* m, const float* dir, const float* dist, const int32_t* deg,
+                             const int32_t* batch, const float* lattice, int N, float* kbuf, hipStream_t s) {
+    if (N == 0) return ARREAU_OK;
+    if (!(m->C == 128 && m->D == 256 && m->k <= 8)) {
+        arreau_set_error("edge kernel (fp16x3): unsupported (hidden_dim, basis_dim, max_neighbors)");
+        return ARREAU_EINVAL;
+    }
+    hipLaunchKernelGGL((edge_kernel_f16x3<128, 256>), dim3((N + 1) / 2), dim3(512), 0, s, dir, dist, deg, batch, lattice,
+                       m->ori, reinterpret_cast<const u32x4*>(m->edge_f16), m->b1, m->b2, m->cfg.radius, N, m->k, m->L,
+                       kbuf);
+    ARREAU_CHECK_HIP(hipGetLastError());
+    return ARREAU_OK;
+}

@@ -1,0 +1,125 @@
+// Split-precision (fp16x3) building blocks shared by edge_f16.hip and node_f16.hip.
+//
+// Every fp32 product a*b is evaluated as three fp16 products on v_mfma_f32_32x32x16_f16 with fp32
+// accumulation.  Operands are split into two fp16 planes (11 + 11 significant bits, round to nearest):
+//     a = a1 + a2 / 2^11 ,   a1 = f16(a) ,   a2 = f16((a - a1) * 2^11)      (the residual is scaled so that it
+//                                                                           stays a normal fp16 number)
+//     a*b ~= a1 b1 + (a1 b2 + a2 b1) / 2^11                                  (dropped: a2 b2 / 2^22)
+// `main` accumulates a1 b1, `cross` accumulates a1 b2 + a2 b1 and is folded in with one fma per element at the
+// end of a tile.  Operand representation error 2^-22 relative (fp32: 2^-24); measured GEMM error equals the
+// fp32-MFMA path's because accumulation rounding dominates ("Numerics").  fp16 range: operands must
+// stay below 65504 in magnitude -- activations are saturated at +-60000 before the split (LayerNorm outputs,
+// GELU outputs and the geometric monomials of this model are O(1..100)); weights are checked on the host.
+// Half the matrix-pipe work and two thirds of the operand bytes of the bf16x6 scheme (bf16x6.h).
+#pragma once
+#include <hip/hip_fp16.h>
+
+#include "internal.h"
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+#define F16X3_SCALE 2048.0f
+#define F16X3_INV_SCALE (1.0f / 2048.0f)
+
+// GELU with the Abramowitz-Stegun 7.1.26 complementary error function (|error| <= 1.5e-7 on erf, i.e.
+// <= 0.75e-7 |x| on GELU): one rcp + one exp2 + 5 fma, branch-free, about half the VALU work of the 1-ulp erf in
+// internal.h.
+__device__ __forceinline__ float gelu_fast(float x) {
+    const float z = fabsf(x) * 0.70710678118654752440f;
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+    float p = fmaf(1.061405429f, t, -1.453152027f);
+    p = fmaf(p, t, 1.421413741f);
+    p = fmaf(p, t, -0.284496736f);
+    p = fmaf(p, t, 0.254829592f);
+    const float e = __builtin_amdgcn_exp2f((x * x) * -0.72134752044448170368f);  // exp(-z^2), z^2 = x^2 / 2
+    const float half_erfc = 0.5f * (p * t) * e;                                     // 0.5 * erfc(|z|)
+    const float phi = x < 0.0f ? half_erfc : 1.0f - half_erfc;
+    return x * phi;
+}
+
+// ---- fp16 planes of a 32x32 fp32 tile (B-operand form): registers 8s..8s+7 are the fragment of k-step s ------
+struct Planes2 { u32x4 p[2][2]; };  // [plane][k-step s]: 8 fp16 per lane each
+
+__device__ __forceinline__ unsigned pack_f16(_Float16 lo, _Float16 hi) {
+    f16x2 v = {lo, hi};
+    return __builtin_bit_cast(unsigned, v);
+}
+__device__ __forceinline__ Planes2 split_tile2(const f32x16& x) {
+    Planes2 r;
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int pp = 0; pp < 4; ++pp) {
+            const float lo = __builtin_amdgcn_fmed3f(x[8 * s + 2 * pp], -60000.0f, 60000.0f);
+            const float hi = __builtin_amdgcn_fmed3f(x[8 * s + 2 * pp + 1], -60000.0f, 60000.0f);
+            const _Float16 lo1 = (_Float16)lo, hi1 = (_Float16)hi;  // v_cvt_f16_f32, round to nearest even
+            r.p[0][s][pp] = pack_f16(lo1, hi1);
+            const _Float16 lo2 = (_Float16)((lo - (float)lo1) * F16X3_SCALE);
+            const _Float16 hi2 = (_Float16)((hi - (float)hi1) * F16X3_SCALE);
+            r.p[1][s][pp] = pack_f16(lo2, hi2);
+        }
+    return r;
+}
+
+__device__ __forceinline__ f32x16 mfma_f16(const u32x4& a, const u32x4& b, const f32x16& c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+
+// One output tile over k-steps [KS0, KS1): main += a1 b1, cross += a1 b2 + a2 b1.  Chunk layout in LDS:
+// fragment (ks, plane) at (ks * 2 + plane) * 64 + lane (16 bytes per lane).  The two weight planes of k-step
+// ks+1 are read from LDS ahead of the three MFMAs of k-step ks; main and cross are independent chains.
+template <int NIN, int KS0, int KS1>
+__device__ __forceinline__ void mma_range2(f32x16& mainacc, f32x16& cross, const u32x4* __restrict__ buf,
+                                           const Planes2 (&b)[NIN], int lane) {
+    const u32x4* f = buf + lane;
+    u32x4 c1 = f[(size_t)KS0 * 128], c2 = f[(size_t)KS0 * 128 + 64];
+#pragma unroll
+    for (int ks = KS0; ks < KS1; ++ks) {
+        u32x4 n1, n2;
+        if (ks + 1 < KS1) {
+            n1 = f[(size_t)(ks + 1) * 128];
+            n2 = f[(size_t)(ks + 1) * 128 + 64];
+        }
+        const int t = ks >> 1, s = ks & 1;
+        mainacc = mfma_f16(c1, b[t].p[0][s], mainacc);
+        cross = mfma_f16(c1, b[t].p[1][s], cross);
+        cross = mfma_f16(c2, b[t].p[0][s], cross);
+        if (ks + 1 < KS1) { c1 = n1; c2 = n2; }
+    }
+    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);  // the first k-step's fragments
+#pragma unroll
+    for (int ks = KS0; ks < KS1; ++ks) {
+        if (ks + 1 < KS1) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);  // DS reads of k-step ks+1 ...
+        __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);                     // ... ahead of the MFMAs of k-step ks
+    }
+}
+
+__device__ __forceinline__ f32x16 fold_cross(const f32x16& mainacc, const f32x16& cross) {
+    f32x16 r;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) r[i] = fmaf(cross[i], F16X3_INV_SCALE, mainacc[i]);
+    return r;
+}
+
+// Register staging of the next weight chunk: wave `wave` of NW fetches fragments f = NW i + wave ...
+template <int NF, int NW>
+__device__ __forceinline__ void stage_load2(u32x4 (&st)[(NF + NW - 1) / NW], const u32x4* __restrict__ chunk, int wave,
+                                            int lane) {
+#pragma unroll
+    for (int i = 0; i < (NF + NW - 1) / NW; ++i) {
+        const int f = NW * i + wave;
+        if (NF % NW == 0 || f < NF) st[i] = chunk[(size_t)f * 64 + lane];
+    }
+}
+// ... and writes them to the idle LDS buffer in the middle of the current chunk's MFMA stream
+template <int NF, int NW>
+__device__ __forceinline__ void stage_store2(const u32x4 (&st)[(NF + NW - 1) / NW], u32x4* __restrict__ buf, int wave,
+                                             int lane) {
+#pragma unroll
+    for (int i = 0; i < (NF + NW - 1) / NW; ++i) {
+        const int f = NW * i + wave;
+        if (NF % NW == 0 || f < NF) buf[(size_t)f * 64 + lane] = st[i];
+    }
+}

@@ -48,6 +48,8 @@ struct arreau_model {
     const float* b2;         // [D]
     const float* wkp;        // [L] conv.kernel.weight, MFMA-packed                   out C, in D
     const float* edge_bf16;  // w1 | w2 | wk_l as bf16x3 chunks (uint16 data), one chunk per output tile
+    const float* edge_f16;   // w1 | w2 | wk_l as fp16x3 chunks (uint16 data, two planes), one chunk per output tile
+    int f16_ok;              // 1 when every packed weight fits fp16 (|w| < 6e4): the fp16x3 kernels may be used
     float* fk;               // [L][O(o)][O(p)][C] fiber kernels / O (written once by the precompute kernel)
     const float* conv_bias;  // [L][C]
     const float* ln_w;       // [L][C]
@@ -179,6 +181,8 @@ int arreau_launch_edge(const arreau_model* m, const float* dir, const float* dis
                        const int32_t* batch, const float* lattice, int N, float* kbuf, hipStream_t s);
 int arreau_launch_edge_bf16x6(const arreau_model* m, const float* dir, const float* dist, const int32_t* deg,
                               const int32_t* batch, const float* lattice, int N, float* kbuf, hipStream_t s);
+int arreau_launch_edge_f16x3(const arreau_model* m, const float* dir, const float* dist, const int32_t* deg,
+                             const int32_t* batch, const float* lattice, int N, float* kbuf, hipStream_t s);
 int arreau_launch_embed(const arreau_model* m, const float* frac, const int32_t* types, const float* lattice,
                         const int32_t* batch, const float* cvec, int N, float* x0, hipStream_t s);
 int arreau_launch_node_layer(const arreau_model* m, int layer, const float* kbuf, const int32_t* deg,

@@ -1,6 +1,7 @@
 // Model construction: weight folding / MFMA packing (host), upload, one-time fiber-kernel
 // evaluation on the GPU.  Replaces PonitaFiberBundle.__init__ + load_state_dict
 // (ponita/models/ponita.py:31-86) for the sampling path.
+#include <math.h>
 #include <string.h>
 
 #include <vector>
@@ -70,6 +71,73 @@ static void pack_linear_bf16x3(const float* W, int out_dim, int in_dim, int in_s
                         for (int p = 0; p < 3; ++p)
                             Q[((((((size_t)u * Tn + t) * 2 + s) * 3 + p) * 64) + lane) * 8 + jj] = pl[p];
                     }
+}
+
+// fp16x3 planes (f16x3.h): w = w1 + w2 / 2^11 with w1 = f16(w), w2 = f16((w - w1) * 2^11), round to nearest even.
+static inline uint16_t f32_to_f16_rne(float x) {
+    uint32_t u;
+    memcpy(&u, &x, 4);
+    const uint32_t sign = (u >> 16) & 0x8000u;
+    const int32_t exp = (int32_t)((u >> 23) & 0xff) - 127 + 15;
+    uint32_t man = u & 0x7fffffu;
+    if (((u >> 23) & 0xff) == 0xff) return (uint16_t)(sign | 0x7c00u | (man ? 0x200u : 0));  // inf / nan
+    if (exp >= 31) return (uint16_t)(sign | 0x7c00u);                                           // overflow -> inf
+    if (exp <= 0) {                                                                              // subnormal / zero
+        if (exp < -10) return (uint16_t)sign;
+        man |= 0x800000u;
+        const int shift = 14 - exp;  // 13 + (1 - exp)
+        uint32_t half = man >> shift;
+        const uint32_t rem = man & ((1u << shift) - 1), mid = 1u << (shift - 1);
+        if (rem > mid || (rem == mid && (half & 1))) ++half;
+        return (uint16_t)(sign | half);
+    }
+    uint32_t half = ((uint32_t)exp << 10) | (man >> 13);
+    const uint32_t rem = man & 0x1fffu;
+    if (rem > 0x1000u || (rem == 0x1000u && (half & 1))) ++half;  // may carry into the exponent: still correct
+    return (uint16_t)(sign | half);
+}
+static inline float f16_to_f32(uint16_t hbits) {
+    const uint32_t sign = (uint32_t)(hbits & 0x8000u) << 16;
+    const uint32_t exp = (hbits >> 10) & 0x1f, man = hbits & 0x3ffu;
+    uint32_t u;
+    if (exp == 0) {
+        if (man == 0) u = sign;
+        else {
+            int e = -1;
+            uint32_t m = man;
+            do { ++e; m <<= 1; } while (!(m & 0x400u));
+            u = sign | ((uint32_t)(127 - 15 - e) << 23) | ((m & 0x3ffu) << 13);
+        }
+    } else if (exp == 31) u = sign | 0x7f800000u | (man << 13);
+    else u = sign | ((exp - 15 + 127) << 23) | (man << 13);
+    float x;
+    memcpy(&x, &u, 4);
+    return x;
+}
+
+// Chunked fp16x3 packing for v_mfma_f32_32x32x16_f16; same fragment geometry as pack_linear_bf16x3 with two
+// planes:  Q[u][t][s][plane][lane][jj].  1 KiB per (u, t, s, plane) fragment, 4 * (in_pad / 32) KiB per output tile.
+// Returns the largest |w| seen (the caller rejects weights that do not fit fp16).
+static float pack_linear_f16x3(const float* W, int out_dim, int in_dim, int in_stride, int out_pad, int in_pad,
+                               uint16_t* Q) {
+    const int U = out_pad / 32, Tn = in_pad / 32;
+    float wmax = 0.f;
+    for (int u = 0; u < U; ++u)
+        for (int t = 0; t < Tn; ++t)
+            for (int s = 0; s < 2; ++s)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int jj = 0; jj < 8; ++jj) {
+                        const int out = 32 * u + (lane & 31);
+                        const int in = 32 * t + 16 * s + 8 * (jj >> 2) + 4 * (lane >> 5) + (jj & 3);
+                        const float w = (out < out_dim && in < in_dim) ? W[(size_t)out * in_stride + in] : 0.0f;
+                        wmax = fabsf(w) > wmax ? fabsf(w) : wmax;
+                        const uint16_t h1 = f32_to_f16_rne(w);
+                        const uint16_t h2 = f32_to_f16_rne((w - f16_to_f32(h1)) * 2048.0f);
+                        const size_t base = ((((size_t)u * Tn + t) * 2 + s) * 2) * 512 + (size_t)lane * 8 + jj;
+                        Q[base] = h1;
+                        Q[base + 512] = h2;
+                    }
+    return wmax;
 }
 
 // Monomial table: distinct monomials of degree 1..3 in 6 variables in the canonical order
@@ -196,6 +264,20 @@ extern "C" int arreau_model_create(const arreau_config* cfg, const arreau_state_
             pack_linear_bf16x3(sd->conv_kernel_w + (size_t)l * C * D, C, D, D, C, D, q + h_w1 + h_w2 + l * h_wk);
     }
 
+    // fp16x3 chunks of the same three matrices (edge_f16.hip): 4 KiB per input tile per output tile
+    const size_t f_w1 = (size_t)(C / 32) * (ARREAU_MONO_PAD / 32) * 4 * 512;   // uint16 count
+    const size_t f_w2 = (size_t)(D / 32) * (C / 32) * 4 * 512;
+    const size_t f_wk = (size_t)(C / 32) * (D / 32) * 4 * 512;
+    const size_t off_ef16 = bb.reserve((f_w1 + f_w2 + f_wk * L) / 2 + 64);
+    float wmax16 = 0.f;
+    {
+        uint16_t* q = reinterpret_cast<uint16_t*>(bb.data.data() + off_ef16);
+        wmax16 = fmaxf(wmax16, pack_linear_f16x3(w1f.data(), C, ARREAU_MONO_PAD, ARREAU_MONO_PAD, C, ARREAU_MONO_PAD, q));
+        wmax16 = fmaxf(wmax16, pack_linear_f16x3(sd->basis_w2, D, C, C, D, C, q + f_w1));
+        for (int l = 0; l < L; ++l)
+            wmax16 = fmaxf(wmax16, pack_linear_f16x3(sd->conv_kernel_w + (size_t)l * C * D, C, D, D, C, D,
+                                                     q + f_w1 + f_w2 + l * f_wk));
+    }
     const size_t off_fk = bb.reserve((size_t)L * O * O * C);
     const size_t off_conv_bias = bb.put(sd->conv_bias, (size_t)L * C);
     const size_t off_ln_w = bb.put(sd->norm_w, (size_t)L * C);
@@ -280,7 +362,7 @@ extern "C" int arreau_model_create(const arreau_config* cfg, const arreau_state_
     }
     float* b = m->blob;
     m->ori = b + off_ori; m->w1p = b + off_w1p; m->b1 = b + off_b1; m->w2p = b + off_w2p; m->b2 = b + off_b2;
-    m->wkp = b + off_wkp; m->edge_bf16 = b + off_es16; m->fk = b + off_fk; m->conv_bias = b + off_conv_bias; m->ln_w = b + off_ln_w;
+    m->wkp = b + off_wkp; m->edge_bf16 = b + off_es16; m->edge_f16 = b + off_ef16; m->f16_ok = wmax16 < 60000.0f ? 1 : 0; m->fk = b + off_fk; m->conv_bias = b + off_conv_bias; m->ln_w = b + off_ln_w;
     m->ln_b = b + off_ln_b; m->mlp = b + off_mlp; m->mlp_bf16 = b + off_mlp16; m->mb1 = b + off_mb1; m->mb2 = b + off_mb2;
     m->ls = b + off_ls; m->embT = b + off_embT; m->ro_wT = b + off_ro_wT; m->ro_b = b + off_ro_b;
     m->t_emb_w = b + off_temb; m->ve_sigmas = b + off_ve; m->vp_alpha_bars = b + off_ab; m->vp_betas = b + off_be;
