@@ -221,11 +221,11 @@ int arreau_launch_edge(const arreau_model* m, const float* dir, const float* dis
         arreau_set_error("edge kernel: unsupported (hidden_dim, basis_dim)");
         return ARREAU_EINVAL;
     }
-    // variant switch (default 3; the fp32-MFMA kernels stay for A/B runs and as the numerical cross-check):
+    // variant switch (default 4; the fp32-MFMA kernels stay for A/B runs and as the numerical cross-check):
     // 0 = 32 rows/wave, 2 waves/SIMD; 1 = 64 rows/wave, 1 wave/SIMD;
     // 2 = 32 rows/wave, 1 wave/SIMD; 3 = bf16x6 split-precision kernel (edge_bf16.hip);
     // 4 = fp16x3 split-precision kernel (edge_f16.hip; falls back to 3 when a weight does not fit fp16)
-    static const int variant = [] { const char* e = getenv("ARREAU_EDGE_VARIANT"); return e ? atoi(e) : 3; }();
+    static const int variant = [] { const char* e = getenv("ARREAU_EDGE_VARIANT"); return e ? atoi(e) : 4; }();
     if (variant == 4 && m->f16_ok) return arreau_launch_edge_f16x3(m, dir, dist, deg, batch, lattice, N, kbuf, s);
     if (variant >= 3) return arreau_launch_edge_bf16x6(m, dir, dist, deg, batch, lattice, N, kbuf, s);
     if (variant == 1) launch_variant<2, 1>(m, dir, dist, deg, batch, lattice, N, kbuf, s);

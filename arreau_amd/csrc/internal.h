@@ -57,12 +57,15 @@ struct arreau_model {
     const float* mlp;        // [L][4 quarters][ linear_1 rows of the quarter (out H/4, in C) | linear_2 columns of the
                              //  quarter (out C, in H/4) ], MFMA-packed: one linear stream per (layer, quarter)
     const float* mlp_bf16;   // the same stream as bf16x3 chunks (uint16 data), 24 KiB per output tile
+    const float* mlp_f16;    // the same stream as fp16x3 chunks (uint16 data), 16 KiB per output tile
     const float* mb1;        // [L][H]
     const float* mb2;        // [L][C]
     const float* ls;         // [L][C] layer_scale (ones when absent)
     const float* embT;       // [S+78][C] x_embedder.weight transposed
     const float* ro_wT;      // [L][C][S+4] read_out weight transposed
     const float* ro_b;       // [L][S+4]
+    const float* ro_wv;      // [L][C] vector read-out weights (column S of read_out_layers), contiguous
+    float ro_bv_host[16];    // [L] vector read-out bias (host copy, passed by value)
     const float* t_emb_w;    // [32]
     const float* ve_sigmas;  // [T+1]
     const float* vp_alpha_bars;  // [T+1]
@@ -190,5 +193,7 @@ int arreau_launch_node_layer(const arreau_model* m, int layer, const float* kbuf
                              float* vsum, int N, hipStream_t s);
 int arreau_launch_mlp_bf16x6(const arreau_model* m, int layer, const float* x_conv, const float* x_in, float* x_out,
                              float* xbar, float* vsum, int N, hipStream_t s);
+int arreau_launch_mlp_f16x3(const arreau_model* m, int layer, const float* x_conv, const float* x_in, float* x_out,
+                            float* xbar, float* vsum, int N, hipStream_t s);
 int arreau_launch_readout(const arreau_model* m, const float* xbar, const float* vsum, const int32_t* offsets,
                           int B, int N, float* gs, float* eps, float* logits, float* len0, hipStream_t s);

@@ -305,6 +305,16 @@ extern "C" int arreau_model_create(const arreau_config* cfg, const arreau_state_
             pack_linear_bf16x3(sd->linear1_w + ((size_t)l * H + (size_t)w * HQ) * C, HQ, C, C, HQ, C, dst);
             pack_linear_bf16x3(sd->linear2_w + (size_t)l * C * H + (size_t)w * HQ, C, HQ, H, C, HQ, dst + hq1);
         }
+    // ... and as fp16x3 chunks (16 KiB per output tile)
+    const size_t fq1 = (size_t)(HQ / 32) * (C / 32) * 4 * 512;   // uint16 count of W1 quarter
+    const size_t fq2 = (size_t)(C / 32) * (HQ / 32) * 4 * 512;   // uint16 count of W2 quarter
+    const size_t off_mlpf16 = bb.reserve((fq1 + fq2) * 4 * L / 2 + 64);
+    for (int l = 0; l < L; ++l)
+        for (int w = 0; w < 4; ++w) {
+            uint16_t* dst = reinterpret_cast<uint16_t*>(bb.data.data() + off_mlpf16) + ((size_t)l * 4 + w) * (fq1 + fq2);
+            wmax16 = fmaxf(wmax16, pack_linear_f16x3(sd->linear1_w + ((size_t)l * H + (size_t)w * HQ) * C, HQ, C, C, HQ, C, dst));
+            wmax16 = fmaxf(wmax16, pack_linear_f16x3(sd->linear2_w + (size_t)l * C * H + (size_t)w * HQ, C, HQ, H, C, HQ, dst + fq1));
+        }
     const size_t off_mb1 = bb.put(sd->linear1_b, (size_t)L * H);
     const size_t off_mb2 = bb.put(sd->linear2_b, (size_t)L * C);
 
@@ -326,6 +336,10 @@ extern "C" int arreau_model_create(const arreau_config* cfg, const arreau_state_
                 tmp[((size_t)l * C + c) * RO + s] = sd->readout_w[((size_t)l * RO + s) * C + c];
     const size_t off_ro_wT = bb.put(tmp.data(), tmp.size());
     const size_t off_ro_b = bb.put(sd->readout_b, (size_t)L * RO);
+    tmp.assign((size_t)L * C, 0.f);
+    for (int l = 0; l < L; ++l)
+        for (int c = 0; c < C; ++c) tmp[(size_t)l * C + c] = sd->readout_w[((size_t)l * RO + S) * C + c];
+    const size_t off_ro_wv = bb.put(tmp.data(), tmp.size());
 
     const size_t off_temb = bb.put(sd->t_emb_w, ARREAU_T_EMB_DIM / 2);
     const size_t off_ve = bb.put(sd->ve_sigmas, (size_t)T + 1);
@@ -363,8 +377,9 @@ extern "C" int arreau_model_create(const arreau_config* cfg, const arreau_state_
     float* b = m->blob;
     m->ori = b + off_ori; m->w1p = b + off_w1p; m->b1 = b + off_b1; m->w2p = b + off_w2p; m->b2 = b + off_b2;
     m->wkp = b + off_wkp; m->edge_bf16 = b + off_es16; m->edge_f16 = b + off_ef16; m->f16_ok = wmax16 < 60000.0f ? 1 : 0; m->fk = b + off_fk; m->conv_bias = b + off_conv_bias; m->ln_w = b + off_ln_w;
-    m->ln_b = b + off_ln_b; m->mlp = b + off_mlp; m->mlp_bf16 = b + off_mlp16; m->mb1 = b + off_mb1; m->mb2 = b + off_mb2;
-    m->ls = b + off_ls; m->embT = b + off_embT; m->ro_wT = b + off_ro_wT; m->ro_b = b + off_ro_b;
+    m->ln_b = b + off_ln_b; m->mlp = b + off_mlp; m->mlp_bf16 = b + off_mlp16; m->mlp_f16 = b + off_mlpf16; m->mb1 = b + off_mb1; m->mb2 = b + off_mb2;
+    m->ls = b + off_ls; m->embT = b + off_embT; m->ro_wT = b + off_ro_wT; m->ro_b = b + off_ro_b; m->ro_wv = b + off_ro_wv;
+    for (int l = 0; l < L; ++l) m->ro_bv_host[l] = sd->readout_b[(size_t)l * RO + S];
     m->t_emb_w = b + off_temb; m->ve_sigmas = b + off_ve; m->vp_alpha_bars = b + off_ab; m->vp_betas = b + off_be;
     m->q1t = b + off_q1t; m->qmats = b + off_qm;
     m->fiber_w1 = b + off_fw1; m->fiber_b1 = b + off_fb1; m->fiber_w2 = b + off_fw2; m->fiber_b2 = b + off_fb2;

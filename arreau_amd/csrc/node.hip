@@ -396,9 +396,12 @@ int arreau_launch_node_layer(const arreau_model* m, int layer, const float* kbuf
     hipLaunchKernelGGL((conv_kernel<128>), dim3(conv_blocks), dim3(512), 0, s, kbuf + (size_t)layer * layer_stride, deg,
                        src, x_in, m->fk + (size_t)layer * 16 * 16 * C, m->conv_bias + (size_t)layer * C, N, m->k, x_conv);
     ARREAU_CHECK_HIP(hipGetLastError());
-    // variant switch: 1 (default) = bf16x6 split-precision MLP kernel (node_bf16.hip); 0 = fp32-MFMA kernel below
-    static const int mlp_variant = [] { const char* e = getenv("ARREAU_MLP_VARIANT"); return e ? atoi(e) : 1; }();
-    if (mlp_variant == 1)
+    // variant switch: 2 (default) = fp16x3 split-precision MLP kernel (node_f16.hip; needs weights that fit fp16);
+    // 1 = bf16x6 split-precision MLP kernel (node_bf16.hip); 0 = fp32-MFMA kernel below
+    static const int mlp_variant = [] { const char* e = getenv("ARREAU_MLP_VARIANT"); return e ? atoi(e) : 2; }();
+    if (mlp_variant == 2 && m->f16_ok)
+        return arreau_launch_mlp_f16x3(m, layer, x_conv, x_in, x_out, xbar, vsum, N, s);
+    if (mlp_variant >= 1)
         return arreau_launch_mlp_bf16x6(m, layer, x_conv, x_in, x_out, xbar, vsum, N, s);
     hipLaunchKernelGGL((mlp_kernel<128, 512>), dim3((N + 3) / 4), dim3(256), 0, s, x_conv, x_in, x_out,
                        m->ln_w + (size_t)layer * C, m->ln_b + (size_t)layer * C, m->mlp + (size_t)layer * mlp_layer,

@@ -29,6 +29,8 @@ MFMA_BF16_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA (spec)
 # The edge kernel evaluates every fp32 product as six bf16 MFMA products (exact 8+8+8-bit operand splits,
 # fp32 accumulation), so its matrix-pipe roof in fp32-equivalent FLOP/s is the bf16 peak / 6.
 BF16X6_EQUIV_PEAK_TFLOPS = MFMA_BF16_PEAK_TFLOPS / 6.0
+# default kernels: three fp16 MFMA products per fp32 product (two 11-bit operand planes) -> fp16 peak / 3
+F16X3_EQUIV_PEAK_TFLOPS = MFMA_BF16_PEAK_TFLOPS / 3.0
 
 
 def edge_kernel_flops_per_row(C=128, D=256, L=5):
@@ -198,8 +200,13 @@ def main():
         edge_flops = e_mean * 16 * edge_kernel_flops_per_row()
         edge_tflops = edge_flops / (mean_ms.value * 1e-3) / 1e12 if mean_ms.value > 0 else 0.0
         step_flops = step_flops_per_atom() * N * (e_mean / (8.0 * N))  # scaled by the edge density actually seen
-        variant = int(os.environ.get("ARREAU_EDGE_VARIANT", "3"))
-        if variant == 3:
+        variant = int(os.environ.get("ARREAU_EDGE_VARIANT", "4"))
+        if variant == 4:
+            edge_kernel_name = ("edge_kernel_f16x3<128,256> (pair invariants + basis MLP + 5 kernel projections; "
+                                "fp32 products as 3 fp16 MFMA products, fp32 accumulate)")
+            edge_peak = F16X3_EQUIV_PEAK_TFLOPS
+            edge_peak_note = "fp32-equivalent roof of the split scheme: dense fp16 MFMA 2500 TFLOP/s / 3 products"
+        elif variant == 3:
             edge_kernel_name = ("edge_kernel_bf16x6<128,256> (pair invariants + basis MLP + 5 kernel projections; "
                                 "fp32 products as 6 bf16 MFMA products, fp32 accumulate)")
             edge_peak = BF16X6_EQUIV_PEAK_TFLOPS
