@@ -221,8 +221,8 @@ extern "C" int arreau_model_create(const arreau_config* cfg, const arreau_state_
     ARREAU_REQUIRE(C == 128 && D == 256, "unsupported hidden_dim/basis_dim (this build instantiates C=128, D=256)");
     ARREAU_REQUIRE(W == 4, "unsupported widening_factor (this build handles 4)");
     ARREAU_REQUIRE(k >= 1 && k <= ARREAU_MAX_K, "max_neighbors must be in 1..8");
-    ARREAU_REQUIRE(S >= 2 && S <= 128, "num_atomic_states must be in 2..128");
-    ARREAU_REQUIRE(L >= 1 && L <= 16 && T >= 2, "bad num_layers / num_timesteps");
+    ARREAU_REQUIRE(S >= 2 && S <= 124, "num_atomic_states must be in 2..124");
+    ARREAU_REQUIRE(L >= 1 && L <= 8 && T >= 2, "bad num_layers (1..8) / num_timesteps");
     const float* need[] = {sd->basis_w1, sd->basis_b1, sd->basis_w2, sd->basis_b2, sd->fiber_w1, sd->fiber_b1,
                            sd->fiber_w2, sd->fiber_b2, sd->x_embedder_w, sd->conv_kernel_w, sd->conv_fiber_w,
                            sd->conv_bias, sd->norm_w, sd->norm_b, sd->linear1_w, sd->linear1_b, sd->linear2_w,

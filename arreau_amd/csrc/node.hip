@@ -423,17 +423,22 @@ int arreau_launch_node_layer(const arreau_model* m, int layer, const float* kbuf
 // over columns).  Kernel 2: one thread per (crystal, g) sums its atoms in order (deterministic).
 // ---------------------------------------------------------------------------------------------
 #define RO_ATOMS 8
+#define RO_COLS 128  // threads per layer group (>= S + 4)
 
-__global__ __launch_bounds__(128) void readout_nodes_kernel(
+// blockDim = RO_COLS * L: thread (l, s) reduces layer l's 128 channels for output column s and the tile's 8
+// atoms; the L partial sums are then added in layer order (deterministic) by the l = 0 group.
+__global__ __launch_bounds__(1024) void readout_nodes_kernel(
     const float* __restrict__ xbar,   // [L][N][C]
     const float* __restrict__ vsum,   // [N][16]
     const float* __restrict__ ro_wT,  // [L][C][S+4]
     const float* __restrict__ ro_b,   // [L][S+4]
     const float* __restrict__ ori, int S, int C, int L, int N, float* __restrict__ eps,
     float* __restrict__ logits, float* __restrict__ gs /*[N][3]*/) {
-    extern __shared__ __attribute__((aligned(16))) float xs[];  // [RO_ATOMS][L*C]
-    const int n0 = blockIdx.x * RO_ATOMS;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
     const int RO = S + 4, LC = L * C;
+    float* xs = smem;                          // [RO_ATOMS][L*C]
+    float* part = smem + RO_ATOMS * LC;        // [L][RO_ATOMS][RO_COLS]
+    const int n0 = blockIdx.x * RO_ATOMS;
     for (int i = threadIdx.x; i < RO_ATOMS * LC; i += blockDim.x) {
         const int a = i / LC, r = i - a * LC;
         const int l = r / C, c = r - l * C;
@@ -441,53 +446,51 @@ __global__ __launch_bounds__(128) void readout_nodes_kernel(
         xs[i] = n < N ? xbar[((size_t)l * N + n) * C + c] : 0.f;
     }
     __syncthreads();
+    const int l = threadIdx.x / RO_COLS, s_out = threadIdx.x - l * RO_COLS;
     const float invL = 1.0f / (float)L;
-    for (int s_out = threadIdx.x; s_out < RO; s_out += blockDim.x) {
-        if (s_out == S) {
-            // vector channel: eps for the tile's atoms
+    if (s_out < RO && s_out != S) {
+        float acc[RO_ATOMS];
+#pragma unroll
+        for (int a = 0; a < RO_ATOMS; ++a) acc[a] = 0.f;
+        const float* w = ro_wT + (size_t)l * C * RO + s_out;
+        for (int c = 0; c < C; c += 4) {
+            const float w0 = w[(size_t)c * RO], w1 = w[(size_t)(c + 1) * RO], w2 = w[(size_t)(c + 2) * RO],
+                        w3 = w[(size_t)(c + 3) * RO];
+#pragma unroll
             for (int a = 0; a < RO_ATOMS; ++a) {
-                const size_t n = (size_t)n0 + a;
-                if (n >= (size_t)N) break;
-                for (int d = 0; d < 3; ++d) {
-                    float acc = 0.f;
-                    for (int o = 0; o < 16; ++o) acc += (vsum[n * 16 + o] * invL) * ori[3 * o + d];
-                    eps[n * 3 + d] = acc * (1.0f / 16.0f);
-                }
+                const f32x4 x = *reinterpret_cast<const f32x4*>(&xs[a * LC + l * C + c]);
+                acc[a] += x[0] * w0;
+                acc[a] += x[1] * w1;
+                acc[a] += x[2] * w2;
+                acc[a] += x[3] * w3;
             }
-            continue;
         }
-        float tot[RO_ATOMS];
+        const float bias = ro_b[l * RO + s_out];
 #pragma unroll
-        for (int a = 0; a < RO_ATOMS; ++a) tot[a] = 0.f;
-        for (int l = 0; l < L; ++l) {
-            float acc[RO_ATOMS];
-#pragma unroll
-            for (int a = 0; a < RO_ATOMS; ++a) acc[a] = 0.f;
-            const float* w = ro_wT + (size_t)l * C * RO + s_out;
-            for (int c = 0; c < C; c += 4) {
-                const float w0 = w[(size_t)c * RO], w1 = w[(size_t)(c + 1) * RO], w2 = w[(size_t)(c + 2) * RO],
-                            w3 = w[(size_t)(c + 3) * RO];
-#pragma unroll
-                for (int a = 0; a < RO_ATOMS; ++a) {
-                    const f32x4 x = *reinterpret_cast<const f32x4*>(&xs[a * LC + l * C + c]);
-                    acc[a] += x[0] * w0;
-                    acc[a] += x[1] * w1;
-                    acc[a] += x[2] * w2;
-                    acc[a] += x[3] * w3;
-                }
+        for (int a = 0; a < RO_ATOMS; ++a) part[(l * RO_ATOMS + a) * RO_COLS + s_out] = acc[a] + bias;
+    } else if (l == 0 && s_out == S) {
+        // vector channel: eps for the tile's atoms (sphere_to_vec of the per-orientation dot products)
+        for (int a = 0; a < RO_ATOMS; ++a) {
+            const size_t n = (size_t)n0 + a;
+            if (n >= (size_t)N) break;
+            for (int d = 0; d < 3; ++d) {
+                float acc = 0.f;
+                for (int o = 0; o < 16; ++o) acc += (vsum[n * 16 + o] * invL) * ori[3 * o + d];
+                eps[n * 3 + d] = acc * (1.0f / 16.0f);
             }
-            const float bias = ro_b[l * RO + s_out];
-#pragma unroll
-            for (int a = 0; a < RO_ATOMS; ++a) tot[a] += acc[a] + bias;
         }
+    }
+    __syncthreads();
+    if (l == 0 && s_out < RO && s_out != S) {
 #pragma unroll
         for (int a = 0; a < RO_ATOMS; ++a) {
             const size_t n = (size_t)n0 + a;
-            if (n < (size_t)N) {
-                const float v = tot[a] * invL;
-                if (s_out < S) logits[n * S + s_out] = v;
-                else gs[n * 3 + (s_out - S - 1)] = v;
-            }
+            if (n >= (size_t)N) break;
+            float tot = 0.f;
+            for (int ll = 0; ll < L; ++ll) tot += part[(ll * RO_ATOMS + a) * RO_COLS + s_out];
+            tot *= invL;
+            if (s_out < S) logits[n * S + s_out] = tot;
+            else gs[n * 3 + (s_out - S - 1)] = tot;
         }
     }
 }
@@ -506,8 +509,12 @@ int arreau_launch_readout(const arreau_model* m, const float* xbar, const float*
                           int N, float* gs, float* eps, float* logits, float* len0, hipStream_t s) {
     if (B == 0) return ARREAU_OK;
     if (N > 0) {
-        const size_t smem = (size_t)RO_ATOMS * m->L * m->C * sizeof(float);
-        hipLaunchKernelGGL(readout_nodes_kernel, dim3((N + RO_ATOMS - 1) / RO_ATOMS), dim3(128), smem, s, xbar, vsum,
+        const size_t smem = ((size_t)RO_ATOMS * m->L * m->C + (size_t)m->L * RO_ATOMS * RO_COLS) * sizeof(float);
+        if (m->L * RO_COLS > 1024 || m->S + 4 > RO_COLS) {
+            arreau_set_error("readout kernel: num_layers * 128 threads must fit one workgroup");
+            return ARREAU_EINVAL;
+        }
+        hipLaunchKernelGGL(readout_nodes_kernel, dim3((N + RO_ATOMS - 1) / RO_ATOMS), dim3(RO_COLS * m->L), smem, s, xbar, vsum,
                            m->ro_wT, m->ro_b, m->ori, m->S, m->C, m->L, N, eps, logits, gs);
         ARREAU_CHECK_HIP(hipGetLastError());
     }

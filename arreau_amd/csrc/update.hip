@@ -104,6 +104,7 @@ __global__ __launch_bounds__(256) void reverse_atoms_kernel(
         const float* q1row = q1t + ((size_t)(t - 1) * S + xt) * S;  // fact1 = Q_t^T[x_t, :]
         const float* qm = qmats + (size_t)(t - 2) * S * S;          // Qbar_{t-1} (reference index t-2)
         float f2a = 0.f, f2b = 0.f;
+#pragma unroll 8
         for (int c = 0; c < S; ++c) {
             const float sc = c < 64 ? __shfl(p0, c, 64) : __shfl(p1, c - 64, 64);  // c is wave-uniform
             if (v0) f2a += sc * qm[(size_t)c * S + s0];
