@@ -104,11 +104,24 @@ __global__ __launch_bounds__(256) void reverse_atoms_kernel(
         const float* q1row = q1t + ((size_t)(t - 1) * S + xt) * S;  // fact1 = Q_t^T[x_t, :]
         const float* qm = qmats + (size_t)(t - 2) * S * S;          // Qbar_{t-1} (reference index t-2)
         float f2a = 0.f, f2b = 0.f;
-#pragma unroll 8
-        for (int c = 0; c < S; ++c) {
-            const float sc = c < 64 ? __shfl(p0, c, 64) : __shfl(p1, c - 64, 64);  // c is wave-uniform
-            if (v0) f2a += sc * qm[(size_t)c * S + s0];
-            if (v1) f2b += sc * qm[(size_t)c * S + s1];
+        // fact2 = softmax . Qbar: rows of Qbar are fetched 16 at a time (independent loads in flight), then the
+        // softmax entries are broadcast from the lanes that hold them
+        for (int c0 = 0; c0 < S; c0 += 16) {
+            float qa[16], qb[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int c = min(c0 + i, S - 1);
+                qa[i] = v0 ? qm[(size_t)c * S + s0] : 0.f;
+                qb[i] = v1 ? qm[(size_t)c * S + s1] : 0.f;
+            }
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int c = c0 + i;  // wave-uniform
+                float sc = c < 64 ? __shfl(p0, c, 64) : __shfl(p1, c - 64, 64);
+                sc = c < S ? sc : 0.f;
+                f2a += sc * qa[i];
+                f2b += sc * qb[i];
+            }
         }
         post0 = v0 ? logf(q1row[s0] + D3PM_EPS) + logf(f2a + D3PM_EPS) : -INFINITY;
         post1 = v1 ? logf(q1row[s1] + D3PM_EPS) + logf(f2b + D3PM_EPS) : -INFINITY;
