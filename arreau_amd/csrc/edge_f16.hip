@@ -64,7 +64,7 @@ __global__ __launch_bounds__(64 * EH_WAVES, 2) void edge_kernel_f16x3(
     constexpr int NST = (NF3 + EH_WAVES - 1) / EH_WAVES;     // fragments a wave stages per chunk (4)
     static_assert(TM == 3 && ((TC + TD) & 1) == 0, "chunk geometry / buffer parity");
     __shared__ u32x4 lds[2][NF3 * 64];                                        // 2 x 32 KiB
-    __shared__ __attribute__((aligned(16))) float otile[EH_WAVES][16 * 36];   // per-wave transpose pad for the stores (half a tile)
+    __shared__ __attribute__((aligned(16))) float otile[EH_WAVES][32 * 36];   // per-wave transpose pad for the stores
 
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int h = lane >> 5, j = lane & 31;
@@ -169,23 +169,17 @@ __global__ __launch_bounds__(64 * EH_WAVES, 2) void edge_kernel_f16x3(
     // whole 128-byte lines (8 lanes per row) instead of 64 scattered 16-byte pieces.
     auto store_tile = [&](const f32x16& t, int cidx_done) {
         const int l = cidx_done / TC, u = cidx_done - l * TC;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const f32x4 v = {t[4 * q], t[4 * q + 1], t[4 * q + 2], t[4 * q + 3]};
+            *reinterpret_cast<f32x4*>(&pad[j * 36 + 8 * q + 4 * h]) = v;
+        }
         float* dst = kbuf + (size_t)l * layer_stride + row0 * C + 32 * u + 4 * (lane & 7);
-        // two passes of 16 rows (one edge slot each) through the 16-row pad; LDS ops of one wave execute in order
 #pragma unroll
-        for (int half = 0; half < 2; ++half) {
-            if ((j >> 4) == half) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const f32x4 v = {t[4 * q], t[4 * q + 1], t[4 * q + 2], t[4 * q + 3]};
-                    *reinterpret_cast<f32x4*>(&pad[(j & 15) * 36 + 8 * q + 4 * h]) = v;
-                }
-            }
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int r = 8 * i + (lane >> 3);  // row within the half: orientation r of slot 2*wn + half
-                const f32x4 v = *reinterpret_cast<const f32x4*>(&pad[r * 36 + 4 * (lane & 7)]);
-                if (2 * wn + half < nd) *reinterpret_cast<f32x4*>(dst + (size_t)(16 * half + r) * C) = v;
-            }
+        for (int i = 0; i < 4; ++i) {
+            const int r = 8 * i + (lane >> 3);  // row of the wave tile: slot 2*wn + (r >> 4), orientation r & 15
+            const f32x4 v = *reinterpret_cast<const f32x4*>(&pad[r * 36 + 4 * (lane & 7)]);
+            if (2 * wn + (r >> 4) < nd) *reinterpret_cast<f32x4*>(dst + (size_t)r * C) = v;
         }
     };
 #pragma unroll 1
@@ -216,17 +210,11 @@ int arreau_launch_edge_f16x3(const arreau_model* m, const float* dir, const floa
         arreau_set_error("edge kernel (fp16x3): unsupported (hidden_dim, basis_dim, max_neighbors)");
         return ARREAU_EINVAL;
     }
-    // ARREAU_EDGE_WAVES: 4 = one receiver per workgroup, two independent workgroups per CU (default);
-    // 8 = two receivers per workgroup, one workgroup per CU
-    static const int waves = [] { const char* e = getenv("ARREAU_EDGE_WAVES"); return e ? atoi(e) : 4; }();
-    if (waves == 8)
-        hipLaunchKernelGGL((edge_kernel_f16x3<128, 256, 8>), dim3((N + 1) / 2), dim3(512), 0, s, dir, dist, deg, batch,
-                           lattice, m->ori, reinterpret_cast<const u32x4*>(m->edge_f16), m->b1, m->b2, m->cfg.radius, N,
-                           m->k, m->L, kbuf);
-    else
-        hipLaunchKernelGGL((edge_kernel_f16x3<128, 256, 4>), dim3(N), dim3(256), 0, s, dir, dist, deg, batch, lattice,
-                           m->ori, reinterpret_cast<const u32x4*>(m->edge_f16), m->b1, m->b2, m->cfg.radius, N, m->k,
-                           m->L, kbuf);
+    // 8 waves = two receivers per workgroup, one workgroup per CU (2 waves per SIMD from the same workgroup).
+    // A 4-wave / two-workgroups-per-CU geometry was tried and dropped: it was not run-to-run reproducible.
+    hipLaunchKernelGGL((edge_kernel_f16x3<128, 256, 8>), dim3((N + 1) / 2), dim3(512), 0, s, dir, dist, deg, batch,
+                       lattice, m->ori, reinterpret_cast<const u32x4*>(m->edge_f16), m->b1, m->b2, m->cfg.radius, N,
+                       m->k, m->L, kbuf);
     ARREAU_CHECK_HIP(hipGetLastError());
     return ARREAU_OK;
 }

@@ -332,3 +332,98 @@ def test_constant_atomic_symbols(dev, small_model):
     m, _, _ = small_model  # z table = 1..11 + mask
     res = m.sample(3, 2, VisualizationSetting.NONE, False, use_constant_atomic_symbols=["C", "H", "O"], max_steps=4)
     assert res.atomic_numbers.tolist() == [6, 1, 8, 6, 1, 8]
+
+
+# ------------------------------------------------------------------------------------------- full-size properties
+def _engine_scores(m, dev, state, t, edges=None):
+    frac, types, lengths, angles, na = state
+    f, ty, le, an, off = _to_dev(dev, *state)
+    t_c = torch.full((len(na),), t, device=dev, dtype=torch.int32)
+    return m.engine().predict_scores(f, ty, le, an, t_c, off, edges=edges)
+
+
+def test_large_cell_regime_vs_oracle(dev, small_model):
+    """BASELINE config 4 regime in small: 64 atoms per crystal (dense PBC graph, every atom at the neighbour cap),
+    2 crystals, full predict_scores (own neighbour list) against the oracle."""
+    m, om32, _ = small_model
+    state = random_state(12, [64, 64], 41, cell=(6.0, 9.0))
+    eps_o, logits_o, len0_o, (ei, _d, _dr, _c, _l) = _oracle_scores(om32, *state, 40)
+    assert ei.shape[1] == 8 * 128  # saturated graph
+    eps, logits, len0 = _engine_scores(m, dev, state, 40)
+    scale = max(1.0, float(logits_o.abs().max()), float(len0_o.abs().max()))
+    assert (eps.cpu() - eps_o).abs().max() <= TOL * scale
+    assert (logits.cpu() - logits_o).abs().max() <= TOL * scale
+    assert (len0.cpu() - len0_o).abs().max() <= TOL * scale * 64
+
+
+@pytest.mark.parametrize("B,n", [(256, 20), (64, 64)])
+def test_full_size_batch_independence_and_determinism(dev, full_model, B, n):
+    """At the benchmark sizes (config 2: 256 x 20; config 4 regime: 64 atoms per crystal) the oracle is too slow,
+    so use size-independent properties: (1) two evaluations are bitwise identical (no atomics, fixed summation
+    order); (2) crystals are independent -- a crystal evaluated inside the big batch gives bitwise the same
+    scores as the same crystal evaluated alone; (3) that lone crystal matches the oracle to 1e-5."""
+    m, om32 = full_model
+    # physical cells (no exactly tied periodic images: the oracle's unstable sort would pick different ones)
+    state = random_state(90, [n] * B, 100 + B, cell=(4.0, 8.0) if n <= 20 else (6.0, 9.0))
+    frac, types, lengths, angles, na = state
+    t = 999
+    a = _engine_scores(m, dev, state, t)
+    b = _engine_scores(m, dev, state, t)
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)
+    assert all(torch.isfinite(x).all() for x in a)
+    for ci in (0, B // 2, B - 1):
+        sl = slice(ci * n, (ci + 1) * n)
+        one = (frac[sl], types[sl], lengths[ci:ci + 1], angles[ci:ci + 1], na[ci:ci + 1])
+        eps1, logits1, len01 = _engine_scores(m, dev, one, t)
+        assert torch.equal(eps1, a[0][sl]) and torch.equal(logits1, a[1][sl]) and torch.equal(len01, a[2][ci:ci + 1])
+    eps_o, logits_o, len0_o, _ = _oracle_scores(om32, *one, t)
+    scale = max(1.0, float(logits_o.abs().max()), float(len0_o.abs().max()))
+    assert (eps1.cpu() - eps_o).abs().max() <= TOL * scale
+    assert (logits1.cpu() - logits_o).abs().max() <= TOL * scale
+    assert (len01.cpu() - len0_o).abs().max() <= TOL * scale * n
+
+
+def test_atom_permutation_equivariance(dev, small_model):
+    """Relabelling the atoms of a crystal permutes the per-atom outputs and leaves the per-crystal output
+    unchanged (up to the summation order inside a receiver's neighbour list)."""
+    m, _, _ = small_model
+    frac, types, lengths, angles, na = random_state(12, [9, 7], 55)
+    perm = torch.cat([torch.randperm(9, generator=torch.Generator().manual_seed(1)),
+                      9 + torch.randperm(7, generator=torch.Generator().manual_seed(2))])
+    a = _engine_scores(m, dev, (frac, types, lengths, angles, na), 30)
+    b = _engine_scores(m, dev, (frac[perm], types[perm], lengths, angles, na), 30)
+    scale = max(1.0, float(a[1].abs().max()))
+    assert (a[0][perm] - b[0]).abs().max() <= TOL * scale
+    assert (a[1][perm] - b[1]).abs().max() <= TOL * scale
+    assert (a[2] - b[2]).abs().max() <= TOL * scale * 9
+
+
+@pytest.mark.parametrize("edge_variant,mlp_variant", [("0", "0"), ("3", "1")])
+def test_alternative_arithmetic_variants_agree(dev, small_model, edge_variant, mlp_variant):
+    """The exact fp32-MFMA kernels and the bf16x6 kernels stay in the library as cross-checks of the default
+    fp16x3 kernels; the variant is read once per process, so run the check in a child process."""
+    import subprocess
+    import sys
+    code = (
+        "import torch, sys; sys.path.insert(0, %r)\n"
+        "from arreau_amd.checkpoint import make_synthetic_model\n"
+        "from arreau_amd.diffusion.diffusion_helpers import crystal_offsets\n"
+        "from tests.helpers import random_state\n"
+        "dev = torch.device('cuda', 0)\n"
+        "m = make_synthetic_model(S=12, seed=1234, num_timesteps=100).to(dev)\n"
+        "frac, types, lengths, angles, na = random_state(12, [8, 8, 5], 77)\n"
+        "d = lambda v: v.to(dev).contiguous()\n"
+        "t_c = torch.full((3,), 50, device=dev, dtype=torch.int32)\n"
+        "out = m.engine().predict_scores(d(frac), d(types.to(torch.int32)), d(lengths), d(angles), t_c, crystal_offsets(na, dev))\n"
+        "torch.save([x.cpu() for x in out], sys.argv[1])\n" % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import tempfile
+    outs = {}
+    with tempfile.TemporaryDirectory() as d:
+        for tag, env in (("default", {}), ("alt", {"ARREAU_EDGE_VARIANT": edge_variant, "ARREAU_MLP_VARIANT": mlp_variant})):
+            path = os.path.join(d, tag + ".pt")
+            subprocess.run([sys.executable, "-c", code, path], check=True, env={**os.environ, **env}, timeout=300)
+            outs[tag] = torch.load(path)
+    scale = max(1.0, float(outs["default"][1].abs().max()))
+    for x, y in zip(outs["default"], outs["alt"]):
+        assert (x - y).abs().max() <= TOL * scale * 8
