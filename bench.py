@@ -228,6 +228,10 @@ def main():
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f32",
+            "dtype_note": "fp32 inputs/outputs/accumulation; each fp32 product of the dense layers is evaluated as 3 fp16 "
+                          "MFMA products (two 11-bit operand planes, f16x3.h) -- fp32-grade accuracy, parity 1e-5 vs the "
+                          "fp32 CPU path (tests/test_gpu_parity.py); ARREAU_EDGE_VARIANT=0 ARREAU_MLP_VARIANT=0 selects "
+                          "the plain fp32-MFMA kernels",
             "data": "synthetic",
             "config": {
                 "workload": f"BASELINE configs[1] per GPU: batch={B} crystals x {n} atoms, 1000-step sampler "
