@@ -126,7 +126,7 @@ class PONITA_DIFFUSION(nn.Module):
     def sample(self, num_atoms_per_sample: int, num_samples_in_batch: int,
                visualization_setting: VisualizationSetting = VisualizationSetting.NONE, show_bonds: bool = False,
                use_constant_atomic_symbols: Optional[list] = None, noise: str = "device",
-               max_steps: Optional[int] = None) -> SampleResult:
+               max_steps: Optional[int] = None, use_graph: Optional[bool] = None) -> SampleResult:
         """lightning_wrappers/diffusion.py:220-253."""
         z_table = AtomicNumberTable(self.z_table_zs.tolist())
         if use_constant_atomic_symbols is not None:
@@ -140,4 +140,4 @@ class PONITA_DIFFUSION(nn.Module):
             model=self, z_table=z_table, t_emb_weights=self.t_emb, num_atoms_per_sample=num_atoms_per_sample,
             num_samples_in_batch=num_samples_in_batch, vis_name=f"{DIFFUSION_DIR}/step",
             visualization_setting=visualization_setting, show_bonds=show_bonds, constant_atoms=constant_atoms,
-            noise=noise, max_steps=max_steps)
+            noise=noise, max_steps=max_steps, use_graph=use_graph)
