@@ -37,9 +37,22 @@ def needs_build():
 
 
 def build(force=False, verbose=True):
-    """Compile every .hip source to an object (in parallel) and link the shared library."""
+    """Compile every .hip source to an object (in parallel) and link the shared library.
+    Serialised across processes with a file lock (one rank builds, the others find the result)."""
     if not force and not needs_build():
         return LIB
+    import fcntl
+    with open(os.path.join(CSRC, ".build_lock"), "w") as lock:
+        fcntl.flock(lock, fcntl.LOCK_EX)
+        try:
+            if not force and not needs_build():
+                return LIB
+            return _build_locked(verbose)
+        finally:
+            fcntl.flock(lock, fcntl.LOCK_UN)
+
+
+def _build_locked(verbose):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     t0 = time.time()
     procs = []
