@@ -127,10 +127,7 @@ __global__ __launch_bounds__(64 * EH_WAVES, 2) void edge_kernel_f16x3(
 #pragma unroll
             for (int r = 0; r < 16; ++r) cross[r] = 0.f;
             mma_range2<TM, 0, 2 * TM>(acc, cross, lds[cur], bm, lane);
-            acc = fold_cross(acc, cross);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] = gelu_fast(acc[r]);
-            h1[u] = split_tile2(acc);
+            h1[u] = gelu_split_tile2(acc, cross, 1.0f);
         }
         if (u + 1 < TC) stage_store2<NF1, EH_WAVES>(reinterpret_cast<u32x4(&)[(NF1 + EH_WAVES - 1) / EH_WAVES]>(st), lds[cur ^ 1], wave, lane);
         else stage_store2<NF2, EH_WAVES>(reinterpret_cast<u32x4(&)[(NF2 + EH_WAVES - 1) / EH_WAVES]>(st), lds[cur ^ 1], wave, lane);
@@ -149,10 +146,7 @@ __global__ __launch_bounds__(64 * EH_WAVES, 2) void edge_kernel_f16x3(
 #pragma unroll
             for (int r = 0; r < 16; ++r) cross[r] = 0.f;
             mma_range2<TC, 0, 2 * TC>(acc, cross, lds[cur], h1, lane);
-            acc = fold_cross(acc, cross);
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[r] = gelu_fast(acc[r]) * window;
-            basis[u] = split_tile2(acc);
+            basis[u] = gelu_split_tile2(acc, cross, window);
         }
         if (u + 1 < TD) stage_store2<NF2, EH_WAVES>(reinterpret_cast<u32x4(&)[(NF2 + EH_WAVES - 1) / EH_WAVES]>(st), lds[cur ^ 1], wave, lane);
         else stage_store2<NF3, EH_WAVES>(st, lds[cur ^ 1], wave, lane);

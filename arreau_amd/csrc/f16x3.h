@@ -23,28 +23,51 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 #define F16X3_SCALE 2048.0f
 #define F16X3_INV_SCALE (1.0f / 2048.0f)
 
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ f32x2 splat2(float v) { return f32x2{v, v}; }
+__device__ __forceinline__ f32x2 fma2(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+#define F16X3_PAIR(v, i) (f32x2{(v)[2 * (i)], (v)[2 * (i) + 1]})
+
 // GELU with the Abramowitz-Stegun 7.1.26 complementary error function (|error| <= 1.5e-7 on erf, i.e.
-// <= 0.75e-7 |x| on GELU): one rcp + one exp2 + 5 fma, branch-free, about half the VALU work of the 1-ulp erf in
-// internal.h.
-__device__ __forceinline__ float gelu_fast(float x) {
-    const float z = fabsf(x) * 0.70710678118654752440f;
-    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
-    float p = fmaf(1.061405429f, t, -1.453152027f);
-    p = fmaf(p, t, 1.421413741f);
-    p = fmaf(p, t, -0.284496736f);
-    p = fmaf(p, t, 0.254829592f);
-    const float e = __builtin_amdgcn_exp2f((x * x) * -0.72134752044448170368f);  // exp(-z^2), z^2 = x^2 / 2
-    const float half_erfc = 0.5f * (p * t) * e;                                     // 0.5 * erfc(|z|)
-    const float phi = x < 0.0f ? half_erfc : 1.0f - half_erfc;
-    return x * phi;
+// <= 0.75e-7 |x| on GELU), branch-free, on register PAIRS: gfx950 issues v_pk_fma_f32 / v_pk_mul_f32 at the
+// rate of the scalar forms, so the polynomial and the products cost half an instruction per element.  Per
+// element: 1 fma(|x|) + 1 rcp + 1 exp2 + 1 max + 1 fma(-|x|) unpacked, 7 packed halves.
+//     0.5 erfc(|z|) = (0.5 poly(t)) t exp(-z^2),  z = |x| / sqrt 2,  t = 1 / (1 + 0.3275911 z)
+//     GELU(x) = x Phi(x) = max(x, 0) - |x| 0.5 erfc(|z|)
+__device__ __forceinline__ f32x2 gelu_fast2(f32x2 x) {
+    f32x2 t;
+    t.x = __builtin_amdgcn_rcpf(fmaf(fabsf(x.x), 0.3275911f * 0.70710678118654752440f, 1.0f));
+    t.y = __builtin_amdgcn_rcpf(fmaf(fabsf(x.y), 0.3275911f * 0.70710678118654752440f, 1.0f));
+    f32x2 p = fma2(splat2(0.5f * 1.061405429f), t, splat2(0.5f * -1.453152027f));
+    p = fma2(p, t, splat2(0.5f * 1.421413741f));
+    p = fma2(p, t, splat2(0.5f * -0.284496736f));
+    p = fma2(p, t, splat2(0.5f * 0.254829592f));
+    const f32x2 q = (x * x) * splat2(-0.72134752044448170368f);  // -z^2 / ln 2
+    f32x2 e;
+    e.x = __builtin_amdgcn_exp2f(q.x);
+    e.y = __builtin_amdgcn_exp2f(q.y);
+    const f32x2 half_erfc = (p * t) * e;
+    f32x2 r;
+    r.x = fmaf(-fabsf(x.x), half_erfc.x, fmaxf(x.x, 0.0f));
+    r.y = fmaf(-fabsf(x.y), half_erfc.y, fmaxf(x.y, 0.0f));
+    return r;
 }
+__device__ __forceinline__ float gelu_fast(float x) { return gelu_fast2(splat2(x)).x; }
 
 // ---- fp16 planes of a 32x32 fp32 tile (B-operand form): registers 8s..8s+7 are the fragment of k-step s ------
 struct Planes2 { u32x4 p[2][2]; };  // [plane][k-step s]: 8 fp16 per lane each
 
-__device__ __forceinline__ unsigned pack_f16(_Float16 lo, _Float16 hi) {
-    f16x2 v = {lo, hi};
-    return __builtin_bit_cast(unsigned, v);
+// Two planes of one register pair: v_cvt_pk_f16_f32 (round to nearest even) for both planes, the residual with
+// packed sub/mul.
+__device__ __forceinline__ void split_pair2(f32x2 v, unsigned& hi, unsigned& lo) {
+    v.x = __builtin_amdgcn_fmed3f(v.x, -60000.0f, 60000.0f);
+    v.y = __builtin_amdgcn_fmed3f(v.y, -60000.0f, 60000.0f);
+    const f16x2 h1 = __builtin_convertvector(v, f16x2);
+    const f32x2 res = (v - __builtin_convertvector(h1, f32x2)) * splat2(F16X3_SCALE);
+    const f16x2 h2 = __builtin_convertvector(res, f16x2);
+    hi = __builtin_bit_cast(unsigned, h1);
+    lo = __builtin_bit_cast(unsigned, h2);
 }
 __device__ __forceinline__ Planes2 split_tile2(const f32x16& x) {
     Planes2 r;
@@ -52,13 +75,25 @@ __device__ __forceinline__ Planes2 split_tile2(const f32x16& x) {
     for (int s = 0; s < 2; ++s)
 #pragma unroll
         for (int pp = 0; pp < 4; ++pp) {
-            const float lo = __builtin_amdgcn_fmed3f(x[8 * s + 2 * pp], -60000.0f, 60000.0f);
-            const float hi = __builtin_amdgcn_fmed3f(x[8 * s + 2 * pp + 1], -60000.0f, 60000.0f);
-            const _Float16 lo1 = (_Float16)lo, hi1 = (_Float16)hi;  // v_cvt_f16_f32, round to nearest even
-            r.p[0][s][pp] = pack_f16(lo1, hi1);
-            const _Float16 lo2 = (_Float16)((lo - (float)lo1) * F16X3_SCALE);
-            const _Float16 hi2 = (_Float16)((hi - (float)hi1) * F16X3_SCALE);
-            r.p[1][s][pp] = pack_f16(lo2, hi2);
+            unsigned hi, lo;
+            split_pair2(F16X3_PAIR(x, 4 * s + pp), hi, lo);
+            r.p[0][s][pp] = hi;
+            r.p[1][s][pp] = lo;
+        }
+    return r;
+}
+// Tile epilogue of a hidden layer: planes of GELU(main + cross / 2^11) * scale.
+__device__ __forceinline__ Planes2 gelu_split_tile2(const f32x16& mainacc, const f32x16& cross, float scale) {
+    Planes2 r;
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int pp = 0; pp < 4; ++pp) {
+            const f32x2 v = fma2(F16X3_PAIR(cross, 4 * s + pp), splat2(F16X3_INV_SCALE), F16X3_PAIR(mainacc, 4 * s + pp));
+            unsigned hi, lo;
+            split_pair2(gelu_fast2(v) * splat2(scale), hi, lo);
+            r.p[0][s][pp] = hi;
+            r.p[1][s][pp] = lo;
         }
     return r;
 }
@@ -99,7 +134,11 @@ __device__ __forceinline__ void mma_range2(f32x16& mainacc, f32x16& cross, const
 __device__ __forceinline__ f32x16 fold_cross(const f32x16& mainacc, const f32x16& cross) {
     f32x16 r;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) r[i] = fmaf(cross[i], F16X3_INV_SCALE, mainacc[i]);
+    for (int i = 0; i < 8; ++i) {
+        const f32x2 v = fma2(F16X3_PAIR(cross, i), splat2(F16X3_INV_SCALE), F16X3_PAIR(mainacc, i));
+        r[2 * i] = v.x;
+        r[2 * i + 1] = v.y;
+    }
     return r;
 }
 

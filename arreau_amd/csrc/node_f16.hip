@@ -114,10 +114,7 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_kernel_f16x3(
             stage_store2<NF, NW>(st, lds[cur ^ 1], wave, lane);
             if (active) {
                 mma_range2<TC, TC, 2 * TC>(acc, cross, lds[cur], xn, lane);
-                acc = fold_cross(acc, cross);
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[r] = gelu_fast(acc[r]);
-                hid[u] = split_tile2(acc);
+                hid[u] = gelu_split_tile2(acc, cross, 1.0f);
             }
             __syncthreads();
         }
