@@ -17,7 +17,7 @@ HEADERS = ["internal.h", "bf16x6.h", "f16x3.h", os.path.join("..", "..", "includ
 LIB = os.path.join(CSRC, "libarreau_hip.so")
 STAMP = os.path.join(CSRC, ".build_stamp")
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
-         "-ffp-contract=on"]
+         "-ffp-contract=on"] + os.environ.get("ARREAU_EXTRA_HIPCC_FLAGS", "").split()
 
 
 def _digest():

@@ -6,9 +6,10 @@
 // LDS hand-overs and store traffic overlap the partner's MFMA stream.
 //
 // Workgroup = 8 waves = the 16 edge slots of two receivers (2 waves per SIMD).  Weight chunks (one 32-row
-// output tile: 12 / 16 / 32 KiB) are shared through a double-buffered LDS ring: each wave fetches 1/8 of
-// the next chunk into registers at the top of a chunk and writes it to the idle buffer in the middle of the
-// chunk's MFMA stream; one barrier per chunk.
+// output tile: 12 / 16 / 32 KiB) are shared through a double-buffered LDS ring filled by LDS-DMA
+// (global_load_lds_dwordx4): each wave starts the copy of 1/8 of the next chunk at the top of a chunk, drains it
+// (vmcnt) after the chunk's MFMA stream and meets the others at the one barrier per chunk -- no staging registers,
+// no ds_write, and the copy's latency is covered by a whole chunk of matrix work.
 #include <stdlib.h>
 #include <utility>
 
@@ -47,6 +48,28 @@ __device__ __forceinline__ f32x16 mono_tile_h(const float (&a)[6], int h, std::i
 }
 
 
+// Phase timing (tools/edge_timing.py; compiled in only with -DARREAU_EDGE_TIMING): wave 0 of every workgroup adds
+// the shader-clock ticks it spent in [set-up, layer 1, layer 2, projections, tail] to these counters.
+#ifdef ARREAU_EDGE_TIMING
+__device__ unsigned long long arreau_edge_ticks[8];
+#define EDGE_TICK(i)                            \
+    do {                                        \
+        const long long now_ = clock64();       \
+        tacc_[i] += now_ - tick_;               \
+        tick_ = now_;                           \
+    } while (0)
+extern "C" int arreau_debug_edge_ticks(unsigned long long* out8, int reset) {
+    if (hipMemcpyFromSymbol(out8, HIP_SYMBOL(arreau_edge_ticks), 64) != hipSuccess) return 1;
+    if (reset) {
+        unsigned long long z[8] = {0};
+        if (hipMemcpyToSymbol(HIP_SYMBOL(arreau_edge_ticks), z, 64) != hipSuccess) return 1;
+    }
+    return 0;
+}
+#else
+#define EDGE_TICK(i)
+#endif
+
 template <int C, int D, int EH_WAVES>
 __global__ __launch_bounds__(64 * EH_WAVES, 2) void edge_kernel_f16x3(
     const float* __restrict__ nbr_dir,   // [N][k][3]
@@ -61,10 +84,10 @@ __global__ __launch_bounds__(64 * EH_WAVES, 2) void edge_kernel_f16x3(
 {
     constexpr int TC = C / 32, TD = D / 32, TM = ARREAU_MONO_PAD / 32;
     constexpr int NF1 = TM * 4, NF2 = TC * 4, NF3 = TD * 4;  // 1 KiB fragments per chunk: 12, 16, 32
-    constexpr int NST = (NF3 + EH_WAVES - 1) / EH_WAVES;     // fragments a wave stages per chunk (4)
     static_assert(TM == 3 && ((TC + TD) & 1) == 0, "chunk geometry / buffer parity");
     __shared__ u32x4 lds[2][NF3 * 64];                                        // 2 x 32 KiB
     __shared__ __attribute__((aligned(16))) float otile[EH_WAVES][32 * 36];   // per-wave transpose pad for the stores
+    __shared__ __attribute__((aligned(16))) float bias_s[C + D];              // b1 | b2 (no global loads beside the DMA)
 
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int h = lane >> 5, j = lane & 31;
@@ -77,9 +100,13 @@ __global__ __launch_bounds__(64 * EH_WAVES, 2) void edge_kernel_f16x3(
     const int o = j & 15;
     const int slot_c = min(slot, k - 1);
 
-    u32x4 st[NST];
+#ifdef ARREAU_EDGE_TIMING
+    long long tick_ = clock64();
+    long long tacc_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
     const u32x4* chunk = stream;
-    stage_load2<NF1, EH_WAVES>(reinterpret_cast<u32x4(&)[(NF1 + EH_WAVES - 1) / EH_WAVES]>(st), chunk, wave, lane);
+    dma_chunk<NF1, EH_WAVES>(chunk, lds[0], wave, lane);
+    if (threadIdx.x < C + D) bias_s[threadIdx.x] = threadIdx.x < C ? b1[threadIdx.x] : b2[threadIdx.x - C];
 
     // ---- per-row attributes (transforms/invariants.py:82-88) ------------------------------------------
     float a[6], window;
@@ -111,53 +138,68 @@ __global__ __launch_bounds__(64 * EH_WAVES, 2) void edge_kernel_f16x3(
     bm[1] = split_tile2(mono_tile_h<1>(a, h, std::make_integer_sequence<int, 16>{}));
     bm[2] = split_tile2(mono_tile_h<2>(a, h, std::make_integer_sequence<int, 16>{}));
 
-    stage_store2<NF1, EH_WAVES>(reinterpret_cast<u32x4(&)[(NF1 + EH_WAVES - 1) / EH_WAVES]>(st), lds[0], wave, lane);
+    dma_wait();
     __syncthreads();
 
+    EDGE_TICK(0);
+    // Stagger (MI355X two-waves-per-SIMD rule): waves w and w+4 share a SIMD and, paced by the same barriers, would
+    // run their MFMA streams and their VALU epilogues (GELU, plane splits, tile stores) at the same moments -- the
+    // matrix pipe idle while both do vector work and vice versa.  Waves 4-7 ("late") therefore run every tile's
+    // epilogue one chunk later, in front of the next chunk's MFMAs, with the folded tile (`pend`) carried across
+    // the barrier in the registers the tile's planes will occupy; waves 0-3 finish each tile before the barrier.
+    // Same arithmetic in the same order per tile: results are bit for bit those of the unstaggered kernel.
+    const bool late = wave >= 4;  // wave-uniform (SGPR)
+    f32x16 pend;
     // ---- layer 1: h = GELU(W1f . mono + b1) -------------------------------------------------------------
     Planes2 h1[TC];
 #pragma unroll
     for (int u = 0; u < TC; ++u) {
         const int cur = u & 1;
         chunk += (size_t)NF1 * 64;
-        if (u + 1 < TC) stage_load2<NF1, EH_WAVES>(reinterpret_cast<u32x4(&)[(NF1 + EH_WAVES - 1) / EH_WAVES]>(st), chunk, wave, lane);
-        else stage_load2<NF2, EH_WAVES>(reinterpret_cast<u32x4(&)[(NF2 + EH_WAVES - 1) / EH_WAVES]>(st), chunk, wave, lane);
+        if (u + 1 < TC) dma_chunk<NF1, EH_WAVES>(chunk, lds[cur ^ 1], wave, lane);
+        else dma_chunk<NF2, EH_WAVES>(chunk, lds[cur ^ 1], wave, lane);
         if (active) {
-            f32x16 acc = arreau_bias_tile(b1, u, h), cross;
+            if (late && u > 0) h1[u - 1] = gelu_split_folded2(pend, 1.0f);
+            f32x16 acc = arreau_bias_tile(bias_s, u, h), cross;
 #pragma unroll
             for (int r = 0; r < 16; ++r) cross[r] = 0.f;
             mma_range2<TM, 0, 2 * TM>(acc, cross, lds[cur], bm, lane);
-            h1[u] = gelu_split_tile2(acc, cross, 1.0f);
+            pend = fold_cross(acc, cross);
+            if (!late) h1[u] = gelu_split_folded2(pend, 1.0f);
         }
-        if (u + 1 < TC) stage_store2<NF1, EH_WAVES>(reinterpret_cast<u32x4(&)[(NF1 + EH_WAVES - 1) / EH_WAVES]>(st), lds[cur ^ 1], wave, lane);
-        else stage_store2<NF2, EH_WAVES>(reinterpret_cast<u32x4(&)[(NF2 + EH_WAVES - 1) / EH_WAVES]>(st), lds[cur ^ 1], wave, lane);
+        dma_wait();
         __syncthreads();
     }
+    EDGE_TICK(1);
     // ---- layer 2: basis = GELU(W2 . h + b2) * window ------------------------------------------------------
     Planes2 basis[TD];
 #pragma unroll
     for (int u = 0; u < TD; ++u) {
         const int cur = (TC + u) & 1;
         chunk += (size_t)NF2 * 64;
-        if (u + 1 < TD) stage_load2<NF2, EH_WAVES>(reinterpret_cast<u32x4(&)[(NF2 + EH_WAVES - 1) / EH_WAVES]>(st), chunk, wave, lane);
-        else stage_load2<NF3, EH_WAVES>(st, chunk, wave, lane);
+        if (u + 1 < TD) dma_chunk<NF2, EH_WAVES>(chunk, lds[cur ^ 1], wave, lane);
+        else dma_chunk<NF3, EH_WAVES>(chunk, lds[cur ^ 1], wave, lane);
         if (active) {
-            f32x16 acc = arreau_bias_tile(b2, u, h), cross;
+            if (late) {
+                if (u == 0) h1[TC - 1] = gelu_split_folded2(pend, 1.0f);
+                else basis[u - 1] = gelu_split_folded2(pend, window);
+            }
+            f32x16 acc = arreau_bias_tile(bias_s + C, u, h), cross;
 #pragma unroll
             for (int r = 0; r < 16; ++r) cross[r] = 0.f;
             mma_range2<TC, 0, 2 * TC>(acc, cross, lds[cur], h1, lane);
-            basis[u] = gelu_split_tile2(acc, cross, window);
+            pend = fold_cross(acc, cross);
+            if (!late) basis[u] = gelu_split_folded2(pend, window);
         }
-        if (u + 1 < TD) stage_store2<NF2, EH_WAVES>(reinterpret_cast<u32x4(&)[(NF2 + EH_WAVES - 1) / EH_WAVES]>(st), lds[cur ^ 1], wave, lane);
-        else stage_store2<NF3, EH_WAVES>(st, lds[cur ^ 1], wave, lane);
+        dma_wait();
         __syncthreads();
     }
+    EDGE_TICK(2);
     // ---- per layer: kernel_l = Wk_l . basis  (conv.py:110), one output tile per chunk ---------------------
     const size_t layer_stride = (size_t)N * k * 16 * C;
     const size_t row0 = ((size_t)node * k + 2 * wn) * 16;  // first K row of this wave's 32-row tile
     const int nchunks = L * TC;
     int cur = 0;  // (TC + TD) is even
-    f32x16 done;  // finished tile of the previous chunk, stored one chunk late (see below)
     float* pad = otile[wave];
     // Transpose a finished 32x32 tile through a wave-private LDS pad so that every store instruction writes
     // whole 128-byte lines (8 lanes per row) instead of 64 scattered 16-byte pieces.
@@ -176,25 +218,33 @@ __global__ __launch_bounds__(64 * EH_WAVES, 2) void edge_kernel_f16x3(
             if (2 * wn + (r >> 4) < nd) *reinterpret_cast<f32x4*>(dst + (size_t)r * C) = v;
         }
     };
+    if (active && late) basis[TD - 1] = gelu_split_folded2(pend, window);
 #pragma unroll 1
     for (int cidx = 0; cidx < nchunks; ++cidx) {
         chunk += (size_t)NF3 * 64;
         const bool more = cidx + 1 < nchunks;  // workgroup-uniform
-        // vmcnt retires in order: the next chunk's fragment loads are issued BEFORE the previous tile's stores,
-        // so waiting for the fragments (mid-chunk) never waits for the stores' HBM round trip.
-        if (more) stage_load2<NF3, EH_WAVES>(st, chunk, wave, lane);
-        if (active && cidx > 0) store_tile(done, cidx - 1);
-        f32x16 acc, cross;
+        // late waves store the previous tile first: its global stores are then older than this chunk's DMA
+        if (active && late && cidx > 0) store_tile(pend, cidx - 1);
+        if (more) dma_chunk<NF3, EH_WAVES>(chunk, lds[cur ^ 1], wave, lane);
+        if (active) {
+            f32x16 acc, cross;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) { acc[r] = 0.0f; cross[r] = 0.0f; }
-        if (active) mma_range2<TD, 0, TD>(acc, cross, lds[cur], basis, lane);
-        if (more) stage_store2<NF3, EH_WAVES>(st, lds[cur ^ 1], wave, lane);
-        if (active) mma_range2<TD, TD, 2 * TD>(acc, cross, lds[cur], basis, lane);
+            for (int r = 0; r < 16; ++r) { acc[r] = 0.0f; cross[r] = 0.0f; }
+            mma_range2<TD, 0, 2 * TD>(acc, cross, lds[cur], basis, lane);
+            pend = fold_cross(acc, cross);
+        }
+        dma_wait();
+        if (active && !late) store_tile(pend, cidx);
         __syncthreads();
-        done = fold_cross(acc, cross);
         cur ^= 1;
     }
-    if (active) store_tile(done, nchunks - 1);
+    EDGE_TICK(3);
+    if (active && late) store_tile(pend, nchunks - 1);
+    EDGE_TICK(4);
+#ifdef ARREAU_EDGE_TIMING
+    if (threadIdx.x == 0)
+        for (int i = 0; i < 8; ++i) atomicAdd(&arreau_edge_ticks[i], (unsigned long long)tacc_[i]);
+#endif
 }
 
 int arreau_launch_edge_f16x3(const arreau_model* m, const float* dir, const float* dist, const int32_t* deg,

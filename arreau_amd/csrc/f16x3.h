@@ -82,20 +82,23 @@ __device__ __forceinline__ Planes2 split_tile2(const f32x16& x) {
         }
     return r;
 }
-// Tile epilogue of a hidden layer: planes of GELU(main + cross / 2^11) * scale.
-__device__ __forceinline__ Planes2 gelu_split_tile2(const f32x16& mainacc, const f32x16& cross, float scale) {
+// Tile epilogue of a hidden layer: planes of GELU(v) * scale for a folded tile v = main + cross / 2^11.
+__device__ __forceinline__ Planes2 gelu_split_folded2(const f32x16& v, float scale) {
     Planes2 r;
 #pragma unroll
     for (int s = 0; s < 2; ++s)
 #pragma unroll
         for (int pp = 0; pp < 4; ++pp) {
-            const f32x2 v = fma2(F16X3_PAIR(cross, 4 * s + pp), splat2(F16X3_INV_SCALE), F16X3_PAIR(mainacc, 4 * s + pp));
             unsigned hi, lo;
-            split_pair2(gelu_fast2(v) * splat2(scale), hi, lo);
+            split_pair2(gelu_fast2(F16X3_PAIR(v, 4 * s + pp)) * splat2(scale), hi, lo);
             r.p[0][s][pp] = hi;
             r.p[1][s][pp] = lo;
         }
     return r;
+}
+__device__ __forceinline__ f32x16 fold_cross(const f32x16& mainacc, const f32x16& cross);
+__device__ __forceinline__ Planes2 gelu_split_tile2(const f32x16& mainacc, const f32x16& cross, float scale) {
+    return gelu_split_folded2(fold_cross(mainacc, cross), scale);
 }
 
 __device__ __forceinline__ f32x16 mfma_f16(const u32x4& a, const u32x4& b, const f32x16& c) {
@@ -105,29 +108,35 @@ __device__ __forceinline__ f32x16 mfma_f16(const u32x4& a, const u32x4& b, const
 // One output tile over k-steps [KS0, KS1): main += a1 b1, cross += a1 b2 + a2 b1.  Chunk layout in LDS:
 // fragment (ks, plane) at (ks * 2 + plane) * 64 + lane (16 bytes per lane).  The two weight planes of k-step
 // ks+1 are read from LDS ahead of the three MFMAs of k-step ks; main and cross are independent chains.
-template <int NIN, int KS0, int KS1>
+template <int NIN, int KS0, int KS1, int PF = 1>
 __device__ __forceinline__ void mma_range2(f32x16& mainacc, f32x16& cross, const u32x4* __restrict__ buf,
                                            const Planes2 (&b)[NIN], int lane) {
+    // PF = how many k-steps the LDS fragment reads run ahead of their MFMAs (register ring of PF + 1 pairs)
     const u32x4* f = buf + lane;
-    u32x4 c1 = f[(size_t)KS0 * 128], c2 = f[(size_t)KS0 * 128 + 64];
+    u32x4 c1[PF + 1], c2[PF + 1];
+#pragma unroll
+    for (int i = 0; i < PF; ++i)
+        if (KS0 + i < KS1) {
+            c1[i] = f[(size_t)(KS0 + i) * 128];
+            c2[i] = f[(size_t)(KS0 + i) * 128 + 64];
+        }
 #pragma unroll
     for (int ks = KS0; ks < KS1; ++ks) {
-        u32x4 n1, n2;
-        if (ks + 1 < KS1) {
-            n1 = f[(size_t)(ks + 1) * 128];
-            n2 = f[(size_t)(ks + 1) * 128 + 64];
+        const int slot = (ks - KS0) % (PF + 1), nslot = (ks - KS0 + PF) % (PF + 1);
+        if (ks + PF < KS1) {
+            c1[nslot] = f[(size_t)(ks + PF) * 128];
+            c2[nslot] = f[(size_t)(ks + PF) * 128 + 64];
         }
         const int t = ks >> 1, s = ks & 1;
-        mainacc = mfma_f16(c1, b[t].p[0][s], mainacc);
-        cross = mfma_f16(c1, b[t].p[1][s], cross);
-        cross = mfma_f16(c2, b[t].p[0][s], cross);
-        if (ks + 1 < KS1) { c1 = n1; c2 = n2; }
+        mainacc = mfma_f16(c1[slot], b[t].p[0][s], mainacc);
+        cross = mfma_f16(c1[slot], b[t].p[1][s], cross);
+        cross = mfma_f16(c2[slot], b[t].p[0][s], cross);
     }
-    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);  // the first k-step's fragments
+    __builtin_amdgcn_sched_group_barrier(0x100, 2 * (PF < KS1 - KS0 ? PF : KS1 - KS0), 0);  // the first PF k-steps' fragments
 #pragma unroll
     for (int ks = KS0; ks < KS1; ++ks) {
-        if (ks + 1 < KS1) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);  // DS reads of k-step ks+1 ...
-        __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);                     // ... ahead of the MFMAs of k-step ks
+        if (ks + PF < KS1) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);  // DS reads of k-step ks+PF ...
+        __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);                      // ... ahead of the MFMAs of k-step ks
     }
 }
 
@@ -141,6 +150,30 @@ __device__ __forceinline__ f32x16 fold_cross(const f32x16& mainacc, const f32x16
     }
     return r;
 }
+
+// LDS-DMA staging of a weight chunk (global_load_lds_dwordx4: each lane's 16 bytes go straight to
+// LDS at wave-uniform base + 16 lane, no VGPR destination, no ds_write).  Wave `wave` of NW moves fragments
+// f = NW i + wave; when NF is not a multiple of NW the surplus waves re-copy an earlier fragment (same bytes, same
+// place) so that every wave issues the same number of DMA instructions.  hipcc does not count inline-asm memory
+// operations: the caller drains them with dma_wait() before the barrier that publishes the chunk, and must keep
+// ordinary global LOADS out of the span where a DMA is in flight (hipcc would wait vmcnt(0) for them).
+__device__ __forceinline__ void glds16(const u32x4* gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+template <int NF, int NW>
+__device__ __forceinline__ void dma_chunk(const u32x4* __restrict__ chunk, u32x4* slot, int wave, int lane) {
+    constexpr int PER = (NF + NW - 1) / NW;
+    const unsigned base = __builtin_amdgcn_readfirstlane((unsigned)(size_t)slot);
+#pragma unroll
+    for (int i = 0; i < PER; ++i) {
+        int f = NW * i + wave;
+        if (NF % NW != 0 && f >= NF) f -= NF % NW;  // wave-uniform; duplicate of a fragment another wave also copies
+        glds16(chunk + (size_t)f * 64 + lane, base + (unsigned)f * 1024u);
+    }
+}
+__device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 // Register staging of the next weight chunk: wave `wave` of NW fetches fragments f = NW i + wave ...
 template <int NF, int NW>
