@@ -84,8 +84,8 @@ __global__ __launch_bounds__(64 * EH_WAVES, 2) void edge_kernel_f16x3(
 {
     constexpr int TC = C / 32, TD = D / 32, TM = ARREAU_MONO_PAD / 32;
     constexpr int NF1 = TM * 4, NF2 = TC * 4, NF3 = TD * 4;  // 1 KiB fragments per chunk: 12, 16, 32
-    static_assert(TM == 3 && ((TC + TD) & 1) == 0, "chunk geometry / buffer parity");
-    __shared__ u32x4 lds[2][NF3 * 64];                                        // 2 x 32 KiB
+    static_assert(TM == 3, "chunk geometry");
+    __shared__ u32x4 lds[3][NF3 * 64];                                        // 3 x 32 KiB ring of weight chunks
     __shared__ __attribute__((aligned(16))) float otile[EH_WAVES][32 * 36];   // per-wave transpose pad for the stores
     __shared__ __attribute__((aligned(16))) float bias_s[C + D];              // b1 | b2 (no global loads beside the DMA)
 
@@ -104,8 +104,11 @@ __global__ __launch_bounds__(64 * EH_WAVES, 2) void edge_kernel_f16x3(
     long long tick_ = clock64();
     long long tacc_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #endif
-    const u32x4* chunk = stream;
-    dma_chunk<NF1, EH_WAVES>(chunk, lds[0], wave, lane);
+    const u32x4* dma_src = stream;  // next chunk to copy
+    dma_chunk<NF1, EH_WAVES>(dma_src, lds[0], wave, lane);
+    dma_src += (size_t)NF1 * 64;
+    dma_chunk<NF1, EH_WAVES>(dma_src, lds[1], wave, lane);
+    dma_src += (size_t)NF1 * 64;
     if (threadIdx.x < C + D) bias_s[threadIdx.x] = threadIdx.x < C ? b1[threadIdx.x] : b2[threadIdx.x - C];
 
     // ---- per-row attributes (transforms/invariants.py:82-88) ------------------------------------------
@@ -142,104 +145,136 @@ __global__ __launch_bounds__(64 * EH_WAVES, 2) void edge_kernel_f16x3(
     __syncthreads();
 
     EDGE_TICK(0);
-    // Stagger (MI355X two-waves-per-SIMD rule): waves w and w+4 share a SIMD and, paced by the same barriers, would
-    // run their MFMA streams and their VALU epilogues (GELU, plane splits, tile stores) at the same moments -- the
-    // matrix pipe idle while both do vector work and vice versa.  Waves 4-7 ("late") therefore run every tile's
-    // epilogue one chunk later, in front of the next chunk's MFMAs, with the folded tile (`pend`) carried across
-    // the barrier in the registers the tile's planes will occupy; waves 0-3 finish each tile before the barrier.
-    // Same arithmetic in the same order per tile: results are bit for bit those of the unstaggered kernel.
-    const bool late = wave >= 4;  // wave-uniform (SGPR)
-    f32x16 pend;
+    // Ring protocol.  Chunk q lives in slot q % 3.  The one barrier per chunk sits in the MIDDLE of the chunk's MFMA
+    // stream (SYNC_q), not at its end: by then every wave has left chunk q-1 (so slot (q+2) % 3 is free) and has
+    // drained its share of the copy of chunk q+1 (issued at SYNC_{q-1}, a whole chunk of matrix work earlier), so
+    // after the barrier chunk q+1 is complete for everybody and the copy of chunk q+2 can start.  A wave therefore
+    // runs from the end of one tile (accumulator drain, GELU / plane split or tile store) straight into the next
+    // tile's MFMAs without meeting anybody -- the two waves of a SIMD drift apart and one's epilogue overlaps the
+    // other's matrix work, instead of both draining the matrix pipe at a common end-of-chunk barrier.
+    const bool late = wave >= 4;  // wave-uniform (SGPR): SIMD partner of wave - 4, syncs later inside a projection chunk
     // ---- layer 1: h = GELU(W1f . mono + b1) -------------------------------------------------------------
     Planes2 h1[TC];
 #pragma unroll
     for (int u = 0; u < TC; ++u) {
-        const int cur = u & 1;
-        chunk += (size_t)NF1 * 64;
-        if (u + 1 < TC) dma_chunk<NF1, EH_WAVES>(chunk, lds[cur ^ 1], wave, lane);
-        else dma_chunk<NF2, EH_WAVES>(chunk, lds[cur ^ 1], wave, lane);
+        f32x16 acc, cross;
         if (active) {
-            if (late && u > 0) h1[u - 1] = gelu_split_folded2(pend, 1.0f);
-            f32x16 acc = arreau_bias_tile(bias_s, u, h), cross;
+            acc = arreau_bias_tile(bias_s, u, h);
 #pragma unroll
             for (int r = 0; r < 16; ++r) cross[r] = 0.f;
-            mma_range2<TM, 0, 2 * TM>(acc, cross, lds[cur], bm, lane);
-            pend = fold_cross(acc, cross);
-            if (!late) h1[u] = gelu_split_folded2(pend, 1.0f);
+            mma_range2<TM, 0, TM>(acc, cross, lds[u % 3], bm, lane);
         }
         dma_wait();
         __syncthreads();
+        if (u + 2 < TC) { dma_chunk<NF1, EH_WAVES>(dma_src, lds[(u + 2) % 3], wave, lane); dma_src += (size_t)NF1 * 64; }
+        else { dma_chunk<NF2, EH_WAVES>(dma_src, lds[(u + 2) % 3], wave, lane); dma_src += (size_t)NF2 * 64; }
+        if (active) {
+            mma_range2<TM, TM, 2 * TM>(acc, cross, lds[u % 3], bm, lane);
+            h1[u] = gelu_split_tile2(acc, cross, 1.0f);
+        }
     }
     EDGE_TICK(1);
     // ---- layer 2: basis = GELU(W2 . h + b2) * window ------------------------------------------------------
     Planes2 basis[TD];
 #pragma unroll
     for (int u = 0; u < TD; ++u) {
-        const int cur = (TC + u) & 1;
-        chunk += (size_t)NF2 * 64;
-        if (u + 1 < TD) dma_chunk<NF2, EH_WAVES>(chunk, lds[cur ^ 1], wave, lane);
-        else dma_chunk<NF3, EH_WAVES>(chunk, lds[cur ^ 1], wave, lane);
+        constexpr int Q0 = TC;
+        f32x16 acc, cross;
         if (active) {
-            if (late) {
-                if (u == 0) h1[TC - 1] = gelu_split_folded2(pend, 1.0f);
-                else basis[u - 1] = gelu_split_folded2(pend, window);
-            }
-            f32x16 acc = arreau_bias_tile(bias_s + C, u, h), cross;
+            acc = arreau_bias_tile(bias_s + C, u, h);
 #pragma unroll
             for (int r = 0; r < 16; ++r) cross[r] = 0.f;
-            mma_range2<TC, 0, 2 * TC>(acc, cross, lds[cur], h1, lane);
-            pend = fold_cross(acc, cross);
-            if (!late) basis[u] = gelu_split_folded2(pend, window);
+            mma_range2<TC, 0, TC>(acc, cross, lds[(Q0 + u) % 3], h1, lane);
         }
         dma_wait();
         __syncthreads();
+        if (u + 2 < TD) { dma_chunk<NF2, EH_WAVES>(dma_src, lds[(Q0 + u + 2) % 3], wave, lane); dma_src += (size_t)NF2 * 64; }
+        else if (u + 2 - TD < L * TC) { dma_chunk<NF3, EH_WAVES>(dma_src, lds[(Q0 + u + 2) % 3], wave, lane); dma_src += (size_t)NF3 * 64; }
+        if (active) {
+            mma_range2<TC, TC, 2 * TC>(acc, cross, lds[(Q0 + u) % 3], h1, lane);
+            basis[u] = gelu_split_tile2(acc, cross, window);
+        }
     }
     EDGE_TICK(2);
     // ---- per layer: kernel_l = Wk_l . basis  (conv.py:110), one output tile per chunk ---------------------
     const size_t layer_stride = (size_t)N * k * 16 * C;
     const size_t row0 = ((size_t)node * k + 2 * wn) * 16;  // first K row of this wave's 32-row tile
     const int nchunks = L * TC;
-    int cur = 0;  // (TC + TD) is even
+    int sl = (TC + TD) % 3;  // ring slot of the current chunk
     float* pad = otile[wave];
-    // Transpose a finished 32x32 tile through a wave-private LDS pad so that every store instruction writes
-    // whole 128-byte lines (8 lanes per row) instead of 64 scattered 16-byte pieces.
-    auto store_tile = [&](const f32x16& t, int cidx_done) {
-        const int l = cidx_done / TC, u = cidx_done - l * TC;
+    const bool full = 2 * wn + 1 < k;  // wave-uniform: the wave's second slot exists
+    // A finished 32x32 tile goes to HBM through a wave-private LDS pad (transposed, so that every store instruction
+    // writes whole 128-byte lines: 8 lanes per row), in two steps that sit half a chunk apart in the instruction
+    // stream: pad_write right behind the tile's last MFMA, pad_store two k-steps into the next tile's MFMAs.
+    auto pad_write = [&](const f32x16& t) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
             const f32x4 v = {t[4 * q], t[4 * q + 1], t[4 * q + 2], t[4 * q + 3]};
             *reinterpret_cast<f32x4*>(&pad[j * 36 + 8 * q + 4 * h]) = v;
         }
+    };
+    // Not predicated on the degree: a slot beyond it gets the zeros its window produced (those rows of the K buffer
+    // are never read), so a wave issues a FIXED number of stores per tile (4, or 2 for the wave whose second slot does
+    // not exist when k is odd) -- which the counted wait at SYNC relies on.
+    auto pad_store = [&](int cidx_done) {
+        const int l = cidx_done / TC, u = cidx_done - l * TC;
         float* dst = kbuf + (size_t)l * layer_stride + row0 * C + 32 * u + 4 * (lane & 7);
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int r = 8 * i + (lane >> 3);  // row of the wave tile: slot 2*wn + (r >> 4), orientation r & 15
             const f32x4 v = *reinterpret_cast<const f32x4*>(&pad[r * 36 + 4 * (lane & 7)]);
-            if (2 * wn + (r >> 4) < nd) *reinterpret_cast<f32x4*>(dst + (size_t)r * C) = v;
+            if (i < 2 || full) *reinterpret_cast<f32x4*>(dst + (size_t)r * C) = v;
         }
     };
-    if (active && late) basis[TD - 1] = gelu_split_folded2(pend, window);
+    // One projection loop per wave class.  X = k-step at which the class takes the chunk's barrier: 1/4 into the
+    // chunk for waves 0-3, 3/4 for waves 4-7, so SIMD partners reach their end-of-tile work half a chunk apart.
+    // At SYNC the wave's queue holds, oldest first, its 4 DMA copies of the next chunk and -- from the second chunk
+    // on -- the stores of the previous tile: the counted wait retires the copies and leaves the stores in flight.
+    auto proj_loop = [&](auto xtag) {
+        constexpr int X = decltype(xtag)::value;
+        static_assert(X >= 2 && X < 2 * TD, "barrier position");
 #pragma unroll 1
-    for (int cidx = 0; cidx < nchunks; ++cidx) {
-        chunk += (size_t)NF3 * 64;
-        const bool more = cidx + 1 < nchunks;  // workgroup-uniform
-        // late waves store the previous tile first: its global stores are then older than this chunk's DMA
-        if (active && late && cidx > 0) store_tile(pend, cidx - 1);
-        if (more) dma_chunk<NF3, EH_WAVES>(chunk, lds[cur ^ 1], wave, lane);
-        if (active) {
+        for (int cidx = 0; cidx < nchunks; ++cidx) {
+            const u32x4* buf = lds[sl];
+            u32x4* free_slot = lds[sl == 0 ? 2 : sl - 1];  // (sl + 2) % 3
             f32x16 acc, cross;
 #pragma unroll
             for (int r = 0; r < 16; ++r) { acc[r] = 0.0f; cross[r] = 0.0f; }
-            mma_range2<TD, 0, 2 * TD>(acc, cross, lds[cur], basis, lane);
-            pend = fold_cross(acc, cross);
+            mma_range2<TD, 0, 2>(acc, cross, buf, basis, lane);
+            if (cidx > 0) pad_store(cidx - 1);
+            mma_range2<TD, 2, X>(acc, cross, buf, basis, lane);
+#ifndef EXP_NOBAR
+            if (cidx == 0) dma_wait();
+            else if (full) dma_wait_but<4>();
+            else dma_wait_but<2>();
+            __syncthreads();
+#ifndef EXP_NODMA
+            if (cidx + 2 < nchunks) dma_chunk<NF3, EH_WAVES>(dma_src, free_slot, wave, lane);
+#endif
+#endif
+            dma_src += (size_t)NF3 * 64;
+            mma_range2<TD, X, 2 * TD>(acc, cross, buf, basis, lane);
+            pad_write(fold_cross(acc, cross));
+            sl = sl == 2 ? 0 : sl + 1;
         }
-        dma_wait();
-        if (active && !late) store_tile(pend, cidx);
-        __syncthreads();
-        cur ^= 1;
+        pad_store(nchunks - 1);
+    };
+    if (!active) {  // no slots: keep the ring turning
+#pragma unroll 1
+        for (int cidx = 0; cidx < nchunks; ++cidx) {
+            u32x4* free_slot = lds[sl == 0 ? 2 : sl - 1];
+            dma_wait();
+            __syncthreads();
+            if (cidx + 2 < nchunks) dma_chunk<NF3, EH_WAVES>(dma_src, free_slot, wave, lane);
+            dma_src += (size_t)NF3 * 64;
+            sl = sl == 2 ? 0 : sl + 1;
+        }
+    } else if (!late) {
+        proj_loop(std::integral_constant<int, TD / 2>{});
+    } else {
+        proj_loop(std::integral_constant<int, TD + TD / 2>{});
     }
     EDGE_TICK(3);
-    if (active && late) store_tile(pend, nchunks - 1);
     EDGE_TICK(4);
 #ifdef ARREAU_EDGE_TIMING
     if (threadIdx.x == 0)

@@ -3,8 +3,10 @@
 // (f16x3.h).
 //
 // One wave = one 32-row tile (2 nodes x 16 orientations).  Workgroup = NW waves sharing each 16 KiB weight
-// chunk (one output tile) through a double-buffered LDS ring; two waves per SIMD, so one wave's VALU
-// phases (LayerNorm, GELU, splits, epilogue) overlap its partner's MFMA stream.  Every wave walks the whole
+// chunk (one output tile) through a three-slot LDS ring filled by LDS-DMA (f16x3.h, edge_f16.hip "ring
+// protocol": the one barrier per chunk sits in the middle of the chunk's MFMA stream, the copy of chunk q+2 starts
+// there and is drained at the next one); two workgroups per CU, so one wave's VALU phases (LayerNorm, GELU,
+// splits, epilogue) overlap the MFMA stream of the other workgroup's wave on the same SIMD.  Every wave walks the whole
 // hidden dimension quarter by quarter,
 //     hid  = GELU(W1[quarter] . xn + b1[quarter])      (xn = LayerNorm of the conv output, split in registers)
 //     out += W2[:, quarter] . hid
@@ -31,9 +33,9 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_kernel_f16x3(
     constexpr int TC = C / 32;
     constexpr int HQ = H / 4, THQ = HQ / 32;
     constexpr int NF = TC * 4;  // 16 fragments (16 KiB) per chunk = one output tile
-    constexpr int NST = (NF + NW - 1) / NW;
     static_assert(THQ == TC, "W1 and W2 quarter chunks have the same size");
-    __shared__ u32x4 lds[2][NF * 64];  // 2 x 16 KiB
+    __shared__ u32x4 lds[3][NF * 64];                              // 3 x 16 KiB ring of weight chunks
+    __shared__ __attribute__((aligned(16))) float bias_s[H];      // mb1: no global loads while a DMA is in flight
 
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int h = lane >> 5, j = lane & 31;
@@ -44,9 +46,12 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_kernel_f16x3(
     const int n = valid ? (int)n_ll : N - 1;  // padding rows read a valid row and write nothing
     const int o = j & 15;
 
-    u32x4 st[NST];
-    const u32x4* chunk = stream;
-    stage_load2<NF, NW>(st, chunk, wave, lane);
+    const u32x4* dma_src = stream;  // next chunk to copy
+    dma_chunk<NF, NW>(dma_src, lds[0], wave, lane);
+    dma_src += (size_t)NF * 64;
+    dma_chunk<NF, NW>(dma_src, lds[1], wave, lane);
+    dma_src += (size_t)NF * 64;
+    for (int i = threadIdx.x; i < H; i += 64 * NW) bias_s[i] = mb1[i];
 
     // ---- load the row in B-operand layout, LayerNorm it (eps 1e-5, biased variance), split ----------------
     const size_t rowoff = ((size_t)n * 16 + o) * C + 4 * h;
@@ -88,7 +93,7 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_kernel_f16x3(
             xn[t] = split_tile2(bx[t]);
         }
     }
-    stage_store2<NF, NW>(st, lds[0], wave, lane);
+    dma_wait();
     __syncthreads();
 
     f32x16 acc_o[TC];
@@ -98,42 +103,42 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_kernel_f16x3(
         for (int r = 0; r < 16; ++r) acc_o[u][r] = 0.f;
 
     // 32 chunks per layer: per quarter 4 chunks of W1 rows (hidden tiles 0..3) then 4 chunks of W2 columns
-    // (output tiles 0..3).  Buffer parity is static inside the quarter (8 chunks) and repeats.
+    // (output tiles 0..3).  Chunk q sits in ring slot q % 3.
+    int sl = 0;
+    auto sync = [&](bool more2) {  // SYNC_q: chunk q+1 complete for everybody, slot of chunk q-1 free -> copy chunk q+2
+        dma_wait();
+        __syncthreads();
+        if (more2) dma_chunk<NF, NW>(dma_src, lds[sl == 0 ? 2 : sl - 1], wave, lane);
+        dma_src += (size_t)NF * 64;
+    };
 #pragma unroll 1
     for (int w = 0; w < 4; ++w) {
         Planes2 hid[THQ];
 #pragma unroll
         for (int u = 0; u < THQ; ++u) {  // ---- hid tile u = GELU(W1q[u] . xn + b1q[u]) ----
-            const int cur = u & 1;
-            chunk += (size_t)NF * 64;
-            stage_load2<NF, NW>(st, chunk, wave, lane);  // always another chunk after a W1 chunk
-            f32x16 acc = arreau_bias_tile(mb1 + w * HQ, u, h), cross;
+            f32x16 acc = arreau_bias_tile(bias_s + w * HQ, u, h), cross;
 #pragma unroll
             for (int r = 0; r < 16; ++r) cross[r] = 0.f;
-            if (active) mma_range2<TC, 0, TC>(acc, cross, lds[cur], xn, lane);
-            stage_store2<NF, NW>(st, lds[cur ^ 1], wave, lane);
+            if (active) mma_range2<TC, 0, TC>(acc, cross, lds[sl], xn, lane);
+            sync(true);  // a W1 chunk is always followed by at least four more
             if (active) {
-                mma_range2<TC, TC, 2 * TC>(acc, cross, lds[cur], xn, lane);
+                mma_range2<TC, TC, 2 * TC>(acc, cross, lds[sl], xn, lane);
                 hid[u] = gelu_split_tile2(acc, cross, 1.0f);
             }
-            __syncthreads();
+            sl = sl == 2 ? 0 : sl + 1;
         }
 #pragma unroll
         for (int u = 0; u < TC; ++u) {  // ---- out tile u += W2[:, quarter][u] . hid ----
-            const int cur = u & 1;
-            chunk += (size_t)NF * 64;
-            const bool more = !(w == 3 && u == TC - 1);  // workgroup-uniform
-            if (more) stage_load2<NF, NW>(st, chunk, wave, lane);
             f32x16 cross;
 #pragma unroll
             for (int r = 0; r < 16; ++r) cross[r] = 0.f;
-            if (active) mma_range2<THQ, 0, THQ>(acc_o[u], cross, lds[cur], hid, lane);
-            if (more) stage_store2<NF, NW>(st, lds[cur ^ 1], wave, lane);
+            if (active) mma_range2<THQ, 0, THQ>(acc_o[u], cross, lds[sl], hid, lane);
+            sync(!(w == 3 && u >= TC - 2));
             if (active) {
-                mma_range2<THQ, THQ, 2 * THQ>(acc_o[u], cross, lds[cur], hid, lane);
+                mma_range2<THQ, THQ, 2 * THQ>(acc_o[u], cross, lds[sl], hid, lane);
                 acc_o[u] = fold_cross(acc_o[u], cross);
             }
-            __syncthreads();
+            sl = sl == 2 ? 0 : sl + 1;
         }
     }
     if (!active) return;
