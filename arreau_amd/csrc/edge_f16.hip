@@ -243,15 +243,11 @@ __global__ __launch_bounds__(64 * EH_WAVES, 2) void edge_kernel_f16x3(
             mma_range2<TD, 0, 2>(acc, cross, buf, basis, lane);
             if (cidx > 0) pad_store(cidx - 1);
             mma_range2<TD, 2, X>(acc, cross, buf, basis, lane);
-#ifndef EXP_NOBAR
             if (cidx == 0) dma_wait();
             else if (full) dma_wait_but<4>();
             else dma_wait_but<2>();
             __syncthreads();
-#ifndef EXP_NODMA
             if (cidx + 2 < nchunks) dma_chunk<NF3, EH_WAVES>(dma_src, free_slot, wave, lane);
-#endif
-#endif
             dma_src += (size_t)NF3 * 64;
             mma_range2<TD, X, 2 * TD>(acc, cross, buf, basis, lane);
             pad_write(fold_cross(acc, cross));

@@ -123,14 +123,10 @@ __device__ __forceinline__ void mma_range2(f32x16& mainacc, f32x16& cross, const
 #pragma unroll
     for (int ks = KS0; ks < KS1; ++ks) {
         const int slot = (ks - KS0) % (PF + 1), nslot = (ks - KS0 + PF) % (PF + 1);
-#ifdef EXP_NOLDS
-        if (ks + PF < KS1) { c1[nslot] = c1[slot]; c2[nslot] = c2[slot]; }
-#else
         if (ks + PF < KS1) {
             c1[nslot] = f[(size_t)(ks + PF) * 128];
             c2[nslot] = f[(size_t)(ks + PF) * 128 + 64];
         }
-#endif
         const int t = ks >> 1, s = ks & 1;
         mainacc = mfma_f16(c1[slot], b[t].p[0][s], mainacc);
         cross = mfma_f16(c1[slot], b[t].p[1][s], cross);
@@ -181,24 +177,3 @@ __device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" :
 // vmcnt retires in issue order (loads, stores and LDS-DMA alike): all but the N youngest operations are done
 template <int N>
 __device__ __forceinline__ void dma_wait_but() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
-
-// Register staging of the next weight chunk: wave `wave` of NW fetches fragments f = NW i + wave ...
-template <int NF, int NW>
-__device__ __forceinline__ void stage_load2(u32x4 (&st)[(NF + NW - 1) / NW], const u32x4* __restrict__ chunk, int wave,
-                                            int lane) {
-#pragma unroll
-    for (int i = 0; i < (NF + NW - 1) / NW; ++i) {
-        const int f = NW * i + wave;
-        if (NF % NW == 0 || f < NF) st[i] = chunk[(size_t)f * 64 + lane];
-    }
-}
-// ... and writes them to the idle LDS buffer in the middle of the current chunk's MFMA stream
-template <int NF, int NW>
-__device__ __forceinline__ void stage_store2(const u32x4 (&st)[(NF + NW - 1) / NW], u32x4* __restrict__ buf, int wave,
-                                             int lane) {
-#pragma unroll
-    for (int i = 0; i < (NF + NW - 1) / NW; ++i) {
-        const int f = NW * i + wave;
-        if (NF % NW == 0 || f < NF) buf[(size_t)f * 64 + lane] = st[i];
-    }
-}

@@ -137,6 +137,7 @@ int arreau_launch_embed(const arreau_model* m, const float* frac, const int32_t*
 // ---------------------------------------------------------------------------------------------
 #define CONV_LDS_STRIDE 132
 
+#define CONV_GROUP 32
 template <int C>
 __global__ __launch_bounds__(512, 4) void conv_kernel(
     const float* __restrict__ kl,        // this layer's kernels [N*k*16][C]
@@ -158,8 +159,18 @@ __global__ __launch_bounds__(512, 4) void conv_kernel(
         for (int p = 0; p < 4; ++p) fkr[o][p] = fk[((size_t)o * 16 + (4 * pq + p)) * C + c];
     const float bias = conv_bias[c];
 
+    // XCD-aware node order.  Workgroups are dealt round-robin over the 8 XCDs (blockIdx % 8 shares an L2); a node's
+    // neighbours are atoms of its own crystal, i.e. nearby node indices.  Blocks of CONV_GROUP consecutive nodes are
+    // dealt to the XCDs, so the x rows an XCD gathers are (almost) only those of its own node blocks and are fetched
+    // into that L2 once instead of into all eight.  With fewer than 8 workgroups the plain order is kept.
+    const bool xcd_order = (gridDim.x & 7) == 0;
+    const int xcd = blockIdx.x & 7, wg_in_xcd = blockIdx.x >> 3, wgs_per_xcd = gridDim.x >> 3;
+    const int n_iter = xcd_order ? ((N + 8 * CONV_GROUP - 1) / (8 * CONV_GROUP)) * CONV_GROUP : N;  // local node slots per XCD
     int buf = 0;
-    for (int n = blockIdx.x; n < N; n += gridDim.x, buf ^= 1) {
+    for (int m = xcd_order ? wg_in_xcd : (int)blockIdx.x; m < n_iter; m += xcd_order ? wgs_per_xcd : (int)gridDim.x) {
+        const int n = xcd_order ? ((m / CONV_GROUP) * 8 + xcd) * CONV_GROUP + (m % CONV_GROUP) : m;
+        if (n >= N) continue;  // workgroup-uniform
+        buf ^= 1;
         // ---- gather . multiply . ordered sum over the in-edges -------------------------------------
         const int nd = min(deg[n], k);
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -392,7 +403,7 @@ int arreau_launch_node_layer(const arreau_model* m, int layer, const float* kbuf
     }
     const size_t layer_stride = (size_t)N * m->k * 16 * C;
     const size_t mlp_layer = (size_t)2 * H * C;  // floats of W1 + W2, packed
-    const int conv_blocks = N < 512 ? N : 512;   // persistent: 2 workgroups of 512 threads per CU
+    const int conv_blocks = N < 512 ? N : 512;   // persistent: 2 workgroups of 512 threads per CU (a multiple of 8: XCD-aware order)
     hipLaunchKernelGGL((conv_kernel<128>), dim3(conv_blocks), dim3(512), 0, s, kbuf + (size_t)layer * layer_stride, deg,
                        src, x_in, m->fk + (size_t)layer * 16 * 16 * C, m->conv_bias + (size_t)layer * C, N, m->k, x_conv);
     ARREAU_CHECK_HIP(hipGetLastError());

@@ -1,0 +1,12 @@
+#!/bin/bash
+# usage: tools/prof_bench.sh <tag> [bench args...]   (GPU box): kernel stats of one bench run, no tests
+tag=$1; shift
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_$tag -- python bench.py --steps 30 --warmup 5 --no-cpu-baseline "$@" > gpurun_out/bench_prof_$tag.json 2> gpurun_out/bench_prof_$tag.err || exit 1
+python - <<PY
+import csv,glob,json
+f=glob.glob("gpurun_out/prof_$tag/*/*kernel_stats.csv")[0]
+for r in list(csv.DictReader(open(f)))[:8]:
+    print(r["Name"][:36].ljust(36), r["Calls"].rjust(4), "%9.1f us" % (float(r["AverageNs"])/1e3), r["Percentage"])
+d=json.load(open("gpurun_out/bench_prof_$tag.json")); print("ms_per_step", d["ms_per_step"], "edge_ms", d["roofline"]["avg_launch_ms"], "frac", d["roofline"]["frac"])
+PY
