@@ -49,8 +49,10 @@ __device__ __forceinline__ f32x2 gelu_fast2(f32x2 x) {
     e.y = __builtin_amdgcn_exp2f(q.y);
     const f32x2 half_erfc = (p * t) * e;
     f32x2 r;
-    r.x = fmaf(-fabsf(x.x), half_erfc.x, fmaxf(x.x, 0.0f));
-    r.y = fmaf(-fabsf(x.y), half_erfc.y, fmaxf(x.y, 0.0f));
+    // max(x, 0) saturated at the fp16 plane range in the same instruction (v_med3): the result lies in
+    // [-0.17, 6e4], so planes of GELU outputs need no further clamp (split_pair2<false>)
+    r.x = fmaf(-fabsf(x.x), half_erfc.x, __builtin_amdgcn_fmed3f(x.x, 0.0f, 60000.0f));
+    r.y = fmaf(-fabsf(x.y), half_erfc.y, __builtin_amdgcn_fmed3f(x.y, 0.0f, 60000.0f));
     return r;
 }
 __device__ __forceinline__ float gelu_fast(float x) { return gelu_fast2(splat2(x)).x; }
@@ -60,9 +62,12 @@ struct Planes2 { u32x4 p[2][2]; };  // [plane][k-step s]: 8 fp16 per lane each
 
 // Two planes of one register pair: v_cvt_pk_f16_f32 (round to nearest even) for both planes, the residual with
 // packed sub/mul.
+template <bool CLAMP = true>
 __device__ __forceinline__ void split_pair2(f32x2 v, unsigned& hi, unsigned& lo) {
-    v.x = __builtin_amdgcn_fmed3f(v.x, -60000.0f, 60000.0f);
-    v.y = __builtin_amdgcn_fmed3f(v.y, -60000.0f, 60000.0f);
+    if (CLAMP) {
+        v.x = __builtin_amdgcn_fmed3f(v.x, -60000.0f, 60000.0f);
+        v.y = __builtin_amdgcn_fmed3f(v.y, -60000.0f, 60000.0f);
+    }
     const f16x2 h1 = __builtin_convertvector(v, f16x2);
     const f32x2 res = (v - __builtin_convertvector(h1, f32x2)) * splat2(F16X3_SCALE);
     const f16x2 h2 = __builtin_convertvector(res, f16x2);
@@ -90,7 +95,7 @@ __device__ __forceinline__ Planes2 gelu_split_folded2(const f32x16& v, float sca
 #pragma unroll
         for (int pp = 0; pp < 4; ++pp) {
             unsigned hi, lo;
-            split_pair2(gelu_fast2(F16X3_PAIR(v, 4 * s + pp)) * splat2(scale), hi, lo);
+            split_pair2<false>(gelu_fast2(F16X3_PAIR(v, 4 * s + pp)) * splat2(scale), hi, lo);  // |scale| <= 1
             r.p[0][s][pp] = hi;
             r.p[1][s][pp] = lo;
         }

@@ -479,8 +479,18 @@ __global__ __launch_bounds__(1024) void readout_nodes_kernel(
         const float bias = ro_b[l * RO + s_out];
 #pragma unroll
         for (int a = 0; a < RO_ATOMS; ++a) part[(l * RO_ATOMS + a) * RO_COLS + s_out] = acc[a] + bias;
-    } else if (l == 0 && s_out == S) {
-        // vector channel: eps for the tile's atoms (sphere_to_vec of the per-orientation dot products)
+    } else if (l == 0 && RO_COLS - RO >= 3 * RO_ATOMS && s_out >= RO && s_out - RO < 3 * RO_ATOMS) {
+        // vector channel on the idle columns of the first layer group: eps component d of atom a of the tile
+        // (sphere_to_vec of the per-orientation dot products)
+        const int a = (s_out - RO) / 3, d = (s_out - RO) - 3 * a;
+        const size_t n = (size_t)n0 + a;
+        if (n < (size_t)N) {
+            float acc = 0.f;
+            for (int o = 0; o < 16; ++o) acc += (vsum[n * 16 + o] * invL) * ori[3 * o + d];
+            eps[n * 3 + d] = acc * (1.0f / 16.0f);
+        }
+    } else if (l == 0 && RO_COLS - RO < 3 * RO_ATOMS && s_out == S) {
+        // (wide species tables leave too few idle columns: one thread walks the tile)
         for (int a = 0; a < RO_ATOMS; ++a) {
             const size_t n = (size_t)n0 + a;
             if (n >= (size_t)N) break;

@@ -399,6 +399,25 @@ def test_atom_permutation_equivariance(dev, small_model):
     assert (a[2] - b[2]).abs().max() <= TOL * scale * 9
 
 
+def test_rotated_lattice_invariance(dev, small_model):
+    """HIP-path port of the reference's integration check (exploration/verify_model_is_equivariant.py:11-18,
+    evaluated at EVAL_EQUIVARIANCE_TIMESTEP = 5, lightning_wrappers/diffusion.py:26): the same crystal with its cell
+    rotated by 90 degrees about x.  The network sees the cell only through (lengths, angles)
+    (diffusion_loss.py:124-127), which the rotation leaves unchanged, so scores, logits and the predicted lengths
+    of the rotated crystal equal those of the original."""
+    m, _, _ = small_model
+    frac, types, lengths, angles, na = random_state(12, [6, 6, 5], 77)
+    lat = OG.lattice_from_params(lengths.double(), angles.double())
+    rot = torch.tensor([[1.0, 0.0, 0.0], [0.0, 0.0, -1.0], [0.0, 1.0, 0.0]], dtype=torch.float64)
+    len_r, ang_r = OG.matrix_to_params(lat @ rot)
+    assert (len_r - lengths.double()).abs().max() < 1e-9 and (ang_r - angles.double()).abs().max() < 1e-9
+    a = _engine_scores(m, dev, (frac, types, lengths, angles, na), 5)
+    b = _engine_scores(m, dev, (frac, types, len_r.float(), ang_r.float(), na), 5)
+    scale = max(1.0, float(a[1].abs().max()))
+    for x, y in zip(a, b):
+        assert (x - y).abs().max() <= TOL * scale
+
+
 @pytest.mark.parametrize("edge_variant,mlp_variant", [("0", "0"), ("3", "1")])
 def test_alternative_arithmetic_variants_agree(dev, small_model, edge_variant, mlp_variant):
     """The exact fp32-MFMA kernels and the bf16x6 kernels stay in the library as cross-checks of the default

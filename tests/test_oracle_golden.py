@@ -80,6 +80,20 @@ def test_known_cells_round_trip_lengths_angles():
     np.testing.assert_allclose(ka2.numpy(), ka.numpy(), atol=1e-12)
 
 
+def test_cell_rotation_leaves_lengths_and_angles_unchanged():
+    """The reference's equivariance check rotates the cell by 90 degrees about x
+    (exploration/verify_model_is_equivariant.py:11-18).  The network is fed (lengths, angles) of the cell
+    (diffusion_loss.py:124-127): those are rotation invariants, so the rotated crystal is the same input."""
+    torch.set_default_dtype(torch.float64)
+    z = load("lattice.npz")
+    cell = T(z["known_cell"])
+    rot = torch.tensor([[1.0, 0.0, 0.0], [0.0, 0.0, -1.0], [0.0, 1.0, 0.0]])
+    l0, a0 = G.matrix_to_params(cell)
+    l1, a1 = G.matrix_to_params(cell @ rot)
+    np.testing.assert_allclose(l1.numpy(), l0.numpy(), atol=1e-12)
+    np.testing.assert_allclose(a1.numpy(), a0.numpy(), atol=1e-12)
+
+
 # ----------------------------------------------------------------------------- schedules + reverse updates
 def test_schedules_match_reference():
     z = load("schedules.npz")
