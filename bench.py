@@ -47,6 +47,12 @@ def step_flops_per_atom(k=8, S=90, C=128, D=256, L=5, O=16, W=4):
     return k * O * per_row + O * per_node_ori
 
 
+def config_label(B, n):
+    """BASELINE.json config the (crystals per GPU, atoms per crystal) pair corresponds to."""
+    return {(1, 8): "BASELINE configs[0]", (256, 20): "BASELINE configs[1]", (1024, 20): "BASELINE configs[2] (8192 / 8 GPUs)",
+            (1024, 64): "BASELINE configs[3]"}.get((B, n), "custom size")
+
+
 def measured_traffic(B, n):
     """HBM bytes per launch of the edge kernel from the committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE,
     separate runs, gfx950 FETCH correction applied) -- only valid for the workload they were taken on."""
@@ -234,7 +240,7 @@ def main():
                           "the plain fp32-MFMA kernels",
             "data": "synthetic",
             "config": {
-                "workload": f"BASELINE configs[1] per GPU: batch={B} crystals x {n} atoms, 1000-step sampler "
+                "workload": f"{config_label(B, n)} per GPU: batch={B} crystals x {n} atoms, 1000-step sampler "
                             f"(T=1000, 999 network evaluations per crystal), fp32",
                 "crystals_per_gpu": B, "atoms_per_crystal": n, "num_timesteps": T,
                 "checkpoint": "synthetic 1.17M-param (S=90,C=128,O=16,D=256,L=5,k=8,R=5), seed 1234",
