@@ -10,7 +10,8 @@ from ctypes import c_char_p, c_double, c_float, c_int32, c_int64, c_size_t, c_vo
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libarreau_hip.so")
+# ARREAU_HIP_LIB: load another build of the same library (A/B timing of two kernel versions on one box)
+LIB_PATH = os.environ.get("ARREAU_HIP_LIB") or os.path.join(_HERE, "csrc", "libarreau_hip.so")
 
 EXPORTS = [
     "arreau_last_error", "arreau_version", "arreau_model_create", "arreau_model_destroy",

@@ -153,6 +153,11 @@ __global__ __launch_bounds__(64 * EH_WAVES, 2) void edge_kernel_f16x3(
     // tile's MFMAs without meeting anybody -- the two waves of a SIMD drift apart and one's epilogue overlaps the
     // other's matrix work, instead of both draining the matrix pipe at a common end-of-chunk barrier.
     const bool late = wave >= 4;  // wave-uniform (SGPR): SIMD partner of wave - 4, syncs later inside a projection chunk
+    unsigned dma_off[NF3 / EH_WAVES];
+    dma_offsets<NF3, EH_WAVES>(dma_off, wave, lane);
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)&lds[0][0]) + 1024u * wave;
+    constexpr unsigned SLOT_BYTES = NF3 * 1024u;
+    unsigned (&dma_off2)[NF2 / EH_WAVES] = reinterpret_cast<unsigned(&)[NF2 / EH_WAVES]>(dma_off);  // same offsets, first two
     // ---- layer 1: h = GELU(W1f . mono + b1) -------------------------------------------------------------
     Planes2 h1[TC];
 #pragma unroll
@@ -167,7 +172,7 @@ __global__ __launch_bounds__(64 * EH_WAVES, 2) void edge_kernel_f16x3(
         dma_wait();
         __syncthreads();
         if (u + 2 < TC) { dma_chunk<NF1, EH_WAVES>(dma_src, lds[(u + 2) % 3], wave, lane); dma_src += (size_t)NF1 * 64; }
-        else { dma_chunk<NF2, EH_WAVES>(dma_src, lds[(u + 2) % 3], wave, lane); dma_src += (size_t)NF2 * 64; }
+        else { dma_chunk_lean<NF2, EH_WAVES>(dma_src, dma_off2, lds0 + ((u + 2) % 3) * SLOT_BYTES); dma_src += (size_t)NF2 * 64; }
         if (active) {
             mma_range2<TM, TM, 2 * TM>(acc, cross, lds[u % 3], bm, lane);
             h1[u] = gelu_split_tile2(acc, cross, 1.0f);
@@ -188,8 +193,8 @@ __global__ __launch_bounds__(64 * EH_WAVES, 2) void edge_kernel_f16x3(
         }
         dma_wait();
         __syncthreads();
-        if (u + 2 < TD) { dma_chunk<NF2, EH_WAVES>(dma_src, lds[(Q0 + u + 2) % 3], wave, lane); dma_src += (size_t)NF2 * 64; }
-        else if (u + 2 - TD < L * TC) { dma_chunk<NF3, EH_WAVES>(dma_src, lds[(Q0 + u + 2) % 3], wave, lane); dma_src += (size_t)NF3 * 64; }
+        if (u + 2 < TD) { dma_chunk_lean<NF2, EH_WAVES>(dma_src, dma_off2, lds0 + ((Q0 + u + 2) % 3) * SLOT_BYTES); dma_src += (size_t)NF2 * 64; }
+        else if (u + 2 - TD < L * TC) { dma_chunk_lean<NF3, EH_WAVES>(dma_src, dma_off, lds0 + ((Q0 + u + 2) % 3) * SLOT_BYTES); dma_src += (size_t)NF3 * 64; }
         if (active) {
             mma_range2<TC, TC, 2 * TC>(acc, cross, lds[(Q0 + u) % 3], h1, lane);
             basis[u] = gelu_split_tile2(acc, cross, window);
@@ -216,52 +221,62 @@ __global__ __launch_bounds__(64 * EH_WAVES, 2) void edge_kernel_f16x3(
     // Not predicated on the degree: a slot beyond it gets the zeros its window produced (those rows of the K buffer
     // are never read), so a wave issues a FIXED number of stores per tile (4, or 2 for the wave whose second slot does
     // not exist when k is odd) -- which the counted wait at SYNC relies on.
-    auto pad_store = [&](int cidx_done) {
-        const int l = cidx_done / TC, u = cidx_done - l * TC;
-        float* dst = kbuf + (size_t)l * layer_stride + row0 * C + 32 * u + 4 * (lane & 7);
+    // Store addressing: wave-uniform byte base of tile (layer l, column tile u) advanced tile by tile + four per-lane
+    // 32-bit offsets computed once (global_store ... saddr form: no 64-bit vector address arithmetic in the loop).
+    unsigned st_off[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) st_off[i] = 4u * ((8 * i + (lane >> 3)) * C + 4 * (lane & 7));  // row 8i + lane/8 of the wave tile
+    auto pad_store = [&](const char* tile_base /* wave-uniform */) {
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-            const int r = 8 * i + (lane >> 3);  // row of the wave tile: slot 2*wn + (r >> 4), orientation r & 15
+            const int r = 8 * i + (lane >> 3);  // slot 2*wn + (r >> 4), orientation r & 15
             const f32x4 v = *reinterpret_cast<const f32x4*>(&pad[r * 36 + 4 * (lane & 7)]);
-            if (i < 2 || full) *reinterpret_cast<f32x4*>(dst + (size_t)r * C) = v;
+            if (i < 2 || full) *reinterpret_cast<f32x4*>(const_cast<char*>(tile_base) + st_off[i]) = v;
         }
     };
     // One projection loop per wave class.  X = k-step at which the class takes the chunk's barrier: 1/4 into the
     // chunk for waves 0-3, 3/4 for waves 4-7, so SIMD partners reach their end-of-tile work half a chunk apart.
     // At SYNC the wave's queue holds, oldest first, its 4 DMA copies of the next chunk and -- from the second chunk
     // on -- the stores of the previous tile: the counted wait retires the copies and leaves the stores in flight.
+    const char* tile0 = reinterpret_cast<const char*>(kbuf + row0 * C);  // (layer 0, column tile 0) of this wave's rows
     auto proj_loop = [&](auto xtag) {
         constexpr int X = decltype(xtag)::value;
         static_assert(X >= 2 && X < 2 * TD, "barrier position");
+        const char* tile_base = tile0;  // tile of the PREVIOUS chunk (the one pad_store writes)
+        int u_prev = 0;
 #pragma unroll 1
         for (int cidx = 0; cidx < nchunks; ++cidx) {
             const u32x4* buf = lds[sl];
-            u32x4* free_slot = lds[sl == 0 ? 2 : sl - 1];  // (sl + 2) % 3
+            const unsigned free_slot = lds0 + (sl == 0 ? 2u : (unsigned)sl - 1u) * SLOT_BYTES;  // (sl + 2) % 3
             f32x16 acc, cross;
 #pragma unroll
             for (int r = 0; r < 16; ++r) { acc[r] = 0.0f; cross[r] = 0.0f; }
             mma_range2<TD, 0, 2>(acc, cross, buf, basis, lane);
-            if (cidx > 0) pad_store(cidx - 1);
+            if (cidx > 0) {
+                pad_store(tile_base);
+                // next tile: 32 columns on, or the first column tile of the next layer
+                tile_base += (++u_prev == TC) ? (u_prev = 0, (ptrdiff_t)layer_stride * 4 - (TC - 1) * 128) : 128;
+            }
             mma_range2<TD, 2, X>(acc, cross, buf, basis, lane);
             if (cidx == 0) dma_wait();
             else if (full) dma_wait_but<4>();
             else dma_wait_but<2>();
             __syncthreads();
-            if (cidx + 2 < nchunks) dma_chunk<NF3, EH_WAVES>(dma_src, free_slot, wave, lane);
+            if (cidx + 2 < nchunks) dma_chunk_lean<NF3, EH_WAVES>(dma_src, dma_off, free_slot);
             dma_src += (size_t)NF3 * 64;
             mma_range2<TD, X, 2 * TD>(acc, cross, buf, basis, lane);
             pad_write(fold_cross(acc, cross));
             sl = sl == 2 ? 0 : sl + 1;
         }
-        pad_store(nchunks - 1);
+        pad_store(tile_base);
     };
     if (!active) {  // no slots: keep the ring turning
 #pragma unroll 1
         for (int cidx = 0; cidx < nchunks; ++cidx) {
-            u32x4* free_slot = lds[sl == 0 ? 2 : sl - 1];
+            const unsigned free_slot = lds0 + (sl == 0 ? 2u : (unsigned)sl - 1u) * SLOT_BYTES;
             dma_wait();
             __syncthreads();
-            if (cidx + 2 < nchunks) dma_chunk<NF3, EH_WAVES>(dma_src, free_slot, wave, lane);
+            if (cidx + 2 < nchunks) dma_chunk_lean<NF3, EH_WAVES>(dma_src, dma_off, free_slot);
             dma_src += (size_t)NF3 * 64;
             sl = sl == 2 ? 0 : sl + 1;
         }
