@@ -163,18 +163,20 @@ __global__ __launch_bounds__(64 * EH_WAVES, 2) void edge_kernel_f16x3(
 #pragma unroll
     for (int u = 0; u < TC; ++u) {
         f32x16 acc, cross;
+        MmaStream2<TM, 2 * TM> ms;
         if (active) {
             acc = arreau_bias_tile(bias_s, u, h);
 #pragma unroll
             for (int r = 0; r < 16; ++r) cross[r] = 0.f;
-            mma_range2<TM, 0, TM>(acc, cross, lds[u % 3], bm, lane);
+            ms.start(lds[u % 3], lane);
+            ms.template run<0, TM>(acc, cross, bm);
         }
         dma_wait();
         __syncthreads();
         if (u + 2 < TC) { dma_chunk<NF1, EH_WAVES>(dma_src, lds[(u + 2) % 3], wave, lane); dma_src += (size_t)NF1 * 64; }
         else { dma_chunk_lean<NF2, EH_WAVES>(dma_src, dma_off2, lds0 + ((u + 2) % 3) * SLOT_BYTES); dma_src += (size_t)NF2 * 64; }
         if (active) {
-            mma_range2<TM, TM, 2 * TM>(acc, cross, lds[u % 3], bm, lane);
+            ms.template run<TM, 2 * TM>(acc, cross, bm);
             h1[u] = gelu_split_tile2(acc, cross, 1.0f);
         }
     }
@@ -185,18 +187,20 @@ __global__ __launch_bounds__(64 * EH_WAVES, 2) void edge_kernel_f16x3(
     for (int u = 0; u < TD; ++u) {
         constexpr int Q0 = TC;
         f32x16 acc, cross;
+        MmaStream2<TC, 2 * TC> ms;
         if (active) {
             acc = arreau_bias_tile(bias_s + C, u, h);
 #pragma unroll
             for (int r = 0; r < 16; ++r) cross[r] = 0.f;
-            mma_range2<TC, 0, TC>(acc, cross, lds[(Q0 + u) % 3], h1, lane);
+            ms.start(lds[(Q0 + u) % 3], lane);
+            ms.template run<0, TC>(acc, cross, h1);
         }
         dma_wait();
         __syncthreads();
         if (u + 2 < TD) { dma_chunk_lean<NF2, EH_WAVES>(dma_src, dma_off2, lds0 + ((Q0 + u + 2) % 3) * SLOT_BYTES); dma_src += (size_t)NF2 * 64; }
         else if (u + 2 - TD < L * TC) { dma_chunk_lean<NF3, EH_WAVES>(dma_src, dma_off, lds0 + ((Q0 + u + 2) % 3) * SLOT_BYTES); dma_src += (size_t)NF3 * 64; }
         if (active) {
-            mma_range2<TC, TC, 2 * TC>(acc, cross, lds[(Q0 + u) % 3], h1, lane);
+            ms.template run<TC, 2 * TC>(acc, cross, h1);
             basis[u] = gelu_split_tile2(acc, cross, window);
         }
     }
@@ -251,20 +255,22 @@ __global__ __launch_bounds__(64 * EH_WAVES, 2) void edge_kernel_f16x3(
             f32x16 acc, cross;
 #pragma unroll
             for (int r = 0; r < 16; ++r) { acc[r] = 0.0f; cross[r] = 0.0f; }
-            mma_range2<TD, 0, 2>(acc, cross, buf, basis, lane);
+            MmaStream2<TD, 2 * TD> ms;
+            ms.start(buf, lane);
+            ms.template run<0, 2>(acc, cross, basis);
             if (cidx > 0) {
                 pad_store(tile_base);
                 // next tile: 32 columns on, or the first column tile of the next layer
                 tile_base += (++u_prev == TC) ? (u_prev = 0, (ptrdiff_t)layer_stride * 4 - (TC - 1) * 128) : 128;
             }
-            mma_range2<TD, 2, X>(acc, cross, buf, basis, lane);
+            ms.template run<2, X>(acc, cross, basis);
             if (cidx == 0) dma_wait();
             else if (full) dma_wait_but<4>();
             else dma_wait_but<2>();
             __syncthreads();
             if (cidx + 2 < nchunks) dma_chunk_lean<NF3, EH_WAVES>(dma_src, dma_off, free_slot);
             dma_src += (size_t)NF3 * 64;
-            mma_range2<TD, X, 2 * TD>(acc, cross, buf, basis, lane);
+            ms.template run<X, 2 * TD>(acc, cross, basis);
             pad_write(fold_cross(acc, cross));
             sl = sl == 2 ? 0 : sl + 1;
         }

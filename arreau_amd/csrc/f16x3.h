@@ -145,6 +145,41 @@ __device__ __forceinline__ void mma_range2(f32x16& mainacc, f32x16& cross, const
     }
 }
 
+// The same stream cut into pieces (a barrier, a tile store ... between them) WITHOUT restarting the fragment
+// prefetch: the reads of the first k-step of the next piece are issued by the piece before it, so their LDS latency
+// is covered by MFMAs instead of being exposed after every cut.  NKS = k-steps of the whole chunk.
+template <int NIN, int NKS>
+struct MmaStream2 {
+    const u32x4* f;
+    u32x4 c1[2], c2[2];
+    __device__ __forceinline__ void start(const u32x4* __restrict__ buf, int lane) {
+        f = buf + lane;
+        c1[0] = f[0];
+        c2[0] = f[64];
+        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+    }
+    template <int KS0, int KS1>
+    __device__ __forceinline__ void run(f32x16& mainacc, f32x16& cross, const Planes2 (&b)[NIN]) {
+#pragma unroll
+        for (int ks = KS0; ks < KS1; ++ks) {
+            const int slot = ks & 1, nslot = slot ^ 1;
+            if (ks + 1 < NKS) {
+                c1[nslot] = f[(size_t)(ks + 1) * 128];
+                c2[nslot] = f[(size_t)(ks + 1) * 128 + 64];
+            }
+            const int t = ks >> 1, s = ks & 1;
+            mainacc = mfma_f16(c1[slot], b[t].p[0][s], mainacc);
+            cross = mfma_f16(c1[slot], b[t].p[1][s], cross);
+            cross = mfma_f16(c2[slot], b[t].p[0][s], cross);
+        }
+#pragma unroll
+        for (int ks = KS0; ks < KS1; ++ks) {
+            if (ks + 1 < NKS) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);  // DS reads of k-step ks+1 ...
+            __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);                     // ... ahead of the MFMAs of k-step ks
+        }
+    }
+};
+
 __device__ __forceinline__ f32x16 fold_cross(const f32x16& mainacc, const f32x16& cross) {
     f32x16 r;
 #pragma unroll
