@@ -2,14 +2,14 @@
 // basis MLP -> window -> L kernel projections, activations in registers) with every fp32 product evaluated
 // as three fp16 MFMA products (f16x3.h): half the matrix-pipe work and two thirds of the operand bytes of
 // the bf16x6 kernel (edge_bf16.hip), 16 registers per activation tile instead of 24 -- which is what lets
-// two waves share a SIMD (256 registers each), so one wave's VALU phases (GELU, splits, attribute set-up),
-// LDS hand-overs and store traffic overlap the partner's MFMA stream.
+// two waves share a SIMD (<= 256 registers each): their vector phases (GELU, splits, attribute set-up) overlap
+// each other, and conversions / transcendentals / LDS and store traffic overlap the partner's MFMA stream (fp32
+// add / mul / fma do not: tools/exp/coexec.hip).
 //
 // Workgroup = 8 waves = the 16 edge slots of two receivers (2 waves per SIMD).  Weight chunks (one 32-row
-// output tile: 12 / 16 / 32 KiB) are shared through a double-buffered LDS ring filled by LDS-DMA
-// (global_load_lds_dwordx4): each wave starts the copy of 1/8 of the next chunk at the top of a chunk, drains it
-// (vmcnt) after the chunk's MFMA stream and meets the others at the one barrier per chunk -- no staging registers,
-// no ds_write, and the copy's latency is covered by a whole chunk of matrix work.
+// output tile: 12 / 16 / 32 KiB) are shared through a three-slot LDS ring filled by LDS-DMA
+// (global_load_lds_dwordx4): no staging registers, no ds_write, one barrier per chunk in the MIDDLE of the chunk's
+// MFMA stream ("ring protocol" below), the copy's latency covered by a whole chunk of matrix work.
 #include <stdlib.h>
 #include <utility>
 
@@ -150,9 +150,8 @@ __global__ __launch_bounds__(64 * EH_WAVES, 2) void edge_kernel_f16x3(
     // drained its share of the copy of chunk q+1 (issued at SYNC_{q-1}, a whole chunk of matrix work earlier), so
     // after the barrier chunk q+1 is complete for everybody and the copy of chunk q+2 can start.  A wave therefore
     // runs from the end of one tile (accumulator drain, GELU / plane split or tile store) straight into the next
-    // tile's MFMAs without meeting anybody -- the two waves of a SIMD drift apart and one's epilogue overlaps the
-    // other's matrix work, instead of both draining the matrix pipe at a common end-of-chunk barrier.
-    const bool late = wave >= 4;  // wave-uniform (SGPR): SIMD partner of wave - 4, syncs later inside a projection chunk
+    // tile's MFMAs without meeting anybody, instead of all waves draining the matrix pipe at a common end-of-chunk
+    // barrier; the fragment prefetch (MmaStream2) runs through the barrier.
     unsigned dma_off[NF3 / EH_WAVES];
     dma_offsets<NF3, EH_WAVES>(dma_off, wave, lane);
     const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)&lds[0][0]) + 1024u * wave;
@@ -238,8 +237,9 @@ __global__ __launch_bounds__(64 * EH_WAVES, 2) void edge_kernel_f16x3(
             if (i < 2 || full) *reinterpret_cast<f32x4*>(const_cast<char*>(tile_base) + st_off[i]) = v;
         }
     };
-    // One projection loop per wave class.  X = k-step at which the class takes the chunk's barrier: 1/4 into the
-    // chunk for waves 0-3, 3/4 for waves 4-7, so SIMD partners reach their end-of-tile work half a chunk apart.
+    // X = k-step at which the chunk's barrier is taken (mid-chunk).  Taking it at different points in the two halves
+    // of the workgroup (SIMD partners a half chunk apart) was measured to make no difference: fp32 vector work and
+    // MFMAs of SIMD partners serialise anyway, so both halves use the same point.
     // At SYNC the wave's queue holds, oldest first, its 4 DMA copies of the next chunk and -- from the second chunk
     // on -- the stores of the previous tile: the counted wait retires the copies and leaves the stores in flight.
     const char* tile0 = reinterpret_cast<const char*>(kbuf + row0 * C);  // (layer 0, column tile 0) of this wave's rows
@@ -286,10 +286,8 @@ __global__ __launch_bounds__(64 * EH_WAVES, 2) void edge_kernel_f16x3(
             dma_src += (size_t)NF3 * 64;
             sl = sl == 2 ? 0 : sl + 1;
         }
-    } else if (!late) {
-        proj_loop(std::integral_constant<int, TD / 2>{});
     } else {
-        proj_loop(std::integral_constant<int, TD + TD / 2>{});
+        proj_loop(std::integral_constant<int, TD>{});
     }
     EDGE_TICK(3);
     EDGE_TICK(4);

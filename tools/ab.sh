@@ -1,9 +1,9 @@
 #!/bin/bash
-# usage: tools/ab.sh [bench args]  (GPU box): time the in-tree library against tools/exp/ab/lib_prev.so, alternating, same box
+# usage: tools/ab.sh [bench args]  (GPU box): time the in-tree library against tools/exp/ab/${AB_LIB:-lib_prev.so}, alternating, same box
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 for rep in 1 2; do
   for which in prev cur; do
-    if [ $which = prev ]; then export ARREAU_HIP_LIB=$GRAFT_REPO_ROOT/tools/exp/ab/lib_prev.so; else unset ARREAU_HIP_LIB; fi
+    if [ $which = prev ]; then export ARREAU_HIP_LIB=$GRAFT_REPO_ROOT/tools/exp/ab/${AB_LIB:-lib_prev.so}; else unset ARREAU_HIP_LIB; fi
     timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/ab_${which}_$rep -- python bench.py --steps 30 --warmup 5 --no-cpu-baseline "$@" > gpurun_out/ab_${which}_$rep.json 2> gpurun_out/ab_${which}_$rep.err || exit 1
     python - <<PY
 import csv,glob,json
