@@ -16,7 +16,10 @@ SOURCES = ["model.hip", "graph.hip", "edge.hip", "edge_bf16.hip", "edge_f16.hip"
 HEADERS = ["internal.h", "bf16x6.h", "f16x3.h", os.path.join("..", "..", "include", "arreau_hip.h")]
 LIB = os.path.join(CSRC, "libarreau_hip.so")
 STAMP = os.path.join(CSRC, ".build_stamp")
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wall", "-Wno-unused-function",
+# Sources whose kernels hand-count s_waitcnt vmcnt(N): a register spill would put scratch loads/stores into the same
+# in-order queue and silently break the count, so the build fails if the compiler reports any scratch for them.
+NO_SCRATCH = {"edge_f16.hip"}
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++20", "-fPIC", "-Wall", "-Wno-unused-function",
          "-ffp-contract=on"] + os.environ.get("ARREAU_EXTRA_HIPCC_FLAGS", "").split()
 
 
@@ -61,10 +64,20 @@ def _build_locked(verbose):
         obj = os.path.join(CSRC, src.replace(".hip", ".o"))
         objs.append(obj)
         cmd = [hipcc] + FLAGS + ["-c", os.path.join(CSRC, src), "-o", obj]
+        if src in NO_SCRATCH:
+            cmd.insert(-4, "-Rpass-analysis=kernel-resource-usage")
         procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
     failed = False
     for src, p in procs:
         out, _ = p.communicate()
+        if p.returncode == 0 and src in NO_SCRATCH:
+            import re
+            scratch = [int(x) for x in re.findall(r"ScratchSize \[bytes/lane\]: (\d+)", out)]
+            if not scratch or max(scratch) != 0:
+                failed = True
+                sys.stderr.write(f"[arreau_amd.build] {src}: kernel uses scratch {scratch} (register spill); "
+                                 "its counted vmcnt waits require none\n")
+            out = ""  # the remarks are not warnings
         if p.returncode != 0:
             failed = True
             sys.stderr.write(f"[arreau_amd.build] {src} failed:\n{out}\n")

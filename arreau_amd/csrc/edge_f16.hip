@@ -89,174 +89,215 @@ __global__ __launch_bounds__(64 * EH_WAVES, 2) void edge_kernel_f16x3(
     __shared__ __attribute__((aligned(16))) float otile[EH_WAVES][32 * 36];   // per-wave transpose pad for the stores
     __shared__ __attribute__((aligned(16))) float bias_s[C + D];              // b1 | b2 (no global loads beside the DMA)
 
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    const int h = lane >> 5, j = lane & 31;
-    const int node_raw = (EH_WAVES / 4) * blockIdx.x + (wave >> 2);
-    const int node = min(node_raw, N - 1);
-    const int wn = wave & 3;                       // wave within its node: slots 2wn, 2wn+1
-    const int nd = node_raw < N ? min(deg[node], k) : 0;
-    const bool active = 2 * wn < nd;               // wave-uniform; idle waves still stage weights and meet the barriers
-    const int slot = 2 * wn + (j >> 4);
-    const int o = j & 15;
-    const int slot_c = min(slot, k - 1);
+    const int wave0 = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane0 = threadIdx.x & 63;
+    const int npairs = (N + EH_WAVES / 4 - 1) / (EH_WAVES / 4);
 
 #ifdef ARREAU_EDGE_TIMING
     long long tick_ = clock64();
     long long tacc_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #endif
-    const u32x4* dma_src = stream;  // next chunk to copy
-    dma_chunk<NF1, EH_WAVES>(dma_src, lds[0], wave, lane);
-    dma_src += (size_t)NF1 * 64;
-    dma_chunk<NF1, EH_WAVES>(dma_src, lds[1], wave, lane);
-    dma_src += (size_t)NF1 * 64;
+    // Persistent workgroup: receiver pairs blockIdx.x, blockIdx.x + gridDim.x, ...  The weight ring keeps turning
+    // across pairs (the chunk sequence simply repeats), so only the first pair waits for its first two chunks.
+    dma_chunk<NF1, EH_WAVES>(stream, lds[0], wave0, lane0);
+    dma_chunk<NF1, EH_WAVES>(stream + (size_t)NF1 * 64, lds[1], wave0, lane0);
     if (threadIdx.x < C + D) bias_s[threadIdx.x] = threadIdx.x < C ? b1[threadIdx.x] : b2[threadIdx.x - C];
-
-    // ---- per-row attributes (transforms/invariants.py:82-88) ------------------------------------------
-    float a[6], window;
-    {
-        const size_t e = (size_t)node * k + slot_c;
-        const float dx = nbr_dir[3 * e + 0], dy = nbr_dir[3 * e + 1], dz = nbr_dir[3 * e + 2];
-        const float dist = nbr_dist[e];
-        const float ox = ori[3 * o + 0], oy = ori[3 * o + 1], oz = ori[3 * o + 2];
-        a[0] = (dx * ox + dy * oy) + dz * oz;
-        const float rx = dx - a[0] * ox, ry = dy - a[0] * oy, rz = dz - a[0] * oz;
-        a[1] = sqrtf((rx * rx + ry * ry) + rz * rz);
-        a[2] = dist;
-        const float* Lm = lattice + 9 * (size_t)batch[node];
-        const float dn = fmaxf(sqrtf((dx * dx + dy * dy) + dz * dz), 1e-8f);
-        const float ux = dx / dn, uy = dy / dn, uz = dz / dn;
-#pragma unroll
-        for (int i = 0; i < 3; ++i) {
-            const float lx = Lm[3 * i], ly = Lm[3 * i + 1], lz = Lm[3 * i + 2];
-            const float ln = fmaxf(sqrtf((lx * lx + ly * ly) + lz * lz), 1e-8f);
-            a[3 + i] = (ux * (lx / ln) + uy * (ly / ln)) + uz * (lz / ln);
-        }
-        const float u = dist / r_max;
-        const float u2 = u * u, u6 = u2 * u2 * u2;
-        const float w = 1.0f - 28.0f * u6 + 48.0f * u6 * u - 21.0f * u6 * u2;
-        window = (slot < nd && dist < r_max) ? w : 0.0f;
-    }
-    Planes2 bm[TM];
-    bm[0] = split_tile2(mono_tile_h<0>(a, h, std::make_integer_sequence<int, 16>{}));
-    bm[1] = split_tile2(mono_tile_h<1>(a, h, std::make_integer_sequence<int, 16>{}));
-    bm[2] = split_tile2(mono_tile_h<2>(a, h, std::make_integer_sequence<int, 16>{}));
-
+    int sl = 0;  // ring slot of the current chunk
+    constexpr unsigned SLOT_BYTES = NF3 * 1024u;
+    auto slot_after = [](int s_, int n) { const int r = s_ + n; return r >= 3 ? r - 3 : r; };  // (s_ + n) % 3 for n <= 2
+    const int nchunks = L * TC;
     dma_wait();
     __syncthreads();
 
-    EDGE_TICK(0);
-    // Ring protocol.  Chunk q lives in slot q % 3.  The one barrier per chunk sits in the MIDDLE of the chunk's MFMA
-    // stream (SYNC_q), not at its end: by then every wave has left chunk q-1 (so slot (q+2) % 3 is free) and has
-    // drained its share of the copy of chunk q+1 (issued at SYNC_{q-1}, a whole chunk of matrix work earlier), so
-    // after the barrier chunk q+1 is complete for everybody and the copy of chunk q+2 can start.  A wave therefore
-    // runs from the end of one tile (accumulator drain, GELU / plane split or tile store) straight into the next
-    // tile's MFMAs without meeting anybody, instead of all waves draining the matrix pipe at a common end-of-chunk
-    // barrier; the fragment prefetch (MmaStream2) runs through the barrier.
-    unsigned dma_off[NF3 / EH_WAVES];
-    dma_offsets<NF3, EH_WAVES>(dma_off, wave, lane);
-    const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)&lds[0][0]) + 1024u * wave;
-    constexpr unsigned SLOT_BYTES = NF3 * 1024u;
-    unsigned (&dma_off2)[NF2 / EH_WAVES] = reinterpret_cast<unsigned(&)[NF2 / EH_WAVES]>(dma_off);  // same offsets, first two
-    // ---- layer 1: h = GELU(W1f . mono + b1) -------------------------------------------------------------
-    Planes2 h1[TC];
+    for (int pair = blockIdx.x; pair < npairs; pair += gridDim.x) {
+        // Everything derived from the lane / wave index is re-derived per pair from values the optimiser cannot see
+        // through: hoisted out of the pair loop those addresses and constants would stay in registers through the
+        // matrix phases, and this kernel must not spill (scratch traffic would count in vmcnt).
+        int lane = lane0, wave = wave0;
+        asm volatile("" : "+v"(lane), "+s"(wave));
+        const int h = lane >> 5, j = lane & 31;
+        const int wn = wave & 3;                       // wave within its node: slots 2wn, 2wn+1
+        const unsigned lane16 = 16u * lane;            // per-lane byte offset inside a 1 KiB fragment
+        const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)&lds[0][0]) + 1024u * wave;
+        const bool has_next = pair + (int)gridDim.x < npairs;  // workgroup-uniform
+        const int node_raw = (EH_WAVES / 4) * pair + (wave >> 2);
+        const int node = min(node_raw, N - 1);
+        const int nd = node_raw < N ? min(deg[node], k) : 0;
+        const bool active = 2 * wn < nd;               // wave-uniform; idle waves still copy weights and meet the barriers
+        const u32x4* dma_src = stream + (size_t)2 * NF1 * 64;  // next chunk to copy: chunk 2 of this pair
+
+        // Ring protocol.  Chunk q lives in the slot after chunk q-1's (three slots).  The one barrier per chunk sits in
+        // the MIDDLE of the chunk's MFMA stream (SYNC_q), not at its end: by then every wave has left chunk q-1 (so its
+        // slot is free) and has drained its share of the copy of chunk q+1 (issued at SYNC_{q-1}, a whole chunk of
+        // matrix work earlier), so after the barrier chunk q+1 is complete for everybody and the copy of chunk q+2 can
+        // start.  A wave therefore runs from the end of one tile (accumulator drain, GELU / plane split or tile store)
+        // straight into the next tile's MFMAs without meeting anybody, instead of all waves draining the matrix pipe
+        // at a common end-of-chunk barrier; the fragment prefetch (MmaStream2) runs through the barrier.
+        auto copy12 = [&](auto qtag) {  // after SYNC_q of a layer-1/2 chunk (q compile-time): start the copy of chunk q+2
+            constexpr int q2 = decltype(qtag)::value + 2;
+            const int dst = slot_after(sl, 2);
+            if constexpr (q2 < TC) {
+                dma_chunk<NF1, EH_WAVES>(dma_src, lds[dst], wave, lane);
+                dma_src += (size_t)NF1 * 64;
+            } else if constexpr (q2 < TC + TD) {
+                dma_chunk_lean<NF2, EH_WAVES>(dma_src, lane16, wave, lds0 + dst * SLOT_BYTES);
+                dma_src += (size_t)NF2 * 64;
+            } else {  // first projection chunks (L * TC >= 2)
+                dma_chunk_lean<NF3, EH_WAVES>(dma_src, lane16, wave, lds0 + dst * SLOT_BYTES);
+                dma_src += (size_t)NF3 * 64;
+            }
+        };
+        auto copy3 = [&](int cidx) {  // after SYNC of projection chunk cidx
+            const int dst = slot_after(sl, 2);
+            if (cidx + 2 < nchunks) dma_chunk_lean<NF3, EH_WAVES>(dma_src, lane16, wave, lds0 + dst * SLOT_BYTES);
+            else if (has_next)  // the next pair's first two chunks
+                dma_chunk<NF1, EH_WAVES>(stream + (size_t)(cidx + 2 - nchunks) * NF1 * 64, lds[dst], wave, lane);
+            dma_src += (size_t)NF3 * 64;
+        };
+
+        if (!active) {
+            // no slots: keep the ring turning
+            [&]<int... Q>(std::integer_sequence<int, Q...>) {
+                ((dma_wait(), __syncthreads(), copy12(std::integral_constant<int, Q>{}), sl = slot_after(sl, 1)), ...);
+            }(std::make_integer_sequence<int, TC + TD>{});
+#pragma unroll 1
+            for (int cidx = 0; cidx < nchunks; ++cidx) {
+                dma_wait();
+                __syncthreads();
+                copy3(cidx);
+                sl = slot_after(sl, 1);
+            }
+            EDGE_TICK(3);
+            continue;
+        }
+
+        const int slot = 2 * wn + (j >> 4);
+        const int o = j & 15;
+        const int slot_c = min(slot, k - 1);
+        // ---- per-row attributes (transforms/invariants.py:82-88) ------------------------------------------
+        float a[6], window;
+        {
+            const size_t e = (size_t)node * k + slot_c;
+            const float dx = nbr_dir[3 * e + 0], dy = nbr_dir[3 * e + 1], dz = nbr_dir[3 * e + 2];
+            const float dist = nbr_dist[e];
+            const float ox = ori[3 * o + 0], oy = ori[3 * o + 1], oz = ori[3 * o + 2];
+            a[0] = (dx * ox + dy * oy) + dz * oz;
+            const float rx = dx - a[0] * ox, ry = dy - a[0] * oy, rz = dz - a[0] * oz;
+            a[1] = sqrtf((rx * rx + ry * ry) + rz * rz);
+            a[2] = dist;
+            const float* Lm = lattice + 9 * (size_t)batch[node];
+            const float dn = fmaxf(sqrtf((dx * dx + dy * dy) + dz * dz), 1e-8f);
+            const float ux = dx / dn, uy = dy / dn, uz = dz / dn;
 #pragma unroll
-    for (int u = 0; u < TC; ++u) {
-        f32x16 acc, cross;
-        MmaStream2<TM, 2 * TM> ms;
-        if (active) {
-            acc = arreau_bias_tile(bias_s, u, h);
+            for (int i = 0; i < 3; ++i) {
+                const float lx = Lm[3 * i], ly = Lm[3 * i + 1], lz = Lm[3 * i + 2];
+                const float ln = fmaxf(sqrtf((lx * lx + ly * ly) + lz * lz), 1e-8f);
+                a[3 + i] = (ux * (lx / ln) + uy * (ly / ln)) + uz * (lz / ln);
+            }
+            const float u = dist / r_max;
+            const float u2 = u * u, u6 = u2 * u2 * u2;
+            const float w = 1.0f - 28.0f * u6 + 48.0f * u6 * u - 21.0f * u6 * u2;
+            window = (slot < nd && dist < r_max) ? w : 0.0f;
+        }
+        Planes2 bm[TM];
+        bm[0] = split_tile2(mono_tile_h<0>(a, h, std::make_integer_sequence<int, 16>{}));
+        bm[1] = split_tile2(mono_tile_h<1>(a, h, std::make_integer_sequence<int, 16>{}));
+        bm[2] = split_tile2(mono_tile_h<2>(a, h, std::make_integer_sequence<int, 16>{}));
+        EDGE_TICK(0);
+
+        // `go` is always 1 but opaque to the compiler: guarding the two MFMA halves of a tile with it keeps every half
+        // tile its own basic block.  Without these block boundaries the scheduler overlaps the next tile's MFMAs with
+        // this tile's epilogue and the accumulators spill (measured: 140 spilled registers).  Everything a guarded
+        // block produces is given a value outside it as well (bias tile / zero planes): a result left undefined on
+        // the other path is turned by the optimiser into a value carried around the pair loop (250 spilled registers).
+        int go = 1;
+        asm volatile("" : "+s"(go));
+        // ---- layer 1: h = GELU(W1f . mono + b1) -------------------------------------------------------------
+        Planes2 h1[TC];
+#pragma unroll
+        for (int u = 0; u < TC; ++u) {
+            f32x16 acc = arreau_bias_tile(bias_s, u, h), cross;
 #pragma unroll
             for (int r = 0; r < 16; ++r) cross[r] = 0.f;
-            ms.start(lds[u % 3], lane);
-            ms.template run<0, TM>(acc, cross, bm);
+            MmaStream2<TM, 2 * TM> ms;
+            ms.start(lds[sl], lane);
+            if (go) ms.template run<0, TM>(acc, cross, bm);
+            dma_wait();
+            __syncthreads();
+            if (u + 2 < TC) copy12(std::integral_constant<int, 0>{});          // an NF1 chunk
+            else copy12(std::integral_constant<int, TC - 2>{});               // an NF2 chunk
+            h1[u] = Planes2{};
+            if (go) {
+                ms.template run<TM, 2 * TM>(acc, cross, bm);
+                h1[u] = gelu_split_tile2(acc, cross, 1.0f);
+            }
+            sl = slot_after(sl, 1);
         }
-        dma_wait();
-        __syncthreads();
-        if (u + 2 < TC) { dma_chunk<NF1, EH_WAVES>(dma_src, lds[(u + 2) % 3], wave, lane); dma_src += (size_t)NF1 * 64; }
-        else { dma_chunk_lean<NF2, EH_WAVES>(dma_src, dma_off2, lds0 + ((u + 2) % 3) * SLOT_BYTES); dma_src += (size_t)NF2 * 64; }
-        if (active) {
-            ms.template run<TM, 2 * TM>(acc, cross, bm);
-            h1[u] = gelu_split_tile2(acc, cross, 1.0f);
-        }
-    }
-    EDGE_TICK(1);
-    // ---- layer 2: basis = GELU(W2 . h + b2) * window ------------------------------------------------------
-    Planes2 basis[TD];
+        EDGE_TICK(1);
+        // ---- layer 2: basis = GELU(W2 . h + b2) * window ------------------------------------------------------
+        Planes2 basis[TD];
 #pragma unroll
-    for (int u = 0; u < TD; ++u) {
-        constexpr int Q0 = TC;
-        f32x16 acc, cross;
-        MmaStream2<TC, 2 * TC> ms;
-        if (active) {
-            acc = arreau_bias_tile(bias_s + C, u, h);
+        for (int u = 0; u < TD; ++u) {
+            f32x16 acc = arreau_bias_tile(bias_s + C, u, h), cross;
 #pragma unroll
             for (int r = 0; r < 16; ++r) cross[r] = 0.f;
-            ms.start(lds[(Q0 + u) % 3], lane);
-            ms.template run<0, TC>(acc, cross, h1);
+            MmaStream2<TC, 2 * TC> ms;
+            ms.start(lds[sl], lane);
+            if (go) ms.template run<0, TC>(acc, cross, h1);
+            dma_wait();
+            __syncthreads();
+            if (u + 2 < TD) copy12(std::integral_constant<int, TC>{});         // an NF2 chunk
+            else copy12(std::integral_constant<int, TC + TD - 2>{});           // an NF3 chunk
+            basis[u] = Planes2{};
+            if (go) {
+                ms.template run<TC, 2 * TC>(acc, cross, h1);
+                basis[u] = gelu_split_tile2(acc, cross, window);
+            }
+            sl = slot_after(sl, 1);
         }
-        dma_wait();
-        __syncthreads();
-        if (u + 2 < TD) { dma_chunk_lean<NF2, EH_WAVES>(dma_src, dma_off2, lds0 + ((Q0 + u + 2) % 3) * SLOT_BYTES); dma_src += (size_t)NF2 * 64; }
-        else if (u + 2 - TD < L * TC) { dma_chunk_lean<NF3, EH_WAVES>(dma_src, dma_off, lds0 + ((Q0 + u + 2) % 3) * SLOT_BYTES); dma_src += (size_t)NF3 * 64; }
-        if (active) {
-            ms.template run<TC, 2 * TC>(acc, cross, h1);
-            basis[u] = gelu_split_tile2(acc, cross, window);
-        }
-    }
-    EDGE_TICK(2);
-    // ---- per layer: kernel_l = Wk_l . basis  (conv.py:110), one output tile per chunk ---------------------
-    const size_t layer_stride = (size_t)N * k * 16 * C;
-    const size_t row0 = ((size_t)node * k + 2 * wn) * 16;  // first K row of this wave's 32-row tile
-    const int nchunks = L * TC;
-    int sl = (TC + TD) % 3;  // ring slot of the current chunk
-    float* pad = otile[wave];
-    const bool full = 2 * wn + 1 < k;  // wave-uniform: the wave's second slot exists
-    // A finished 32x32 tile goes to HBM through a wave-private LDS pad (transposed, so that every store instruction
-    // writes whole 128-byte lines: 8 lanes per row), in two steps that sit half a chunk apart in the instruction
-    // stream: pad_write right behind the tile's last MFMA, pad_store two k-steps into the next tile's MFMAs.
-    auto pad_write = [&](const f32x16& t) {
+        EDGE_TICK(2);
+        // ---- per layer: kernel_l = Wk_l . basis  (conv.py:110), one output tile per chunk ---------------------
+        const size_t layer_stride = (size_t)N * k * 16 * C;
+        const size_t row0 = ((size_t)node * k + 2 * wn) * 16;  // first K row of this wave's 32-row tile
+        float* pad = otile[wave];
+        const bool full = 2 * wn + 1 < k;  // wave-uniform: the wave's second slot exists
+        // A finished 32x32 tile goes to HBM through a wave-private LDS pad (transposed, so that every store instruction
+        // writes whole 128-byte lines: 8 lanes per row), in two steps that sit apart in the instruction stream:
+        // pad_write right behind the tile's last MFMA, pad_store two k-steps into the next tile's MFMAs.
+        auto pad_write = [&](const f32x16& t) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const f32x4 v = {t[4 * q], t[4 * q + 1], t[4 * q + 2], t[4 * q + 3]};
-            *reinterpret_cast<f32x4*>(&pad[j * 36 + 8 * q + 4 * h]) = v;
-        }
-    };
-    // Not predicated on the degree: a slot beyond it gets the zeros its window produced (those rows of the K buffer
-    // are never read), so a wave issues a FIXED number of stores per tile (4, or 2 for the wave whose second slot does
-    // not exist when k is odd) -- which the counted wait at SYNC relies on.
-    // Store addressing: wave-uniform byte base of tile (layer l, column tile u) advanced tile by tile + four per-lane
-    // 32-bit offsets computed once (global_store ... saddr form: no 64-bit vector address arithmetic in the loop).
-    unsigned st_off[4];
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 v = {t[4 * q], t[4 * q + 1], t[4 * q + 2], t[4 * q + 3]};
+                *reinterpret_cast<f32x4*>(&pad[j * 36 + 8 * q + 4 * h]) = v;
+            }
+        };
+        // Not predicated on the degree: a slot beyond it gets the zeros its window produced (those rows of the K
+        // buffer are never read), so a wave issues a FIXED number of stores per tile (4, or 2 for the wave whose second
+        // slot does not exist when k is odd) -- which the counted wait at SYNC relies on.  Addressing: wave-uniform
+        // byte base of tile (layer l, column tile u), advanced tile by tile, + four per-lane 32-bit offsets.
+        const unsigned st_off = 4u * ((lane >> 3) * C + 4 * (lane & 7));  // row lane/8 (+ 8i, uniform) of the wave tile
+        auto pad_store = [&](const char* tile_base /* wave-uniform */) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) st_off[i] = 4u * ((8 * i + (lane >> 3)) * C + 4 * (lane & 7));  // row 8i + lane/8 of the wave tile
-    auto pad_store = [&](const char* tile_base /* wave-uniform */) {
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int r = 8 * i + (lane >> 3);  // slot 2*wn + (r >> 4), orientation r & 15
-            const f32x4 v = *reinterpret_cast<const f32x4*>(&pad[r * 36 + 4 * (lane & 7)]);
-            if (i < 2 || full) *reinterpret_cast<f32x4*>(const_cast<char*>(tile_base) + st_off[i]) = v;
-        }
-    };
-    // X = k-step at which the chunk's barrier is taken (mid-chunk).  Taking it at different points in the two halves
-    // of the workgroup (SIMD partners a half chunk apart) was measured to make no difference: fp32 vector work and
-    // MFMAs of SIMD partners serialise anyway, so both halves use the same point.
-    // At SYNC the wave's queue holds, oldest first, its 4 DMA copies of the next chunk and -- from the second chunk
-    // on -- the stores of the previous tile: the counted wait retires the copies and leaves the stores in flight.
-    const char* tile0 = reinterpret_cast<const char*>(kbuf + row0 * C);  // (layer 0, column tile 0) of this wave's rows
-    auto proj_loop = [&](auto xtag) {
-        constexpr int X = decltype(xtag)::value;
-        static_assert(X >= 2 && X < 2 * TD, "barrier position");
-        const char* tile_base = tile0;  // tile of the PREVIOUS chunk (the one pad_store writes)
+            for (int i = 0; i < 4; ++i) {
+                const int r = 8 * i + (lane >> 3);  // slot 2*wn + (r >> 4), orientation r & 15
+                const f32x4 v = *reinterpret_cast<const f32x4*>(&pad[r * 36 + 4 * (lane & 7)]);
+                if (i < 2 || full) *reinterpret_cast<f32x4*>(const_cast<char*>(tile_base) + 32 * i * C + st_off) = v;
+            }
+        };
+        // X = k-step at which the chunk's barrier is taken (mid-chunk).  Taking it at different points in the two
+        // halves of the workgroup (SIMD partners a half chunk apart) was measured to make no difference: fp32 vector
+        // work and MFMAs of SIMD partners serialise anyway, so both halves use the same point.
+        // At SYNC the wave's queue holds, oldest first, its DMA copies of the next chunk and -- from the second chunk
+        // on -- the stores of the previous tile: the counted wait retires the copies and leaves the stores in flight.
+        constexpr int X = TD;
+        const char* tile_base = reinterpret_cast<const char*>(kbuf + row0 * C);  // tile the next pad_store writes
         int u_prev = 0;
 #pragma unroll 1
         for (int cidx = 0; cidx < nchunks; ++cidx) {
-            const u32x4* buf = lds[sl];
-            const unsigned free_slot = lds0 + (sl == 0 ? 2u : (unsigned)sl - 1u) * SLOT_BYTES;  // (sl + 2) % 3
             f32x16 acc, cross;
 #pragma unroll
             for (int r = 0; r < 16; ++r) { acc[r] = 0.0f; cross[r] = 0.0f; }
             MmaStream2<TD, 2 * TD> ms;
-            ms.start(buf, lane);
+            ms.start(lds[sl], lane);
             ms.template run<0, 2>(acc, cross, basis);
             if (cidx > 0) {
                 pad_store(tile_base);
@@ -268,28 +309,14 @@ __global__ __launch_bounds__(64 * EH_WAVES, 2) void edge_kernel_f16x3(
             else if (full) dma_wait_but<4>();
             else dma_wait_but<2>();
             __syncthreads();
-            if (cidx + 2 < nchunks) dma_chunk_lean<NF3, EH_WAVES>(dma_src, dma_off, free_slot);
-            dma_src += (size_t)NF3 * 64;
+            copy3(cidx);
             ms.template run<X, 2 * TD>(acc, cross, basis);
             pad_write(fold_cross(acc, cross));
-            sl = sl == 2 ? 0 : sl + 1;
+            sl = slot_after(sl, 1);
         }
         pad_store(tile_base);
-    };
-    if (!active) {  // no slots: keep the ring turning
-#pragma unroll 1
-        for (int cidx = 0; cidx < nchunks; ++cidx) {
-            const unsigned free_slot = lds0 + (sl == 0 ? 2u : (unsigned)sl - 1u) * SLOT_BYTES;
-            dma_wait();
-            __syncthreads();
-            if (cidx + 2 < nchunks) dma_chunk_lean<NF3, EH_WAVES>(dma_src, dma_off, free_slot);
-            dma_src += (size_t)NF3 * 64;
-            sl = sl == 2 ? 0 : sl + 1;
-        }
-    } else {
-        proj_loop(std::integral_constant<int, TD>{});
-    }
-    EDGE_TICK(3);
+        EDGE_TICK(3);
+    }  // pair loop
     EDGE_TICK(4);
 #ifdef ARREAU_EDGE_TIMING
     if (threadIdx.x == 0)
@@ -306,7 +333,19 @@ int arreau_launch_edge_f16x3(const arreau_model* m, const float* dir, const floa
     }
     // 8 waves = two receivers per workgroup, one workgroup per CU (2 waves per SIMD from the same workgroup).
     // A 4-wave / two-workgroups-per-CU geometry was tried and dropped: it was not run-to-run reproducible.
-    hipLaunchKernelGGL((edge_kernel_f16x3<128, 256, 8>), dim3((N + 1) / 2), dim3(512), 0, s, dir, dist, deg, batch,
+    // Persistent: one workgroup per CU walks the receiver pairs with stride gridDim (ARREAU_EDGE_WGS overrides the
+    // workgroup count, e.g. to (N+1)/2 for one pair per workgroup).
+    static const int wgs_env = [] { const char* e = getenv("ARREAU_EDGE_WGS"); return e ? atoi(e) : 0; }();
+    int n_cu = 256;
+    {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+            n_cu = prop.multiProcessorCount;
+    }
+    const int npairs = (N + 1) / 2;
+    const int wgs = wgs_env > 0 ? (wgs_env < npairs ? wgs_env : npairs) : (npairs < n_cu ? npairs : n_cu);
+    hipLaunchKernelGGL((edge_kernel_f16x3<128, 256, 8>), dim3(wgs), dim3(512), 0, s, dir, dist, deg, batch,
                        lattice, m->ori, reinterpret_cast<const u32x4*>(m->edge_f16), m->b1, m->b2, m->cfg.radius, N,
                        m->k, m->L, kbuf);
     ARREAU_CHECK_HIP(hipGetLastError());

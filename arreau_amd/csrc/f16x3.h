@@ -213,24 +213,21 @@ __device__ __forceinline__ void dma_chunk(const u32x4* __restrict__ chunk, u32x4
         glds16(chunk + (size_t)f * 64 + lane, base + (unsigned)f * 1024u);
     }
 }
-// Lean form for loops: the chunk's byte address is a wave-uniform 64-bit base (SGPR pair, advanced by the caller),
-// each lane adds a 32-bit offset computed once (voff[i] = 16 lane + 1024 (NW i + wave)), and M0 is written directly
-// (it is dead everywhere else in these kernels): 2 scalar + 1 vector-memory instruction per KiB fragment.
+// Lean form for loops: fragment f = NW i + wave of the chunk is addressed as a wave-uniform 64-bit base (SGPR pair:
+// chunk + 1024 f, scalar arithmetic) plus ONE per-lane 32-bit offset (16 lane) shared by all fragments, and M0 is
+// written directly (it is dead everywhere else in these kernels): scalar work + 1 vector-memory instruction per
+// KiB fragment, one VGPR in total.
 template <int NF, int NW>
-__device__ __forceinline__ void dma_offsets(unsigned (&voff)[NF / NW], int wave, int lane) {
-    static_assert(NF % NW == 0, "dma_chunk_lean: whole fragments per wave");
-#pragma unroll
-    for (int i = 0; i < NF / NW; ++i) voff[i] = 16u * lane + 1024u * (NW * i + wave);
-}
-template <int NF, int NW>
-__device__ __forceinline__ void dma_chunk_lean(const void* chunk_uniform, const unsigned (&voff)[NF / NW],
+__device__ __forceinline__ void dma_chunk_lean(const void* chunk_uniform, unsigned lane16, int wave,
                                                unsigned slot_plus_wave /* LDS byte address of the slot + 1024 wave */) {
+    static_assert(NF % NW == 0, "dma_chunk_lean: whole fragments per wave");
+    const char* base = static_cast<const char*>(chunk_uniform) + 1024 * wave;
 #pragma unroll
     for (int i = 0; i < NF / NW; ++i)
         asm volatile("s_add_u32 m0, %2, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
                      :
-                     : "v"(voff[i]), "s"(chunk_uniform), "s"(slot_plus_wave), "n"(1024 * NW * i)
-                     : "memory");
+                     : "v"(lane16), "s"(base + 1024 * NW * i), "s"(slot_plus_wave), "n"(1024 * NW * i)
+                     : "memory", "scc");  // s_add_u32 writes SCC
 }
 __device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 // vmcnt retires in issue order (loads, stores and LDS-DMA alike): all but the N youngest operations are done

@@ -105,13 +105,12 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_kernel_f16x3(
     // 32 chunks per layer: per quarter 4 chunks of W1 rows (hidden tiles 0..3) then 4 chunks of W2 columns
     // (output tiles 0..3).  Chunk q sits in ring slot q % 3.
     int sl = 0;
-    unsigned dma_off[NF / NW];
-    dma_offsets<NF, NW>(dma_off, wave, lane);
+    const unsigned lane16 = 16u * lane;
     const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)&lds[0][0]) + 1024u * wave;
     auto sync = [&](bool more2) {  // SYNC_q: chunk q+1 complete for everybody, slot of chunk q-1 free -> copy chunk q+2
         dma_wait();
         __syncthreads();
-        if (more2) dma_chunk_lean<NF, NW>(dma_src, dma_off, lds0 + (sl == 0 ? 2u : (unsigned)sl - 1u) * (NF * 1024u));
+        if (more2) dma_chunk_lean<NF, NW>(dma_src, lane16, wave, lds0 + (sl == 0 ? 2u : (unsigned)sl - 1u) * (NF * 1024u));
         dma_src += (size_t)NF * 64;
     };
 #pragma unroll 1
