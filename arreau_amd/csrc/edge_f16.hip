@@ -336,13 +336,13 @@ int arreau_launch_edge_f16x3(const arreau_model* m, const float* dir, const floa
     // Persistent: one workgroup per CU walks the receiver pairs with stride gridDim (ARREAU_EDGE_WGS overrides the
     // workgroup count, e.g. to (N+1)/2 for one pair per workgroup).
     static const int wgs_env = [] { const char* e = getenv("ARREAU_EDGE_WGS"); return e ? atoi(e) : 0; }();
-    int n_cu = 256;
-    {
+    static const int n_cu = [] {  // CUs of the current device (one process drives one GPU)
         int dev = 0;
         hipDeviceProp_t prop;
         if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
-            n_cu = prop.multiProcessorCount;
-    }
+            return (int)prop.multiProcessorCount;
+        return 256;
+    }();
     const int npairs = (N + 1) / 2;
     const int wgs = wgs_env > 0 ? (wgs_env < npairs ? wgs_env : npairs) : (npairs < n_cu ? npairs : n_cu);
     hipLaunchKernelGGL((edge_kernel_f16x3<128, 256, 8>), dim3(wgs), dim3(512), 0, s, dir, dist, deg, batch,
