@@ -213,6 +213,140 @@ __global__ __launch_bounds__(512, 4) void conv_kernel(
 }
 
 // ---------------------------------------------------------------------------------------------
+// K4a, streamed form (k = 8): the same arithmetic as conv_kernel, but the receiver's K block (8 slots x 16
+// orientations x C floats = 64 KiB, contiguous in HBM) is copied straight into LDS by LDS-DMA two receivers ahead
+// -- no registers are tied up by bytes in flight, so a whole 64 KiB HBM request per receiver overlaps the arithmetic
+// of the two receivers before it -- and the senders' x rows of the next receiver are requested (all 8 slots at
+// once) before the current receiver's orientation mix.  One workgroup of 512 threads per CU (LDS: 2 x 64 KiB K
+// blocks + 2 tiles).  Loads and copies are inline asm with hand-counted vmcnt (loads, stores and DMA retire in issue
+// order): at the top of a receiver the queue holds, oldest first, [K(i) copy: 8 per wave] [x(i): 8] [K(i+1): 8]
+// [4 stores of receiver i-1] -> vmcnt(12) retires what receiver i needs and leaves the rest in flight.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void conv_glds16(const void* gsrc_lane, unsigned lds_dst) {
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(gsrc_lane), "s"(lds_dst) : "memory");
+}
+__device__ __forceinline__ f32x4 conv_load16(const void* p) {
+    f32x4 v;
+    asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(p) : "memory");
+    return v;
+}
+template <int C>
+__global__ __launch_bounds__(512, 2) void conv_kernel_streamed(
+    const float* __restrict__ kl,        // this layer's kernels [N*8*16][C]
+    const int32_t* __restrict__ deg, const int32_t* __restrict__ src,
+    const float* __restrict__ x_in,      // [N][16][C]
+    const float* __restrict__ fk,        // [16(o)][16(p)][C]
+    const float* __restrict__ conv_bias, int N,
+    float* __restrict__ x_conv)          // [N][16][C]
+{
+    static_assert(C == 128, "thread mapping assumes C = 128");
+    constexpr int K = 8;
+    constexpr unsigned KBLOCK = K * 16 * C * 4;  // 64 KiB per receiver
+    __shared__ __attribute__((aligned(16))) float kbuf_s[2][K * 16 * C];
+    __shared__ __attribute__((aligned(16))) float tile[2][16 * CONV_LDS_STRIDE];
+    const int tid = threadIdx.x;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int c = tid & 127, pq = tid >> 7;    // mix role: channel, quarter of the output orientations
+    const int c4 = tid & 31, o_row = tid >> 5;  // gather role: float4 column, orientation row
+    float fkr[16][4];
+#pragma unroll
+    for (int o = 0; o < 16; ++o)
+#pragma unroll
+        for (int p = 0; p < 4; ++p) fkr[o][p] = fk[((size_t)o * 16 + (4 * pq + p)) * C + c];
+    float bias = conv_bias[c];
+    // Consume the loads above here, outside the loop: hipcc then waits for them now, and not -- with the vmcnt(0) it
+    // would have to use, since it cannot see the asm requests -- in front of their first use inside the loop.
+#pragma unroll
+    for (int o = 0; o < 16; ++o)
+#pragma unroll
+        for (int p = 0; p < 4; ++p) asm volatile("" : "+v"(fkr[o][p]));
+    asm volatile("" : "+v"(bias));
+
+    // XCD-aware receiver order (see conv_kernel); the i-th receiver of this workgroup, or -1
+    const bool xcd_order = (gridDim.x & 7) == 0;
+    const int xcd = blockIdx.x & 7, wg_in_xcd = blockIdx.x >> 3, wgs_per_xcd = gridDim.x >> 3;
+    const int n_iter = xcd_order ? ((N + 8 * CONV_GROUP - 1) / (8 * CONV_GROUP)) * CONV_GROUP : N;
+    const int m_step = xcd_order ? wgs_per_xcd : (int)gridDim.x;
+    auto node_of = [&](int m) { return xcd_order ? ((m / CONV_GROUP) * 8 + xcd) * CONV_GROUP + (m % CONV_GROUP) : m; };
+    auto next_valid = [&](int m) {  // first local index >= m with a receiver < N, or n_iter
+        while (m < n_iter && node_of(m) >= N) m += m_step;
+        return m;
+    };
+    const unsigned kb0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)&kbuf_s[0][0]);
+    auto copy_k = [&](int n, int b) {  // this wave's 8 KiB of receiver n's K block -> kbuf_s[b]
+        const char* g = reinterpret_cast<const char*>(kl) + (size_t)n * KBLOCK + 8192u * wave + 16u * lane;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) conv_glds16(g + 1024 * i, kb0 + b * KBLOCK + 8192u * wave + 1024u * i);
+    };
+    f32x4 xv[K];
+    auto load_x = [&](int n) {
+        const int32_t* srow = src + (size_t)n * K;
+#pragma unroll
+        for (int s_ = 0; s_ < K; ++s_) {
+            const int sn = max(srow[s_], 0);  // unused slots: any valid row, dropped by the select below
+            xv[s_] = conv_load16(x_in + ((size_t)sn * 16 + o_row) * C + 4 * c4);
+        }
+    };
+
+    int m0 = next_valid(xcd_order ? wg_in_xcd : (int)blockIdx.x);
+    if (m0 >= n_iter) return;
+    int m1 = next_valid(m0 + m_step);
+    // prologue: queue = [K(0)] [x(0)] [K(1)] (+ nothing)
+    copy_k(node_of(m0), 0);
+    load_x(node_of(m0));
+    if (m1 < n_iter) copy_k(node_of(m1), 1);
+    int b = 0;
+    bool first = true;
+    for (int m = m0; m < n_iter;) {
+        const int n = node_of(m);
+        const int mn = next_valid(m + m_step);             // next receiver
+        const int mnn = mn < n_iter ? next_valid(mn + m_step) : n_iter;  // the one after
+        const int nd = min(deg[n], K);                     // scalar load
+        // wait for K(n) (this wave's share) and x(n); the younger K(next) copy and the previous stores stay in flight
+        if (mn < n_iter) {
+            if (first) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+        } else {
+            if (first) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        }
+#pragma unroll
+        for (int s_ = 0; s_ < K; ++s_) asm volatile("" : "+v"(xv[s_]));  // the loaded values exist from here on
+        __syncthreads();  // every wave's share of K(n) has landed
+        // ---- multiply . ordered sum over the in-edges -----------------------------------------------------
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        const float* kb = &kbuf_s[b][o_row * C + 4 * c4];
+#pragma unroll
+        for (int s_ = 0; s_ < K; ++s_) {
+            const f32x4 kv = *reinterpret_cast<const f32x4*>(kb + s_ * 16 * C);
+            const bool on = s_ < nd;  // product rounded, then added in edge order (messages -> index_add_)
+            acc[0] = on ? __fadd_rn(acc[0], __fmul_rn(kv[0], xv[s_][0])) : acc[0];
+            acc[1] = on ? __fadd_rn(acc[1], __fmul_rn(kv[1], xv[s_][1])) : acc[1];
+            acc[2] = on ? __fadd_rn(acc[2], __fmul_rn(kv[2], xv[s_][2])) : acc[2];
+            acc[3] = on ? __fadd_rn(acc[3], __fmul_rn(kv[3], xv[s_][3])) : acc[3];
+        }
+        *reinterpret_cast<f32x4*>(&tile[b][o_row * CONV_LDS_STRIDE + 4 * c4]) = acc;
+        __syncthreads();  // tile[b] complete; nobody reads kbuf_s[b] any more
+        // ---- requests for the receivers ahead: x(next) first, then the K block of the one after ------------
+        if (mn < n_iter) load_x(node_of(mn));
+        if (mnn < n_iter) copy_k(node_of(mnn), b);
+        // ---- depth-wise orientation mix ------------------------------------------------------------
+        float out[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int o = 0; o < 16; ++o) {
+            const float xo = tile[b][o * CONV_LDS_STRIDE + c];
+#pragma unroll
+            for (int p = 0; p < 4; ++p) out[p] += xo * fkr[o][p];
+        }
+#pragma unroll
+        for (int p = 0; p < 4; ++p) x_conv[((size_t)n * 16 + (4 * pq + p)) * C + c] = out[p] + bias;
+        first = false;
+        b ^= 1;
+        m = mn;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // K4b: ConvNext block of one layer on MFMA (convnext.py:25-32) + read-out partials (ponita.py:105-117).
 // A 32-row tile (2 nodes x 16 orientations) is shared by a PAIR of waves, each owning half of the hidden
 // units (finer tasks balance the 1024 SIMDs at small batches); the pair meets once, through LDS, to add
@@ -404,8 +538,16 @@ int arreau_launch_node_layer(const arreau_model* m, int layer, const float* kbuf
     const size_t layer_stride = (size_t)N * m->k * 16 * C;
     const size_t mlp_layer = (size_t)2 * H * C;  // floats of W1 + W2, packed
     const int conv_blocks = N < 512 ? N : 512;   // persistent: 2 workgroups of 512 threads per CU (a multiple of 8: XCD-aware order)
-    hipLaunchKernelGGL((conv_kernel<128>), dim3(conv_blocks), dim3(512), 0, s, kbuf + (size_t)layer * layer_stride, deg,
-                       src, x_in, m->fk + (size_t)layer * 16 * 16 * C, m->conv_bias + (size_t)layer * C, N, m->k, x_conv);
+    // conv variant: 1 (default, k = 8 only) = streamed form (K blocks by LDS-DMA, one workgroup per CU); 0 = register form
+    static const int conv_variant = [] { const char* e = getenv("ARREAU_CONV_VARIANT"); return e ? atoi(e) : 1; }();
+    if (conv_variant == 1 && m->k == 8) {
+        const int blocks = N < 256 ? N : 256;
+        hipLaunchKernelGGL((conv_kernel_streamed<128>), dim3(blocks), dim3(512), 0, s, kbuf + (size_t)layer * layer_stride, deg,
+                           src, x_in, m->fk + (size_t)layer * 16 * 16 * C, m->conv_bias + (size_t)layer * C, N, x_conv);
+    } else {
+        hipLaunchKernelGGL((conv_kernel<128>), dim3(conv_blocks), dim3(512), 0, s, kbuf + (size_t)layer * layer_stride, deg,
+                           src, x_in, m->fk + (size_t)layer * 16 * 16 * C, m->conv_bias + (size_t)layer * C, N, m->k, x_conv);
+    }
     ARREAU_CHECK_HIP(hipGetLastError());
     // variant switch: 2 (default) = fp16x3 split-precision MLP kernel (node_f16.hip; needs weights that fit fp16);
     // 1 = bf16x6 split-precision MLP kernel (node_bf16.hip); 0 = fp32-MFMA kernel below
