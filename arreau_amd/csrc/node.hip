@@ -216,11 +216,11 @@ __global__ __launch_bounds__(512, 4) void conv_kernel(
 // K4a, streamed form (k = 8): the same arithmetic as conv_kernel, but the receiver's K block (8 slots x 16
 // orientations x C floats = 64 KiB, contiguous in HBM) is copied straight into LDS by LDS-DMA two receivers ahead
 // -- no registers are tied up by bytes in flight, so a whole 64 KiB HBM request per receiver overlaps the arithmetic
-// of the two receivers before it -- and the senders' x rows of the next receiver are requested (all 8 slots at
-// once) before the current receiver's orientation mix.  One workgroup of 512 threads per CU (LDS: 2 x 64 KiB K
+// of the two receivers before it -- and the senders' x rows are requested (all 8 slots at once) two receivers
+// ahead as well, into a second register set.  One workgroup of 512 threads per CU (LDS: 2 x 64 KiB K
 // blocks + 2 tiles).  Loads and copies are inline asm with hand-counted vmcnt (loads, stores and DMA retire in issue
-// order): at the top of a receiver the queue holds, oldest first, [K(i) copy: 8 per wave] [x(i): 8] [K(i+1): 8]
-// [4 stores of receiver i-1] -> vmcnt(12) retires what receiver i needs and leaves the rest in flight.
+// order): at the top of receiver i the queue ends with [x(i+1): 8] [K(i+1) copy: 8 per wave] [4 stores of receiver
+// i-1] -> vmcnt(20) retires what receiver i needs and leaves the rest in flight.
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ void conv_glds16(const void* gsrc_lane, unsigned lds_dst) {
     asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(gsrc_lane), "s"(lds_dst) : "memory");
@@ -278,71 +278,85 @@ __global__ __launch_bounds__(512, 2) void conv_kernel_streamed(
 #pragma unroll
         for (int i = 0; i < 8; ++i) conv_glds16(g + 1024 * i, kb0 + b * KBLOCK + 8192u * wave + 1024u * i);
     };
-    f32x4 xv[K];
-    auto load_x = [&](int n) {
+    f32x4 xv[2][K];  // x rows of the current and of the next receiver (static parity: the loop body is unrolled by two)
+    auto load_x = [&](int n, auto par) {
         const int32_t* srow = src + (size_t)n * K;
 #pragma unroll
         for (int s_ = 0; s_ < K; ++s_) {
             const int sn = max(srow[s_], 0);  // unused slots: any valid row, dropped by the select below
-            xv[s_] = conv_load16(x_in + ((size_t)sn * 16 + o_row) * C + 4 * c4);
+            xv[decltype(par)::value][s_] = conv_load16(x_in + ((size_t)sn * 16 + o_row) * C + 4 * c4);
         }
     };
+    using P0 = std::integral_constant<int, 0>;
+    using P1 = std::integral_constant<int, 1>;
 
-    int m0 = next_valid(xcd_order ? wg_in_xcd : (int)blockIdx.x);
-    if (m0 >= n_iter) return;
-    int m1 = next_valid(m0 + m_step);
-    // prologue: queue = [K(0)] [x(0)] [K(1)] (+ nothing)
-    copy_k(node_of(m0), 0);
-    load_x(node_of(m0));
-    if (m1 < n_iter) copy_k(node_of(m1), 1);
-    int b = 0;
+    int m = next_valid(xcd_order ? wg_in_xcd : (int)blockIdx.x);
+    if (m >= n_iter) return;
+    int mn = next_valid(m + m_step);
+    // prologue: queue = [x(0)] [K(0)] [x(1)] [K(1)]
+    load_x(node_of(m), P0{});
+    copy_k(node_of(m), 0);
+    if (mn < n_iter) {
+        load_x(node_of(mn), P1{});
+        copy_k(node_of(mn), 1);
+    }
     bool first = true;
-    for (int m = m0; m < n_iter;) {
+    // One receiver.  PAR = parity of its position in this workgroup's sequence = its K buffer, tile and xv set.
+    auto receiver = [&](auto par) {
+        constexpr int PAR = decltype(par)::value;
         const int n = node_of(m);
-        const int mn = next_valid(m + m_step);             // next receiver
-        const int mnn = mn < n_iter ? next_valid(mn + m_step) : n_iter;  // the one after
-        const int nd = min(deg[n], K);                     // scalar load
-        // wait for K(n) (this wave's share) and x(n); the younger K(next) copy and the previous stores stay in flight
+        const int mnn = mn < n_iter ? next_valid(mn + m_step) : n_iter;  // the receiver after the next
+        const int nd = min(deg[n], K);                                   // scalar load
+        // Requests are issued after the second barrier of a receiver as [x(+2): 8] [K(+2): 8] and followed by its
+        // 4 stores.  Receiver i needs x(i), K(i); younger than those are the requests for i+1 (16, if it exists) and
+        // the stores of i-1 (4, unless i is the first): they stay in flight.
         if (mn < n_iter) {
-            if (first) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
+            if (first) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
         } else {
             if (first) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         }
 #pragma unroll
-        for (int s_ = 0; s_ < K; ++s_) asm volatile("" : "+v"(xv[s_]));  // the loaded values exist from here on
+        for (int s_ = 0; s_ < K; ++s_) asm volatile("" : "+v"(xv[PAR][s_]));  // the loaded values exist from here on
         __syncthreads();  // every wave's share of K(n) has landed
         // ---- multiply . ordered sum over the in-edges -----------------------------------------------------
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        const float* kb = &kbuf_s[b][o_row * C + 4 * c4];
+        const float* kb = &kbuf_s[PAR][o_row * C + 4 * c4];
 #pragma unroll
         for (int s_ = 0; s_ < K; ++s_) {
             const f32x4 kv = *reinterpret_cast<const f32x4*>(kb + s_ * 16 * C);
             const bool on = s_ < nd;  // product rounded, then added in edge order (messages -> index_add_)
-            acc[0] = on ? __fadd_rn(acc[0], __fmul_rn(kv[0], xv[s_][0])) : acc[0];
-            acc[1] = on ? __fadd_rn(acc[1], __fmul_rn(kv[1], xv[s_][1])) : acc[1];
-            acc[2] = on ? __fadd_rn(acc[2], __fmul_rn(kv[2], xv[s_][2])) : acc[2];
-            acc[3] = on ? __fadd_rn(acc[3], __fmul_rn(kv[3], xv[s_][3])) : acc[3];
+            acc[0] = on ? __fadd_rn(acc[0], __fmul_rn(kv[0], xv[PAR][s_][0])) : acc[0];
+            acc[1] = on ? __fadd_rn(acc[1], __fmul_rn(kv[1], xv[PAR][s_][1])) : acc[1];
+            acc[2] = on ? __fadd_rn(acc[2], __fmul_rn(kv[2], xv[PAR][s_][2])) : acc[2];
+            acc[3] = on ? __fadd_rn(acc[3], __fmul_rn(kv[3], xv[PAR][s_][3])) : acc[3];
         }
-        *reinterpret_cast<f32x4*>(&tile[b][o_row * CONV_LDS_STRIDE + 4 * c4]) = acc;
-        __syncthreads();  // tile[b] complete; nobody reads kbuf_s[b] any more
-        // ---- requests for the receivers ahead: x(next) first, then the K block of the one after ------------
-        if (mn < n_iter) load_x(node_of(mn));
-        if (mnn < n_iter) copy_k(node_of(mnn), b);
+        *reinterpret_cast<f32x4*>(&tile[PAR][o_row * CONV_LDS_STRIDE + 4 * c4]) = acc;
+        __syncthreads();  // tile[PAR] complete; nobody reads kbuf_s[PAR] or xv[PAR] any more
+        // ---- requests for the receiver after the next (same parity) -----------------------------------------
+        if (mnn < n_iter) {
+            load_x(node_of(mnn), par);
+            copy_k(node_of(mnn), PAR);
+        }
         // ---- depth-wise orientation mix ------------------------------------------------------------
         float out[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int o = 0; o < 16; ++o) {
-            const float xo = tile[b][o * CONV_LDS_STRIDE + c];
+            const float xo = tile[PAR][o * CONV_LDS_STRIDE + c];
 #pragma unroll
             for (int p = 0; p < 4; ++p) out[p] += xo * fkr[o][p];
         }
 #pragma unroll
         for (int p = 0; p < 4; ++p) x_conv[((size_t)n * 16 + (4 * pq + p)) * C + c] = out[p] + bias;
         first = false;
-        b ^= 1;
         m = mn;
+        mn = mnn;
+    };
+    while (m < n_iter) {
+        receiver(P0{});
+        if (m >= n_iter) break;
+        receiver(P1{});
     }
 }
 
