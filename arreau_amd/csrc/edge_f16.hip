@@ -185,15 +185,16 @@ __global__ __launch_bounds__(64 * EH_WAVES, 2) void edge_kernel_f16x3(
             a[1] = sqrtf((rx * rx + ry * ry) + rz * rz);
             a[2] = dist;
             const float* Lm = lattice + 9 * (size_t)batch[node];
-            const float dn = fmaxf(sqrtf((dx * dx + dy * dy) + dz * dz), 1e-8f);
-            const float ux = dx / dn, uy = dy / dn, uz = dz / dn;
+            // reciprocals by v_rcp_f32 (1 ulp) instead of IEEE division sequences: far inside the 1e-5 parity budget
+            const float inv_dn = __builtin_amdgcn_rcpf(fmaxf(sqrtf((dx * dx + dy * dy) + dz * dz), 1e-8f));
+            const float ux = dx * inv_dn, uy = dy * inv_dn, uz = dz * inv_dn;
 #pragma unroll
             for (int i = 0; i < 3; ++i) {
                 const float lx = Lm[3 * i], ly = Lm[3 * i + 1], lz = Lm[3 * i + 2];
-                const float ln = fmaxf(sqrtf((lx * lx + ly * ly) + lz * lz), 1e-8f);
-                a[3 + i] = (ux * (lx / ln) + uy * (ly / ln)) + uz * (lz / ln);
+                const float inv_ln = __builtin_amdgcn_rcpf(fmaxf(sqrtf((lx * lx + ly * ly) + lz * lz), 1e-8f));
+                a[3 + i] = (ux * (lx * inv_ln) + uy * (ly * inv_ln)) + uz * (lz * inv_ln);
             }
-            const float u = dist / r_max;
+            const float u = dist * __builtin_amdgcn_rcpf(r_max);
             const float u2 = u * u, u6 = u2 * u2 * u2;
             const float w = 1.0f - 28.0f * u6 + 48.0f * u6 * u - 21.0f * u6 * u2;
             window = (slot < nd && dist < r_max) ? w : 0.0f;
