@@ -13,9 +13,24 @@
 // so there is no cross-wave reduction; the epilogue (bias, layer scale, residual, orientation mean, vector
 // read-out) stays in registers.
 #include <stdlib.h>
+#include <utility>
 
 #include "f16x3.h"
 #include "internal.h"
+
+// Sum over the 16 lanes of a DPP row (the 16 orientations of a node), every lane receiving the total: a butterfly
+// of v_add_f32 with DPP operands (quad_perm xor 1, quad_perm xor 2, row_half_mirror, row_mirror) -- the same pairs
+// in the same order as an xor-shuffle butterfly (bit-identical sums), without its 4 LDS permutes per value.
+__device__ __forceinline__ float row16_sum(float v) {
+    auto dpp = [](float x, auto ctrl) {
+        return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), decltype(ctrl)::value, 0xf, 0xf, false));
+    };
+    v += dpp(v, std::integral_constant<int, 0xB1>{});   // quad_perm [1,0,3,2]
+    v += dpp(v, std::integral_constant<int, 0x4E>{});   // quad_perm [2,3,0,1]
+    v += dpp(v, std::integral_constant<int, 0x141>{});  // row_half_mirror
+    v += dpp(v, std::integral_constant<int, 0x140>{});  // row_mirror
+    return v;
+}
 
 template <int C, int H, int NW>
 __global__ __launch_bounds__(64 * NW, 2) void mlp_kernel_f16x3(
@@ -165,10 +180,7 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_kernel_f16x3(
             for (int m = 0; m < 4; ++m) vdot += xo[m] * wvv[m];
             f32x4 sum = xo;
 #pragma unroll
-            for (int off = 1; off < 16; off <<= 1) {
-#pragma unroll
-                for (int m = 0; m < 4; ++m) sum[m] += __shfl_xor(sum[m], off, 64);
-            }
+            for (int m = 0; m < 4; ++m) sum[m] = row16_sum(sum[m]);
             if (valid && o == 0) {
                 const f32x4 mean = {sum[0] * inv16, sum[1] * inv16, sum[2] * inv16, sum[3] * inv16};
                 *reinterpret_cast<f32x4*>(xbar + (size_t)n * C + c0) = mean;
