@@ -470,6 +470,37 @@ def test_alternative_arithmetic_variants_agree(dev, small_model, edge_variant, m
         assert (x - y).abs().max() <= TOL * scale * 8
 
 
+def test_launch_geometry_switches_are_bitwise_neutral(dev):
+    """The register form of the conv kernel (ARREAU_CONV_VARIANT=0) and the streamed LDS-DMA form, and the persistent
+    edge kernel at one receiver pair per workgroup (ARREAU_EDGE_WGS large) versus one workgroup per CU, evaluate the
+    same sums in the same order: outputs must be bit-identical (full-size model, 96 crystals x 20 atoms, so that
+    workgroups of the default geometry walk several receivers)."""
+    import subprocess
+    import sys
+    import tempfile
+    code = (
+        "import torch, sys; sys.path.insert(0, %r)\n"
+        "from arreau_amd.checkpoint import make_synthetic_model\n"
+        "from arreau_amd.diffusion.diffusion_helpers import crystal_offsets\n"
+        "from tests.helpers import random_state\n"
+        "dev = torch.device('cuda', 0)\n"
+        "m = make_synthetic_model(S=90, seed=1234).to(dev)\n"
+        "frac, types, lengths, angles, na = random_state(90, [20] * 96, 5, sampler_like=True)\n"
+        "d = lambda v: v.to(dev).contiguous()\n"
+        "t_c = torch.full((96,), 500, device=dev, dtype=torch.int32)\n"
+        "out = m.engine().predict_scores(d(frac), d(types.to(torch.int32)), d(lengths), d(angles), t_c, crystal_offsets(na, dev))\n"
+        "torch.save([x.cpu() for x in out], sys.argv[1])\n" % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    outs = {}
+    with tempfile.TemporaryDirectory() as d:
+        for tag, env in (("default", {}), ("conv0", {"ARREAU_CONV_VARIANT": "0"}), ("wgs", {"ARREAU_EDGE_WGS": "100000"})):
+            path = os.path.join(d, tag + ".pt")
+            subprocess.run([sys.executable, "-c", code, path], check=True, env={**os.environ, **env}, timeout=300)
+            outs[tag] = torch.load(path)
+    for tag in ("conv0", "wgs"):
+        for x, y in zip(outs["default"], outs[tag]):
+            assert torch.equal(x, y), tag
+
+
 def test_graph_replay_matches_eager_loop(dev, small_model):
     """The HIP-graph replay of the sampler step (device noise) follows the same trajectory as the eager loop:
     same seeds -> identical final state (the captured kernels, their order and the Philox offsets are the same)."""
