@@ -163,7 +163,7 @@ __global__ __launch_bounds__(512, 4) void conv_kernel(
     // neighbours are atoms of its own crystal, i.e. nearby node indices.  Blocks of CONV_GROUP consecutive nodes are
     // dealt to the XCDs, so the x rows an XCD gathers are (almost) only those of its own node blocks and are fetched
     // into that L2 once instead of into all eight.  With fewer than 8 workgroups the plain order is kept.
-    const bool xcd_order = (gridDim.x & 7) == 0;
+    const bool xcd_order = (gridDim.x & 7) == 0 && N >= 32 * CONV_GROUP;  // small batches: one receiver per workgroup first
     const int xcd = blockIdx.x & 7, wg_in_xcd = blockIdx.x >> 3, wgs_per_xcd = gridDim.x >> 3;
     const int n_iter = xcd_order ? ((N + 8 * CONV_GROUP - 1) / (8 * CONV_GROUP)) * CONV_GROUP : N;  // local node slots per XCD
     int buf = 0;
@@ -263,7 +263,7 @@ __global__ __launch_bounds__(512, 2) void conv_kernel_streamed(
     asm volatile("" : "+v"(bias));
 
     // XCD-aware receiver order (see conv_kernel); the i-th receiver of this workgroup, or -1
-    const bool xcd_order = (gridDim.x & 7) == 0;
+    const bool xcd_order = (gridDim.x & 7) == 0 && N >= 32 * CONV_GROUP;  // small batches: one receiver per workgroup first
     const int xcd = blockIdx.x & 7, wg_in_xcd = blockIdx.x >> 3, wgs_per_xcd = gridDim.x >> 3;
     const int n_iter = xcd_order ? ((N + 8 * CONV_GROUP - 1) / (8 * CONV_GROUP)) * CONV_GROUP : N;
     const int m_step = xcd_order ? wgs_per_xcd : (int)gridDim.x;
