@@ -71,7 +71,7 @@ class DiffusionLoss(nn.Module):
         return eng.predict_scores(frac, ty, lengths, ang, t_c, off, edges=edges)
 
     @torch.no_grad()
-    def sample(self, *, model, z_table: AtomicNumberTable, t_emb_weights=None, num_atoms_per_sample: int,
+    def sample(self, *, model, z_table: AtomicNumberTable, t_emb_weights=None, num_atoms_per_sample,
                num_samples_in_batch: int, vis_name: str = "", visualization_setting=VisualizationSetting.NONE,
                show_bonds: bool = False, constant_atoms: Optional[torch.Tensor] = None, noise: str = "device",
                max_steps: Optional[int] = None, use_graph: Optional[bool] = None) -> SampleResult:
@@ -91,13 +91,20 @@ class DiffusionLoss(nn.Module):
         eng = model.engine()
         dev = eng.device
         S = len(z_table)
-        B, n = int(num_samples_in_batch), int(num_atoms_per_sample)
-        N = B * n
+        B = int(num_samples_in_batch)
+        # Extension over the reference (uniform n only, diffusion_loss.py:308): a sequence gives each crystal of
+        # the batch its own atom count (the HIP path works on CSR offsets, so ragged batches cost nothing extra).
+        if isinstance(num_atoms_per_sample, (int, np.integer)):
+            num_atoms = torch.full((B,), int(num_atoms_per_sample))
+        else:
+            num_atoms = torch.as_tensor([int(v) for v in num_atoms_per_sample], dtype=torch.long)
+            if num_atoms.numel() != B or int(num_atoms.min()) < 1:
+                raise ValueError("num_atoms_per_sample must be an int or hold one positive count per crystal of the batch")
+        N = int(num_atoms.sum())
         dt = torch.get_default_dtype()
         angles = torch.tensor(np.array([sample_bravais_angles("monoclinic") for _ in range(B)]))
         lengths = torch.randn([B, 3])
         frac_x = torch.randn([N, 3], dtype=dt) * pos_sigma_max
-        num_atoms = torch.full((B,), n)
         if constant_atoms is not None:
             atom_types = torch.as_tensor(constant_atoms).reshape(-1).long()
             if atom_types.numel() != N:

@@ -123,13 +123,16 @@ class PONITA_DIFFUSION(nn.Module):
         return logits, eps.unsqueeze(1), len0, None, [None] * self.model.num_layers
 
     @torch.no_grad()
-    def sample(self, num_atoms_per_sample: int, num_samples_in_batch: int,
+    def sample(self, num_atoms_per_sample, num_samples_in_batch: int,
                visualization_setting: VisualizationSetting = VisualizationSetting.NONE, show_bonds: bool = False,
                use_constant_atomic_symbols: Optional[list] = None, noise: str = "device",
                max_steps: Optional[int] = None, use_graph: Optional[bool] = None) -> SampleResult:
-        """lightning_wrappers/diffusion.py:220-253."""
+        """lightning_wrappers/diffusion.py:220-253.  `num_atoms_per_sample` may also be a sequence with one atom count
+        per crystal of the batch (extension; the reference supports a single int)."""
         z_table = AtomicNumberTable(self.z_table_zs.tolist())
         if use_constant_atomic_symbols is not None:
+            if not isinstance(num_atoms_per_sample, (int, np.integer)):
+                raise ValueError("use_constant_atomic_symbols needs a uniform num_atoms_per_sample")
             # one index per atom of a crystal, tiled over the batch (the reference's np.repeat at :236
             # interleaves instead of tiling and only works for single-species lists; tiling is the intent)
             idx = atomic_symbols_to_indices(z_table, use_constant_atomic_symbols)

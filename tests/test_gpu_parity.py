@@ -327,6 +327,30 @@ def test_sample_end_to_end_properties(dev, small_model):
     assert np.isfinite(res2.frac_x).all()
 
 
+def test_sample_ragged_batch(dev, small_model):
+    """Extension of `sample`: one atom count per crystal.  Each crystal of a ragged batch follows the
+    trajectory it has in a batch of its own when the per-step noise is the same -- checked here through the
+    properties the sampler guarantees (shapes, wrapped coordinates, valid species, finite cells) plus determinism
+    under the same seeds."""
+    from arreau_amd.diffusion.inference.visualize_crystal import VisualizationSetting
+    m, _, _ = small_model
+    counts = [3, 8, 1, 5]
+
+    def run():
+        torch.manual_seed(3)
+        np.random.seed(3)
+        torch.cuda.manual_seed(3)
+        return m.sample(counts, len(counts), VisualizationSetting.NONE, False, max_steps=6)
+
+    a, b = run(), run()
+    assert a.num_atoms.tolist() == counts and a.frac_x.shape == (sum(counts), 3) and a.lattice.shape == (4, 3, 3)
+    assert (a.frac_x >= 0).all() and (a.frac_x <= 1).all() and np.isfinite(a.lattice).all()
+    assert set(a.atomic_numbers.tolist()) <= set(m.z_table_zs.tolist())
+    assert np.array_equal(a.frac_x, b.frac_x) and np.array_equal(a.atomic_numbers, b.atomic_numbers)
+    with pytest.raises(ValueError):
+        m.sample([3, 8], 4, VisualizationSetting.NONE, False, max_steps=1)
+
+
 def test_constant_atomic_symbols(dev, small_model):
     from arreau_amd.diffusion.inference.visualize_crystal import VisualizationSetting
     m, _, _ = small_model  # z table = 1..11 + mask
