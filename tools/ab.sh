@@ -1,5 +1,8 @@
 #!/bin/bash
-# usage: tools/ab.sh [bench args]  (GPU box): time the in-tree library against tools/exp/ab/${AB_LIB:-lib_prev.so}, alternating, same box
+# usage: tools/ab.sh [bench args]  (GPU box): time the in-tree library against another build of it (tools/exp/ab/${AB_LIB:-lib_prev.so}),
+# alternating, on the same box (box-to-box spread is +-3 %, within one box +-0.5 %).  Prepare the other build in this container first:
+#   git stash; python -m arreau_amd.build; mkdir -p tools/exp/ab; cp arreau_amd/csrc/libarreau_hip.so tools/exp/ab/lib_prev.so
+#   git stash pop; python -m arreau_amd.build
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 for rep in 1 2; do
   for which in prev cur; do
