@@ -117,7 +117,7 @@ extern "C" int arreau_predict_scores(const arreau_model* m, const float* d_frac,
     if ((rc = arreau_launch_prep(m, d_frac, d_lengths, d_angles, d_t, d_off, B, N, w.lattice, w.cart, w.batch, w.cvec, s)))
         return rc;
     if (!use_given_edges) {
-        if ((rc = arreau_launch_neighbor(w.cart, w.lattice, d_off, B, N, m->cfg.radius, m->k, deg, src, w.cell, dir,
+        if ((rc = arreau_launch_neighbor(w.cart, w.lattice, d_off, w.batch, B, N, m->cfg.radius, m->k, deg, src, w.cell, dir,
                                          dist, s)))
             return rc;
     }

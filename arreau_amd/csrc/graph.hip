@@ -103,13 +103,16 @@ __device__ __forceinline__ Cand arreau_candidate(const float* __restrict__ cart,
 }
 
 __global__ __launch_bounds__(256) void neighbor_kernel(
-    const float* __restrict__ cart, const float* __restrict__ lattice, const int32_t* __restrict__ offsets, int B,
+    const float* __restrict__ cart, const float* __restrict__ lattice, const int32_t* __restrict__ offsets,
+    const int32_t* __restrict__ batch /* [N] crystal of atom, or null */, int B,
     int N, float r2, int k, int32_t* __restrict__ deg, int32_t* __restrict__ src, int32_t* __restrict__ cell,
     float* __restrict__ dir, float* __restrict__ dist) {
     const int i = (int)((blockIdx.x * (unsigned)blockDim.x + threadIdx.x) >> 6);
     const int lane = threadIdx.x & 63;
     if (i >= N) return;  // wave-uniform
-    const int b = arreau_find_crystal(offsets, B, i);
+    // the crystal of the receiver: one load when the caller has the atom -> crystal map (prep_kernel writes it),
+    // otherwise a binary search over the offsets (log2 B dependent loads)
+    const int b = batch ? batch[i] : arreau_find_crystal(offsets, B, i);
     const int first = offsets[b];
     const int ncand = (offsets[b + 1] - first) * 27;
     float Lm[9];
@@ -164,14 +167,14 @@ __global__ __launch_bounds__(256) void neighbor_kernel(
     }
 }
 
-int arreau_launch_neighbor(const float* cart, const float* lattice, const int32_t* offsets, int B, int N,
-                           float radius, int k, int32_t* deg, int32_t* src, int32_t* cell, float* dir, float* dist,
+int arreau_launch_neighbor(const float* cart, const float* lattice, const int32_t* offsets, const int32_t* batch,
+                           int B, int N, float radius, int k, int32_t* deg, int32_t* src, int32_t* cell, float* dir, float* dist,
                            hipStream_t s) {
     if (N == 0) return ARREAU_OK;
     const float r2 = (float)((double)radius * (double)radius);
     const int waves_per_block = 4;
     hipLaunchKernelGGL(neighbor_kernel, dim3((N + waves_per_block - 1) / waves_per_block), dim3(64 * waves_per_block),
-                       0, s, cart, lattice, offsets, B, N, r2, k, deg, src, cell, dir, dist);
+                       0, s, cart, lattice, offsets, batch, B, N, r2, k, deg, src, cell, dir, dist);
     ARREAU_CHECK_HIP(hipGetLastError());
     return ARREAU_OK;
 }
@@ -182,7 +185,7 @@ extern "C" int arreau_radius_graph_pbc(const float* d_cart, const float* d_latti
     ARREAU_REQUIRE(d_cart && d_lattice && d_off && d_deg && d_src && d_cell && d_dir && d_dist,
                    "arreau_radius_graph_pbc: null pointer");
     ARREAU_REQUIRE(B >= 1 && N >= 0 && k >= 1 && k <= 64 && radius > 0.f, "arreau_radius_graph_pbc: bad size");
-    return arreau_launch_neighbor(d_cart, d_lattice, d_off, B, N, radius, k, d_deg, d_src, d_cell, d_dir, d_dist,
+    return arreau_launch_neighbor(d_cart, d_lattice, d_off, nullptr, B, N, radius, k, d_deg, d_src, d_cell, d_dir, d_dist,
                                   (hipStream_t)stream);
 }
 

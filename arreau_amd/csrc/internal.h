@@ -174,7 +174,7 @@ __device__ __forceinline__ float arreau_gelu(float x) {
 
 // launchers implemented in the other translation units ------------------------------------------
 int arreau_launch_fiber_precompute(arreau_model* m, hipStream_t s);
-int arreau_launch_neighbor(const float* cart, const float* lattice, const int32_t* offsets, int B, int N,
+int arreau_launch_neighbor(const float* cart, const float* lattice, const int32_t* offsets, const int32_t* batch, int B, int N,
                            float radius, int k, int32_t* deg, int32_t* src, int32_t* cell, float* dir, float* dist,
                            hipStream_t s);
 int arreau_launch_prep(const arreau_model* m, const float* frac, const float* lengths, const float* angles,
