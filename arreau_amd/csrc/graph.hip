@@ -120,15 +120,38 @@ __global__ __launch_bounds__(256) void neighbor_kernel(
     for (int q = 0; q < 9; ++q) Lm[q] = lattice[9 * b + q];
     const float pix = cart[3 * (size_t)i], piy = cart[3 * (size_t)i + 1], piz = cart[3 * (size_t)i + 2];
 
+    // Crystals of up to 64 * NBR_KEYS / 27 = 28 atoms (wave-uniform test): every lane evaluates its candidates once
+    // and keeps their keys in registers; each of the k selection rounds is then a scan of those keys.  Larger
+    // crystals re-evaluate the candidates in every round (same keys, same selection).
+    constexpr int NBR_KEYS = 12;
+    const bool cached = ncand <= 64 * NBR_KEYS;
+    unsigned long long keys[NBR_KEYS];
+    if (cached) {
+#pragma unroll
+        for (int q = 0; q < NBR_KEYS; ++q) {
+            const int c = lane + 64 * q;
+            keys[q] = ~0ull;
+            if (c < ncand) {
+                const Cand cd = arreau_candidate(cart, first, c, Lm, pix, piy, piz);
+                if (cd.d2 <= r2 && cd.d2 > 0.0001f) keys[q] = ((unsigned long long)__float_as_uint(cd.d2) << 32) | (unsigned)c;
+            }
+        }
+    }
     unsigned long long last = 0ull, mine = ~0ull;
     int count = 0;
     for (int s = 0; s < k; ++s) {
         unsigned long long best = ~0ull;
-        for (int c = lane; c < ncand; c += 64) {
-            const Cand cd = arreau_candidate(cart, first, c, Lm, pix, piy, piz);
-            if (cd.d2 <= r2 && cd.d2 > 0.0001f) {
-                const unsigned long long key = ((unsigned long long)__float_as_uint(cd.d2) << 32) | (unsigned)c;
-                if (key > last && key < best) best = key;
+        if (cached) {
+#pragma unroll
+            for (int q = 0; q < NBR_KEYS; ++q)
+                if (keys[q] > last && keys[q] < best) best = keys[q];
+        } else {
+            for (int c = lane; c < ncand; c += 64) {
+                const Cand cd = arreau_candidate(cart, first, c, Lm, pix, piy, piz);
+                if (cd.d2 <= r2 && cd.d2 > 0.0001f) {
+                    const unsigned long long key = ((unsigned long long)__float_as_uint(cd.d2) << 32) | (unsigned)c;
+                    if (key > last && key < best) best = key;
+                }
             }
         }
 #pragma unroll
