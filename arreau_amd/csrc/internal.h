@@ -64,6 +64,7 @@ struct arreau_model {
     const float* embT;       // [S+78][C] x_embedder.weight transposed
     const float* ro_wT;      // [L][C][S+4] read_out weight transposed
     const float* ro_b;       // [L][S+4]
+    const float* ro_pack;    // [L][(S+4 padded to 32)/32][C/32][1024] read_out weights as fp32-MFMA fragment streams
     const float* ro_wv;      // [L][C] vector read-out weights (column S of read_out_layers), contiguous
     float ro_bv_host[16];    // [L] vector read-out bias (host copy, passed by value)
     const float* t_emb_w;    // [32]

@@ -336,6 +336,13 @@ extern "C" int arreau_model_create(const arreau_config* cfg, const arreau_state_
                 tmp[((size_t)l * C + c) * RO + s] = sd->readout_w[((size_t)l * RO + s) * C + c];
     const size_t off_ro_wT = bb.put(tmp.data(), tmp.size());
     const size_t off_ro_b = bb.put(sd->readout_b, (size_t)L * RO);
+    // the same weights as MFMA fragment streams (readout_mfma_kernel): per layer RO_PAD/32 output tiles x C/32 input
+    // tiles of 1024 floats, + ARREAU_PF groups of slack behind the last layer for the prefetch ring
+    const int RO_PAD = RO <= 96 ? 96 : ((RO + 31) / 32) * 32;  // the kernel is instantiated for three output tiles
+    const size_t ro_layer = (size_t)(RO_PAD / 32) * (C / 32) * ARREAU_PACK_TILE_FLOATS;
+    tmp.assign((size_t)L * ro_layer + (size_t)ARREAU_PF * 256, 0.f);
+    for (int l = 0; l < L; ++l) pack_linear(sd->readout_w + (size_t)l * RO * C, RO, C, C, RO_PAD, C, tmp.data() + (size_t)l * ro_layer);
+    const size_t off_ro_pack = bb.put(tmp.data(), tmp.size());
     tmp.assign((size_t)L * C, 0.f);
     for (int l = 0; l < L; ++l)
         for (int c = 0; c < C; ++c) tmp[(size_t)l * C + c] = sd->readout_w[((size_t)l * RO + S) * C + c];
@@ -378,7 +385,7 @@ extern "C" int arreau_model_create(const arreau_config* cfg, const arreau_state_
     m->ori = b + off_ori; m->w1p = b + off_w1p; m->b1 = b + off_b1; m->w2p = b + off_w2p; m->b2 = b + off_b2;
     m->wkp = b + off_wkp; m->edge_bf16 = b + off_es16; m->edge_f16 = b + off_ef16; m->f16_ok = wmax16 < 60000.0f ? 1 : 0; m->fk = b + off_fk; m->conv_bias = b + off_conv_bias; m->ln_w = b + off_ln_w;
     m->ln_b = b + off_ln_b; m->mlp = b + off_mlp; m->mlp_bf16 = b + off_mlp16; m->mlp_f16 = b + off_mlpf16; m->mb1 = b + off_mb1; m->mb2 = b + off_mb2;
-    m->ls = b + off_ls; m->embT = b + off_embT; m->ro_wT = b + off_ro_wT; m->ro_b = b + off_ro_b; m->ro_wv = b + off_ro_wv;
+    m->ls = b + off_ls; m->embT = b + off_embT; m->ro_wT = b + off_ro_wT; m->ro_b = b + off_ro_b; m->ro_pack = b + off_ro_pack; m->ro_wv = b + off_ro_wv;
     for (int l = 0; l < L; ++l) m->ro_bv_host[l] = sd->readout_b[(size_t)l * RO + S];
     m->t_emb_w = b + off_temb; m->ve_sigmas = b + off_ve; m->vp_alpha_bars = b + off_ab; m->vp_betas = b + off_be;
     m->q1t = b + off_q1t; m->qmats = b + off_qm;

@@ -672,6 +672,89 @@ __global__ __launch_bounds__(1024) void readout_nodes_kernel(
     }
 }
 
+// Read-out on the fp32 matrix pipe (exact fp32 products, v_mfma_f32_32x32x2_f32): workgroup = 32 atoms, wave l =
+// layer l.  Y_l^T[out, atom] = W_l[out, :] . xbar_l[atom, :] for the (S+4 padded to 96) outputs as three 32x32 tiles
+// (weights streamed from their packed form, xbar rows loaded straight into the B-operand layout); the L partial
+// tiles meet in LDS and are added in layer order (deterministic), biases included, then scaled by 1/L.
+// The vector channel (column S) is not read from here (its per-orientation form comes from the MLP kernel).
+template <int C, int ROT /* output tiles */>
+__global__ __launch_bounds__(512) void readout_mfma_kernel(
+    const float* __restrict__ xbar,     // [L][N][C]
+    const float* __restrict__ vsum,     // [N][16]
+    const float* __restrict__ ro_pack,  // [L][ROT][C/32][1024]
+    const float* __restrict__ ro_b,     // [L][S+4]
+    const float* __restrict__ ori, int S, int L, int N, float* __restrict__ eps, float* __restrict__ logits,
+    float* __restrict__ gs /*[N][3]*/) {
+    constexpr int TC = C / 32;
+    extern __shared__ __attribute__((aligned(16))) float part[];  // [L][ROT][64 lanes][16]
+    const int lane = threadIdx.x & 63, l = threadIdx.x >> 6;
+    const int h = lane >> 5, j = lane & 31;
+    const int n0 = blockIdx.x * 32;
+    const int RO = S + 4;
+    const float invL = 1.0f / (float)L;
+    {
+        const int n = min(n0 + j, N - 1);  // padding atoms read a valid row and write nothing
+        const float* rowp = xbar + ((size_t)l * N + n) * C + 4 * h;
+        f32x16 bx[TC][1];
+#pragma unroll
+        for (int t = 0; t < TC; ++t)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(rowp + 32 * t + 8 * q);
+                bx[t][0][4 * q] = v[0]; bx[t][0][4 * q + 1] = v[1]; bx[t][0][4 * q + 2] = v[2]; bx[t][0][4 * q + 3] = v[3];
+            }
+        const float* region = ro_pack + (size_t)l * ROT * TC * ARREAU_PACK_TILE_FLOATS + lane * 4;
+        f32x4 ring[ARREAU_PF];
+#pragma unroll
+        for (int i = 0; i < ARREAU_PF; ++i) ring[i] = *reinterpret_cast<const f32x4*>(region + (size_t)i * 256);
+        constexpr int G = 4 * TC;
+#pragma unroll
+        for (int u = 0; u < ROT; ++u) {
+            f32x16 acc[1];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int col = 32 * u + (r & 3) + 8 * (r >> 2) + 4 * h;
+                acc[0][r] = col < RO ? ro_b[l * RO + col] : 0.0f;
+            }
+            arreau_stream_tile<G, TC, 1>(acc, ring, region, u * G, bx);
+            float* dst = part + (((size_t)l * ROT + u) * 64 + lane) * 16;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                *reinterpret_cast<f32x4*>(dst + 4 * q) = f32x4{acc[0][4 * q], acc[0][4 * q + 1], acc[0][4 * q + 2], acc[0][4 * q + 3]};
+        }
+    }
+    __syncthreads();
+    // ordered sum over the layers; thread -> (tile u, lane ln, register group q)
+    for (int i = threadIdx.x; i < ROT * 64 * 4; i += blockDim.x) {
+        const int q = i & 3, ln = (i >> 2) & 63, u = i >> 8;
+        f32x4 tot = {0.f, 0.f, 0.f, 0.f};
+        for (int ll = 0; ll < L; ++ll) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(part + (((size_t)ll * ROT + u) * 64 + ln) * 16 + 4 * q);
+            tot[0] += v[0]; tot[1] += v[1]; tot[2] += v[2]; tot[3] += v[3];
+        }
+        const int n = n0 + (ln & 31);
+        if (n < N) {
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                const int col = 32 * u + m + 8 * q + 4 * (ln >> 5);
+                const float v = tot[m] * invL;
+                if (col < S) logits[(size_t)n * S + col] = v;
+                else if (col > S && col < RO) gs[(size_t)n * 3 + (col - S - 1)] = v;
+            }
+        }
+    }
+    // vector channel: eps component d of atom a (sphere_to_vec of the per-orientation dot products)
+    if (threadIdx.x < 96) {
+        const int a = threadIdx.x / 3, dd = threadIdx.x - 3 * a;
+        const size_t n = (size_t)n0 + a;
+        if (n < (size_t)N) {
+            float acc = 0.f;
+            for (int o = 0; o < 16; ++o) acc += (vsum[n * 16 + o] * invL) * ori[3 * o + dd];
+            eps[n * 3 + dd] = acc * (1.0f / 16.0f);
+        }
+    }
+}
+
 __global__ void readout_crystals_kernel(const float* __restrict__ gs, const int32_t* __restrict__ offsets, int B,
                                         float* __restrict__ len0) {
     const int idx = blockIdx.x * blockDim.x + threadIdx.x;
@@ -691,8 +774,19 @@ int arreau_launch_readout(const arreau_model* m, const float* xbar, const float*
             arreau_set_error("readout kernel: num_layers * 128 threads must fit one workgroup");
             return ARREAU_EINVAL;
         }
-        hipLaunchKernelGGL(readout_nodes_kernel, dim3((N + RO_ATOMS - 1) / RO_ATOMS), dim3(RO_COLS * m->L), smem, s, xbar, vsum,
-                           m->ro_wT, m->ro_b, m->ori, m->S, m->C, m->L, N, eps, logits, gs);
+        // read-out variant: 1 (default) = fp32-MFMA kernel (needs S + 4 <= 96, L <= 8); 0 = vector kernel
+        static const int ro_variant = [] { const char* e = getenv("ARREAU_READOUT_VARIANT"); return e ? atoi(e) : 1; }();
+        if (ro_variant == 1 && m->S + 4 <= 96 && m->L <= 8 && m->C == 128) {
+            const size_t smem_m = (size_t)m->L * 3 * 64 * 16 * sizeof(float);
+            static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&readout_mfma_kernel<128, 3>),
+                                                               hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 3 * 64 * 16 * 4);
+            ARREAU_CHECK_HIP(attr);
+            hipLaunchKernelGGL((readout_mfma_kernel<128, 3>), dim3((N + 31) / 32), dim3(64 * m->L), smem_m, s, xbar, vsum,
+                               m->ro_pack, m->ro_b, m->ori, m->S, m->L, N, eps, logits, gs);
+        } else {
+            hipLaunchKernelGGL(readout_nodes_kernel, dim3((N + RO_ATOMS - 1) / RO_ATOMS), dim3(RO_COLS * m->L), smem, s, xbar, vsum,
+                               m->ro_wT, m->ro_b, m->ori, m->S, m->C, m->L, N, eps, logits, gs);
+        }
         ARREAU_CHECK_HIP(hipGetLastError());
     }
     hipLaunchKernelGGL(readout_crystals_kernel, dim3((3 * B + 127) / 128), dim3(128), 0, s, gs, offsets, B, len0);
