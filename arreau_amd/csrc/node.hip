@@ -91,32 +91,44 @@ __global__ __launch_bounds__(256) void embed_kernel(
     const float* __restrict__ frac, const int32_t* __restrict__ types, const float* __restrict__ lattice,
     const int32_t* __restrict__ batch, const float* __restrict__ cvec, const float* __restrict__ ori,
     const float* __restrict__ embT, int S, int C, int N, float* __restrict__ x0) {
+    // thread = (atom n, float4 column c4): the atom's scalar part and the four vector-channel weight rows are
+    // loaded once and serve all 16 orientations (16 coalesced 512-byte row stores per 32 lanes)
     const int C4 = C / 4;
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= (long long)N * ARREAU_ORI * C4) return;
+    if (idx >= (long long)N * C4) return;
     const int c4 = (int)(idx % C4);
-    const int o = (int)((idx / C4) % ARREAU_ORI);
-    const int n = (int)(idx / ((long long)C4 * ARREAU_ORI));
+    const int n = (int)(idx / C4);
     const int b = batch[n];
     int ty = types[n];
     ty = ty < 0 ? 0 : (ty >= S ? S - 1 : ty);
-    const float ox = ori[3 * o], oy = ori[3 * o + 1], oz = ori[3 * o + 2];
     const float* Lm = lattice + 9 * (size_t)b;
-    float proj[4];
-    proj[0] = (frac[3 * (size_t)n] * ox + frac[3 * (size_t)n + 1] * oy) + frac[3 * (size_t)n + 2] * oz;
+    float vec[4][3];
 #pragma unroll
-    for (int v = 0; v < 3; ++v) proj[1 + v] = (Lm[3 * v] * ox + Lm[3 * v + 1] * oy) + Lm[3 * v + 2] * oz;
+    for (int d = 0; d < 3; ++d) vec[0][d] = frac[3 * (size_t)n + d];
+#pragma unroll
+    for (int v = 0; v < 3; ++v)
+#pragma unroll
+        for (int d = 0; d < 3; ++d) vec[1 + v][d] = Lm[3 * v + d];
     const f32x4* e4 = reinterpret_cast<const f32x4*>(embT);
-    f32x4 acc = e4[(size_t)ty * C4 + c4] + reinterpret_cast<const f32x4*>(cvec)[(size_t)b * C4 + c4];
+    const f32x4 base = e4[(size_t)ty * C4 + c4] + reinterpret_cast<const f32x4*>(cvec)[(size_t)b * C4 + c4];
+    f32x4 ev[4];
 #pragma unroll
-    for (int v = 0; v < 4; ++v) acc += e4[(size_t)(S + 74 + v) * C4 + c4] * proj[v];
-    reinterpret_cast<f32x4*>(x0)[idx] = acc;
+    for (int v = 0; v < 4; ++v) ev[v] = e4[(size_t)(S + 74 + v) * C4 + c4];
+    f32x4* out = reinterpret_cast<f32x4*>(x0) + (size_t)n * ARREAU_ORI * C4 + c4;
+#pragma unroll
+    for (int o = 0; o < ARREAU_ORI; ++o) {
+        const float ox = ori[3 * o], oy = ori[3 * o + 1], oz = ori[3 * o + 2];
+        f32x4 acc = base;
+#pragma unroll
+        for (int v = 0; v < 4; ++v) acc += ev[v] * ((vec[v][0] * ox + vec[v][1] * oy) + vec[v][2] * oz);
+        out[(size_t)o * C4] = acc;
+    }
 }
 
 int arreau_launch_embed(const arreau_model* m, const float* frac, const int32_t* types, const float* lattice,
                         const int32_t* batch, const float* cvec, int N, float* x0, hipStream_t s) {
     if (N == 0) return ARREAU_OK;
-    const long long total = (long long)N * ARREAU_ORI * (m->C / 4);
+    const long long total = (long long)N * (m->C / 4);
     hipLaunchKernelGGL(embed_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, frac, types, lattice, batch,
                        cvec, m->ori, m->embT, m->S, m->C, N, x0);
     ARREAU_CHECK_HIP(hipGetLastError());
