@@ -63,11 +63,16 @@ __global__ __launch_bounds__(256) void reverse_atoms_kernel(
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int i = blockIdx.x * 4 + wave;
     if (i >= N) return;  // wave-uniform; no block-level barrier below
-    // crystal of this atom
+    // crystal of this atom = largest b with offsets[b] <= i: a 64-ary search by the whole wave (each level one
+    // load per lane + a ballot) instead of log2(B) dependent loads
     int lo = 0, hi = B;
     while (hi - lo > 1) {
-        const int mid = (lo + hi) >> 1;
-        if (offsets[mid] <= i) lo = mid; else hi = mid;
+        const int span = hi - lo, step = (span + 63) >> 6;
+        const int probe = lo + lane * step;
+        const bool le = probe < hi && offsets[probe] <= i;       // monotone in lane: true for lanes 0..c-1
+        const int c = __builtin_popcountll(__ballot(le));         // c >= 1 because offsets[lo] <= i
+        lo = lo + (c - 1) * step;
+        hi = min(lo + step, hi);
     }
     int t = tstep[lo];
     t = t < 1 ? 1 : (t > T ? T : t);
