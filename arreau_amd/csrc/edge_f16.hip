@@ -95,6 +95,7 @@ __global__ __launch_bounds__(64 * EH_WAVES, 2) void edge_kernel_f16x3(
 #ifdef ARREAU_EDGE_TIMING
     long long tick_ = clock64();
     long long tacc_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const long long c_start_ = tick_, w_start_ = wall_clock64();  // shader clock vs the constant 100 MHz counter
 #endif
     // Persistent workgroup: receiver pairs blockIdx.x, blockIdx.x + gridDim.x, ...  The weight ring keeps turning
     // across pairs (the chunk sequence simply repeats), so only the first pair waits for its first two chunks.
@@ -320,6 +321,8 @@ __global__ __launch_bounds__(64 * EH_WAVES, 2) void edge_kernel_f16x3(
     }  // pair loop
     EDGE_TICK(4);
 #ifdef ARREAU_EDGE_TIMING
+    tacc_[5] = clock64() - c_start_;        // whole kernel, shader-clock ticks (slot 5)
+    tacc_[6] = wall_clock64() - w_start_;   // whole kernel, 100 MHz ticks (slot 6)
     if (threadIdx.x == 0)
         for (int i = 0; i < 8; ++i) atomicAdd(&arreau_edge_ticks[i], (unsigned long long)tacc_[i]);
 #endif

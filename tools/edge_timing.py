@@ -56,3 +56,5 @@ wgs = N // 2
 for i, nm in enumerate(names):
     print("%-26s %6.1f%%   %9.0f ticks / workgroup" % (nm, 100.0 * ticks[i] / tot, ticks[i] / reps / wgs))
 print("total ticks / workgroup %.0f" % (tot / reps / wgs))
+if ticks[6]:
+    print("shader clock while the kernel runs: %.0f MHz (clock64 / wall_clock64 x 100 MHz)" % (100.0 * ticks[5] / ticks[6]))
