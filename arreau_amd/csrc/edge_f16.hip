@@ -236,7 +236,23 @@ __global__ __launch_bounds__(64 * EH_WAVES, 2) void edge_kernel_f16x3(
         }
         EDGE_TICK(1);
         // ---- layer 2: basis = GELU(W2 . h + b2) * window ------------------------------------------------------
-        Planes2 basis[TD];
+        // The projection loop runs on 16x16x32 MFMAs: each finished basis tile is re-laid once, through the wave's LDS
+        // pad, from the (h, row j) lane layout of the 32x32 accumulators into the (c = orientation, g) layout of the
+        // two 16-column blocks nb (= the wave's two edge slots): lane (c, g) takes the 16 bytes that lane
+        // (h = g >> 1, j = 16 nb + c) holds for k-step s = g & 1.
+        u32x4 b16[2][TD][2];  // [column block][k-block = basis tile][plane]
+        u32x4* pad16 = reinterpret_cast<u32x4*>(otile[wave]);
+        const int c16 = lane & 15, g16 = lane >> 4;
+        auto relayout = [&](const Planes2& pl, int u) {
+#pragma unroll
+            for (int plane = 0; plane < 2; ++plane) {
+                pad16[(j * 2 + h) * 2 + 0] = pl.p[plane][0];
+                pad16[(j * 2 + h) * 2 + 1] = pl.p[plane][1];
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb)
+                    b16[nb][u][plane] = pad16[((16 * nb + c16) * 2 + (g16 >> 1)) * 2 + (g16 & 1)];
+            }
+        };
 #pragma unroll
         for (int u = 0; u < TD; ++u) {
             f32x16 acc = arreau_bias_tile(bias_s + C, u, h), cross;
@@ -249,10 +265,11 @@ __global__ __launch_bounds__(64 * EH_WAVES, 2) void edge_kernel_f16x3(
             __syncthreads();
             if (u + 2 < TD) copy12(std::integral_constant<int, TC>{});         // an NF2 chunk
             else copy12(std::integral_constant<int, TC + TD - 2>{});           // an NF3 chunk
-            basis[u] = Planes2{};
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb) { b16[nb][u][0] = u32x4{0, 0, 0, 0}; b16[nb][u][1] = u32x4{0, 0, 0, 0}; }
             if (go) {
                 ms.template run<TC, 2 * TC>(acc, cross, h1);
-                basis[u] = gelu_split_tile2(acc, cross, window);
+                relayout(gelu_split_tile2(acc, cross, window), u);
             }
             sl = slot_after(sl, 1);
         }
@@ -260,63 +277,52 @@ __global__ __launch_bounds__(64 * EH_WAVES, 2) void edge_kernel_f16x3(
         // ---- per layer: kernel_l = Wk_l . basis  (conv.py:110), one output tile per chunk ---------------------
         const size_t layer_stride = (size_t)N * k * 16 * C;
         const size_t row0 = ((size_t)node * k + 2 * wn) * 16;  // first K row of this wave's 32-row tile
-        float* pad = otile[wave];
-        const bool full = 2 * wn + 1 < k;  // wave-uniform: the wave's second slot exists
-        // A finished 32x32 tile goes to HBM through a wave-private LDS pad (transposed, so that every store instruction
-        // writes whole 128-byte lines: 8 lanes per row), in two steps that sit apart in the instruction stream:
-        // pad_write right behind the tile's last MFMA, pad_store two k-steps into the next tile's MFMAs.
-        auto pad_write = [&](const f32x16& t) {
+        const bool full = 2 * wn + 1 < k;  // wave-uniform: the wave's second slot (column block 1) exists
+        // Stores: accumulator register r of tile (mt, nb) is output column 16 mt + 4 g + r of row 16 nb + c: one
+        // 16-byte store per lane and tile, 64 contiguous bytes per row and instruction (the two mt tiles complete the
+        // row's 128-byte line).  Not predicated on the degree: a slot beyond it gets the zeros its window produced
+        // (those rows of the K buffer are never read), so a wave issues a FIXED number of stores per tile (4, or 2 for
+        // the wave whose second slot does not exist when k is odd) -- which the counted wait at SYNC relies on.
+        const unsigned st_off = 4u * (c16 * C + 4 * g16);
+        auto store_tile16 = [&](const Acc16& a, const char* tile_base /* wave-uniform */) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const f32x4 v = {t[4 * q], t[4 * q + 1], t[4 * q + 2], t[4 * q + 3]};
-                *reinterpret_cast<f32x4*>(&pad[j * 36 + 8 * q + 4 * h]) = v;
-            }
-        };
-        // Not predicated on the degree: a slot beyond it gets the zeros its window produced (those rows of the K
-        // buffer are never read), so a wave issues a FIXED number of stores per tile (4, or 2 for the wave whose second
-        // slot does not exist when k is odd) -- which the counted wait at SYNC relies on.  Addressing: wave-uniform
-        // byte base of tile (layer l, column tile u), advanced tile by tile, + four per-lane 32-bit offsets.
-        const unsigned st_off = 4u * ((lane >> 3) * C + 4 * (lane & 7));  // row lane/8 (+ 8i, uniform) of the wave tile
-        auto pad_store = [&](const char* tile_base /* wave-uniform */) {
+            for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int r = 8 * i + (lane >> 3);  // slot 2*wn + (r >> 4), orientation r & 15
-                const f32x4 v = *reinterpret_cast<const f32x4*>(&pad[r * 36 + 4 * (lane & 7)]);
-                if (i < 2 || full) *reinterpret_cast<f32x4*>(const_cast<char*>(tile_base) + 32 * i * C + st_off) = v;
-            }
+                for (int mt = 0; mt < 2; ++mt) {
+                    f32x4v v;
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) v[r] = fmaf(a.x[mt][nb][r], F16X3_INV_SCALE, a.m[mt][nb][r]);
+                    if (nb == 0 || full)
+                        *reinterpret_cast<f32x4v*>(const_cast<char*>(tile_base) + 64 * nb * C + 64 * mt + st_off) = v;
+                }
         };
-        // X = k-step at which the chunk's barrier is taken (mid-chunk).  Taking it at different points in the two
-        // halves of the workgroup (SIMD partners a half chunk apart) was measured to make no difference: fp32 vector
-        // work and MFMAs of SIMD partners serialise anyway, so both halves use the same point.
-        // At SYNC the wave's queue holds, oldest first, its DMA copies of the next chunk and -- from the second chunk
-        // on -- the stores of the previous tile: the counted wait retires the copies and leaves the stores in flight.
-        constexpr int X = TD;
-        const char* tile_base = reinterpret_cast<const char*>(kbuf + row0 * C);  // tile the next pad_store writes
-        int u_prev = 0;
+        // ST = step (of 2 TD) at which the chunk's barrier is taken (mid-chunk).  At SYNC the wave's queue holds, oldest
+        // first, its DMA copies of the next chunk and -- from the second chunk on -- the stores of the previous tile
+        // (issued at that tile's end): the counted wait retires the copies and leaves the stores in flight.
+        constexpr int ST = TD;
+        const char* tile_base = reinterpret_cast<const char*>(kbuf + row0 * C);  // tile of the current chunk
+        int u_cur = 0;
 #pragma unroll 1
         for (int cidx = 0; cidx < nchunks; ++cidx) {
-            f32x16 acc, cross;
+            Acc16 acc;
 #pragma unroll
-            for (int r = 0; r < 16; ++r) { acc[r] = 0.0f; cross[r] = 0.0f; }
-            MmaStream2<TD, 2 * TD> ms;
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb) { acc.m[mt][nb] = f32x4v{0.f, 0.f, 0.f, 0.f}; acc.x[mt][nb] = f32x4v{0.f, 0.f, 0.f, 0.f}; }
+            MmaStream16<TD> ms;
             ms.start(lds[sl], lane);
-            ms.template run<0, 2>(acc, cross, basis);
-            if (cidx > 0) {
-                pad_store(tile_base);
-                // next tile: 32 columns on, or the first column tile of the next layer
-                tile_base += (++u_prev == TC) ? (u_prev = 0, (ptrdiff_t)layer_stride * 4 - (TC - 1) * 128) : 128;
-            }
-            ms.template run<2, X>(acc, cross, basis);
+            ms.template run<0, ST>(acc, b16);
             if (cidx == 0) dma_wait();
             else if (full) dma_wait_but<4>();
             else dma_wait_but<2>();
             __syncthreads();
             copy3(cidx);
-            ms.template run<X, 2 * TD>(acc, cross, basis);
-            pad_write(fold_cross(acc, cross));
+            ms.template run<ST, 2 * TD>(acc, b16);
+            store_tile16(acc, tile_base);
+            // next tile: 32 columns on, or the first column tile of the next layer
+            tile_base += (++u_cur == TC) ? (u_cur = 0, (ptrdiff_t)layer_stride * 4 - (TC - 1) * 128) : 128;
             sl = slot_after(sl, 1);
         }
-        pad_store(tile_base);
         EDGE_TICK(3);
     }  // pair loop
     EDGE_TICK(4);

@@ -180,6 +180,55 @@ struct MmaStream2 {
     }
 };
 
+// ---- v_mfma_f32_16x16x32_f16 form of the same split product, for a wave's 32 rows as two 16-column blocks nb ------
+// Under the chip's power limit this shape holds a higher clock than 32x32x16 (1875 vs 1572 MHz in bare streams:
+// tools/exp/mfma_shape.hip) at the same cycles per FLOP, and each weight fragment serves both column blocks.
+// Lane (c = lane & 15, g = lane >> 4): B operand = 8 halves of row c of the block (k order 8 g + e), accumulator
+// register r = output row 4 g + r of the 16-row tile.
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ f32x4v mfma16_f16(const u32x4& a, const u32x4& b, const f32x4v& c) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+struct Acc16 { f32x4v m[2][2], x[2][2]; };  // [16-row tile mt][column block nb]: main and cross accumulators
+
+// One chunk = 32 output rows x NKB k-blocks of 32: fragments (kb, mt, plane) at ((kb * 2 + mt) * 2 + plane) * 64 + lane.
+// Step st = kb * 2 + mt: two fragment reads (both planes), six MFMAs.  The reads of step st+1 are issued ahead of the
+// MFMAs of step st and run through cuts of the stream, as in MmaStream2.
+template <int NKB>
+struct MmaStream16 {
+    const u32x4* f;
+    u32x4 a1[2], a2[2];
+    __device__ __forceinline__ void start(const u32x4* __restrict__ buf, int lane) {
+        f = buf + lane;
+        a1[0] = f[0];
+        a2[0] = f[64];
+        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+    }
+    template <int ST0, int ST1>
+    __device__ __forceinline__ void run(Acc16& acc, const u32x4 (&b)[2][NKB][2]) {
+#pragma unroll
+        for (int st = ST0; st < ST1; ++st) {
+            const int slot = st & 1, nslot = slot ^ 1;
+            if (st + 1 < 2 * NKB) {
+                a1[nslot] = f[(size_t)(st + 1) * 128];
+                a2[nslot] = f[(size_t)(st + 1) * 128 + 64];
+            }
+            const int kb = st >> 1, mt = st & 1;
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb) {
+                acc.m[mt][nb] = mfma16_f16(a1[slot], b[nb][kb][0], acc.m[mt][nb]);
+                acc.x[mt][nb] = mfma16_f16(a1[slot], b[nb][kb][1], acc.x[mt][nb]);
+                acc.x[mt][nb] = mfma16_f16(a2[slot], b[nb][kb][0], acc.x[mt][nb]);
+            }
+        }
+#pragma unroll
+        for (int st = ST0; st < ST1; ++st) {
+            if (st + 1 < 2 * NKB) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+            __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
+        }
+    }
+};
+
 __device__ __forceinline__ f32x16 fold_cross(const f32x16& mainacc, const f32x16& cross) {
     f32x16 r;
 #pragma unroll

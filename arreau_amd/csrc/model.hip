@@ -140,6 +140,35 @@ static float pack_linear_f16x3(const float* W, int out_dim, int in_dim, int in_s
     return wmax;
 }
 
+// The same weights for v_mfma_f32_16x16x32_f16 (the projection loop of edge_f16.hip): an output tile of 32 rows is two
+// 16-row MFMA tiles mt, its K range is walked in 32-column blocks kb.  Fragment (kb, mt, plane) = 1 KiB at index
+// (kb * 2 + mt) * 2 + plane of the chunk; lane (m = lane & 15, g = lane >> 4) holds the 8 halves e of output row
+// 32 u + 16 mt + m whose input columns are, in the MFMA's k order 8 g + e,
+//     32 kb + 16 (g & 1) + 8 (e >> 2) + 4 (g >> 1) + (e & 3)
+// -- the order in which the activation planes of f16x3.h (k-step s = g & 1 of lane half h = g >> 1) land in the
+// B operand after their relayout.
+static float pack_linear_f16x3_m16(const float* W, int out_dim, int in_dim, int in_stride, uint16_t* Q) {
+    const int U = out_dim / 32, KB = in_dim / 32;
+    float wmax = 0.f;
+    for (int u = 0; u < U; ++u)
+        for (int kb = 0; kb < KB; ++kb)
+            for (int mt = 0; mt < 2; ++mt)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int e = 0; e < 8; ++e) {
+                        const int g = lane >> 4;
+                        const int out = 32 * u + 16 * mt + (lane & 15);
+                        const int in = 32 * kb + 16 * (g & 1) + 8 * (e >> 2) + 4 * (g >> 1) + (e & 3);
+                        const float w = W[(size_t)out * in_stride + in];
+                        wmax = fabsf(w) > wmax ? fabsf(w) : wmax;
+                        const uint16_t h1 = f32_to_f16_rne(w);
+                        const uint16_t h2 = f32_to_f16_rne((w - f16_to_f32(h1)) * 2048.0f);
+                        const size_t base = (((size_t)u * KB + kb) * 2 + mt) * 2 * 512 + (size_t)lane * 8 + e;
+                        Q[base] = h1;
+                        Q[base + 512] = h2;
+                    }
+    return wmax;
+}
+
 // Monomial table: distinct monomials of degree 1..3 in 6 variables in the canonical order
 // (i), (i<=j), (i<=j<=k), each lexicographic.  The device code (edge.hip) generates them in the
 // same order.
@@ -275,8 +304,8 @@ extern "C" int arreau_model_create(const arreau_config* cfg, const arreau_state_
         wmax16 = fmaxf(wmax16, pack_linear_f16x3(w1f.data(), C, ARREAU_MONO_PAD, ARREAU_MONO_PAD, C, ARREAU_MONO_PAD, q));
         wmax16 = fmaxf(wmax16, pack_linear_f16x3(sd->basis_w2, D, C, C, D, C, q + f_w1));
         for (int l = 0; l < L; ++l)
-            wmax16 = fmaxf(wmax16, pack_linear_f16x3(sd->conv_kernel_w + (size_t)l * C * D, C, D, D, C, D,
-                                                     q + f_w1 + f_w2 + l * f_wk));
+            wmax16 = fmaxf(wmax16, pack_linear_f16x3_m16(sd->conv_kernel_w + (size_t)l * C * D, C, D, D,
+                                                         q + f_w1 + f_w2 + l * f_wk));
     }
     const size_t off_fk = bb.reserve((size_t)L * O * O * C);
     const size_t off_conv_bias = bb.put(sd->conv_bias, (size_t)L * C);
