@@ -84,7 +84,7 @@ __global__ __launch_bounds__(64 * EH_WAVES, 2) void edge_kernel_f16x3(
 {
     constexpr int TC = C / 32, TD = D / 32, TM = ARREAU_MONO_PAD / 32;
     constexpr int NF1 = TM * 4, NF2 = TC * 4, NF3 = TD * 4;  // 1 KiB fragments per chunk: 12, 16, 32
-    static_assert(TM == 3, "chunk geometry");
+    static_assert(TM == 3 && (TC & 1) == 0, "chunk geometry (projection tiles are walked in pairs)");
     __shared__ u32x4 lds[3][NF3 * 64];                                        // 3 x 32 KiB ring of weight chunks
     __shared__ __attribute__((aligned(16))) float otile[EH_WAVES][32 * 36];   // per-wave transpose pad for the stores
     __shared__ __attribute__((aligned(16))) float bias_s[C + D];              // b1 | b2 (no global loads beside the DMA)
@@ -241,17 +241,27 @@ __global__ __launch_bounds__(64 * EH_WAVES, 2) void edge_kernel_f16x3(
         // two 16-column blocks nb (= the wave's two edge slots): lane (c, g) takes the 16 bytes that lane
         // (h = g >> 1, j = 16 nb + c) holds for k-step s = g & 1.
         u32x4 b16[2][TD][2];  // [column block][k-block = basis tile][plane]
+#pragma unroll
+        for (int u = 0; u < TD; ++u)
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb) { b16[nb][u][0] = u32x4{0, 0, 0, 0}; b16[nb][u][1] = u32x4{0, 0, 0, 0}; }
         u32x4* pad16 = reinterpret_cast<u32x4*>(otile[wave]);
         const int c16 = lane & 15, g16 = lane >> 4;
-        auto relayout = [&](const Planes2& pl, int u) {
+        // (the pad holds one tile: 2 planes x 2 KiB.  A tile is written right after its epilogue and read back in
+        // front of the next tile's write, a whole chunk later, so neither LDS latency is waited for.)
+        auto relayout_write = [&](const Planes2& pl) {
 #pragma unroll
             for (int plane = 0; plane < 2; ++plane) {
-                pad16[(j * 2 + h) * 2 + 0] = pl.p[plane][0];
-                pad16[(j * 2 + h) * 2 + 1] = pl.p[plane][1];
+                pad16[128 * plane + (j * 2 + h) * 2 + 0] = pl.p[plane][0];
+                pad16[128 * plane + (j * 2 + h) * 2 + 1] = pl.p[plane][1];
+            }
+        };
+        auto relayout_read = [&](int u) {
+#pragma unroll
+            for (int plane = 0; plane < 2; ++plane)
 #pragma unroll
                 for (int nb = 0; nb < 2; ++nb)
-                    b16[nb][u][plane] = pad16[((16 * nb + c16) * 2 + (g16 >> 1)) * 2 + (g16 & 1)];
-            }
+                    b16[nb][u][plane] = pad16[128 * plane + ((16 * nb + c16) * 2 + (g16 >> 1)) * 2 + (g16 & 1)];
         };
 #pragma unroll
         for (int u = 0; u < TD; ++u) {
@@ -265,14 +275,15 @@ __global__ __launch_bounds__(64 * EH_WAVES, 2) void edge_kernel_f16x3(
             __syncthreads();
             if (u + 2 < TD) copy12(std::integral_constant<int, TC>{});         // an NF2 chunk
             else copy12(std::integral_constant<int, TC + TD - 2>{});           // an NF3 chunk
-#pragma unroll
-            for (int nb = 0; nb < 2; ++nb) { b16[nb][u][0] = u32x4{0, 0, 0, 0}; b16[nb][u][1] = u32x4{0, 0, 0, 0}; }
             if (go) {
                 ms.template run<TC, 2 * TC>(acc, cross, h1);
-                relayout(gelu_split_tile2(acc, cross, window), u);
+                const Planes2 pl = gelu_split_tile2(acc, cross, window);
+                if (u > 0) relayout_read(u - 1);
+                relayout_write(pl);
             }
             sl = slot_after(sl, 1);
         }
+        relayout_read(TD - 1);
         EDGE_TICK(2);
         // ---- per layer: kernel_l = Wk_l . basis  (conv.py:110), one output tile per chunk ---------------------
         const size_t layer_stride = (size_t)N * k * 16 * C;
@@ -298,31 +309,45 @@ __global__ __launch_bounds__(64 * EH_WAVES, 2) void edge_kernel_f16x3(
         };
         // ST = step (of 2 TD) at which the chunk's barrier is taken (mid-chunk).  At SYNC the wave's queue holds, oldest
         // first, its DMA copies of the next chunk and -- from the second chunk on -- the stores of the previous tile
-        // (issued at that tile's end): the counted wait retires the copies and leaves the stores in flight.
+        // (issued two steps into this chunk): the counted wait retires the copies and leaves the stores in flight.
         constexpr int ST = TD;
-        const char* tile_base = reinterpret_cast<const char*>(kbuf + row0 * C);  // tile of the current chunk
+        const char* tile_base = reinterpret_cast<const char*>(kbuf + row0 * C);  // tile the next store_tile16 writes
         int u_cur = 0;
-#pragma unroll 1
-        for (int cidx = 0; cidx < nchunks; ++cidx) {
-            Acc16 acc;
+        Acc16 prev;  // accumulators of the previous tile (folded and stored two steps into the next one)
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb) { prev.m[mt][nb] = f32x4v{0.f, 0.f, 0.f, 0.f}; prev.x[mt][nb] = f32x4v{0.f, 0.f, 0.f, 0.f}; }
+        // two accumulator sets alternate between consecutive tiles (the loop is unrolled by two; nchunks = L * TC is even)
+        auto chunk = [&](int cidx, Acc16& acc, const Acc16& prv) {
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
                 for (int nb = 0; nb < 2; ++nb) { acc.m[mt][nb] = f32x4v{0.f, 0.f, 0.f, 0.f}; acc.x[mt][nb] = f32x4v{0.f, 0.f, 0.f, 0.f}; }
             MmaStream16<TD> ms;
             ms.start(lds[sl], lane);
-            ms.template run<0, ST>(acc, b16);
+            ms.template run<0, 2>(acc, b16);
+            if (cidx > 0) {  // the previous tile leaves while this tile's first MFMAs run
+                store_tile16(prv, tile_base);
+                // next tile: 32 columns on, or the first column tile of the next layer
+                tile_base += (++u_cur == TC) ? (u_cur = 0, (ptrdiff_t)layer_stride * 4 - (TC - 1) * 128) : 128;
+            }
+            ms.template run<2, ST>(acc, b16);
             if (cidx == 0) dma_wait();
             else if (full) dma_wait_but<4>();
             else dma_wait_but<2>();
             __syncthreads();
             copy3(cidx);
             ms.template run<ST, 2 * TD>(acc, b16);
-            store_tile16(acc, tile_base);
-            // next tile: 32 columns on, or the first column tile of the next layer
-            tile_base += (++u_cur == TC) ? (u_cur = 0, (ptrdiff_t)layer_stride * 4 - (TC - 1) * 128) : 128;
             sl = slot_after(sl, 1);
+        };
+        Acc16 accA;
+#pragma unroll 1
+        for (int cidx = 0; cidx < nchunks; cidx += 2) {
+            chunk(cidx, accA, prev);
+            chunk(cidx + 1, prev, accA);
         }
+        store_tile16(prev, tile_base);
         EDGE_TICK(3);
     }  // pair loop
     EDGE_TICK(4);
