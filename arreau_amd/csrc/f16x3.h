@@ -206,6 +206,10 @@ struct MmaStream16 {
     }
     template <int ST0, int ST1>
     __device__ __forceinline__ void run(Acc16& acc, const u32x4 (&b)[2][NKB][2]) {
+        run<ST0, ST1>(acc.m, acc.x, b);
+    }
+    template <int ST0, int ST1>
+    __device__ __forceinline__ void run(f32x4v (&am)[2][2], f32x4v (&ax)[2][2], const u32x4 (&b)[2][NKB][2]) {
 #pragma unroll
         for (int st = ST0; st < ST1; ++st) {
             const int slot = st & 1, nslot = slot ^ 1;
@@ -216,9 +220,9 @@ struct MmaStream16 {
             const int kb = st >> 1, mt = st & 1;
 #pragma unroll
             for (int nb = 0; nb < 2; ++nb) {
-                acc.m[mt][nb] = mfma16_f16(a1[slot], b[nb][kb][0], acc.m[mt][nb]);
-                acc.x[mt][nb] = mfma16_f16(a1[slot], b[nb][kb][1], acc.x[mt][nb]);
-                acc.x[mt][nb] = mfma16_f16(a2[slot], b[nb][kb][0], acc.x[mt][nb]);
+                am[mt][nb] = mfma16_f16(a1[slot], b[nb][kb][0], am[mt][nb]);
+                ax[mt][nb] = mfma16_f16(a1[slot], b[nb][kb][1], ax[mt][nb]);
+                ax[mt][nb] = mfma16_f16(a2[slot], b[nb][kb][0], ax[mt][nb]);
             }
         }
 #pragma unroll
@@ -228,6 +232,38 @@ struct MmaStream16 {
         }
     }
 };
+
+// Closed form of the above for register-starved kernels: steps [ST0, ST1) with their own fragment prefetch, nothing
+// carried across the call (no fragment registers live over a barrier).
+template <int NKB, int ST0, int ST1>
+__device__ __forceinline__ void mma16_range(f32x4v (&am)[2][2], f32x4v (&ax)[2][2], const u32x4* __restrict__ buf,
+                                            const u32x4 (&b)[2][NKB][2], int lane) {
+    const u32x4* f = buf + lane;
+    u32x4 a1[2], a2[2];
+    a1[ST0 & 1] = f[(size_t)ST0 * 128];
+    a2[ST0 & 1] = f[(size_t)ST0 * 128 + 64];
+#pragma unroll
+    for (int st = ST0; st < ST1; ++st) {
+        const int slot = st & 1, nslot = slot ^ 1;
+        if (st + 1 < ST1) {
+            a1[nslot] = f[(size_t)(st + 1) * 128];
+            a2[nslot] = f[(size_t)(st + 1) * 128 + 64];
+        }
+        const int kb = st >> 1, mt = st & 1;
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) {
+            am[mt][nb] = mfma16_f16(a1[slot], b[nb][kb][0], am[mt][nb]);
+            ax[mt][nb] = mfma16_f16(a1[slot], b[nb][kb][1], ax[mt][nb]);
+            ax[mt][nb] = mfma16_f16(a2[slot], b[nb][kb][0], ax[mt][nb]);
+        }
+    }
+    __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+#pragma unroll
+    for (int st = ST0; st < ST1; ++st) {
+        if (st + 1 < ST1) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
+    }
+}
 
 __device__ __forceinline__ f32x16 fold_cross(const f32x16& mainacc, const f32x16& cross) {
     f32x16 r;

@@ -58,6 +58,7 @@ struct arreau_model {
                              //  quarter (out C, in H/4) ], MFMA-packed: one linear stream per (layer, quarter)
     const float* mlp_bf16;   // the same stream as bf16x3 chunks (uint16 data), 24 KiB per output tile
     const float* mlp_f16;    // the same stream as fp16x3 chunks (uint16 data), 16 KiB per output tile
+    const float* mlp_f16m;   // ... as fp16x3 chunks for v_mfma_f32_16x16x32_f16 (node_f16m.hip)
     const float* mb1;        // [L][H]
     const float* mb2;        // [L][C]
     const float* ls;         // [L][C] layer_scale (ones when absent)
@@ -194,6 +195,8 @@ int arreau_launch_node_layer(const arreau_model* m, int layer, const float* kbuf
                              float* vsum, int N, hipStream_t s);
 int arreau_launch_mlp_bf16x6(const arreau_model* m, int layer, const float* x_conv, const float* x_in, float* x_out,
                              float* xbar, float* vsum, int N, hipStream_t s);
+int arreau_launch_mlp_f16x3_m16(const arreau_model* m, int layer, const float* x_conv, const float* x_in, float* x_out,
+                                float* xbar, float* vsum, int N, hipStream_t s);
 int arreau_launch_mlp_f16x3(const arreau_model* m, int layer, const float* x_conv, const float* x_in, float* x_out,
                             float* xbar, float* vsum, int N, hipStream_t s);
 int arreau_launch_readout(const arreau_model* m, const float* xbar, const float* vsum, const int32_t* offsets,

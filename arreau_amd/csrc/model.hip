@@ -147,7 +147,10 @@ static float pack_linear_f16x3(const float* W, int out_dim, int in_dim, int in_s
 //     32 kb + 16 (g & 1) + 8 (e >> 2) + 4 (g >> 1) + (e & 3)
 // -- the order in which the activation planes of f16x3.h (k-step s = g & 1 of lane half h = g >> 1) land in the
 // B operand after their relayout.
-static float pack_linear_f16x3_m16(const float* W, int out_dim, int in_dim, int in_stride, uint16_t* Q) {
+// `native` selects the k order of a chain that stays in 16x16 tiles (node_f16m.hip): the B operand of the next layer is
+// then built in-lane from the accumulators of the two 16-row tiles mt of a 32-row chunk (register r of tile mt = row
+// 16 mt + 4 g + r), i.e. half e = 4 mt + r of lane group g is input column 32 kb + 16 (e >> 2) + 4 g + (e & 3).
+static float pack_linear_f16x3_m16(const float* W, int out_dim, int in_dim, int in_stride, uint16_t* Q, bool native = false) {
     const int U = out_dim / 32, KB = in_dim / 32;
     float wmax = 0.f;
     for (int u = 0; u < U; ++u)
@@ -157,7 +160,8 @@ static float pack_linear_f16x3_m16(const float* W, int out_dim, int in_dim, int 
                     for (int e = 0; e < 8; ++e) {
                         const int g = lane >> 4;
                         const int out = 32 * u + 16 * mt + (lane & 15);
-                        const int in = 32 * kb + 16 * (g & 1) + 8 * (e >> 2) + 4 * (g >> 1) + (e & 3);
+                        const int in = native ? 32 * kb + 16 * (e >> 2) + 4 * g + (e & 3)
+                                              : 32 * kb + 16 * (g & 1) + 8 * (e >> 2) + 4 * (g >> 1) + (e & 3);
                         const float w = W[(size_t)out * in_stride + in];
                         wmax = fabsf(w) > wmax ? fabsf(w) : wmax;
                         const uint16_t h1 = f32_to_f16_rne(w);
@@ -344,6 +348,14 @@ extern "C" int arreau_model_create(const arreau_config* cfg, const arreau_state_
             wmax16 = fmaxf(wmax16, pack_linear_f16x3(sd->linear1_w + ((size_t)l * H + (size_t)w * HQ) * C, HQ, C, C, HQ, C, dst));
             wmax16 = fmaxf(wmax16, pack_linear_f16x3(sd->linear2_w + (size_t)l * C * H + (size_t)w * HQ, C, HQ, H, C, HQ, dst + fq1));
         }
+    // ... and as fp16x3 chunks for the 16x16x32 kernel (native k order), same sizes
+    const size_t off_mlpf16m = bb.reserve((fq1 + fq2) * 4 * L / 2 + 64);
+    for (int l = 0; l < L; ++l)
+        for (int w = 0; w < 4; ++w) {
+            uint16_t* dst = reinterpret_cast<uint16_t*>(bb.data.data() + off_mlpf16m) + ((size_t)l * 4 + w) * (fq1 + fq2);
+            pack_linear_f16x3_m16(sd->linear1_w + ((size_t)l * H + (size_t)w * HQ) * C, HQ, C, C, dst, true);
+            pack_linear_f16x3_m16(sd->linear2_w + (size_t)l * C * H + (size_t)w * HQ, C, HQ, H, dst + fq1, true);
+        }
     const size_t off_mb1 = bb.put(sd->linear1_b, (size_t)L * H);
     const size_t off_mb2 = bb.put(sd->linear2_b, (size_t)L * C);
 
@@ -413,7 +425,7 @@ extern "C" int arreau_model_create(const arreau_config* cfg, const arreau_state_
     float* b = m->blob;
     m->ori = b + off_ori; m->w1p = b + off_w1p; m->b1 = b + off_b1; m->w2p = b + off_w2p; m->b2 = b + off_b2;
     m->wkp = b + off_wkp; m->edge_bf16 = b + off_es16; m->edge_f16 = b + off_ef16; m->f16_ok = wmax16 < 60000.0f ? 1 : 0; m->fk = b + off_fk; m->conv_bias = b + off_conv_bias; m->ln_w = b + off_ln_w;
-    m->ln_b = b + off_ln_b; m->mlp = b + off_mlp; m->mlp_bf16 = b + off_mlp16; m->mlp_f16 = b + off_mlpf16; m->mb1 = b + off_mb1; m->mb2 = b + off_mb2;
+    m->ln_b = b + off_ln_b; m->mlp = b + off_mlp; m->mlp_bf16 = b + off_mlp16; m->mlp_f16 = b + off_mlpf16; m->mlp_f16m = b + off_mlpf16m; m->mb1 = b + off_mb1; m->mb2 = b + off_mb2;
     m->ls = b + off_ls; m->embT = b + off_embT; m->ro_wT = b + off_ro_wT; m->ro_b = b + off_ro_b; m->ro_pack = b + off_ro_pack; m->ro_wv = b + off_ro_wv;
     for (int l = 0; l < L; ++l) m->ro_bv_host[l] = sd->readout_b[(size_t)l * RO + S];
     m->t_emb_w = b + off_temb; m->ve_sigmas = b + off_ve; m->vp_alpha_bars = b + off_ab; m->vp_betas = b + off_be;

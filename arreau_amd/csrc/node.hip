@@ -576,10 +576,12 @@ int arreau_launch_node_layer(const arreau_model* m, int layer, const float* kbuf
                            src, x_in, m->fk + (size_t)layer * 16 * 16 * C, m->conv_bias + (size_t)layer * C, N, m->k, x_conv);
     }
     ARREAU_CHECK_HIP(hipGetLastError());
-    // variant switch: 2 (default) = fp16x3 split-precision MLP kernel (node_f16.hip; needs weights that fit fp16);
-    // 1 = bf16x6 split-precision MLP kernel (node_bf16.hip); 0 = fp32-MFMA kernel below
-    static const int mlp_variant = [] { const char* e = getenv("ARREAU_MLP_VARIANT"); return e ? atoi(e) : 2; }();
-    if (mlp_variant == 2 && m->f16_ok)
+    // variant switch: 3 (default) = fp16x3 on 16x16x32 MFMAs (node_f16m.hip); 2 = fp16x3 on 32x32x16 MFMAs (node_f16.hip) -- both
+    // need weights that fit fp16; 1 = bf16x6 split-precision MLP kernel (node_bf16.hip); 0 = fp32-MFMA kernel below
+    static const int mlp_variant = [] { const char* e = getenv("ARREAU_MLP_VARIANT"); return e ? atoi(e) : 3; }();
+    if (mlp_variant == 3 && m->f16_ok)
+        return arreau_launch_mlp_f16x3_m16(m, layer, x_conv, x_in, x_out, xbar, vsum, N, s);
+    if (mlp_variant >= 2 && m->f16_ok)
         return arreau_launch_mlp_f16x3(m, layer, x_conv, x_in, x_out, xbar, vsum, N, s);
     if (mlp_variant >= 1)
         return arreau_launch_mlp_bf16x6(m, layer, x_conv, x_in, x_out, xbar, vsum, N, s);

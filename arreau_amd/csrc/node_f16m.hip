@@ -1,0 +1,278 @@
+// K4b, fp16x3 split precision on v_mfma_f32_16x16x32_f16 (default): the ConvNext block of one layer
+// (convnext.py:25-32) + read-out partials (ponita.py:105-117).  Same algorithm, chunking and ring protocol as
+// node_f16.hip; what differs is the matrix instruction and with it the register layouts.
+//
+// Why: under the chip's power limit the 16x16x32 form holds a higher clock than 32x32x16 at the same cycles per FLOP
+// (1875 vs 1572 MHz in bare streams, tools/exp/mfma_shape.hip).
+//
+// Layout.  One wave = 32 rows = two column blocks nb of 16: nb = node of the tile (n = 2 tile + nb), column
+// c = lane & 15 = orientation.  Lane group g = lane >> 4 splits the K range: as B operand a lane holds, per 32-wide
+// k-block kb, the 8 values e of its row with input index  32 kb + 16 (e >> 2) + 4 g + (e & 3)  (k order 8 g + e);
+// as accumulator of the 16-row output tile mt of a 32-row chunk, register r is output row 16 mt + 4 g + r.  The
+// accumulators of the two tiles mt of a chunk are therefore, in place, the B operand of the next layer's k-block
+// (e = 4 mt + r): the chain stays in registers with no relayout, as in the 32x32 kernels.  Weights are packed to that
+// k order on the host (pack_linear_f16x3_m16, native mode).
+#include <stdlib.h>
+#include <utility>
+
+#include "f16x3.h"
+#include "internal.h"
+
+namespace {
+// Sum over the 16 lanes of a DPP row (= the 16 orientations of a node at fixed g), every lane receiving the total.
+__device__ __forceinline__ float row16_sum_m(float v) {
+    auto dpp = [](float x, auto ctrl) {
+        return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), decltype(ctrl)::value, 0xf, 0xf, false));
+    };
+    v += dpp(v, std::integral_constant<int, 0xB1>{});   // quad_perm [1,0,3,2]
+    v += dpp(v, std::integral_constant<int, 0x4E>{});   // quad_perm [2,3,0,1]
+    v += dpp(v, std::integral_constant<int, 0x141>{});  // row_half_mirror
+    v += dpp(v, std::integral_constant<int, 0x140>{});  // row_mirror
+    return v;
+}
+// sum over the four lane groups g of a column (lanes c, c+16, c+32, c+48)
+__device__ __forceinline__ float group4_sum(float v) {
+    v += __shfl_xor(v, 16, 64);
+    v += __shfl_xor(v, 32, 64);
+    return v;
+}
+// planes of 8 fp32 values (e = 0..7) -> two u32x4 (8 halves each)
+template <bool CLAMP>
+__device__ __forceinline__ void split8(const float (&v)[8], u32x4& hi, u32x4& lo) {
+#pragma unroll
+    for (int pp = 0; pp < 4; ++pp) {
+        unsigned a, b;
+        split_pair2<CLAMP>(f32x2{v[2 * pp], v[2 * pp + 1]}, a, b);
+        hi[pp] = a;
+        lo[pp] = b;
+    }
+}
+}  // namespace
+
+template <int C, int H, int NW>
+__global__ __launch_bounds__(64 * NW, 2) void mlp_kernel_f16x3_m16(
+    const float* __restrict__ x_conv,    // [N][16][C]  conv output (pre-LayerNorm)
+    const float* __restrict__ x_in, float* __restrict__ x_out,
+    const float* __restrict__ ln_w, const float* __restrict__ ln_b,
+    const u32x4* __restrict__ stream,    // this layer: [4 quarters][W1 quarter: 4 chunks | W2 quarter: 4 chunks], 16 frags per chunk
+    const float* __restrict__ mb1, const float* __restrict__ mb2, const float* __restrict__ ls,
+    const float* __restrict__ wv,        // [C] vector read-out weights of this layer (column S of read_out_layers)
+    float bv, int N, int first_layer,
+    float* __restrict__ xbar,            // [N][C] this layer
+    float* __restrict__ vsum)            // [N][16]
+{
+    static_assert(C == 128 && H == 512, "chunking below assumes C = 128, H = 512");
+    constexpr int KC = C / 32;            // k-blocks of the C inputs
+    constexpr int HQ = H / 4, KH = HQ / 32;  // hidden quarter, its k-blocks
+    constexpr int NF = KC * 4;            // 16 fragments (16 KiB) per chunk = 32 output rows
+    static_assert(KH == KC, "W1 and W2 quarter chunks have the same size");
+    __shared__ u32x4 lds[3][NF * 64];                              // 3 x 16 KiB ring of weight chunks
+    __shared__ __attribute__((aligned(16))) float bias_s[H];      // mb1: no global loads while a DMA is in flight
+
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int cp = lane & 15, gp = lane >> 4;  // prologue / matrix-phase copies
+    const long long tile = (long long)blockIdx.x * NW + wave;
+    const bool active = 2 * tile < N;  // wave-uniform; idle waves still copy weights and meet the barriers
+    int nrow[2];                       // node of column block nb (padding: a valid node, nothing written)
+    bool valid[2];
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) {
+        const long long n_ll = 2 * tile + nb;
+        valid[nb] = n_ll < N;
+        nrow[nb] = valid[nb] ? (int)n_ll : N - 1;
+    }
+
+    const u32x4* dma_src = stream;  // next chunk to copy
+    dma_chunk<NF, NW>(dma_src, lds[0], wave, lane);
+    dma_src += (size_t)NF * 64;
+    dma_chunk<NF, NW>(dma_src, lds[1], wave, lane);
+    dma_src += (size_t)NF * 64;
+    for (int i = threadIdx.x; i < H; i += 64 * NW) bias_s[i] = mb1[i];
+
+    // ---- load the rows in B-operand layout, LayerNorm them (eps 1e-5, biased variance), split ---------------
+    u32x4 xn[2][KC][2];  // [column block][k-block][plane]
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) {
+        const float* rowp = x_conv + ((size_t)nrow[nb] * 16 + cp) * C + 4 * gp;
+        float x[KC][8];
+        float sum = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < KC; ++kb)
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(rowp + 32 * kb + 16 * hf);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) x[kb][4 * hf + r] = v[r];
+                sum += (v[0] + v[1]) + (v[2] + v[3]);
+            }
+        const float mean = group4_sum(sum) * (1.0f / C);
+        float sq = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < KC; ++kb)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float dlt = x[kb][e] - mean;
+                x[kb][e] = dlt;
+                sq += dlt * dlt;
+            }
+        const float rstd = 1.0f / sqrtf(group4_sum(sq) * (1.0f / C) + 1e-5f);
+#pragma unroll
+        for (int kb = 0; kb < KC; ++kb) {
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {
+                const f32x4 gw = *reinterpret_cast<const f32x4*>(ln_w + 32 * kb + 16 * hf + 4 * gp);
+                const f32x4 gb = *reinterpret_cast<const f32x4*>(ln_b + 32 * kb + 16 * hf + 4 * gp);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) x[kb][4 * hf + r] = x[kb][4 * hf + r] * rstd * gw[r] + gb[r];
+            }
+            split8<true>(x[kb], xn[nb][kb][0], xn[nb][kb][1]);
+        }
+    }
+    dma_wait();
+    __syncthreads();
+
+    f32x4v acc_o[KC][2][2];  // [output chunk u][16-row tile mt][column block nb]
+#pragma unroll
+    for (int u = 0; u < KC; ++u)
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb) acc_o[u][mt][nb] = f32x4v{0.f, 0.f, 0.f, 0.f};
+
+    // 32 chunks per layer: per quarter 4 chunks of W1 rows (32 hidden units each) then 4 chunks of W2 columns (32
+    // outputs each).  Chunk q sits in ring slot q % 3; SYNC_q in the middle of its MFMA stream (edge_f16.hip).
+    int sl = 0;
+    const unsigned lane16 = 16u * lane;
+    const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)&lds[0][0]) + 1024u * wave;
+    auto sync = [&](bool more2) {
+        dma_wait();
+        __syncthreads();
+        if (more2) dma_chunk_lean<NF, NW>(dma_src, lane16, wave, lds0 + (sl == 0 ? 2u : (unsigned)sl - 1u) * (NF * 1024u));
+        dma_src += (size_t)NF * 64;
+    };
+    constexpr int ST = KC;  // step (of 2 KC) at which the barrier is taken
+#pragma unroll 1
+    for (int w = 0; w < 4; ++w) {
+        u32x4 hid[2][KH][2];  // [column block][k-block = hidden chunk][plane]
+#pragma unroll
+        for (int u = 0; u < KH; ++u) {  // ---- hidden chunk u = GELU(W1q[u] . xn + b1q[u]) ----
+            Acc16 acc;
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                const f32x4 b = *reinterpret_cast<const f32x4*>(bias_s + w * HQ + 32 * u + 16 * mt + 4 * gp);
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb) {
+                    acc.m[mt][nb] = f32x4v{b[0], b[1], b[2], b[3]};
+                    acc.x[mt][nb] = f32x4v{0.f, 0.f, 0.f, 0.f};
+                }
+            }
+            if (active) mma16_range<KC, 0, ST>(acc.m, acc.x, lds[sl], xn, lane);
+            sync(true);  // a W1 chunk is always followed by at least four more
+            if (active) {
+                mma16_range<KC, ST, 2 * KC>(acc.m, acc.x, lds[sl], xn, lane);
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb) {
+                    float v[8];
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                        for (int pr = 0; pr < 2; ++pr) {
+                            const f32x2 pre = fma2(f32x2{acc.x[mt][nb][2 * pr], acc.x[mt][nb][2 * pr + 1]}, splat2(F16X3_INV_SCALE),
+                                                   f32x2{acc.m[mt][nb][2 * pr], acc.m[mt][nb][2 * pr + 1]});
+                            const f32x2 act = gelu_fast2(pre);
+                            v[4 * mt + 2 * pr] = act.x;
+                            v[4 * mt + 2 * pr + 1] = act.y;
+                        }
+                    split8<false>(v, hid[nb][u][0], hid[nb][u][1]);
+                }
+            }
+            sl = sl == 2 ? 0 : sl + 1;
+        }
+#pragma unroll
+        for (int u = 0; u < KC; ++u) {  // ---- output chunk u += W2[:, quarter][u] . hid ----
+            f32x4v cross[2][2];  // acc_o[u] itself is the main accumulator
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb) cross[mt][nb] = f32x4v{0.f, 0.f, 0.f, 0.f};
+            if (active) mma16_range<KH, 0, ST>(acc_o[u], cross, lds[sl], hid, lane);
+            sync(!(w == 3 && u >= KC - 2));
+            if (active) {
+                mma16_range<KH, ST, 2 * KH>(acc_o[u], cross, lds[sl], hid, lane);
+#pragma unroll
+                for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) acc_o[u][mt][nb][r] = fmaf(cross[mt][nb][r], F16X3_INV_SCALE, acc_o[u][mt][nb][r]);
+            }
+            sl = sl == 2 ? 0 : sl + 1;
+        }
+    }
+    if (!active) return;
+
+    // ---- bias, layer scale, residual; write x_out; read-out partials (all in registers) ------------------
+    // (lane-derived indices are re-derived here from a value the optimiser cannot see through, so that they do not
+    // occupy registers through the matrix phases)
+    int lane_e = lane;
+    asm volatile("" : "+v"(lane_e));
+    const int c = lane_e & 15, g = lane_e >> 4;
+    const float inv16 = 1.0f / 16.0f;
+    float vdot[2] = {0.f, 0.f};
+#pragma unroll
+    for (int u = 0; u < KC; ++u)
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            const int c0 = 32 * u + 16 * mt + 4 * g;  // this lane's four channels
+            const f32x4 b2v = *reinterpret_cast<const f32x4*>(mb2 + c0);
+            const f32x4 lsv = *reinterpret_cast<const f32x4*>(ls + c0);
+            const f32x4 wvv = *reinterpret_cast<const f32x4*>(wv + c0);
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb) {
+                const size_t off = ((size_t)nrow[nb] * 16 + c) * C + c0;
+                const f32x4 xi = *reinterpret_cast<const f32x4*>(x_in + off);
+                f32x4 xo;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) xo[r] = (acc_o[u][mt][nb][r] + b2v[r]) * lsv[r] + xi[r];
+                if (valid[nb]) *reinterpret_cast<f32x4*>(x_out + off) = xo;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) vdot[nb] += xo[r] * wvv[r];
+                f32x4 sum;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) sum[r] = row16_sum_m(xo[r]);
+                if (valid[nb] && c == 0) {
+                    const f32x4 mean = {sum[0] * inv16, sum[1] * inv16, sum[2] * inv16, sum[3] * inv16};
+                    *reinterpret_cast<f32x4*>(xbar + (size_t)nrow[nb] * C + c0) = mean;
+                }
+            }
+        }
+#pragma unroll
+    for (int nb = 0; nb < 2; ++nb) {
+        const float tot = group4_sum(vdot[nb]);
+        if (valid[nb] && g == 0) {
+            const size_t o = (size_t)nrow[nb] * 16 + c;
+            vsum[o] = (first_layer ? 0.0f : vsum[o]) + (tot + bv);
+        }
+    }
+}
+
+int arreau_launch_mlp_f16x3_m16(const arreau_model* m, int layer, const float* x_conv, const float* x_in, float* x_out,
+                                float* xbar, float* vsum, int N, hipStream_t s) {
+    if (N == 0) return ARREAU_OK;
+    const int C = m->C, H = m->H;
+    if (!(C == 128 && H == 512)) {
+        arreau_set_error("mlp kernel (fp16x3, 16x16x32): unsupported (hidden_dim, widening_factor)");
+        return ARREAU_EINVAL;
+    }
+    constexpr int NW = 4;
+    const size_t layer_u32x4 = (size_t)2 * H * C * 2 * 2 / 16;  // bytes of W1 + W2 as 2 fp16 planes, in 16-byte units
+    const long long tiles = ((long long)N + 1) / 2;
+    hipLaunchKernelGGL((mlp_kernel_f16x3_m16<128, 512, NW>), dim3((unsigned)((tiles + NW - 1) / NW)), dim3(64 * NW), 0, s,
+                       x_conv, x_in, x_out, m->ln_w + (size_t)layer * C, m->ln_b + (size_t)layer * C,
+                       reinterpret_cast<const u32x4*>(m->mlp_f16m) + (size_t)layer * layer_u32x4,
+                       m->mb1 + (size_t)layer * H, m->mb2 + (size_t)layer * C, m->ls + (size_t)layer * C,
+                       m->ro_wv + (size_t)layer * C, m->ro_bv_host[layer], N, layer == 0 ? 1 : 0,
+                       xbar + (size_t)layer * N * C, vsum);
+    ARREAU_CHECK_HIP(hipGetLastError());
+    return ARREAU_OK;
+}

@@ -464,10 +464,11 @@ def test_rotated_lattice_invariance(dev, small_model):
         assert (x - y).abs().max() <= TOL * scale
 
 
-@pytest.mark.parametrize("edge_variant,mlp_variant", [("0", "0"), ("3", "1")])
+@pytest.mark.parametrize("edge_variant,mlp_variant", [("0", "0"), ("3", "1"), ("4", "2")])
 def test_alternative_arithmetic_variants_agree(dev, small_model, edge_variant, mlp_variant):
-    """The exact fp32-MFMA kernels and the bf16x6 kernels stay in the library as cross-checks of the default
-    fp16x3 kernels; the variant is read once per process, so run the check in a child process."""
+    """The exact fp32-MFMA kernels, the bf16x6 kernels and the 32x32x16 form of the fp16x3 MLP kernel stay in the
+    library as cross-checks of the default kernels (fp16x3 on 16x16x32 MFMAs); the variant is read once per process,
+    so run the check in a child process."""
     import subprocess
     import sys
     code = (
