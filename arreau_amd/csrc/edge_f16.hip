@@ -213,42 +213,21 @@ __global__ __launch_bounds__(64 * EH_WAVES, 2) void edge_kernel_f16x3(
         // the other path is turned by the optimiser into a value carried around the pair loop (250 spilled registers).
         int go = 1;
         asm volatile("" : "+s"(go));
-        // ---- layer 1: h = GELU(W1f . mono + b1) -------------------------------------------------------------
-        Planes2 h1[TC];
-#pragma unroll
-        for (int u = 0; u < TC; ++u) {
-            f32x16 acc = arreau_bias_tile(bias_s, u, h), cross;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) cross[r] = 0.f;
-            MmaStream2<TM, 2 * TM> ms;
-            ms.start(lds[sl], lane);
-            if (go) ms.template run<0, TM>(acc, cross, bm);
-            dma_wait();
-            __syncthreads();
-            if (u + 2 < TC) copy12(std::integral_constant<int, 0>{});          // an NF1 chunk
-            else copy12(std::integral_constant<int, TC - 2>{});               // an NF2 chunk
-            h1[u] = Planes2{};
-            if (go) {
-                ms.template run<TM, 2 * TM>(acc, cross, bm);
-                h1[u] = gelu_split_tile2(acc, cross, 1.0f);
-            }
-            sl = slot_after(sl, 1);
-        }
-        EDGE_TICK(1);
-        // ---- layer 2: basis = GELU(W2 . h + b2) * window ------------------------------------------------------
-        // The projection loop runs on 16x16x32 MFMAs: each finished basis tile is re-laid once, through the wave's LDS
-        // pad, from the (h, row j) lane layout of the 32x32 accumulators into the (c = orientation, g) layout of the
-        // two 16-column blocks nb (= the wave's two edge slots): lane (c, g) takes the 16 bytes that lane
-        // (h = g >> 1, j = 16 nb + c) holds for k-step s = g & 1.
-        u32x4 b16[2][TD][2];  // [column block][k-block = basis tile][plane]
-#pragma unroll
-        for (int u = 0; u < TD; ++u)
-#pragma unroll
-            for (int nb = 0; nb < 2; ++nb) { b16[nb][u][0] = u32x4{0, 0, 0, 0}; b16[nb][u][1] = u32x4{0, 0, 0, 0}; }
+        // Layers 2 and the projections run on 16x16x32 MFMAs (f16x3.h: higher held clock under the power limit); layer 1
+        // stays on 32x32x16 (its B operand, the monomials, is computed per lane in that layout).  Each finished layer-1
+        // tile is re-laid once, through the wave's LDS pad, from the (h, row j) lane layout of the 32x32 accumulators
+        // into the (c = orientation, g) layout of the two 16-column blocks nb (= the wave's two edge slots): lane
+        // (c, g) takes the 16 bytes that lane (h = g >> 1, j = 16 nb + c) holds for k-step s = g & 1.  The pad holds one
+        // tile (2 planes x 2 KiB): a tile is written right after its epilogue and read back in front of the next
+        // tile's write, a whole chunk later, so neither LDS latency is waited for.  From layer 2 on the chain stays in
+        // the 16x16 layout (accumulators of the two 16-row tiles of a chunk = B operand of the next k-block).
         u32x4* pad16 = reinterpret_cast<u32x4*>(otile[wave]);
         const int c16 = lane & 15, g16 = lane >> 4;
-        // (the pad holds one tile: 2 planes x 2 KiB.  A tile is written right after its epilogue and read back in
-        // front of the next tile's write, a whole chunk later, so neither LDS latency is waited for.)
+        u32x4 h16[2][TC][2];  // layer-1 output as B operand: [column block][k-block = layer-1 tile][plane]
+#pragma unroll
+        for (int u = 0; u < TC; ++u)
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb) { h16[nb][u][0] = u32x4{0, 0, 0, 0}; h16[nb][u][1] = u32x4{0, 0, 0, 0}; }
         auto relayout_write = [&](const Planes2& pl) {
 #pragma unroll
             for (int plane = 0; plane < 2; ++plane) {
@@ -261,29 +240,77 @@ __global__ __launch_bounds__(64 * EH_WAVES, 2) void edge_kernel_f16x3(
             for (int plane = 0; plane < 2; ++plane)
 #pragma unroll
                 for (int nb = 0; nb < 2; ++nb)
-                    b16[nb][u][plane] = pad16[128 * plane + ((16 * nb + c16) * 2 + (g16 >> 1)) * 2 + (g16 & 1)];
+                    h16[nb][u][plane] = pad16[128 * plane + ((16 * nb + c16) * 2 + (g16 >> 1)) * 2 + (g16 & 1)];
         };
+        // ---- layer 1: h = GELU(W1f . mono + b1) -------------------------------------------------------------
 #pragma unroll
-        for (int u = 0; u < TD; ++u) {
-            f32x16 acc = arreau_bias_tile(bias_s + C, u, h), cross;
+        for (int u = 0; u < TC; ++u) {
+            f32x16 acc = arreau_bias_tile(bias_s, u, h), cross;
 #pragma unroll
             for (int r = 0; r < 16; ++r) cross[r] = 0.f;
-            MmaStream2<TC, 2 * TC> ms;
+            MmaStream2<TM, 2 * TM> ms;
             ms.start(lds[sl], lane);
-            if (go) ms.template run<0, TC>(acc, cross, h1);
+            if (go) ms.template run<0, TM>(acc, cross, bm);
             dma_wait();
             __syncthreads();
-            if (u + 2 < TD) copy12(std::integral_constant<int, TC>{});         // an NF2 chunk
-            else copy12(std::integral_constant<int, TC + TD - 2>{});           // an NF3 chunk
+            if (u + 2 < TC) copy12(std::integral_constant<int, 0>{});          // an NF1 chunk
+            else copy12(std::integral_constant<int, TC - 2>{});               // an NF2 chunk
             if (go) {
-                ms.template run<TC, 2 * TC>(acc, cross, h1);
-                const Planes2 pl = gelu_split_tile2(acc, cross, window);
+                ms.template run<TM, 2 * TM>(acc, cross, bm);
+                const Planes2 pl = gelu_split_tile2(acc, cross, 1.0f);
                 if (u > 0) relayout_read(u - 1);
                 relayout_write(pl);
             }
             sl = slot_after(sl, 1);
         }
-        relayout_read(TD - 1);
+        relayout_read(TC - 1);
+        // the cut-off windows of this lane's two rows (slot 2 wn + nb, orientation c) sit in lanes 16 nb + c
+        float win16[2];
+        win16[0] = __shfl(window, c16, 64);
+        win16[1] = __shfl(window, 16 + c16, 64);
+        EDGE_TICK(1);
+        // ---- layer 2: basis = GELU(W2 . h + b2) * window ------------------------------------------------------
+        u32x4 b16[2][TD][2];  // [column block][k-block = 32 basis functions][plane]
+#pragma unroll
+        for (int u = 0; u < TD; ++u) {
+            Acc16 acc;
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                const f32x4 bv4 = *reinterpret_cast<const f32x4*>(bias_s + C + 32 * u + 16 * mt + 4 * g16);
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb) {
+                    acc.m[mt][nb] = f32x4v{bv4[0], bv4[1], bv4[2], bv4[3]};
+                    acc.x[mt][nb] = f32x4v{0.f, 0.f, 0.f, 0.f};
+                }
+            }
+            MmaStream16<TC> ms;
+            ms.start(lds[sl], lane);
+            if (go) ms.template run<0, TC>(acc, h16);
+            dma_wait();
+            __syncthreads();
+            if (u + 2 < TD) copy12(std::integral_constant<int, TC>{});         // an NF2 chunk
+            else copy12(std::integral_constant<int, TC + TD - 2>{});           // an NF3 chunk
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb) { b16[nb][u][0] = u32x4{0, 0, 0, 0}; b16[nb][u][1] = u32x4{0, 0, 0, 0}; }
+            if (go) {
+                ms.template run<TC, 2 * TC>(acc, h16);
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb) {
+#pragma unroll
+                    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                        for (int pr = 0; pr < 2; ++pr) {
+                            const f32x2 pre = fma2(f32x2{acc.x[mt][nb][2 * pr], acc.x[mt][nb][2 * pr + 1]}, splat2(F16X3_INV_SCALE),
+                                                   f32x2{acc.m[mt][nb][2 * pr], acc.m[mt][nb][2 * pr + 1]});
+                            unsigned hi, lo;
+                            split_pair2<false>(gelu_fast2(pre) * splat2(win16[nb]), hi, lo);  // |window| <= 1
+                            b16[nb][u][0][2 * mt + pr] = hi;
+                            b16[nb][u][1][2 * mt + pr] = lo;
+                        }
+                }
+            }
+            sl = slot_after(sl, 1);
+        }
         EDGE_TICK(2);
         // ---- per layer: kernel_l = Wk_l . basis  (conv.py:110), one output tile per chunk ---------------------
         const size_t layer_stride = (size_t)N * k * 16 * C;

@@ -306,10 +306,10 @@ extern "C" int arreau_model_create(const arreau_config* cfg, const arreau_state_
     {
         uint16_t* q = reinterpret_cast<uint16_t*>(bb.data.data() + off_ef16);
         wmax16 = fmaxf(wmax16, pack_linear_f16x3(w1f.data(), C, ARREAU_MONO_PAD, ARREAU_MONO_PAD, C, ARREAU_MONO_PAD, q));
-        wmax16 = fmaxf(wmax16, pack_linear_f16x3(sd->basis_w2, D, C, C, D, C, q + f_w1));
+        wmax16 = fmaxf(wmax16, pack_linear_f16x3_m16(sd->basis_w2, D, C, C, q + f_w1));  // K = re-laid layer-1 tiles
         for (int l = 0; l < L; ++l)
             wmax16 = fmaxf(wmax16, pack_linear_f16x3_m16(sd->conv_kernel_w + (size_t)l * C * D, C, D, D,
-                                                         q + f_w1 + f_w2 + l * f_wk));
+                                                         q + f_w1 + f_w2 + l * f_wk, true));  // K = basis, native order
     }
     const size_t off_fk = bb.reserve((size_t)L * O * O * C);
     const size_t off_conv_bias = bb.put(sd->conv_bias, (size_t)L * C);
