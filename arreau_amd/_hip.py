@@ -18,7 +18,12 @@ EXPORTS = [
     "arreau_model_config", "arreau_workspace_bytes", "arreau_lattice_from_params", "arreau_frac_to_cart",
     "arreau_radius_graph_pbc", "arreau_compact_edges", "arreau_edges_to_slots", "arreau_predict_scores",
     "arreau_reverse_step", "arreau_profile_edge_kernel", "arreau_edge_kernel_time_ms",
+    "arreau_model_status", "arreau_model_set_variant", "arreau_ponita_forward",
 ]
+
+STATUS_NONFINITE, STATUS_BAD_TIMESTEP, STATUS_BAD_TYPE = 1, 2, 4
+EDGE_KERNELS = {0: "fp32-mfma", 1: "fp32-mfma", 2: "fp32-mfma", 3: "bf16x6", 4: "fp16x3"}
+MLP_KERNELS = {0: "fp32-mfma", 1: "bf16x6", 2: "fp16x3-32x32x16", 3: "fp16x3-16x16x32"}
 
 
 class ArreauHipError(RuntimeError):
@@ -32,6 +37,10 @@ class Config(Structure):
         ("max_neighbors", c_int32), ("num_timesteps", c_int32), ("radius", c_float),
         ("has_layer_scale", c_int32),
     ]
+
+
+class Status(Structure):
+    _fields_ = [("flags", c_int32), ("edge_kernel", c_int32), ("mlp_kernel", c_int32), ("conv_kernel", c_int32)]
 
 
 _SD_FIELDS = [
@@ -76,6 +85,10 @@ def lib():
     L.arreau_predict_scores.argtypes = ([c_void_p] * 7 + [c_int32, c_int32, c_int32] + [c_void_p] * 7 +
                                         [c_void_p, c_size_t, c_void_p])
     L.arreau_reverse_step.argtypes = [c_void_p] * 7 + [c_int32, c_int32] + [c_void_p] * 8
+    L.arreau_model_status.argtypes = [c_void_p, POINTER(Status), c_int32, c_void_p]
+    L.arreau_model_set_variant.argtypes = [c_void_p, c_int32, c_int32]
+    L.arreau_ponita_forward.argtypes = ([c_void_p] * 5 + [c_int32, c_int32] + [c_void_p] * 7 +
+                                        [c_void_p, c_size_t, c_void_p])
     L.arreau_profile_edge_kernel.argtypes = [c_int32]
     L.arreau_edge_kernel_time_ms.argtypes = [POINTER(c_double), POINTER(c_int64)]
     for name in EXPORTS:

@@ -90,6 +90,45 @@ extern "C" int arreau_edge_kernel_time_ms(double* mean_ms, int64_t* launches) {
     return ARREAU_OK;
 }
 
+namespace {
+// the edge kernel, bracketed by hipEvents on its own stream when bench.py asked for its launch time
+int run_edge_kernel(const arreau_model* m, const float* dir, const float* dist, const int32_t* deg, const Workspace& w,
+                    int N, hipStream_t s) {
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    bool prof = false;
+    {
+        std::lock_guard<std::mutex> lock(g_prof.mu);
+        prof = g_prof.enabled;
+    }
+    if (prof) {
+        ARREAU_CHECK_HIP(hipEventCreate(&e0));
+        ARREAU_CHECK_HIP(hipEventCreate(&e1));
+        ARREAU_CHECK_HIP(hipEventRecord(e0, s));
+    }
+    const int rc = arreau_launch_edge(m, dir, dist, deg, w.batch, w.lattice, N, w.kbuf, s);
+    if (prof) {
+        ARREAU_CHECK_HIP(hipEventRecord(e1, s));
+        std::lock_guard<std::mutex> lock(g_prof.mu);
+        g_prof.events.emplace_back(e0, e1);
+    }
+    return rc;
+}
+
+// interaction layers (conv.py:105-129 + convnext.py:20-33) on the embedded features in w.xa, then the read-outs
+int run_layers_and_readout(const arreau_model* m, const Workspace& w, const int32_t* deg, const int32_t* src,
+                           const int32_t* d_off, int B, int N, float* d_eps, float* d_logits, float* d_len0,
+                           hipStream_t s) {
+    int rc;
+    float* xin = w.xa;
+    float* xout = w.xb;
+    for (int l = 0; l < m->L; ++l) {
+        if ((rc = arreau_launch_node_layer(m, l, w.kbuf, deg, src, xin, w.xc, xout, w.xbar, w.vsum, N, s))) return rc;
+        float* tmp = xin; xin = xout; xout = tmp;
+    }
+    return arreau_launch_readout(m, w.xbar, w.vsum, d_off, B, N, w.gs, d_eps, d_logits, d_len0, s);
+}
+}  // namespace
+
 extern "C" int arreau_predict_scores(const arreau_model* m, const float* d_frac, const int32_t* d_types,
                                      const float* d_lengths, const float* d_angles, const int32_t* d_t,
                                      const int32_t* d_off, int32_t B, int32_t N, int32_t use_given_edges,
@@ -121,30 +160,31 @@ extern "C" int arreau_predict_scores(const arreau_model* m, const float* d_frac,
                                          dist, s)))
             return rc;
     }
-    hipEvent_t e0 = nullptr, e1 = nullptr;
-    bool prof = false;
-    {
-        std::lock_guard<std::mutex> lock(g_prof.mu);
-        prof = g_prof.enabled;
-    }
-    if (prof) {
-        ARREAU_CHECK_HIP(hipEventCreate(&e0));
-        ARREAU_CHECK_HIP(hipEventCreate(&e1));
-        ARREAU_CHECK_HIP(hipEventRecord(e0, s));
-    }
-    rc = arreau_launch_edge(m, dir, dist, deg, w.batch, w.lattice, N, w.kbuf, s);
-    if (prof) {
-        ARREAU_CHECK_HIP(hipEventRecord(e1, s));
-        std::lock_guard<std::mutex> lock(g_prof.mu);
-        g_prof.events.emplace_back(e0, e1);
-    }
-    if (rc) return rc;
+    if ((rc = run_edge_kernel(m, dir, dist, deg, w, N, s))) return rc;
     if ((rc = arreau_launch_embed(m, d_frac, d_types, w.lattice, w.batch, w.cvec, N, w.xa, s))) return rc;
-    float* xin = w.xa;
-    float* xout = w.xb;
-    for (int l = 0; l < m->L; ++l) {
-        if ((rc = arreau_launch_node_layer(m, l, w.kbuf, deg, src, xin, w.xc, xout, w.xbar, w.vsum, N, s))) return rc;
-        float* tmp = xin; xin = xout; xout = tmp;
+    return run_layers_and_readout(m, w, deg, src, d_off, B, N, d_eps, d_logits, d_len0, s);
+}
+
+// PonitaFiberBundle.forward on the reference's own batch attributes (the inner operator seam).
+extern "C" int arreau_ponita_forward(const arreau_model* m, const float* d_x, const float* d_vec, const float* d_lattice,
+                                     const int32_t* d_off, int32_t B, int32_t N, const int32_t* d_deg,
+                                     const int32_t* d_src, const float* d_dir, const float* d_dist, float* d_logits,
+                                     float* d_vec_out, float* d_global_scalar, void* d_workspace,
+                                     size_t workspace_bytes, void* stream) {
+    ARREAU_REQUIRE(m && d_x && d_vec && d_lattice && d_off && d_deg && d_src && d_dir && d_dist && d_logits && d_vec_out &&
+                       d_global_scalar, "arreau_ponita_forward: null pointer");
+    ARREAU_REQUIRE(B >= 1 && N >= 0, "arreau_ponita_forward: bad size");
+    ARREAU_REQUIRE(d_workspace != nullptr, "arreau_ponita_forward: null workspace");
+    Workspace w = carve(&m->cfg, N, B, d_workspace, workspace_bytes);
+    if (w.bytes > workspace_bytes) {
+        arreau_set_error("arreau_ponita_forward: workspace too small");
+        return ARREAU_ECAPACITY;
     }
-    return arreau_launch_readout(m, w.xbar, w.vsum, d_off, B, N, w.gs, d_eps, d_logits, d_len0, s);
+    hipStream_t s = (hipStream_t)stream;
+    int rc;
+    if ((rc = arreau_launch_batch_index(d_off, B, N, w.batch, s))) return rc;
+    w.lattice = const_cast<float*>(d_lattice);  // the edge kernel reads the caller's cells (cos features, invariants.py:82-85)
+    if ((rc = run_edge_kernel(m, d_dir, d_dist, d_deg, w, N, s))) return rc;
+    if ((rc = arreau_launch_embed_general(m, d_x, d_vec, N, w.xa, s))) return rc;
+    return run_layers_and_readout(m, w, d_deg, d_src, d_off, B, N, d_vec_out, d_logits, d_global_scalar, s);
 }

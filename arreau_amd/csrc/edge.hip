@@ -225,9 +225,16 @@ int arreau_launch_edge(const arreau_model* m, const float* dir, const float* dis
     // 0 = 32 rows/wave, 2 waves/SIMD; 1 = 64 rows/wave, 1 wave/SIMD;
     // 2 = 32 rows/wave, 1 wave/SIMD; 3 = bf16x6 split-precision kernel (edge_bf16.hip);
     // 4 = fp16x3 split-precision kernel (edge_f16.hip; falls back to 3 when a weight does not fit fp16)
-    static const int variant = [] { const char* e = getenv("ARREAU_EDGE_VARIANT"); return e ? atoi(e) : 4; }();
-    if (variant == 4 && m->f16_ok) return arreau_launch_edge_f16x3(m, dir, dist, deg, batch, lattice, N, kbuf, s);
-    if (variant >= 3) return arreau_launch_edge_bf16x6(m, dir, dist, deg, batch, lattice, N, kbuf, s);
+    const int variant = m->edge_variant;
+    if (variant == 4 && m->f16_ok) {
+        m->ran_edge = 4;
+        return arreau_launch_edge_f16x3(m, dir, dist, deg, batch, lattice, N, kbuf, s);
+    }
+    if (variant >= 3) {
+        m->ran_edge = 3;
+        return arreau_launch_edge_bf16x6(m, dir, dist, deg, batch, lattice, N, kbuf, s);
+    }
+    m->ran_edge = variant == 1 ? 1 : (variant == 2 ? 2 : 0);
     if (variant == 1) launch_variant<2, 1>(m, dir, dist, deg, batch, lattice, N, kbuf, s);
     else if (variant == 2) launch_variant<1, 1>(m, dir, dist, deg, batch, lattice, N, kbuf, s);
     else launch_variant<1, 2>(m, dir, dist, deg, batch, lattice, N, kbuf, s);

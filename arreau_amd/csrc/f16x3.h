@@ -8,8 +8,9 @@
 // `main` accumulates a1 b1, `cross` accumulates a1 b2 + a2 b1 and is folded in with one fma per element at the
 // end of a tile.  Operand representation error 2^-22 relative (fp32: 2^-24); measured GEMM error equals the
 // fp32-MFMA path's because accumulation rounding dominates ("Numerics").  fp16 range: operands must
-// stay below 65504 in magnitude -- activations are saturated at +-60000 before the split (LayerNorm outputs,
-// GELU outputs and the geometric monomials of this model are O(1..100)); weights are checked on the host.
+// stay below 65504 in magnitude (LayerNorm outputs, GELU outputs and the geometric monomials of this model are
+// O(1..100)); weights are checked on the host, activations are NOT clamped: one beyond the range becomes an inf
+// plane, reaches the outputs as NaN and raises the sticky ARREAU_STATUS_NONFINITE flag (arreau_model_status).
 // Half the matrix-pipe work and two thirds of the operand bytes of the bf16x6 scheme (bf16x6.h).
 #pragma once
 #include <hip/hip_fp16.h>
@@ -49,10 +50,11 @@ __device__ __forceinline__ f32x2 gelu_fast2(f32x2 x) {
     e.y = __builtin_amdgcn_exp2f(q.y);
     const f32x2 half_erfc = (p * t) * e;
     f32x2 r;
-    // max(x, 0) saturated at the fp16 plane range in the same instruction (v_med3): the result lies in
-    // [-0.17, 6e4], so planes of GELU outputs need no further clamp (split_pair2<false>)
-    r.x = fmaf(-fabsf(x.x), half_erfc.x, __builtin_amdgcn_fmed3f(x.x, 0.0f, 60000.0f));
-    r.y = fmaf(-fabsf(x.y), half_erfc.y, __builtin_amdgcn_fmed3f(x.y, 0.0f, 60000.0f));
+    // max(x, 0) as v_med3 with an infinite upper bound (v_med3 co-executes with the partner wave's MFMAs,
+    // tools/exp/coexec.hip).  Nothing is clamped to the fp16 range: a value >= 65520 overflows its fp16 plane to
+    // inf, propagates as inf/NaN to the network outputs and sets ARREAU_STATUS_NONFINITE in the read-out kernel.
+    r.x = fmaf(-fabsf(x.x), half_erfc.x, __builtin_amdgcn_fmed3f(x.x, 0.0f, INFINITY));
+    r.y = fmaf(-fabsf(x.y), half_erfc.y, __builtin_amdgcn_fmed3f(x.y, 0.0f, INFINITY));
     return r;
 }
 __device__ __forceinline__ float gelu_fast(float x) { return gelu_fast2(splat2(x)).x; }
@@ -64,10 +66,7 @@ struct Planes2 { u32x4 p[2][2]; };  // [plane][k-step s]: 8 fp16 per lane each
 // packed sub/mul.
 template <bool CLAMP = true>
 __device__ __forceinline__ void split_pair2(f32x2 v, unsigned& hi, unsigned& lo) {
-    if (CLAMP) {
-        v.x = __builtin_amdgcn_fmed3f(v.x, -60000.0f, 60000.0f);
-        v.y = __builtin_amdgcn_fmed3f(v.y, -60000.0f, 60000.0f);
-    }
+    // (CLAMP is kept in the signature for the callers; no clamp is applied -- see gelu_fast2: overflow is loud)
     const f16x2 h1 = __builtin_convertvector(v, f16x2);
     const f32x2 res = (v - __builtin_convertvector(h1, f32x2)) * splat2(F16X3_SCALE);
     const f16x2 h2 = __builtin_convertvector(res, f16x2);

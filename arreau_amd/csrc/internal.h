@@ -50,6 +50,11 @@ struct arreau_model {
     const float* edge_bf16;  // w1 | w2 | wk_l as bf16x3 chunks (uint16 data), one chunk per output tile
     const float* edge_f16;   // w1 | w2 | wk_l as fp16x3 chunks (uint16 data, two planes), one chunk per output tile
     int f16_ok;              // 1 when every packed weight fits fp16 (|w| < 6e4): the fp16x3 kernels may be used
+    // Arithmetic / geometry variants requested for this model (defaults from ARREAU_*_VARIANT at create,
+    // arreau_model_set_variant overrides) and what the last arreau_predict_scores actually launched.
+    int edge_variant, mlp_variant, conv_variant, readout_variant;
+    mutable int ran_edge, ran_mlp, ran_conv;
+    int32_t* status;         // device word of sticky ARREAU_STATUS_* bits (written by the kernels with atomicOr)
     float* fk;               // [L][O(o)][O(p)][C] fiber kernels / O (written once by the precompute kernel)
     const float* conv_bias;  // [L][C]
     const float* ln_w;       // [L][C]
@@ -190,6 +195,8 @@ int arreau_launch_edge_f16x3(const arreau_model* m, const float* dir, const floa
                              const int32_t* batch, const float* lattice, int N, float* kbuf, hipStream_t s);
 int arreau_launch_embed(const arreau_model* m, const float* frac, const int32_t* types, const float* lattice,
                         const int32_t* batch, const float* cvec, int N, float* x0, hipStream_t s);
+int arreau_launch_embed_general(const arreau_model* m, const float* x, const float* vec, int N, float* x0, hipStream_t s);
+int arreau_launch_batch_index(const int32_t* offsets, int B, int N, int32_t* batch, hipStream_t s);
 int arreau_launch_node_layer(const arreau_model* m, int layer, const float* kbuf, const int32_t* deg,
                              const int32_t* src, const float* x_in, float* x_conv, float* x_out, float* xbar,
                              float* vsum, int N, hipStream_t s);

@@ -2,6 +2,7 @@
 // evaluation on the GPU.  Replaces PonitaFiberBundle.__init__ + load_state_dict
 // (ponita/models/ponita.py:31-86) for the sampling path.
 #include <math.h>
+#include <stdlib.h>
 #include <string.h>
 
 #include <vector>
@@ -401,6 +402,7 @@ extern "C" int arreau_model_create(const arreau_config* cfg, const arreau_state_
     const size_t off_fw2 = bb.put(sd->fiber_w2, (size_t)D * C);
     const size_t off_fb2 = bb.put(sd->fiber_b2, D);
     const size_t off_fwk = bb.put(sd->conv_fiber_w, (size_t)L * C * D);
+    const size_t off_status = bb.reserve(64);  // zero-initialised sticky status word (+ pad)
 
     arreau_model* m = new arreau_model();
     memset(m, 0, sizeof(*m));
@@ -432,6 +434,13 @@ extern "C" int arreau_model_create(const arreau_config* cfg, const arreau_state_
     m->q1t = b + off_q1t; m->qmats = b + off_qm;
     m->fiber_w1 = b + off_fw1; m->fiber_b1 = b + off_fb1; m->fiber_w2 = b + off_fw2; m->fiber_b2 = b + off_fb2;
     m->fiber_wk = b + off_fwk;
+    m->status = reinterpret_cast<int32_t*>(b + off_status);
+    auto env_int = [](const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; };
+    m->edge_variant = env_int("ARREAU_EDGE_VARIANT", 4);
+    m->mlp_variant = env_int("ARREAU_MLP_VARIANT", 3);
+    m->conv_variant = env_int("ARREAU_CONV_VARIANT", 1);
+    m->readout_variant = env_int("ARREAU_READOUT_VARIANT", 1);
+    m->ran_edge = m->ran_mlp = m->ran_conv = -1;
 
     int rc = arreau_launch_fiber_precompute(m, s);
     if (rc == ARREAU_OK) {
@@ -459,6 +468,29 @@ extern "C" void arreau_model_destroy(arreau_model* model) {
 extern "C" int arreau_model_config(const arreau_model* model, arreau_config* out_cfg) {
     ARREAU_REQUIRE(model && out_cfg, "arreau_model_config: null argument");
     *out_cfg = model->cfg;
+    return ARREAU_OK;
+}
+
+extern "C" int arreau_model_set_variant(arreau_model* model, int32_t edge_variant, int32_t mlp_variant) {
+    ARREAU_REQUIRE(model, "arreau_model_set_variant: null model");
+    ARREAU_REQUIRE(edge_variant >= -1 && edge_variant <= 4 && mlp_variant >= -1 && mlp_variant <= 3,
+                   "arreau_model_set_variant: edge variant must be in 0..4, mlp variant in 0..3 (-1 keeps)");
+    if (edge_variant >= 0) model->edge_variant = edge_variant;
+    if (mlp_variant >= 0) model->mlp_variant = mlp_variant;
+    return ARREAU_OK;
+}
+
+extern "C" int arreau_model_status(const arreau_model* model, arreau_status* out, int32_t reset, void* stream) {
+    ARREAU_REQUIRE(model && out, "arreau_model_status: null argument");
+    hipStream_t s = (hipStream_t)stream;
+    int32_t flags = 0;
+    ARREAU_CHECK_HIP(hipMemcpyAsync(&flags, model->status, sizeof(flags), hipMemcpyDeviceToHost, s));
+    if (reset) ARREAU_CHECK_HIP(hipMemsetAsync(model->status, 0, sizeof(int32_t), s));
+    ARREAU_CHECK_HIP(hipStreamSynchronize(s));
+    out->flags = flags;
+    out->edge_kernel = model->ran_edge;
+    out->mlp_kernel = model->ran_mlp;
+    out->conv_kernel = model->ran_conv;
     return ARREAU_OK;
 }
 

@@ -30,7 +30,8 @@ __global__ __launch_bounds__(128) void prep_kernel(
     const float* __restrict__ frac, const float* __restrict__ lengths, const float* __restrict__ angles,
     const int32_t* __restrict__ tstep, const int32_t* __restrict__ offsets, const float* __restrict__ betas,
     const float* __restrict__ t_emb_w, const float* __restrict__ embT, int S, int C, int T,
-    float* __restrict__ lattice, float* __restrict__ cart, int32_t* __restrict__ batch, float* __restrict__ cvec) {
+    float* __restrict__ lattice, float* __restrict__ cart, int32_t* __restrict__ batch, float* __restrict__ cvec,
+    int32_t* __restrict__ status) {
     __shared__ float feat[ARREAU_T_EMB_DIM + ARREAU_N_CRYSTAL_FEATS];
     __shared__ float Lm[9];
     const int b = blockIdx.x;
@@ -45,6 +46,7 @@ __global__ __launch_bounds__(128) void prep_kernel(
     if (threadIdx.x < 32) {
         // GaussianFourierProjection of betas[t] (diffusion_helpers.py:23-25; diffusion_loss.py:126-127)
         int t = tstep[b];
+        if ((t < 0 || t > T) && threadIdx.x == 0) atomicOr(status, ARREAU_STATUS_BAD_TIMESTEP);  // clamped, but flagged
         t = t < 0 ? 0 : (t > T ? T : t);
         const float proj = ((betas[t] * t_emb_w[threadIdx.x]) * 2.0f) * 3.14159265358979323846f;
         feat[threadIdx.x] = sinf(proj);
@@ -79,7 +81,7 @@ int arreau_launch_prep(const arreau_model* m, const float* frac, const float* le
                        int32_t* batch, float* cvec, hipStream_t s) {
     if (B == 0) return ARREAU_OK;
     hipLaunchKernelGGL(prep_kernel, dim3(B), dim3(128), 0, s, frac, lengths, angles, t, offsets, m->vp_betas,
-                       m->t_emb_w, m->embT, m->S, m->C, m->T, lattice, cart, batch, cvec);
+                       m->t_emb_w, m->embT, m->S, m->C, m->T, lattice, cart, batch, cvec, m->status);
     ARREAU_CHECK_HIP(hipGetLastError());
     return ARREAU_OK;
 }
@@ -91,7 +93,7 @@ int arreau_launch_prep(const arreau_model* m, const float* frac, const float* le
 __global__ __launch_bounds__(256) void embed_kernel(
     const float* __restrict__ frac, const int32_t* __restrict__ types, const float* __restrict__ lattice,
     const int32_t* __restrict__ batch, const float* __restrict__ cvec, const float* __restrict__ ori,
-    const float* __restrict__ embT, int S, int C, int N, float* __restrict__ x0) {
+    const float* __restrict__ embT, int S, int C, int N, float* __restrict__ x0, int32_t* __restrict__ status) {
     // thread = (atom n, float4 column c4): the atom's scalar part and the four vector-channel weight rows are
     // loaded once and serve all 16 orientations (16 coalesced 512-byte row stores per 32 lanes)
     const int C4 = C / 4;
@@ -101,6 +103,7 @@ __global__ __launch_bounds__(256) void embed_kernel(
     const int n = (int)(idx / C4);
     const int b = batch[n];
     int ty = types[n];
+    if ((ty < 0 || ty >= S) && c4 == 0) atomicOr(status, ARREAU_STATUS_BAD_TYPE);  // clamped, but flagged
     ty = ty < 0 ? 0 : (ty >= S ? S - 1 : ty);
     const float* Lm = lattice + 9 * (size_t)b;
     float vec[4][3];
@@ -131,7 +134,71 @@ int arreau_launch_embed(const arreau_model* m, const float* frac, const int32_t*
     if (N == 0) return ARREAU_OK;
     const long long total = (long long)N * (m->C / 4);
     hipLaunchKernelGGL(embed_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, frac, types, lattice, batch,
-                       cvec, m->ori, m->embT, m->S, m->C, N, x0);
+                       cvec, m->ori, m->embT, m->S, m->C, N, x0, m->status);
+    ARREAU_CHECK_HIP(hipGetLastError());
+    return ARREAU_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Embedding of caller-supplied node features (the inner operator seam, arreau_ponita_forward):
+//   x0[n][o][c] = sum_{i < S+74} x[n][i] * W[c][i] + sum_v W[c][S+74+v] * (vec[n][v] . ori[o])
+// i.e. x_embedder (ponita.py:70,98) applied to cat(scalar_to_sphere(x), vec_to_sphere(vec))
+// (position_orientation_graph.py:82-86, to_from_sphere.py:4-8) for ANY x -- soft type vectors, a per-atom time
+// embedding, whatever the caller assembled -- not only the one-hot/per-crystal form the sampler produces.
+// Thread = (atom n, float4 column c4): the scalar part is one pass over the atom's S+74 features (x row broadcast
+// from L1, weight rows coalesced over c4), shared by the 16 orientations.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void embed_general_kernel(
+    const float* __restrict__ x, const float* __restrict__ vec, const float* __restrict__ ori,
+    const float* __restrict__ embT, int S, int C, int N, float* __restrict__ x0) {
+    const int C4 = C / 4;
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (long long)N * C4) return;
+    const int c4 = (int)(idx % C4);
+    const int n = (int)(idx / C4);
+    const int F = S + 74;
+    const f32x4* e4 = reinterpret_cast<const f32x4*>(embT);
+    const float* xr = x + (size_t)n * F;
+    f32x4 base = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+    for (int i = 0; i < F; ++i) base += e4[(size_t)i * C4 + c4] * xr[i];
+    float v[4][3];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int d = 0; d < 3; ++d) v[q][d] = vec[((size_t)n * 4 + q) * 3 + d];
+    f32x4 ev[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) ev[q] = e4[(size_t)(F + q) * C4 + c4];
+    f32x4* out = reinterpret_cast<f32x4*>(x0) + (size_t)n * ARREAU_ORI * C4 + c4;
+#pragma unroll
+    for (int o = 0; o < ARREAU_ORI; ++o) {
+        const float ox = ori[3 * o], oy = ori[3 * o + 1], oz = ori[3 * o + 2];
+        f32x4 acc = base;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc += ev[q] * ((v[q][0] * ox + v[q][1] * oy) + v[q][2] * oz);
+        out[(size_t)o * C4] = acc;
+    }
+}
+
+int arreau_launch_embed_general(const arreau_model* m, const float* x, const float* vec, int N, float* x0, hipStream_t s) {
+    if (N == 0) return ARREAU_OK;
+    const long long total = (long long)N * (m->C / 4);
+    hipLaunchKernelGGL(embed_general_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, vec, m->ori, m->embT,
+                       m->S, m->C, N, x0);
+    ARREAU_CHECK_HIP(hipGetLastError());
+    return ARREAU_OK;
+}
+
+// node -> crystal map from the CSR offsets (graph.batch of the reference, diffusion_loss.py:330-335)
+__global__ void batch_index_kernel(const int32_t* __restrict__ offsets, int B, int32_t* __restrict__ batch) {
+    const int b = blockIdx.x;
+    for (int i = offsets[b] + threadIdx.x; i < offsets[b + 1]; i += blockDim.x) batch[i] = b;
+}
+
+int arreau_launch_batch_index(const int32_t* offsets, int B, int N, int32_t* batch, hipStream_t s) {
+    if (N == 0 || B == 0) return ARREAU_OK;
+    hipLaunchKernelGGL(batch_index_kernel, dim3(B), dim3(64), 0, s, offsets, B, batch);
     ARREAU_CHECK_HIP(hipGetLastError());
     return ARREAU_OK;
 }
@@ -566,7 +633,8 @@ int arreau_launch_node_layer(const arreau_model* m, int layer, const float* kbuf
     const size_t mlp_layer = (size_t)2 * H * C;  // floats of W1 + W2, packed
     const int conv_blocks = N < 512 ? N : 512;   // persistent: 2 workgroups of 512 threads per CU (a multiple of 8: XCD-aware order)
     // conv variant: 1 (default, k = 8 only) = streamed form (K blocks by LDS-DMA, one workgroup per CU); 0 = register form
-    static const int conv_variant = [] { const char* e = getenv("ARREAU_CONV_VARIANT"); return e ? atoi(e) : 1; }();
+    const int conv_variant = m->conv_variant;
+    m->ran_conv = (conv_variant == 1 && m->k == 8) ? 1 : 0;
     if (conv_variant == 1 && m->k == 8) {
         const int blocks = N < 256 ? N : 256;
         hipLaunchKernelGGL((conv_kernel_streamed<128>), dim3(blocks), dim3(512), 0, s, kbuf + (size_t)layer * layer_stride, deg,
@@ -578,13 +646,20 @@ int arreau_launch_node_layer(const arreau_model* m, int layer, const float* kbuf
     ARREAU_CHECK_HIP(hipGetLastError());
     // variant switch: 3 (default) = fp16x3 on 16x16x32 MFMAs (node_f16m.hip); 2 = fp16x3 on 32x32x16 MFMAs (node_f16.hip) -- both
     // need weights that fit fp16; 1 = bf16x6 split-precision MLP kernel (node_bf16.hip); 0 = fp32-MFMA kernel below
-    static const int mlp_variant = [] { const char* e = getenv("ARREAU_MLP_VARIANT"); return e ? atoi(e) : 3; }();
-    if (mlp_variant == 3 && m->f16_ok)
+    const int mlp_variant = m->mlp_variant;
+    if (mlp_variant == 3 && m->f16_ok) {
+        m->ran_mlp = 3;
         return arreau_launch_mlp_f16x3_m16(m, layer, x_conv, x_in, x_out, xbar, vsum, N, s);
-    if (mlp_variant >= 2 && m->f16_ok)
+    }
+    if (mlp_variant >= 2 && m->f16_ok) {
+        m->ran_mlp = 2;
         return arreau_launch_mlp_f16x3(m, layer, x_conv, x_in, x_out, xbar, vsum, N, s);
-    if (mlp_variant >= 1)
+    }
+    if (mlp_variant >= 1) {
+        m->ran_mlp = 1;
         return arreau_launch_mlp_bf16x6(m, layer, x_conv, x_in, x_out, xbar, vsum, N, s);
+    }
+    m->ran_mlp = 0;
     hipLaunchKernelGGL((mlp_kernel<128, 512>), dim3((N + 3) / 4), dim3(256), 0, s, x_conv, x_in, x_out,
                        m->ln_w + (size_t)layer * C, m->ln_b + (size_t)layer * C, m->mlp + (size_t)layer * mlp_layer,
                        m->mb1 + (size_t)layer * H, m->mb2 + (size_t)layer * C, m->ls + (size_t)layer * C,
@@ -615,7 +690,7 @@ __global__ __launch_bounds__(1024) void readout_nodes_kernel(
     const float* __restrict__ ro_wT,  // [L][C][S+4]
     const float* __restrict__ ro_b,   // [L][S+4]
     const float* __restrict__ ori, int S, int C, int L, int N, float* __restrict__ eps,
-    float* __restrict__ logits, float* __restrict__ gs /*[N][3]*/) {
+    float* __restrict__ logits, float* __restrict__ gs /*[N][3]*/, int32_t* __restrict__ status) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int RO = S + 4, LC = L * C;
     float* xs = smem;                          // [RO_ATOMS][L*C]
@@ -659,6 +734,7 @@ __global__ __launch_bounds__(1024) void readout_nodes_kernel(
             float acc = 0.f;
             for (int o = 0; o < 16; ++o) acc += (vsum[n * 16 + o] * invL) * ori[3 * o + d];
             eps[n * 3 + d] = acc * (1.0f / 16.0f);
+            if (!(fabsf(acc) < INFINITY)) atomicOr(status, ARREAU_STATUS_NONFINITE);
         }
     } else if (l == 0 && RO_COLS - RO < 3 * RO_ATOMS && s_out == S) {
         // (wide species tables leave too few idle columns: one thread walks the tile)
@@ -669,6 +745,7 @@ __global__ __launch_bounds__(1024) void readout_nodes_kernel(
                 float acc = 0.f;
                 for (int o = 0; o < 16; ++o) acc += (vsum[n * 16 + o] * invL) * ori[3 * o + d];
                 eps[n * 3 + d] = acc * (1.0f / 16.0f);
+                if (!(fabsf(acc) < INFINITY)) atomicOr(status, ARREAU_STATUS_NONFINITE);
             }
         }
     }
@@ -681,6 +758,7 @@ __global__ __launch_bounds__(1024) void readout_nodes_kernel(
             float tot = 0.f;
             for (int ll = 0; ll < L; ++ll) tot += part[(ll * RO_ATOMS + a) * RO_COLS + s_out];
             tot *= invL;
+            if (!(fabsf(tot) < INFINITY)) atomicOr(status, ARREAU_STATUS_NONFINITE);
             if (s_out < S) logits[n * S + s_out] = tot;
             else gs[n * 3 + (s_out - S - 1)] = tot;
         }
@@ -699,7 +777,7 @@ __global__ __launch_bounds__(512) void readout_mfma_kernel(
     const float* __restrict__ ro_pack,  // [L][ROT][C/32][1024]
     const float* __restrict__ ro_b,     // [L][S+4]
     const float* __restrict__ ori, int S, int L, int N, float* __restrict__ eps, float* __restrict__ logits,
-    float* __restrict__ gs /*[N][3]*/) {
+    float* __restrict__ gs /*[N][3]*/, int32_t* __restrict__ status) {
     constexpr int TC = C / 32;
     extern __shared__ __attribute__((aligned(16))) float part[];  // [L][ROT][64 lanes][16]
     const int lane = threadIdx.x & 63, l = threadIdx.x >> 6;
@@ -740,6 +818,7 @@ __global__ __launch_bounds__(512) void readout_mfma_kernel(
     }
     __syncthreads();
     // ordered sum over the layers; thread -> (tile u, lane ln, register group q)
+    bool bad = false;  // a non-finite output (an overflowed fp16 plane upstream, or non-finite inputs) sets the sticky flag
     for (int i = threadIdx.x; i < ROT * 64 * 4; i += blockDim.x) {
         const int q = i & 3, ln = (i >> 2) & 63, u = i >> 8;
         f32x4 tot = {0.f, 0.f, 0.f, 0.f};
@@ -753,6 +832,7 @@ __global__ __launch_bounds__(512) void readout_mfma_kernel(
             for (int m = 0; m < 4; ++m) {
                 const int col = 32 * u + m + 8 * q + 4 * (ln >> 5);
                 const float v = tot[m] * invL;
+                if (col < RO && col != S && !(fabsf(v) < INFINITY)) bad = true;
                 if (col < S) logits[(size_t)n * S + col] = v;
                 else if (col > S && col < RO) gs[(size_t)n * 3 + (col - S - 1)] = v;
             }
@@ -766,8 +846,10 @@ __global__ __launch_bounds__(512) void readout_mfma_kernel(
             float acc = 0.f;
             for (int o = 0; o < 16; ++o) acc += (vsum[n * 16 + o] * invL) * ori[3 * o + dd];
             eps[n * 3 + dd] = acc * (1.0f / 16.0f);
+            if (!(fabsf(acc) < INFINITY)) bad = true;
         }
     }
+    if (bad) atomicOr(status, ARREAU_STATUS_NONFINITE);
 }
 
 __global__ void readout_crystals_kernel(const float* __restrict__ gs, const int32_t* __restrict__ offsets, int B,
@@ -790,17 +872,17 @@ int arreau_launch_readout(const arreau_model* m, const float* xbar, const float*
             return ARREAU_EINVAL;
         }
         // read-out variant: 1 (default) = fp32-MFMA kernel (needs S + 4 <= 96, L <= 8); 0 = vector kernel
-        static const int ro_variant = [] { const char* e = getenv("ARREAU_READOUT_VARIANT"); return e ? atoi(e) : 1; }();
+        const int ro_variant = m->readout_variant;
         if (ro_variant == 1 && m->S + 4 <= 96 && m->L <= 8 && m->C == 128) {
             const size_t smem_m = (size_t)m->L * 3 * 64 * 16 * sizeof(float);
             static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&readout_mfma_kernel<128, 3>),
                                                                hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 3 * 64 * 16 * 4);
             ARREAU_CHECK_HIP(attr);
             hipLaunchKernelGGL((readout_mfma_kernel<128, 3>), dim3((N + 31) / 32), dim3(64 * m->L), smem_m, s, xbar, vsum,
-                               m->ro_pack, m->ro_b, m->ori, m->S, m->L, N, eps, logits, gs);
+                               m->ro_pack, m->ro_b, m->ori, m->S, m->L, N, eps, logits, gs, m->status);
         } else {
             hipLaunchKernelGGL(readout_nodes_kernel, dim3((N + RO_ATOMS - 1) / RO_ATOMS), dim3(RO_COLS * m->L), smem, s, xbar, vsum,
-                               m->ro_wT, m->ro_b, m->ori, m->S, m->C, m->L, N, eps, logits, gs);
+                               m->ro_wT, m->ro_b, m->ori, m->S, m->C, m->L, N, eps, logits, gs, m->status);
         }
         ARREAU_CHECK_HIP(hipGetLastError());
     }

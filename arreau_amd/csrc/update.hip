@@ -9,10 +9,11 @@ __global__ void reverse_lattice_kernel(float* __restrict__ lengths, const float*
                                        const int32_t* __restrict__ tstep, const int32_t* __restrict__ offsets,
                                        const float* __restrict__ len0, const float* __restrict__ z,
                                        const float* __restrict__ alpha_bars, const float* __restrict__ betas, int B,
-                                       int T, float* __restrict__ lattice) {
+                                       int T, float* __restrict__ lattice, int32_t* __restrict__ status) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
     int t = tstep[b];
+    if (t < 1 || t > T) atomicOr(status, ARREAU_STATUS_BAD_TIMESTEP);  // clamped, but flagged
     t = t < 1 ? 1 : (t > T ? T : t);
     const float n = (float)(offsets[b + 1] - offsets[b]);
     const float ab_t = alpha_bars[t], ab_p = alpha_bars[t - 1], beta = betas[t];
@@ -59,7 +60,7 @@ __global__ __launch_bounds__(256) void reverse_atoms_kernel(
     const int32_t* __restrict__ offsets, int B, int N, const float* __restrict__ eps,
     const float* __restrict__ logits, const float* __restrict__ z_frac, const float* __restrict__ u_types,
     const float* __restrict__ ve_sigmas, const float* __restrict__ q1t, const float* __restrict__ qmats, int S,
-    int T) {
+    int T, int32_t* __restrict__ status) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int i = blockIdx.x * 4 + wave;
     if (i >= N) return;  // wave-uniform; no block-level barrier below
@@ -105,6 +106,7 @@ __global__ __launch_bounds__(256) void reverse_atoms_kernel(
         for (int off = 32; off >= 1; off >>= 1) sum += __shfl_xor(sum, off, 64);
         const float p0 = e0 / sum, p1 = e1 / sum;  // softmax of the x0 logits; lane holds classes s0, s1
         int xt = types[i];
+        if ((xt < 0 || xt >= S) && lane == 0) atomicOr(status, ARREAU_STATUS_BAD_TYPE);  // clamped, but flagged
         xt = xt < 0 ? 0 : (xt >= S ? S - 1 : xt);
         const float* q1row = q1t + ((size_t)(t - 1) * S + xt) * S;  // fact1 = Q_t^T[x_t, :]
         const float* qm = qmats + (size_t)(t - 2) * S * S;          // Qbar_{t-1} (reference index t-2)
@@ -165,11 +167,11 @@ extern "C" int arreau_reverse_step(const arreau_model* m, float* d_frac, int32_t
     ARREAU_REQUIRE(B >= 1 && N >= 0, "arreau_reverse_step: bad size");
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(reverse_lattice_kernel, dim3((B + 127) / 128), dim3(128), 0, s, d_lengths, d_angles, d_t, d_off,
-                       d_len0, d_z_lattice, m->vp_alpha_bars, m->vp_betas, B, m->T, d_lattice);
+                       d_len0, d_z_lattice, m->vp_alpha_bars, m->vp_betas, B, m->T, d_lattice, m->status);
     ARREAU_CHECK_HIP(hipGetLastError());
     if (N > 0) {
         hipLaunchKernelGGL(reverse_atoms_kernel, dim3((N + 3) / 4), dim3(256), 0, s, d_frac, d_types, d_t, d_off, B, N,
-                           d_eps, d_logits, d_z_frac, d_u_types, m->ve_sigmas, m->q1t, m->qmats, m->S, m->T);
+                           d_eps, d_logits, d_z_frac, d_u_types, m->ve_sigmas, m->q1t, m->qmats, m->S, m->T, m->status);
         ARREAU_CHECK_HIP(hipGetLastError());
     }
     return ARREAU_OK;

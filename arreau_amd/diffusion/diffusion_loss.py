@@ -174,6 +174,7 @@ class DiffusionLoss(nn.Module):
                 done += 1
                 if done >= n_steps:
                     break
+        eng.check_status()  # sticky device flags (non-finite outputs, clamped indices): raise instead of returning them
         atomic_numbers = atomic_number_indexes_to_atomic_numbers(z_table, types_d.cpu().numpy())
         return SampleResult(num_atoms=num_atoms.numpy(), frac_x=frac_d.cpu().numpy().astype(np.float64),
                             atomic_numbers=atomic_numbers, lattice=lattice_d.cpu().numpy().astype(np.float64))

@@ -85,6 +85,57 @@ class HipEngine:
             pass
 
     # ------------------------------------------------------------------------------------------
+    def status(self, reset=False):
+        """Sticky device-side condition flags + the kernel families the last predict_scores launched
+        (arreau_model_status; synchronises the stream)."""
+        st = _hip.Status()
+        _hip.check(_hip.lib().arreau_model_status(self._handle, ctypes.byref(st), int(bool(reset)),
+                                                   _hip.stream_ptr(self.device)), "arreau_model_status")
+        return {"flags": int(st.flags), "edge_kernel": _hip.EDGE_KERNELS.get(st.edge_kernel, "none"),
+                "mlp_kernel": _hip.MLP_KERNELS.get(st.mlp_kernel, "none"), "edge_variant": int(st.edge_kernel),
+                "mlp_variant": int(st.mlp_kernel), "conv_variant": int(st.conv_kernel)}
+
+    def check_status(self, reset=True):
+        """Raise if a kernel flagged a condition under which its results must not be trusted."""
+        st = self.status(reset=reset)
+        f = st["flags"]
+        if f:
+            why = []
+            if f & _hip.STATUS_NONFINITE:
+                why.append("a network output is inf/NaN (an activation left the fp16 range of the fp16x3 kernels, "
+                           "or the inputs/weights are non-finite); ARREAU_EDGE_VARIANT=3 ARREAU_MLP_VARIANT=1 selects the "
+                           "full-range bf16x6 kernels")
+            if f & _hip.STATUS_BAD_TIMESTEP:
+                why.append("a timestep index was outside the schedule")
+            if f & _hip.STATUS_BAD_TYPE:
+                why.append("an atom-type index was outside [0, num_atomic_states)")
+            raise _hip.ArreauHipError("arreau_hip status flags %d: %s" % (f, "; ".join(why)))
+        return st
+
+    def set_variant(self, edge=-1, mlp=-1):
+        """Select the arithmetic of the dense kernels (edge: 0 fp32 MFMA, 3 bf16x6, 4 fp16x3; mlp: 0 fp32 MFMA,
+        1 bf16x6, 2/3 fp16x3); -1 keeps."""
+        _hip.check(_hip.lib().arreau_model_set_variant(self._handle, int(edge), int(mlp)), "arreau_model_set_variant")
+
+    def ponita_forward(self, x, vec, lattice, offsets, edges):
+        """The inner operator seam (PonitaFiberBundle.forward on the reference's batch attributes).
+        x [N,S+74], vec [N,4,3], lattice [B,3,3] f32; offsets [B+1] i32; edges = slot arrays (deg, src, dir, dist).
+        Returns (logits [N,S], vec_out [N,1,3], global_scalar [B,3])."""
+        dev = self.device
+        N, B = x.shape[0], lattice.shape[0]
+        if x.shape[1] != self.S + 74 or tuple(vec.shape) != (N, 4, 3):
+            raise ValueError(f"x must be [N,{self.S + 74}] and vec [N,4,3]; got {tuple(x.shape)}, {tuple(vec.shape)}")
+        logits = torch.empty((N, self.S), device=dev, dtype=torch.float32)
+        vec_out = torch.empty((N, 1, 3), device=dev, dtype=torch.float32)
+        gscalar = torch.empty((B, 3), device=dev, dtype=torch.float32)
+        ws = self.workspace(N, B)
+        deg, src, direction, dist = edges
+        _hip.check(_hip.lib().arreau_ponita_forward(
+            self._handle, _hip.ptr(x), _hip.ptr(vec), _hip.ptr(lattice), _hip.ptr(offsets), B, N, _hip.ptr(deg),
+            _hip.ptr(src), _hip.ptr(direction), _hip.ptr(dist), _hip.ptr(logits), _hip.ptr(vec_out), _hip.ptr(gscalar),
+            _hip.ptr(ws), ws.numel(), _hip.stream_ptr(dev)), "arreau_ponita_forward")
+        return logits, vec_out, gscalar
+
     def workspace(self, N, B):
         if self._ws is None or N > self._ws_cap[0] or B > self._ws_cap[1]:
             capN, capB = max(N, self._ws_cap[0]), max(B, self._ws_cap[1])

@@ -61,20 +61,9 @@ def generate_n_crystals(sample_fn: Callable[[int, int], SampleResult], num_cryst
 
 
 def save_sample_results(crystals: SampleResult, filename: str):
-    """Same dataset names as the reference's crystals.h5 group (process_generated_crystals.py:8-15);
-    HDF5 when h5py is importable, otherwise .npz with identical keys."""
-    os.makedirs(os.path.dirname(os.path.abspath(filename)), exist_ok=True)
-    fields = dict(frac_x=crystals.frac_x, atomic_numbers=crystals.atomic_numbers, lattice=crystals.lattice,
-                  idx_start=crystals.idx_start, num_atoms=crystals.num_atoms)
-    if filename.endswith((".h5", ".hdf5")):
-        import h5py  # raises if missing: the caller asked for HDF5 explicitly
-        with h5py.File(filename, "w") as fh:
-            group = fh.create_group("crystals")
-            for k, v in fields.items():
-                group.create_dataset(k, data=v)
-    else:
-        np.savez(filename, **fields)
-    return filename
+    """The reference's crystals.h5 layout (diffusion/inference/process_generated_crystals.py:8-15)."""
+    from .diffusion.inference.process_generated_crystals import save_sample_results_to_hdf5
+    return save_sample_results_to_hdf5(crystals, filename)
 
 
 def main():
@@ -85,16 +74,30 @@ def main():
     ap.add_argument("--num_atoms", type=int, default=4)
     ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--out", type=str, default="out/crystals.npz")
+    ap.add_argument("--seed", type=int, default=None, help="seed of the host/device generators (rank is added)")
     args = ap.parse_args()
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # ARREAU_GENERATE_BACKEND=gloo + ARREAU_GENERATE_ONE_DEVICE=1 rehearse several ranks on a one-GPU box (the only
+    # communication is the final gather of host arrays, so the backend is not on the data path)
+    if os.environ.get("ARREAU_GENERATE_ONE_DEVICE", "0") == "1":
+        local_rank = 0
+    backend = os.environ.get("ARREAU_GENERATE_BACKEND", "nccl")
     torch.cuda.set_device(local_rank)
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
     from .diffusion.inference.visualize_crystal import VisualizationSetting
     from .lightning_wrappers.diffusion import PONITA_DIFFUSION
     model = PONITA_DIFFUSION.load_from_checkpoint(args.model_path, map_location=f"cuda:{local_rank}", strict=False)
+    if args.seed is not None:
+        import numpy as np
+        torch.manual_seed(args.seed + rank)
+        np.random.seed(args.seed + rank)
     fn = lambda n, b: model.sample(n, b, VisualizationSetting.NONE, False)
     res = generate_n_crystals(fn, args.num_crystals, args.num_atoms, args.batch, rank, world)
     if rank == 0:

@@ -94,33 +94,35 @@ class PONITA_DIFFUSION(nn.Module):
     def forward(self, graph):
         """model(batch) of diffusion_loss.py:183-189 / PonitaFiberBundle.forward (ponita.py:88-123).
         `graph` carries x [N,S+74], vec [N,4,3], edge_index [2,E] (sender, receiver; receiver-sorted),
-        dists [E], inter_atom_direction [E,3], lattice [B,3,3], batch [N], num_atoms [B].  Returns the
+        dists [E], inter_atom_direction [E,3], lattice [B,3,3], batch [N] (sorted), num_atoms [B].  Returns the
         reference's 5-tuple (logits [N,S], vec [N,1,3], global_scalar [B,3], None, [None]*L).
 
-        The engine consumes the sampler state, so the node features are decoded back to it: class index
-        = argmax of the one-hot block, per-crystal features from the first atom of each crystal."""
+        The tensors are consumed as they are (arreau_ponita_forward embeds the given x and vec with the general
+        x . W^T): nothing is decoded back to a sampler state, so soft type vectors, per-atom time embeddings or a
+        lattice that disagrees with the length features give what the reference network gives for them."""
         eng = self.engine()
-        S = self.num_atomic_states
-        x = graph.x
-        n_cpu = torch.as_tensor(graph.num_atoms).to("cpu", torch.int64)
-        first = (torch.cumsum(n_cpu, 0) - n_cpu).to(x.device)
-        types = x[:, :S].argmax(dim=1)
-        t_emb = x[first, S:S + 64]
-        lengths = x[first, S + 65:S + 68]
-        angles = x[first, S + 68:S + 71]
-        frac = graph.vec[:, 0, :]
-        # the time feature is a function of betas[t]; recover t by matching the embedding
-        betas = self.diffusion_loss.lattice_diffusion.betas.to(x.device, torch.float64)
-        w = self.t_emb.gaussian_fourier_proj_w.to(x.device, torch.float64)
-        table = torch.sin(betas[:, None] * w[None, :] * 2 * np.pi)
-        t_c = torch.cdist(t_emb[:, :32].to(torch.float64), table).argmin(dim=1)
         dev = eng.device
-        edges = eng.edges_to_slots(graph.edge_index, graph.dists, graph.inter_atom_direction, x.shape[0])
-        eps, logits, len0 = eng.predict_scores(
-            frac.to(dev, torch.float32).contiguous(), types.to(dev, torch.int32).contiguous(),
-            lengths.to(dev, torch.float32).contiguous(), angles.to(dev, torch.float32).contiguous(),
-            t_c.to(dev, torch.int32).contiguous(), crystal_offsets(n_cpu, dev), edges=edges)
-        return logits, eps.unsqueeze(1), len0, None, [None] * self.model.num_layers
+        x = graph.x
+        N = x.shape[0]
+        num_atoms = getattr(graph, "num_atoms", None)
+        batch = getattr(graph, "batch", None)
+        if num_atoms is None:
+            if batch is None:
+                raise ValueError("graph needs num_atoms or batch")
+            num_atoms = torch.bincount(torch.as_tensor(batch).to("cpu", torch.int64))
+        n_cpu = torch.as_tensor(num_atoms).to("cpu", torch.int64)
+        if int(n_cpu.sum()) != N:
+            raise ValueError("num_atoms does not add up to the number of nodes")
+        if batch is not None:
+            expect = torch.arange(n_cpu.numel()).repeat_interleave(n_cpu)
+            if not torch.equal(torch.as_tensor(batch).to("cpu", torch.int64), expect):
+                raise ValueError("graph.batch must list the atoms of each crystal contiguously, crystals in order")
+        f32 = lambda t: torch.as_tensor(t).to(dev, torch.float32).contiguous()
+        edges = eng.edges_to_slots(graph.edge_index, graph.dists, graph.inter_atom_direction, N)
+        logits, vec_out, gscalar = eng.ponita_forward(f32(x), f32(graph.vec), f32(graph.lattice),
+                                                      crystal_offsets(n_cpu, dev), edges)
+        eng.check_status()
+        return logits, vec_out, gscalar, None, [None] * self.model.num_layers
 
     @torch.no_grad()
     def sample(self, num_atoms_per_sample, num_samples_in_batch: int,

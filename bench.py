@@ -1,21 +1,27 @@
 #!/usr/bin/env python3
 """Benchmark of the reverse-diffusion sampling step on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W          (N = 1)
+    python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
-A "step" is one iteration of the sampling loop (diffusion/diffusion_loss.py:318-347 of the reference)
-over one batch: predict_scores (PBC neighbour list + Ponita score network) + the three noise draws +
-the reverse updates.  Workload at every N: BASELINE.json configs[1] per GPU -- 256 crystals x 20 atoms,
-T = 1000, fp32, synthetic 1.17M-parameter checkpoint (C=128, O=16, D=256, L=5, S=90), state drawn like
-the sampler's start.  Crystals are independent, so ranks hold disjoint sub-batches and there is no
-data-path collective (weak scaling); RCCL is used only for the timing barrier / max-over-ranks.
+Both forms run N ranks, one per GPU: with `--gpus N > 1` and no WORLD_SIZE in the environment bench.py starts the N
+rank processes itself (before anything touches a GPU), otherwise it is one rank of an existing launch.
+
+A "step" is one iteration of the sampling loop (diffusion/diffusion_loss.py:318-347 of the reference) over one batch:
+predict_scores (PBC neighbour list + Ponita score network) + the three noise draws + the reverse updates.  Workload at
+every N (default): BASELINE.json configs[1] per GPU -- 256 crystals x 20 atoms, T = 1000, fp32, synthetic
+1.17M-parameter checkpoint (C=128, O=16, D=256, L=5, S=90), state drawn like the sampler's start.  `--config c1|c3|c4`
+selects the other BASELINE configurations (c1: 1 crystal x 8 atoms, T = 100; c3: 1024 x 20 per GPU; c4: 1024 x 64).
+Crystals are independent, so ranks hold disjoint sub-batches and there is no data-path collective (weak scaling); the
+process group is used only for the timing barrier / max-over-ranks.
 
 Prints ONE JSON line on rank 0 (see the keys at the bottom).
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -25,12 +31,14 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: HBM3E 8 TB/s (spec)
 MFMA_F32_PEAK_TFLOPS = 157.3  # MI355X_MICROARCH.md: fp32-input MFMA = vector peak
-MFMA_BF16_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 MFMA (spec)
-# The edge kernel evaluates every fp32 product as six bf16 MFMA products (exact 8+8+8-bit operand splits,
-# fp32 accumulation), so its matrix-pipe roof in fp32-equivalent FLOP/s is the bf16 peak / 6.
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # MI355X_MICROARCH.md: dense bf16 / fp16 MFMA (spec)
+# bf16x6: every fp32 product as six bf16 MFMA products -> roof in fp32-equivalent FLOP/s = 16-bit peak / 6
 BF16X6_EQUIV_PEAK_TFLOPS = MFMA_BF16_PEAK_TFLOPS / 6.0
 # default kernels: three fp16 MFMA products per fp32 product (two 11-bit operand planes) -> fp16 peak / 3
 F16X3_EQUIV_PEAK_TFLOPS = MFMA_BF16_PEAK_TFLOPS / 3.0
+
+CONFIGS = {  # name -> (crystals per GPU, atoms per crystal, num_timesteps)
+    "c1": (1, 8, 100), "c2": (256, 20, 1000), "c3": (1024, 20, 1000), "c4": (1024, 64, 1000)}
 
 
 def edge_kernel_flops_per_row(C=128, D=256, L=5):
@@ -85,30 +93,126 @@ def host_cores():
     return int(os.environ.get("ARREAU_CPU_THREADS", min(n, 32)))
 
 
-def main():
+def parse_args(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch-per-gpu", type=int, default=256, help="crystals per GPU (configs[1]: 256)")
-    ap.add_argument("--atoms", type=int, default=20, help="atoms per crystal (configs[1]: 20)")
+    ap.add_argument("--config", choices=sorted(CONFIGS), default=None, help="BASELINE configuration (default c2)")
+    ap.add_argument("--batch-per-gpu", type=int, default=None, help="crystals per GPU (configs[1]: 256)")
+    ap.add_argument("--atoms", type=int, default=None, help="atoms per crystal (configs[1]: 20)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-fp32-variant", action="store_true", help="skip the second timed loop on the fp32-MFMA kernels")
     ap.add_argument("--cpu-steps", type=int, default=2)
-    args = ap.parse_args()
+    args = ap.parse_args(argv)
+    B, n, T = CONFIGS[args.config or "c2"]
+    args.batch_per_gpu = args.batch_per_gpu or B
+    args.atoms = args.atoms or n
+    args.T = T
+    return args
+
+
+# --------------------------------------------------------------------------------------------------------------
+# self-launch: `python bench.py --gpus N` (no torchrun) starts N rank processes, one per GPU
+# --------------------------------------------------------------------------------------------------------------
+def launch_ranks(n, argv, stub=False):
+    """Start `n` copies of this script as ranks 0..n-1 (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their
+    environment) BEFORE this process touches a GPU; rank 0's stdout (the JSON line) is passed through.  Returns the
+    exit code (non-zero if any rank failed; the others are then stopped by PID)."""
+    if not stub:
+        import torch
+        have = torch.cuda.device_count()  # does not initialise the GPU runtime in this process
+        if have < n:
+            log(f"--gpus {n} requested but only {have} GPU(s) are visible")
+            return 2
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), ARREAU_BENCH_CHILD="1")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + list(argv), env=env,
+                                      stdout=None if r == 0 else subprocess.DEVNULL))
+    rc = 0
+    live = list(procs)
+    while live:
+        time.sleep(0.2)
+        for p in list(live):
+            code = p.poll()
+            if code is None:
+                continue
+            live.remove(p)
+            if code != 0 and rc == 0:
+                rc = code
+                for q in live:  # a failed rank leaves the others waiting at a barrier: stop them (exact PIDs)
+                    q.terminate()
+    return rc
+
+
+def main():
+    args = parse_args()
+    stub = os.environ.get("ARREAU_BENCH_STUB", "0") == "1"  # CPU rehearsal of the launcher / timing protocol (tests)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(launch_ranks(args.gpus, sys.argv[1:], stub=stub))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if stub:
+        return run_stub(args, rank, world)
+    return run_rank(args, rank, local_rank, world)
+
+
+def run_stub(args, rank, world):
+    """The launcher / barrier / max-over-ranks protocol with a stand-in step on the CPU (gloo): what the world_size-2
+    CPU test exercises; prints the same JSON skeleton."""
+    import torch
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo")
+    for _ in range(args.warmup):
+        time.sleep(0.001)
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        time.sleep(0.002 * (1 + rank))  # rank 1 is slower: the reported time must be the max
+    local = time.perf_counter() - t0  # this rank's own work, before it waits for the others
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    per_rank = [local]
+    if world > 1:
+        tt = torch.tensor([local, elapsed], dtype=torch.float64)
+        gathered = [torch.zeros_like(tt) for _ in range(world)]
+        dist.all_gather(gathered, tt)
+        per_rank = [float(g[0]) for g in gathered]
+        elapsed = max(float(g[1]) for g in gathered)
+    if rank == 0:
+        print(json.dumps({"metric": "stub", "value": world * args.batch_per_gpu * args.steps / elapsed, "n_gpus": world,
+                          "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+                          "per_rank_ms": [1e3 * e / args.steps for e in per_rank]}), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def run_rank(args, rank, local_rank, world):
+    import ctypes
 
     import numpy as np
     import torch
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus != world and world > 1:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
     # ARREAU_BENCH_BACKEND=gloo + ARREAU_BENCH_ONE_DEVICE=1 rehearse the multi-rank path on a one-GPU box
     backend = os.environ.get("ARREAU_BENCH_BACKEND", "nccl")
     one_device = os.environ.get("ARREAU_BENCH_ONE_DEVICE", "0") == "1"
+    if not one_device and local_rank >= torch.cuda.device_count():
+        raise SystemExit(f"rank {rank}: LOCAL_RANK {local_rank} but {torch.cuda.device_count()} GPU(s) visible")
     dev = torch.device("cuda", 0 if one_device else local_rank)
     torch.cuda.set_device(dev)
     dist = None
@@ -125,10 +229,10 @@ def main():
     from arreau_amd.checkpoint import make_synthetic_model
     from arreau_amd.diffusion.diffusion_helpers import crystal_offsets
 
-    S, T = 90, 1000
+    S, T = 90, args.T
     B, n = args.batch_per_gpu, args.atoms
     N = B * n
-    model = make_synthetic_model(S=S, seed=1234).to(dev)  # same weights on every rank
+    model = make_synthetic_model(S=S, seed=1234, num_timesteps=T).to(dev)  # same weights on every rank
     eng = model.engine()
 
     # sampler-start state (diffusion_loss.py:294-316), different crystals per rank
@@ -173,7 +277,19 @@ def main():
         _, _, _, edges = eng.predict_scores(frac_d, types_d, len_d, ang_d, t_d, off_d, return_edges=True)
         return int(edges[0].sum().item())
 
-    log(f"rank {rank}: model packed, state ready (B={B}, n={n}); warm-up {args.warmup} steps")
+    local_elapsed = [0.0]
+
+    def timed_loop(steps):
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            one_step()
+        torch.cuda.synchronize(dev)
+        local_elapsed[0] = time.perf_counter() - t0  # this rank's own work, before it waits for the others
+        sync()
+        return time.perf_counter() - t0
+
+    log(f"rank {rank}: model packed, state ready (B={B}, n={n}, T={T}); warm-up {args.warmup} steps")
     for _ in range(args.warmup):
         one_step()
     torch.cuda.synchronize(dev)
@@ -181,22 +297,42 @@ def main():
     t_d.fill_(timestep[0])
     e_start = degree_sum()
     _hip.check(_hip.lib().arreau_profile_edge_kernel(1), "profile on")
-    sync()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        one_step()
-    sync()
-    elapsed = time.perf_counter() - t0
-    import ctypes
+    elapsed = timed_loop(args.steps)
     mean_ms, launches = ctypes.c_double(), ctypes.c_int64()
     _hip.check(_hip.lib().arreau_edge_kernel_time_ms(ctypes.byref(mean_ms), ctypes.byref(launches)), "edge time")
     _hip.check(_hip.lib().arreau_profile_edge_kernel(0), "profile off")
     e_end = degree_sum()
+    status = eng.check_status()  # raises on non-finite outputs / clamped indices; names the kernels that really ran
 
+    per_rank = [local_elapsed[0]]
     if dist is not None:
-        tt = torch.tensor([elapsed], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+        tt = torch.tensor([local_elapsed[0], elapsed], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
+        gathered = [torch.zeros_like(tt) for _ in range(world)]
+        dist.all_gather(gathered, tt)
+        per_rank = [float(g[0]) for g in gathered]
+        elapsed = max(float(g[1]) for g in gathered)  # barrier-to-barrier time, MAX over ranks
+
+    # second, short timed loop on the exact fp32-MFMA kernels (v_mfma_f32_32x32x2_f32): what the same step costs
+    # without the split-precision scheme, priced against the 157.3 TFLOP/s fp32 matrix peak
+    fp32_variant = None
+    if not args.no_fp32_variant and world == 1:
+        eng.set_variant(0, 0)
+        k32 = max(3, min(10, args.steps))
+        for _ in range(2):
+            one_step()
+        _hip.check(_hip.lib().arreau_profile_edge_kernel(1), "profile on")
+        el32 = timed_loop(k32)
+        m32, l32 = ctypes.c_double(), ctypes.c_int64()
+        _hip.check(_hip.lib().arreau_edge_kernel_time_ms(ctypes.byref(m32), ctypes.byref(l32)), "edge time")
+        _hip.check(_hip.lib().arreau_profile_edge_kernel(0), "profile off")
+        st32 = eng.check_status()
+        eng.set_variant(4, 3)
+        e32 = degree_sum()
+        fl32 = e32 * 16 * edge_kernel_flops_per_row()
+        fp32_variant = {"kernels": [st32["edge_kernel"], st32["mlp_kernel"]], "steps": k32,
+                        "ms_per_step": 1e3 * el32 / k32, "edge_avg_launch_ms": m32.value,
+                        "edge_tflops": fl32 / (m32.value * 1e-3) / 1e12 if m32.value > 0 else 0.0,
+                        "frac_of_157.3": (fl32 / (m32.value * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS) if m32.value > 0 else 0.0}
 
     if rank == 0:
         log(f"timed region: {args.steps} steps in {elapsed:.3f} s")
@@ -206,13 +342,13 @@ def main():
         edge_flops = e_mean * 16 * edge_kernel_flops_per_row()
         edge_tflops = edge_flops / (mean_ms.value * 1e-3) / 1e12 if mean_ms.value > 0 else 0.0
         step_flops = step_flops_per_atom() * N * (e_mean / (8.0 * N))  # scaled by the edge density actually seen
-        variant = int(os.environ.get("ARREAU_EDGE_VARIANT", "4"))
-        if variant == 4:
+        ran = status["edge_kernel"]
+        if ran == "fp16x3":
             edge_kernel_name = ("edge_kernel_f16x3<128,256> (pair invariants + basis MLP + 5 kernel projections; "
                                 "fp32 products as 3 fp16 MFMA products, fp32 accumulate)")
             edge_peak = F16X3_EQUIV_PEAK_TFLOPS
             edge_peak_note = "fp32-equivalent roof of the split scheme: dense fp16 MFMA 2500 TFLOP/s / 3 products"
-        elif variant == 3:
+        elif ran == "bf16x6":
             edge_kernel_name = ("edge_kernel_bf16x6<128,256> (pair invariants + basis MLP + 5 kernel projections; "
                                 "fp32 products as 6 bf16 MFMA products, fp32 accumulate)")
             edge_peak = BF16X6_EQUIV_PEAK_TFLOPS
@@ -230,18 +366,20 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": ms_per_step,
+            "per_rank_ms": [1e3 * e / args.steps for e in per_rank],
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
             "dtype": "f32",
-            "dtype_note": "fp32 inputs/outputs/accumulation; each fp32 product of the dense layers is evaluated as 3 fp16 "
-                          "MFMA products (two 11-bit operand planes, f16x3.h) -- fp32-grade accuracy, parity 1e-5 vs the "
-                          "fp32 CPU path (tests/test_gpu_parity.py); ARREAU_EDGE_VARIANT=0 ARREAU_MLP_VARIANT=0 selects "
-                          "the plain fp32-MFMA kernels",
+            "dtype_note": "fp32 inputs/outputs/accumulation; kernels that ran (reported by the library, "
+                          f"arreau_model_status): edge={status['edge_kernel']}, mlp={status['mlp_kernel']}.  fp16x3 = each "
+                          "fp32 product of the dense layers as 3 fp16 MFMA products (two 11-bit operand planes, f16x3.h); "
+                          "measured deviations from the fp32 / fp64 CPU oracle: profiles/parity_r02.json; "
+                          "roofline.fp32_mfma_variant = the same step on the plain fp32-MFMA kernels",
             "data": "synthetic",
             "config": {
-                "workload": f"{config_label(B, n)} per GPU: batch={B} crystals x {n} atoms, 1000-step sampler "
-                            f"(T=1000, 999 network evaluations per crystal), fp32",
+                "workload": f"{config_label(B, n)} per GPU: batch={B} crystals x {n} atoms, {T}-step sampler "
+                            f"(T={T}, {T - 1} network evaluations per crystal), fp32",
                 "crystals_per_gpu": B, "atoms_per_crystal": n, "num_timesteps": T,
                 "checkpoint": "synthetic 1.17M-param (S=90,C=128,O=16,D=256,L=5,k=8,R=5), seed 1234",
                 "edges_per_atom_start": e_start / N, "edges_per_atom_end": e_end / N,
@@ -257,19 +395,22 @@ def main():
                 "peak_note": edge_peak_note, "frac_of_fp32_mfma_peak": edge_tflops / MFMA_F32_PEAK_TFLOPS,
                 "avg_launch_ms": mean_ms.value, "launches_timed": int(launches.value),
                 "algorithmic_flops_per_launch": edge_flops,
+                "fp32_mfma_variant": fp32_variant,
             },
         }
         if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(model, B, n, args.cpu_steps)
+            out["cpu_baseline"] = cpu_baseline(model, B, n, T, args.cpu_steps)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
 
 
-def cpu_baseline(model, B, n, steps):
-    """The oracle (CPU restatement of the reference step, pure PyTorch, all host cores) timed on a bounded
-    sample of the SAME workload: `steps` full steps of the B x n batch after one warm-up step."""
+def cpu_baseline(model, B, n, T, steps):
+    """The oracle (CPU restatement of the reference step, pure PyTorch, all host cores) timed on a bounded sample of
+    the SAME workload: for the default batch `steps` full steps after one warm-up; for config 1 (1 crystal x 8 atoms,
+    T = 100) the whole 99-step sampler, as SURVEY 8(d) asks; for batches too large for a few seconds per CPU step
+    (config 3/4) a slice of the crystals at the same atoms per crystal, which says so in `sample`."""
     import numpy as np
     import torch
     import torch.nn.functional as F
@@ -279,34 +420,50 @@ def cpu_baseline(model, B, n, steps):
     cores = host_cores()
     torch.set_num_threads(cores)
     log(f"cpu baseline: {cores} threads")
+    Bc = B
+    note = ""
+    while Bc * n > 256 * 20 and Bc > 1:  # bound one CPU step to the cost of the default batch
+        Bc //= 2
+    if Bc != B:
+        note = f" -- a {Bc}-crystal slice of the {B}-crystal batch, same atoms per crystal"
+    full_sampler = B * n <= 64  # config 1: run every timestep
     res = {}
     for dtype, tag in ((torch.float32, "f32"), (torch.float64, "f64")):
         om = oracle_from_module(model, dtype)
-        S, T = om.hp["S"], om.hp["T"]
+        S = om.hp["S"]
         torch.manual_seed(0)
         np.random.seed(0)
-        frac, types, lengths, angles, num_atoms = OS.init_state(om, n, B, dtype)
-        batch = torch.arange(B).repeat_interleave(n)
-        N = B * n
-        times = []
-        t = T - 1
-        for it in range(steps + 1):
+        frac, types, lengths, angles, num_atoms = OS.init_state(om, n, Bc, dtype)
+        batch = torch.arange(Bc).repeat_interleave(n)
+        N = Bc * n
+        if full_sampler:
             t0 = time.perf_counter()
-            scores = OS.predict_scores(om, frac, F.one_hot(types, S), torch.full((N,), t), num_atoms, lengths,
-                                       angles, batch)
-            noise = OS.StepNoise(torch.randn(B, 3, dtype=dtype), torch.randn(N, 3, dtype=dtype),
-                                 torch.rand(N, S, dtype=dtype))
-            frac, types, lengths, _ = OS.reverse_step(om, frac, types, lengths, angles, num_atoms, scores, t, noise)
-            times.append(time.perf_counter() - t0)
-            log(f"cpu baseline {tag} step {it}: {times[-1]:.2f} s")
-            t -= 1
-        per_step = float(np.mean(times[1:]))
-        res[tag] = B / per_step
-        if tag == "f32" and per_step * (steps + 1) > 40:
+            OS.sample(om, n, Bc, dtype, state=(frac, types, lengths, angles, num_atoms))
+            total = time.perf_counter() - t0
+            per_step = total / (T - 1)
+            log(f"cpu baseline {tag}: {T - 1} steps (whole sampler) in {total:.2f} s")
+        else:
+            times = []
+            t = T - 1
+            for it in range(steps + 1):
+                t0 = time.perf_counter()
+                scores = OS.predict_scores(om, frac, F.one_hot(types, S), torch.full((N,), t), num_atoms, lengths,
+                                           angles, batch)
+                noise = OS.StepNoise(torch.randn(Bc, 3, dtype=dtype), torch.randn(N, 3, dtype=dtype),
+                                     torch.rand(N, S, dtype=dtype))
+                frac, types, lengths, _ = OS.reverse_step(om, frac, types, lengths, angles, num_atoms, scores, t, noise)
+                times.append(time.perf_counter() - t0)
+                log(f"cpu baseline {tag} step {it}: {times[-1]:.2f} s")
+                t -= 1
+            per_step = float(np.mean(times[1:]))
+        res[tag] = Bc / per_step
+        if tag == "f32" and not full_sampler and per_step * (steps + 1) > 40:
             break  # keep the default run bounded on slow hosts
+    what = (f"the whole {T - 1}-step sampler of batch={Bc} x {n} atoms" if full_sampler
+            else f"{steps} full steps of batch={Bc} x {n} atoms after 1 warm-up")
     return {
         "value": res["f32"], "unit": "crystal-steps/s", "cores": cores, "kind": "port",
-        "sample": f"{steps} full steps of batch={B} x {n} atoms after 1 warm-up (oracle, torch CPU, {cores} threads)",
+        "sample": f"{what} (oracle, torch CPU, {cores} threads){note}",
         "value_f64": res.get("f64"),
     }
 

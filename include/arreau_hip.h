@@ -106,6 +106,33 @@ int arreau_model_create(const arreau_config* cfg, const arreau_state_dict* h_sd,
 void arreau_model_destroy(arreau_model* model);
 int arreau_model_config(const arreau_model* model, arreau_config* out_cfg);
 
+/* Sticky condition bits collected on the device while kernels run (nothing is checked on the host per call, so
+ * the launch functions stay asynchronous).  A set bit means results since the last reset must not be trusted:
+ *   NONFINITE    a network output (eps, logits, pred_lengths_0) was inf/NaN -- this is how an activation beyond the
+ *                fp16 range of the split-precision kernels (|v| >= 65520) surfaces: the planes overflow to inf and the
+ *                value propagates as NaN instead of being clamped silently;
+ *   BAD_TIMESTEP a timestep outside [0, T] (predict_scores) / [1, T] (reverse_step) was clamped;
+ *   BAD_TYPE     an atom-type index outside [0, S) was clamped.
+ * edge_kernel / mlp_kernel / conv_kernel name the kernel family the last arreau_predict_scores really launched
+ * (edge: 0-2 fp32 MFMA, 3 bf16x6, 4 fp16x3; mlp: 0 fp32 MFMA, 1 bf16x6, 2 fp16x3 32x32x16, 3 fp16x3 16x16x32;
+ * conv: 0 register form, 1 streamed form, 2 fused into the MLP kernel) -- e.g. 3/1 instead of 4/3 when a weight does not
+ * fit fp16.  The reference has no counterpart (Python raises on bad indices: F.one_hot, tensor indexing). */
+#define ARREAU_STATUS_NONFINITE 1
+#define ARREAU_STATUS_BAD_TIMESTEP 2
+#define ARREAU_STATUS_BAD_TYPE 4
+typedef struct arreau_status {
+    int32_t flags;
+    int32_t edge_kernel;
+    int32_t mlp_kernel;
+    int32_t conv_kernel;
+} arreau_status;
+/* Reads (and with reset != 0 clears) the status word; synchronises `stream`. */
+int arreau_model_status(const arreau_model* model, arreau_status* out, int32_t reset, void* stream);
+/* Selects the arithmetic of the dense kernels for this model (-1 keeps the current choice); the defaults come from
+ * the environment (ARREAU_EDGE_VARIANT, ARREAU_MLP_VARIANT) at arreau_model_create.  Used by the parity report and
+ * bench.py to time/compare the exact fp32-MFMA kernels against the default fp16x3 ones in one process. */
+int arreau_model_set_variant(arreau_model* model, int32_t edge_variant, int32_t mlp_variant);
+
 /* Scratch for one step over at most max_atoms atoms / max_crystals crystals. */
 size_t arreau_workspace_bytes(const arreau_config* cfg, int64_t max_atoms, int64_t max_crystals);
 
@@ -170,6 +197,21 @@ int arreau_predict_scores(const arreau_model* model,
                           int32_t use_given_edges,
                           int32_t* d_deg, int32_t* d_src, float* d_dir, float* d_dist,
                           float* d_eps, float* d_logits, float* d_len0,
+                          void* d_workspace, size_t workspace_bytes, void* stream);
+
+/* The inner operator seam: `model(batch)` at diffusion/diffusion_loss.py:183-189, i.e. PonitaFiberBundle.forward
+ * (ponita/models/ponita.py:88-123) on the batch attributes the reference assembles at diffusion_loss.py:156-180:
+ *   d_x[N, S+74]   batch.x   scalar node features (any values: the embedding is the general x . W^T, :98)
+ *   d_vec[N,4,3]   batch.vec (fractional coordinate, then the three lattice rows; diffusion_loss.py:158)
+ *   d_lattice[B,3,3] batch.lattice (only the edge cosine features read it, transforms/invariants.py:82-85)
+ *   d_crystal_offsets[B+1]  CSR form of batch.batch / batch.num_atoms (atoms of a crystal contiguous)
+ *   slot-form edges (arreau_edges_to_slots converts batch.edge_index / dists / inter_atom_direction).
+ * Outputs: the reference's return tuple (ponita.py:123) without its None entries:
+ *   d_logits[N,S] (output_scalar), d_vec_out[N,1,3] (output_vec), d_global_scalar[B,3] (global_add_pool, :152). */
+int arreau_ponita_forward(const arreau_model* model, const float* d_x, const float* d_vec, const float* d_lattice,
+                          const int32_t* d_crystal_offsets, int32_t B, int32_t N,
+                          const int32_t* d_deg, const int32_t* d_src, const float* d_dir, const float* d_dist,
+                          float* d_logits, float* d_vec_out, float* d_global_scalar,
                           void* d_workspace, size_t workspace_bytes, void* stream);
 
 /* The four state updates of one loop iteration (diffusion/diffusion_loss.py:338-347):

@@ -1,0 +1,41 @@
+"""bench.py's own multi-rank launch (`python bench.py --gpus N` with no torchrun around it), rehearsed on the CPU with
+a stand-in step: N rank processes are started, meet at the barriers, and rank 0 reports n_gpus = N with the MAX over
+ranks as the step time."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def _run(args, **env):
+    e = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    e.update(env)
+    return subprocess.run([sys.executable, BENCH] + args, env=e, capture_output=True, text=True, timeout=180)
+
+
+def test_self_launch_two_ranks_stub():
+    p = _run(["--gpus", "2", "--steps", "5", "--warmup", "1"], ARREAU_BENCH_STUB="1")
+    assert p.returncode == 0, p.stderr
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1  # rank 0 only
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 5 and len(d["per_rank_ms"]) == 2
+    assert d["per_rank_ms"][1] > d["per_rank_ms"][0]  # the stub's rank 1 is slower ...
+    assert d["ms_per_step"] >= max(d["per_rank_ms"])  # ... and the reported time covers the slowest rank
+
+
+def test_self_launch_refuses_when_gpus_are_missing():
+    """Without the stub, asking for more GPUs than are visible must fail loudly (never a silent 1-GPU run)."""
+    import torch
+    want = torch.cuda.device_count() + 2
+    p = _run(["--gpus", str(want), "--steps", "1", "--warmup", "0"])
+    assert p.returncode != 0
+    assert "GPU(s) are visible" in p.stderr and not p.stdout.strip()
+
+
+def test_world_size_mismatch_is_an_error():
+    p = _run(["--gpus", "1", "--steps", "1", "--warmup", "0"], ARREAU_BENCH_STUB="1", WORLD_SIZE="2", RANK="0")
+    assert p.returncode != 0 and "WORLD_SIZE" in p.stderr

@@ -200,22 +200,84 @@ def test_predict_scores_own_neighbor_list(dev, small_model, num_atoms, sampler_l
 
 
 def test_forward_operator_seam(dev, small_model):
-    """PONITA_DIFFUSION.forward(graph) with the reference's batch attributes (diffusion_loss.py:156-189)."""
+    """PONITA_DIFFUSION.forward(graph) = arreau_ponita_forward on the reference's batch attributes
+    (diffusion_loss.py:156-189), first with the features the sampler assembles, then with features the sampler
+    could NOT have produced -- soft type vectors, a different time embedding per atom, perturbed per-crystal
+    scalars, vec rows that disagree with graph.lattice -- against the oracle's ponita_forward on the same tensors:
+    the seam consumes x and vec as given (general x . W^T), nothing is decoded back to a sampler state."""
     from types import SimpleNamespace
+    from oracle import ponita as OP
     m, om32, _ = small_model
     frac, types, lengths, angles, na = state = random_state(12, [5, 6], 21)
     t = 33
     x, cart, vec, lattice = OS.assemble_features(om32, frac, F.one_hot(types, 12), torch.full((11,), t), na, lengths,
                                                  angles)
     eps_o, logits_o, len0_o, (ei, dists, direction, _c, _l) = _oracle_scores(om32, *state, t)
-    graph = SimpleNamespace(x=x.float().to(dev), vec=vec.to(dev), edge_index=ei.to(dev), dists=dists.to(dev),
-                            inter_atom_direction=direction.to(dev), lattice=lattice.to(dev), num_atoms=na,
-                            batch=torch.arange(2).repeat_interleave(na).to(dev))
-    logits, vec_out, gscalar, gvec, edge_out = m(graph)
+    batch = torch.arange(2).repeat_interleave(na)
+    mk = lambda xx, vv: SimpleNamespace(x=xx.float().to(dev), vec=vv.to(dev), edge_index=ei.to(dev), dists=dists.to(dev),
+                                        inter_atom_direction=direction.to(dev), lattice=lattice.to(dev), num_atoms=na,
+                                        batch=batch.to(dev))
+    logits, vec_out, gscalar, gvec, edge_out = m(mk(x, vec))
     assert vec_out.shape == (11, 1, 3) and gvec is None and edge_out == [None] * 5
     assert (logits.cpu() - logits_o).abs().max() <= TOL * max(1.0, float(logits_o.abs().max()))
-    assert (vec_out.squeeze(1).cpu() - eps_o).abs().max() <= TOL
+    assert (vec_out.squeeze(1).cpu() - eps_o).abs().max() <= TOL * max(1.0, float(eps_o.abs().max()))
     assert (gscalar.cpu() - len0_o).abs().max() <= TOL * 6 * max(1.0, float(len0_o.abs().max()))
+    # features outside the sampler's image
+    g = torch.Generator().manual_seed(5)
+    x2 = x.float().clone()
+    x2[:, :12] = torch.softmax(torch.randn(11, 12, generator=g), dim=1)
+    x2[:, 12:76] = torch.randn(11, 64, generator=g)
+    x2[:, 76:] += 0.1 * torch.randn(11, 10, generator=g)
+    vec2 = vec.float() + 0.05 * torch.randn(vec.shape, generator=g)
+    lo, vo, go = OP.ponita_forward(om32.sd, om32.hp, x2, vec2, ei, dists, direction, lattice.float(), batch, batch[ei[0]],
+                                   om32.ori_grid)
+    logits, vec_out, gscalar, _, _ = m(mk(x2, vec2))
+    assert (logits.cpu() - lo).abs().max() <= TOL * max(1.0, float(lo.abs().max()))
+    assert (vec_out.cpu() - vo).abs().max() <= TOL * max(1.0, float(vo.abs().max()))
+    assert (gscalar.cpu() - go).abs().max() <= TOL * 6 * max(1.0, float(go.abs().max()))
+    assert (logits.cpu() - logits_o).abs().max() > 1e-3  # and it really is a different answer than the decoded state's
+    with pytest.raises(ValueError):  # atoms of a crystal must be contiguous
+        bad = mk(x, vec)
+        bad.batch = torch.tensor([0, 1] * 5 + [1]).to(dev)
+        m(bad)
+
+
+def test_status_flags_overflow_and_bad_indices(dev):
+    """No silent saturation: an activation beyond the fp16 range of the fp16x3 kernels becomes an inf plane, reaches the
+    outputs as NaN and sets the sticky NONFINITE flag, which HipEngine.check_status raises; the same model evaluates
+    fine on the full-range bf16x6 kernels.  Out-of-range type / timestep indices are flagged, not silently clamped."""
+    from arreau_amd import _hip
+    from arreau_amd.checkpoint import make_synthetic_model
+    m = make_synthetic_model(S=12, seed=7, num_timesteps=100)
+    with torch.no_grad():  # blow up the hidden units of the first ConvNext MLP: |linear_1 output| >> 65504
+        m.model.interaction_layers[0].linear_1.weight.mul_(1.5e5)
+    m = m.to(dev)
+    eng = m.engine()
+    state = random_state(12, [8, 8], 3)
+    f, ty, le, an, off = _to_dev(dev, *state)
+    t_c = torch.full((2,), 50, device=dev, dtype=torch.int32)
+    st0 = eng.status(reset=True)
+    assert st0["flags"] == 0
+    eps, logits, len0 = eng.predict_scores(f, ty, le, an, t_c, off)
+    st = eng.status()
+    assert st["edge_kernel"] == "fp16x3" and st["mlp_kernel"] == "fp16x3-16x16x32"
+    assert st["flags"] & _hip.STATUS_NONFINITE and not torch.isfinite(logits).all()
+    with pytest.raises(_hip.ArreauHipError):
+        eng.check_status()
+    assert eng.status()["flags"] == 0  # check_status resets
+    eng.set_variant(3, 1)  # bf16x6: full fp32 range
+    eps, logits, len0 = eng.predict_scores(f, ty, le, an, t_c, off)
+    st = eng.check_status()
+    assert st["edge_kernel"] == "bf16x6" and st["mlp_kernel"] == "bf16x6" and torch.isfinite(logits).all()
+    # indices
+    bad_ty = ty.clone()
+    bad_ty[3] = 12
+    eng.predict_scores(f, bad_ty, le, an, t_c, off)
+    assert eng.status(reset=True)["flags"] & _hip.STATUS_BAD_TYPE
+    bad_t = torch.full((2,), 101, device=dev, dtype=torch.int32)
+    eng.predict_scores(f, ty, le, an, bad_t, off)
+    assert eng.status(reset=True)["flags"] & _hip.STATUS_BAD_TIMESTEP
+    eng.close()
 
 
 def test_full_size_architecture_parity(dev, full_model):
@@ -351,6 +413,105 @@ def test_sample_ragged_batch(dev, small_model):
         m.sample([3, 8], 4, VisualizationSetting.NONE, False, max_steps=1)
 
 
+def test_ragged_batch_trajectory_parity(dev, small_model):
+    """Ragged batches (one atom count per crystal) against the oracle, whose predict_scores / reverse_step
+    take ragged num_atoms: six denoising steps with injected noise.  (1) teacher-forced: at every step the HIP scores
+    and updated state from the oracle's state; (2) free-running: the HIP trajectory from the same start and noise stays
+    on the oracle's (no type decision is near a tie for this seed)."""
+    from arreau_amd.diffusion.diffusion_helpers import crystal_offsets
+    m, om32, _ = small_model
+    S, counts = 12, [3, 8, 1, 5, 2]
+    frac, types, lengths, angles, na = random_state(S, counts, 17, sampler_like=True)
+    frac = frac % 1
+    B, N = len(counts), sum(counts)
+    batch = torch.arange(B).repeat_interleave(na)
+    off = crystal_offsets(na, dev)
+    eng = m.engine()
+    d = lambda v: v.to(dev).contiguous()
+    g = torch.Generator().manual_seed(3)
+    f_h, ty_h, le_h = d(frac.clone()), d(types.to(torch.int32)), d(lengths.clone())  # free-running HIP state
+    an = d(angles)
+    lat = torch.zeros(B, 3, 3, device=dev)
+    worst = 0.0
+    for t in (99, 98, 97, 3, 2, 1):
+        scores = OS.predict_scores(om32, frac, F.one_hot(types, S), torch.full((N,), t), na, lengths, angles, batch)
+        noise = OS.StepNoise(torch.randn(B, 3, generator=g), torch.randn(N, 3, generator=g), torch.rand(N, S, generator=g))
+        t_c = torch.full((B,), t, device=dev, dtype=torch.int32)
+        # (1) teacher-forced from the oracle's state
+        f, ty, le = d(frac.clone()), d(types.to(torch.int32)), d(lengths.clone())
+        eps, logits, len0 = eng.predict_scores(f, ty, le, an, t_c, off)
+        scale = max(1.0, float(scores[1].abs().max()))
+        assert (eps.cpu() - scores[0]).abs().max() <= TOL * max(1.0, float(scores[0].abs().max())), t
+        assert (logits.cpu() - scores[1]).abs().max() <= TOL * scale, t
+        assert (len0.cpu() - scores[2]).abs().max() <= TOL * max(counts) * max(1.0, float(scores[2].abs().max())), t
+        # (2) free-running HIP state, same noise
+        eps_h, logits_h, len0_h = eng.predict_scores(f_h, ty_h, le_h, an, t_c, off)
+        eng.reverse_step(f_h, ty_h, le_h, an, t_c, off, eps_h, logits_h, len0_h, d(noise.z_lattice), d(noise.z_frac),
+                         d(noise.u_types), lat)
+        frac, types, lengths, lat_o = OS.reverse_step(om32, frac, types, lengths, angles, na, scores, t, noise)
+        df = (f_h.cpu() - frac).abs()
+        worst = max(worst, float(torch.minimum(df, 1 - df).max()), float((le_h.cpu() - lengths).abs().max()))
+        assert torch.equal(ty_h.cpu().long(), types), t
+    assert worst <= 1e-4, worst  # six steps of accumulated rounding, no divergence
+    eng.check_status()
+
+
+def test_free_running_sampler_matches_oracle_sampler(dev, small_model):
+    """PONITA_DIFFUSION.sample(noise="reference") draws the initial state and the per-step noise from the host
+    generators in the reference's order (diffusion_loss.py:294-316; diffusion_helpers.py:79,193-197; d3pm.py:206), so
+    under the same seeds it walks the trajectory of the oracle's sampler: compared after 25 free-running steps."""
+    from arreau_amd.diffusion.inference.visualize_crystal import VisualizationSetting
+    m, om32, _ = small_model
+    n_per, B, steps = 6, 3, 25
+    torch.manual_seed(21)
+    np.random.seed(21)
+    f_o, ty_o, len_o, lat_o = OS.sample(om32, n_per, B, torch.float32, max_steps=steps)
+    torch.manual_seed(21)
+    np.random.seed(21)
+    res = m.sample(n_per, B, VisualizationSetting.NONE, False, noise="reference", max_steps=steps)
+    df = np.abs(res.frac_x - f_o.numpy().astype(np.float64))
+    assert np.minimum(df, 1 - df).max() <= 1e-4
+    np.testing.assert_allclose(res.lattice, lat_o.numpy(), atol=1e-4 * max(1.0, float(lat_o.abs().max())), rtol=0)
+    zs = np.asarray(m.z_table_zs.tolist())
+    assert np.array_equal(res.atomic_numbers, zs[ty_o.numpy()])
+
+
+def test_generate_two_ranks_through_the_real_sampler(dev, tmp_path):
+    """arreau_amd.generate (the role of main_diffusion_generate.py:52-94) driven end to end: a Lightning-format
+    checkpoint on disk, two ranks (gloo, sharing this box's one GPU), the real PONITA_DIFFUSION.sample on each, results
+    gathered on rank 0 in crystal order and written in the crystals.h5 layout.  Rank 0's crystals must equal, bit for
+    bit, the single-process run of the same slice under the same seed."""
+    import socket
+    import subprocess
+    import sys
+    from arreau_amd.checkpoint import make_synthetic_model, save_lightning_checkpoint
+    from arreau_amd.diffusion.inference.process_generated_crystals import get_one_crystal, load_sample_results_from_hdf5
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    ckpt = save_lightning_checkpoint(str(tmp_path / "last.ckpt"), make_synthetic_model(S=12, seed=3, num_timesteps=30))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    env.update(ARREAU_GENERATE_BACKEND="gloo", ARREAU_GENERATE_ONE_DEVICE="1", PYTHONPATH=root)
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    common = ["--model_path", ckpt, "--num_atoms", "4", "--batch", "2", "--seed", "5"]
+    out2 = str(tmp_path / "two" / "crystals.npz")
+    subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                    "127.0.0.1", "--master-port", str(port), "-m", "arreau_amd.generate", "--num_crystals", "6", "--out",
+                    out2] + common, check=True, env=env, cwd=root, timeout=600)
+    out1 = str(tmp_path / "one" / "crystals.npz")
+    subprocess.run([sys.executable, "-m", "arreau_amd.generate", "--num_crystals", "3", "--out", out1] + common,
+                   check=True, env=env, cwd=root, timeout=600)
+    two, one = load_sample_results_from_hdf5(out2), load_sample_results_from_hdf5(out1)
+    assert two.num_atoms.tolist() == [4] * 6 and two.idx_start.tolist() == [0, 4, 8, 12, 16, 20]
+    assert two.frac_x.shape == (24, 3) and two.lattice.shape == (6, 3, 3)
+    assert np.isfinite(two.frac_x).all() and (two.frac_x >= 0).all() and (two.frac_x <= 1).all()
+    assert set(two.atomic_numbers.tolist()) <= set(float(z) for z in list(range(1, 12)) + [2001])
+    for i in range(3):  # rank 0's slice = the single-process run
+        for a, b in zip(get_one_crystal(two, i), get_one_crystal(one, i)):
+            assert np.array_equal(a, b)
+    assert not np.array_equal(two.frac_x[:12], two.frac_x[12:])  # rank 1 sampled its own crystals
+
+
 def test_constant_atomic_symbols(dev, small_model):
     from arreau_amd.diffusion.inference.visualize_crystal import VisualizationSetting
     m, _, _ = small_model  # z table = 1..11 + mask
@@ -445,23 +606,48 @@ def test_many_ragged_crystals_persistent_edge_workgroups(dev, small_model):
     assert (len0.cpu() - len0_o).abs().max() <= TOL * scale * max(num_atoms)
 
 
-def test_rotated_lattice_invariance(dev, small_model):
-    """HIP-path port of the reference's integration check (exploration/verify_model_is_equivariant.py:11-18,
-    evaluated at EVAL_EQUIVARIANCE_TIMESTEP = 5, lightning_wrappers/diffusion.py:26): the same crystal with its cell
-    rotated by 90 degrees about x.  The network sees the cell only through (lengths, angles)
-    (diffusion_loss.py:124-127), which the rotation leaves unchanged, so scores, logits and the predicted lengths
-    of the rotated crystal equal those of the original."""
-    m, _, _ = small_model
-    frac, types, lengths, angles, na = random_state(12, [6, 6, 5], 77)
-    lat = OG.lattice_from_params(lengths.double(), angles.double())
-    rot = torch.tensor([[1.0, 0.0, 0.0], [0.0, 0.0, -1.0], [0.0, 1.0, 0.0]], dtype=torch.float64)
-    len_r, ang_r = OG.matrix_to_params(lat @ rot)
-    assert (len_r - lengths.double()).abs().max() < 1e-9 and (ang_r - angles.double()).abs().max() < 1e-9
-    a = _engine_scores(m, dev, (frac, types, lengths, angles, na), 5)
-    b = _engine_scores(m, dev, (frac, types, len_r.float(), ang_r.float(), na), 5)
-    scale = max(1.0, float(a[1].abs().max()))
-    for x, y in zip(a, b):
-        assert (x - y).abs().max() <= TOL * scale
+def _rotation(axis, angle):
+    axis = np.asarray(axis, dtype=np.float64)
+    axis = axis / np.linalg.norm(axis)
+    K = np.array([[0, -axis[2], axis[1]], [axis[2], 0, -axis[0]], [-axis[1], axis[0], 0]])
+    return torch.tensor(np.eye(3) + np.sin(angle) * K + (1 - np.cos(angle)) * (K @ K), dtype=torch.float32)
+
+
+@pytest.mark.parametrize("rot", ["x90", "general"])
+def test_rotation_equivariance_through_the_kernels(dev, rot):
+    """Equivariance check that reaches the kernels (the reference's own check, exploration/verify_model_is_equivariant.py
+    :11-18 at t = 5, only rotates the cell, which the network sees through (lengths, angles) alone -- it never changes
+    a number a kernel reads).  Here every Cartesian input of the operator seam is rotated by R -- neighbour
+    directions, the cell rows, the vector features -- together with the orientation grid; all pair invariants
+    (dir . ori, |dir - (dir . ori) ori|, cos(dir, cell rows), vec . ori, ori . ori) are then unchanged in exact
+    arithmetic while the numbers the edge / embed / read-out kernels load are all different.  Expected: same logits
+    and global scalars, output vectors rotated by R."""
+    from types import SimpleNamespace
+    from arreau_amd.checkpoint import make_synthetic_model
+    R = _rotation([1, 0, 0], np.pi / 2) if rot == "x90" else _rotation([0.3, -1.0, 0.5], 1.1)
+    m = make_synthetic_model(S=12, seed=1234, num_timesteps=100)
+    grid = m.model.ori_grid.clone()
+    m_rot = make_synthetic_model(S=12, seed=1234, num_timesteps=100, ori_grid=grid @ R)
+    assert torch.equal(m.state_dict()["model.x_embedder.weight"], m_rot.state_dict()["model.x_embedder.weight"])
+    m, m_rot = m.to(dev), m_rot.to(dev)
+    om32 = oracle_from_module(m, torch.float32)
+    frac, types, lengths, angles, na = state = random_state(12, [6, 6, 5], 77)
+    N = 17
+    x, cart, vec, lattice = OS.assemble_features(om32, frac, F.one_hot(types, 12), torch.full((N,), 5), na, lengths,
+                                                 angles)
+    _, _, _, (ei, dists, direction, _c, _l) = _oracle_scores(om32, *state, 5)
+    batch = torch.arange(3).repeat_interleave(na)
+    mk = lambda vv, dd, ll: SimpleNamespace(x=x.float().to(dev), vec=vv.to(dev), edge_index=ei.to(dev),
+                                            dists=dists.to(dev), inter_atom_direction=dd.to(dev), lattice=ll.to(dev),
+                                            num_atoms=na, batch=batch.to(dev))
+    logits_a, vec_a, gs_a, _, _ = m(mk(vec.float(), direction, lattice.float()))
+    logits_b, vec_b, gs_b, _, _ = m_rot(mk(vec.float() @ R, direction @ R, lattice.float() @ R))
+    assert (direction @ R - direction).abs().max() > 0.5  # the kernels really saw different inputs
+    scale = max(1.0, float(logits_a.abs().max()))
+    assert (logits_a - logits_b).abs().max() <= 2 * TOL * scale
+    assert (gs_a - gs_b).abs().max() <= 2 * TOL * 6 * max(1.0, float(gs_a.abs().max()))
+    assert (vec_a.squeeze(1) @ R.to(dev) - vec_b.squeeze(1)).abs().max() <= 2 * TOL * max(1.0, float(vec_a.abs().max()))
+    assert (vec_a - vec_b).abs().max() > 1e-3 * float(vec_a.abs().max())  # and the vector output did rotate
 
 
 @pytest.mark.parametrize("edge_variant,mlp_variant", [("0", "0"), ("3", "1"), ("4", "2")])

@@ -1,0 +1,83 @@
+"""Host-side pieces of the product path that need no GPU: the S2 grid generator the product uses (row a10), and the
+result wire format with the reference's slicing helpers (row f2)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from arreau_amd.diffusion.diffusion_loss import SampleResult
+from arreau_amd.diffusion.inference.process_generated_crystals import (KEYS, get_crystal_indexes, get_one_crystal,
+                                                                        load_sample_results_from_hdf5,
+                                                                        save_sample_results_to_hdf5)
+from arreau_amd.generate import concat_results
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.mark.parametrize("O", [8, 16])
+def test_product_uniform_grid_s2_matches_reference_fixture(O):
+    """arreau_amd.ponita.geometry.rotation.uniform_grid_s2 (the copy PONITA_DIFFUSION really calls) reproduces the grid
+    the reference's uniform_grid_s2 generated under the same seed (tests/golden/ori_grid.npz, made by
+    oracle/gen_golden.py from ponita/geometry/rotation.py:947-1009)."""
+    from arreau_amd.ponita.geometry.rotation import uniform_grid_s2
+    z = np.load(os.path.join(GOLDEN, "ori_grid.npz"))
+    torch.manual_seed(int(z[f"seed_{O}"]))
+    grid = uniform_grid_s2(O)
+    np.testing.assert_allclose(grid.numpy(), z[f"ori_grid_{O}"], rtol=0, atol=2e-6)
+    np.testing.assert_allclose(np.linalg.norm(grid.numpy(), axis=-1), 1.0, atol=1e-6)
+    # an explicit generator gives the same grid as the global one under the same seed
+    g = torch.Generator().manual_seed(int(z[f"seed_{O}"]))
+    assert torch.equal(uniform_grid_s2(O, generator=g), grid)
+
+
+def _ragged_result(counts, seed=0):
+    rng = np.random.RandomState(seed)
+    parts = []
+    for c in counts:  # one SampleResult per "batch" of one crystal, as model.sample returns them
+        parts.append(SampleResult(frac_x=rng.rand(c, 3), atomic_numbers=rng.randint(1, 90, size=c),
+                                  lattice=rng.rand(1, 3, 3) * 5, num_atoms=np.array([c])))
+    return concat_results(parts), parts
+
+
+def test_crystals_wire_format_round_trip_and_slicing(tmp_path):
+    counts = [3, 1, 7, 4]
+    res, parts = _ragged_result(counts)
+    assert res.idx_start.tolist() == [0, 3, 4, 11]  # main_diffusion_generate.py:70: first atom of each crystal
+    path = save_sample_results_to_hdf5(res, str(tmp_path / "out" / "crystals.npz"))
+    with np.load(path) as z:
+        assert sorted(z.files) == sorted(KEYS)
+        # dtypes of the reference's arrays (np.empty -> float64, arange/full -> int64; main_diffusion_generate.py:67-72)
+        assert z["frac_x"].dtype == np.float64 and z["atomic_numbers"].dtype == np.float64
+        assert z["lattice"].dtype == np.float64 and z["idx_start"].dtype == np.int64 and z["num_atoms"].dtype == np.int64
+    back = load_sample_results_from_hdf5(path)
+    for k in KEYS:
+        np.testing.assert_array_equal(getattr(back, k), np.asarray(getattr(res, k), dtype=getattr(back, k).dtype))
+    for i, (c, p) in enumerate(zip(counts, parts)):  # process_generated_crystals.py:33-47
+        start, end = get_crystal_indexes(back, i)
+        assert end - start == c
+        lattice, frac_x, zs = get_one_crystal(back, i)
+        np.testing.assert_array_equal(lattice, p.lattice[0])
+        np.testing.assert_array_equal(frac_x, p.frac_x)
+        np.testing.assert_array_equal(zs, p.atomic_numbers.astype(np.float64))
+
+
+def test_crystals_wire_format_rejects_inconsistent_arrays(tmp_path):
+    res, _ = _ragged_result([2, 2])
+    res.idx_start = None
+    with pytest.raises(ValueError):
+        save_sample_results_to_hdf5(res, str(tmp_path / "x.npz"))
+    res, _ = _ragged_result([2, 2])
+    res.frac_x = res.frac_x[:3]
+    with pytest.raises(ValueError):
+        save_sample_results_to_hdf5(res, str(tmp_path / "x.npz"))
+
+
+def test_crystals_hdf5_when_h5py_is_present(tmp_path):
+    h5py = pytest.importorskip("h5py")
+    res, _ = _ragged_result([2, 5])
+    path = save_sample_results_to_hdf5(res, str(tmp_path / "crystals.h5"))
+    with h5py.File(path, "r") as fh:
+        assert sorted(fh["crystals"].keys()) == sorted(KEYS)
+    back = load_sample_results_from_hdf5(path)
+    np.testing.assert_array_equal(back.frac_x, res.frac_x)
