@@ -15,12 +15,21 @@ CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 SOURCES = ["model.hip", "graph.hip", "edge.hip", "edge_bf16.hip", "edge_f16.hip", "node.hip", "node_bf16.hip", "node_f16.hip", "node_f16m.hip", "update.hip", "api.hip"]
 HEADERS = ["internal.h", "bf16x6.h", "f16x3.h", os.path.join("..", "..", "include", "arreau_hip.h")]
 LIB = os.path.join(CSRC, "libarreau_hip.so")
+# Debug twin: the same sources with -DARREAU_DEBUG_WAIT_ALL (every hand-counted `s_waitcnt vmcnt(N)` becomes vmcnt(0)).
+# Its outputs must be bit-identical to the product library's (test_counted_waits_match_full_waits); only the sources
+# that contain counted waits are recompiled for it.
+LIB_DEBUG_WAIT = os.path.join(CSRC, "libarreau_hip_dbgwait.so")
+DEBUG_WAIT_SOURCES = ["edge_f16.hip", "node.hip"]
 STAMP = os.path.join(CSRC, ".build_stamp")
-# Sources whose kernels hand-count s_waitcnt vmcnt(N): a register spill would put scratch loads/stores into the same
-# in-order queue and silently break the count, so the build fails if the compiler reports any scratch for them.
-NO_SCRATCH = {"edge_f16.hip"}
-FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++20", "-fPIC", "-Wall", "-Wno-unused-function",
-         "-ffp-contract=on"] + os.environ.get("ARREAU_EXTRA_HIPCC_FLAGS", "").split()
+# Kernels that hand-count s_waitcnt vmcnt(N) or drain LDS-DMA copies with asm waits hipcc cannot see: a register spill
+# would put scratch loads/stores into the same in-order queue and silently break the protocol, so the build fails if
+# the compiler reports scratch for them.  source -> substrings of the (mangled) kernel names to check (None = all).
+NO_SCRATCH = {"edge_f16.hip": None, "node.hip": ["conv_kernel_streamed"], "node_f16.hip": None, "node_f16m.hip": None}
+# -Wno-inline-asm: the lean LDS-DMA asm lists "m0" as clobbered (it overwrites M0 and does not restore it); clang warns
+# that reserved registers in a clobber list are not preserved for us -- which is what is declared, not asked for.  The
+# ISA check below verifies that the compiler itself never uses M0 in those kernels.
+FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++20", "-fPIC", "-Wall", "-Wno-unused-function", "-Wno-inline-asm",
+         "-Wno-unused-but-set-variable", "-ffp-contract=on"] + os.environ.get("ARREAU_EXTRA_HIPCC_FLAGS", "").split()
 
 
 def _digest():
@@ -33,7 +42,7 @@ def _digest():
 
 
 def needs_build():
-    if not os.path.exists(LIB) or not os.path.exists(STAMP):
+    if not os.path.exists(LIB) or not os.path.exists(LIB_DEBUG_WAIT) or not os.path.exists(STAMP):
         return True
     with open(STAMP) as fh:
         return fh.read().strip() != _digest()
@@ -55,29 +64,90 @@ def build(force=False, verbose=True):
             fcntl.flock(lock, fcntl.LOCK_UN)
 
 
-def _build_locked(verbose):
-    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    t0 = time.time()
-    procs = []
-    objs = []
-    for src in SOURCES:
-        obj = os.path.join(CSRC, src.replace(".hip", ".o"))
+def _scratch_by_kernel(remarks):
+    """{kernel name: scratch bytes per lane} from -Rpass-analysis=kernel-resource-usage output."""
+    import re
+    out, name = {}, None
+    for line in remarks.splitlines():
+        m = re.search(r"Function Name: (\S+)", line)
+        if m:
+            name = m.group(1)
+        m = re.search(r"ScratchSize \[bytes/lane\]: (\d+)", line)
+        if m and name is not None:
+            out[name] = int(m.group(1))
+    return out
+
+
+def _drop_remarks(diag):
+    """Compiler output without the resource-usage remark blocks (remark line + quoted source + caret)."""
+    import re
+    keep, skipping = [], False
+    for line in diag.splitlines():
+        if re.match(r"^\S+:\d+:\d+: (warning|error|note|remark):", line) or re.match(r"^remark:", line):
+            skipping = "remark:" in line
+        elif re.match(r"^\d+ warnings? generated", line):
+            continue
+        if not skipping:
+            keep.append(line)
+    return "\n".join(keep)
+
+
+_M0_ALLOWED = (r"s_mov_b32 m0, s\d+$", r"s_add_u32 m0, s\d+, (0x[0-9a-f]+|\d+|s\d+)$", r"s_mov_b32 s\d+, m0$")
+
+
+def _m0_violations(asm_text):
+    """The LDS-DMA asm of these sources writes M0 itself (f16x3.h: glds16 saves/restores it, dma_chunk_lean and
+    conv_glds16 overwrite it).  That is only sound while the compiler has no use of M0 of its own in the same kernels:
+    every instruction of the device ISA that names m0 must be one of the asm's own forms."""
+    import re
+    bad = []
+    for line in asm_text.splitlines():
+        ins = line.split(";")[0].strip()
+        if "m0" not in ins or ins.startswith((".", "//")):
+            continue
+        if not any(re.search(pat, ins) for pat in _M0_ALLOWED):
+            bad.append(ins)
+    return bad
+
+
+def _compile_all(hipcc, sources, objdir, extra_flags, verbose):
+    import glob
+    import shutil
+    import tempfile
+    os.makedirs(objdir, exist_ok=True)
+    procs, objs = [], []
+    for src in sources:
+        obj = os.path.join(objdir, src.replace(".hip", ".o"))
         objs.append(obj)
-        cmd = [hipcc] + FLAGS + ["-c", os.path.join(CSRC, src), "-o", obj]
-        if src in NO_SCRATCH:
-            cmd.insert(-4, "-Rpass-analysis=kernel-resource-usage")
-        procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+        cmd = [hipcc] + FLAGS + extra_flags
+        tmp = None
+        if src in NO_SCRATCH:  # + keep the device ISA for the M0 check (temporaries go to a scratch directory)
+            tmp = tempfile.mkdtemp(prefix="arreau_isa_")
+            cmd += ["-Rpass-analysis=kernel-resource-usage", "-save-temps"]
+        cmd += ["-c", os.path.join(CSRC, src), "-o", obj]
+        procs.append((src, tmp, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, cwd=tmp)))
     failed = False
-    for src, p in procs:
+    for src, tmp, p in procs:
         out, _ = p.communicate()
+        if tmp is not None:
+            if p.returncode == 0:
+                isa = glob.glob(os.path.join(tmp, "*-hip-amdgcn-amd-amdhsa-gfx950.s"))
+                bad = _m0_violations(open(isa[0]).read()) if isa else ["device ISA not found"]
+                if bad:
+                    failed = True
+                    sys.stderr.write(f"[arreau_amd.build] {src}: M0 is used outside the LDS-DMA asm ({bad[:4]}); the asm "
+                                     "overwrites M0 without restoring it\n")
+            shutil.rmtree(tmp, ignore_errors=True)
         if p.returncode == 0 and src in NO_SCRATCH:
-            import re
-            scratch = [int(x) for x in re.findall(r"ScratchSize \[bytes/lane\]: (\d+)", out)]
-            if not scratch or max(scratch) != 0:
+            scratch = _scratch_by_kernel(out)
+            want = NO_SCRATCH[src]
+            checked = {k: v for k, v in scratch.items() if want is None or any(w in k for w in want)}
+            bad = {k: v for k, v in checked.items() if v != 0}
+            if not checked or bad:
                 failed = True
-                sys.stderr.write(f"[arreau_amd.build] {src}: kernel uses scratch {scratch} (register spill); "
-                                 "its counted vmcnt waits require none\n")
-            out = ""  # the remarks are not warnings
+                sys.stderr.write(f"[arreau_amd.build] {src}: kernels with hand-written wait protocols must not use scratch "
+                                 f"(register spill); compiler reports {bad or 'no kernels'}\n")
+            out = _drop_remarks(out)
         if p.returncode != 0:
             failed = True
             sys.stderr.write(f"[arreau_amd.build] {src} failed:\n{out}\n")
@@ -85,11 +155,24 @@ def _build_locked(verbose):
             sys.stderr.write(f"[arreau_amd.build] {src}:\n{out}\n")
     if failed:
         raise RuntimeError("hipcc failed (see messages above)")
+    return objs
+
+
+def _build_locked(verbose):
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    t0 = time.time()
+    objs = _compile_all(hipcc, SOURCES, CSRC, [], verbose)
     subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB] + objs)
+    dbg_dir = os.path.join(CSRC, "dbgwait")
+    dbg = _compile_all(hipcc, DEBUG_WAIT_SOURCES, dbg_dir, ["-DARREAU_DEBUG_WAIT_ALL"], verbose)
+    dbg_objs = [os.path.join(dbg_dir, os.path.basename(o)) if os.path.basename(o).replace(".o", ".hip") in DEBUG_WAIT_SOURCES
+                else o for o in objs]
+    assert all(os.path.exists(o) for o in dbg_objs) and len(dbg) == len(DEBUG_WAIT_SOURCES)
+    subprocess.check_call([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", LIB_DEBUG_WAIT] + dbg_objs)
     with open(STAMP, "w") as fh:
         fh.write(_digest())
     if verbose:
-        sys.stderr.write(f"[arreau_amd.build] built {LIB} in {time.time() - t0:.1f}s\n")
+        sys.stderr.write(f"[arreau_amd.build] built {LIB} (+ debug-wait twin) in {time.time() - t0:.1f}s\n")
     return LIB
 
 

@@ -330,8 +330,13 @@ __global__ __launch_bounds__(64 * EH_WAVES, 2) void edge_kernel_f16x3(
                     f32x4v v;
 #pragma unroll
                     for (int r = 0; r < 4; ++r) v[r] = fmaf(a.x[mt][nb][r], F16X3_INV_SCALE, a.m[mt][nb][r]);
+                    // asm store: the counted wait at SYNC assumes exactly 4 (or 2) store instructions per tile
+                    // (scalar base + one per-lane 32-bit offset + immediate: no 64-bit vector address arithmetic)
                     if (nb == 0 || full)
-                        *reinterpret_cast<f32x4v*>(const_cast<char*>(tile_base) + 64 * nb * C + 64 * mt + st_off) = v;
+                        asm volatile("global_store_dwordx4 %0, %1, %2 offset:%3"
+                                     :
+                                     : "v"(st_off), "v"(v), "s"(tile_base + 64 * nb * C), "n"(64 * mt)
+                                     : "memory");
                 }
         };
         // ST = step (of 2 TD) at which the chunk's barrier is taken (mid-chunk).  At SYNC the wave's queue holds, oldest

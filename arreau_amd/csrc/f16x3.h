@@ -311,9 +311,17 @@ __device__ __forceinline__ void dma_chunk_lean(const void* chunk_uniform, unsign
         asm volatile("s_add_u32 m0, %2, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, %1"
                      :
                      : "v"(lane16), "s"(base + 1024 * NW * i), "s"(slot_plus_wave), "n"(1024 * NW * i)
-                     : "memory", "scc");  // s_add_u32 writes SCC
+                     : "memory", "scc", "m0");  // s_add_u32 writes SCC; M0 is overwritten and not restored
 }
 __device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 // vmcnt retires in issue order (loads, stores and LDS-DMA alike): all but the N youngest operations are done
+// (-DARREAU_DEBUG_WAIT_ALL, the debug build of arreau_amd/build.py, turns every counted wait into vmcnt(0): the
+// outputs of the two builds must be bit-identical -- tests/test_gpu_parity.py::test_counted_waits_match_full_waits)
 template <int N>
-__device__ __forceinline__ void dma_wait_but() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+__device__ __forceinline__ void dma_wait_but() {
+#ifdef ARREAU_DEBUG_WAIT_ALL
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#else
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+#endif
+}

@@ -303,12 +303,17 @@ __global__ __launch_bounds__(512, 4) void conv_kernel(
 // i-1] -> vmcnt(20) retires what receiver i needs and leaves the rest in flight.
 // ---------------------------------------------------------------------------------------------
 __device__ __forceinline__ void conv_glds16(const void* gsrc_lane, unsigned lds_dst) {
-    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(gsrc_lane), "s"(lds_dst) : "memory");
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(gsrc_lane), "s"(lds_dst) : "memory", "m0");
 }
 __device__ __forceinline__ f32x4 conv_load16(const void* p) {
     f32x4 v;
     asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(p) : "memory");
     return v;
+}
+// stores as asm as well: the counted waits assume EXACTLY four store instructions per receiver
+template <int IMM>
+__device__ __forceinline__ void conv_store4(const float* base_uniform, unsigned lane_off, float v) {
+    asm volatile("global_store_dword %0, %1, %2 offset:%3" : : "v"(lane_off), "v"(v), "s"(base_uniform), "n"(IMM) : "memory");
 }
 template <int C>
 __global__ __launch_bounds__(512, 2) void conv_kernel_streamed(
@@ -390,6 +395,9 @@ __global__ __launch_bounds__(512, 2) void conv_kernel_streamed(
         // Requests are issued after the second barrier of a receiver as [x(+2): 8] [K(+2): 8] and followed by its
         // 4 stores.  Receiver i needs x(i), K(i); younger than those are the requests for i+1 (16, if it exists) and
         // the stores of i-1 (4, unless i is the first): they stay in flight.
+#ifdef ARREAU_DEBUG_WAIT_ALL  // debug build: every counted wait becomes vmcnt(0); outputs must not change
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#else
         if (mn < n_iter) {
             if (first) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
@@ -397,6 +405,7 @@ __global__ __launch_bounds__(512, 2) void conv_kernel_streamed(
             if (first) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         }
+#endif
 #pragma unroll
         for (int s_ = 0; s_ < K; ++s_) asm volatile("" : "+v"(xv[PAR][s_]));  // the loaded values exist from here on
         __syncthreads();  // every wave's share of K(n) has landed
@@ -427,8 +436,14 @@ __global__ __launch_bounds__(512, 2) void conv_kernel_streamed(
 #pragma unroll
             for (int p = 0; p < 4; ++p) out[p] += xo * fkr[o][p];
         }
-#pragma unroll
-        for (int p = 0; p < 4; ++p) x_conv[((size_t)n * 16 + (4 * pq + p)) * C + c] = out[p] + bias;
+        {
+            const float* xbase = x_conv + (size_t)n * 16 * C;  // wave-uniform
+            const unsigned loff = 4u * ((4 * pq) * C + c);
+            conv_store4<0>(xbase, loff, out[0] + bias);
+            conv_store4<4 * C>(xbase, loff, out[1] + bias);
+            conv_store4<8 * C>(xbase, loff, out[2] + bias);
+            conv_store4<12 * C>(xbase, loff, out[3] + bias);
+        }
         first = false;
         m = mn;
         mn = mnn;
