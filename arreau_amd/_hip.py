@@ -19,6 +19,7 @@ EXPORTS = [
     "arreau_radius_graph_pbc", "arreau_compact_edges", "arreau_edges_to_slots", "arreau_predict_scores",
     "arreau_reverse_step", "arreau_profile_edge_kernel", "arreau_edge_kernel_time_ms",
     "arreau_model_status", "arreau_model_set_variant", "arreau_ponita_forward",
+    "arreau_diffusion_noise", "arreau_diffusion_losses",
 ]
 
 STATUS_NONFINITE, STATUS_BAD_TIMESTEP, STATUS_BAD_TYPE = 1, 2, 4
@@ -89,6 +90,8 @@ def lib():
     L.arreau_model_set_variant.argtypes = [c_void_p, c_int32, c_int32]
     L.arreau_ponita_forward.argtypes = ([c_void_p] * 5 + [c_int32, c_int32] + [c_void_p] * 7 +
                                         [c_void_p, c_size_t, c_void_p])
+    L.arreau_diffusion_noise.argtypes = [c_void_p] * 6 + [c_int32, c_int32] + [c_void_p] * 11
+    L.arreau_diffusion_losses.argtypes = [c_void_p] * 10 + [c_int32, c_int32] + [c_void_p] * 6
     L.arreau_profile_edge_kernel.argtypes = [c_int32]
     L.arreau_edge_kernel_time_ms.argtypes = [POINTER(c_double), POINTER(c_int64)]
     for name in EXPORTS:

@@ -1,5 +1,7 @@
-"""DiffusionLoss: the sampling loop of the reference (diffusion/diffusion_loss.py:276-377) driving
-the HIP engine.  Training (`__call__`) is out of this build's scope and raises."""
+"""DiffusionLoss: the sampling loop of the reference (diffusion/diffusion_loss.py:276-377) and the forward part of
+its training loss (`__call__`, :204-274) driving the HIP engine.  The backward pass through the network kernels is not
+built yet, so `__call__` returns the loss value (and the gradients with respect to the network outputs), not an
+autograd graph."""
 from dataclasses import dataclass
 from typing import Optional
 
@@ -41,8 +43,59 @@ class DiffusionLoss(nn.Module):
         self.lattice_diffusion = VP_lattice(num_steps=self.T, power=lattice_power, clipmax=lattice_clipmax)
         self.num_atomic_states = num_atomic_states
 
-    def __call__(self, *a, **kw):
-        raise NotImplementedError("score-matching training is not part of this build (sampling path only)")
+    def __call__(self, model, batch, t_emb_weights=None, timestep=None, noise=None, return_parts=False):
+        """diffusion_loss.py:204-274: sample a timestep per crystal, noise (coordinates, atom types, cell lengths),
+        evaluate the score network on the noised batch and return `coord + atom-type + lattice` error (weights 1).
+
+        `batch` carries X0 [N,3] fractional coordinates, A0 [N] class indices, L0 [B*3,3] or [B,3,3] cells and
+        num_atoms [B] (the fields of the reference's PyG `Data`, lattice_dataset.py:96-104).  Random draws follow the
+        reference's order: randint(1, T+1) [B,1] unless `timestep` is given (:213-221), randn_like(X0) (VE_pbc.forward),
+        rand(N,S) (D3PM.get_xt), randn_like(lengths) (VP_lattice.forward), from torch's global CPU generator;
+        `noise=(z_frac, u_types, z_lengths)` injects them instead (parity tests).  Everything else runs in
+        libarreau_hip.so (arreau_diffusion_noise -> arreau_predict_scores -> arreau_diffusion_losses).
+
+        Returns the scalar loss (a 0-d float32 CUDA tensor); with return_parts=True also a dict of the three errors,
+        the noised inputs, the network outputs and d(loss)/d(outputs)."""
+        eng = model.engine()
+        dev = eng.device
+        S = self.num_atomic_states
+        n_cpu = torch.as_tensor(batch.num_atoms).to("cpu", torch.int64)
+        B, N = int(n_cpu.numel()), int(n_cpu.sum())
+        frac0 = torch.as_tensor(batch.X0)
+        if frac0.shape != (N, 3):
+            raise ValueError("batch.X0 must be [sum(num_atoms), 3]")
+        if timestep is None:
+            t = torch.randint(1, self.T + 1, size=(B, 1)).long()
+        elif torch.is_tensor(timestep) and timestep.numel() == B:
+            t = timestep.reshape(B, 1).long().cpu()
+        else:
+            t = torch.ones((B, 1)).long() * int(timestep)
+        if int(t.min()) < 1 or int(t.max()) > self.T:
+            raise ValueError(f"timestep must be in 1..{self.T}")
+        if noise is None:
+            dt = torch.get_default_dtype()
+            z_frac = torch.randn((N, 3), dtype=dt)
+            u_types = torch.rand((N, S))
+            z_len = torch.randn((B, 3), dtype=dt)
+        else:
+            z_frac, u_types, z_len = noise
+        f32 = lambda v: torch.as_tensor(v).to(device=dev, dtype=torch.float32).contiguous()
+        i32 = lambda v: torch.as_tensor(v).to(device=dev, dtype=torch.int32).contiguous()
+        off = crystal_offsets(n_cpu, dev)
+        t_d = i32(t.reshape(B))
+        types0 = i32(batch.A0)
+        nz = eng.diffusion_noise(f32(frac0), types0, f32(torch.as_tensor(batch.L0).reshape(-1, 3, 3)), t_d, off,
+                                 f32(z_frac), f32(u_types), f32(z_len))
+        eps, logits, len0 = eng.predict_scores(nz["noisy_frac"], nz["noisy_types"], nz["noisy_lengths"], nz["angles"],
+                                               t_d, off)
+        losses, grads = eng.diffusion_losses(eps, nz["target_eps"], logits, types0, nz["noisy_types"], t_d, len0,
+                                             nz["lengths"], off, with_grads=True)
+        eng.check_status()
+        if return_parts:
+            return losses[0], dict(error_frac_x=losses[1], error_atomic_type=losses[2], error_lattice=losses[3],
+                                   vb=losses[4], ce=losses[5], pred_eps=eps, logits=logits, pred_lengths=len0,
+                                   grad_eps=grads[0], grad_logits=grads[1], grad_lengths=grads[2], timestep=t_d, **nz)
+        return losses[0]
 
     # ------------------------------------------------------------------------------------------
     def predict_scores(self, noisy_frac_x, noisy_atom_types, t_feat, num_atoms, noisy_lengths, angles, model,

@@ -136,6 +136,42 @@ class HipEngine:
             _hip.ptr(ws), ws.numel(), _hip.stream_ptr(dev)), "arreau_ponita_forward")
         return logits, vec_out, gscalar
 
+    def diffusion_noise(self, frac0, types0, lattice0, t_crystal, offsets, z_frac, u_types, z_lengths):
+        """Forward noising of a clean batch (arreau_diffusion_noise).  Returns dict(noisy_frac, target_eps, noisy_types,
+        noisy_lengths, lengths, angles)."""
+        dev = self.device
+        N, B = frac0.shape[0], lattice0.shape[0]
+        f32 = dict(device=dev, dtype=torch.float32)
+        out = dict(noisy_frac=torch.empty((N, 3), **f32), target_eps=torch.empty((N, 3), **f32),
+                   noisy_types=torch.empty(N, device=dev, dtype=torch.int32), noisy_lengths=torch.empty((B, 3), **f32),
+                   lengths=torch.empty((B, 3), **f32), angles=torch.empty((B, 3), **f32))
+        inv = torch.empty((B, 3, 3), **f32)
+        _hip.check(_hip.lib().arreau_diffusion_noise(
+            self._handle, _hip.ptr(frac0), _hip.ptr(types0), _hip.ptr(lattice0), _hip.ptr(t_crystal), _hip.ptr(offsets),
+            B, N, _hip.ptr(z_frac), _hip.ptr(u_types), _hip.ptr(z_lengths), _hip.ptr(out["noisy_frac"]),
+            _hip.ptr(out["target_eps"]), _hip.ptr(out["noisy_types"]), _hip.ptr(out["noisy_lengths"]),
+            _hip.ptr(out["lengths"]), _hip.ptr(out["angles"]), _hip.ptr(inv), _hip.stream_ptr(dev)),
+            "arreau_diffusion_noise")
+        return out
+
+    def diffusion_losses(self, pred_eps, target_eps, logits, types0, noisy_types, t_crystal, pred_lengths, lengths,
+                         offsets, with_grads=False):
+        """The three training errors (arreau_diffusion_losses).  Returns losses[6] = (loss, error_frac_x,
+        error_atomic_type, error_lattice, vb, ce) [+ (grad_eps, grad_logits, grad_lengths)]."""
+        dev = self.device
+        N, B = pred_eps.shape[0], pred_lengths.shape[0]
+        f32 = dict(device=dev, dtype=torch.float32)
+        terms = torch.empty((N, 3), **f32)
+        losses = torch.empty(6, **f32)
+        g = (torch.empty((N, 3), **f32), torch.empty((N, self.S), **f32), torch.empty((B, 3), **f32)) if with_grads \
+            else (None, None, None)
+        _hip.check(_hip.lib().arreau_diffusion_losses(
+            self._handle, _hip.ptr(pred_eps), _hip.ptr(target_eps), _hip.ptr(logits), _hip.ptr(types0),
+            _hip.ptr(noisy_types), _hip.ptr(t_crystal), _hip.ptr(pred_lengths), _hip.ptr(lengths), _hip.ptr(offsets), B, N,
+            _hip.ptr(terms), _hip.ptr(losses), _hip.ptr(g[0]), _hip.ptr(g[1]), _hip.ptr(g[2]), _hip.stream_ptr(dev)),
+            "arreau_diffusion_losses")
+        return (losses, g) if with_grads else losses
+
     def workspace(self, N, B):
         if self._ws is None or N > self._ws_cap[0] or B > self._ws_cap[1]:
             capN, capB = max(N, self._ws_cap[0]), max(B, self._ws_cap[1])

@@ -228,6 +228,38 @@ int arreau_reverse_step(const arreau_model* model,
                         const float* d_z_lattice, const float* d_z_frac, const float* d_u_types,
                         float* d_lattice, void* stream);
 
+/* ---- score-matching training loss, forward part (BASELINE config 5) ------------------------------------------ */
+
+/* The forward-noising half of DiffusionLoss.__call__ (diffusion/diffusion_loss.py:222-234), random draws supplied by
+ * the caller in the reference's order (z_frac: randn_like(frac_x0), diffusion_helpers.py:45; u_types: rand(N,S),
+ * d3pm.py:141; z_lengths: randn_like(lengths), diffusion_helpers.py:158); d_t[B] in 1..T (diffusion_loss.py:213-216):
+ *   VE_pbc.forward (diffusion_helpers.py:43-63, with min_distance_sqr_pbc :254-325 and cart_to_frac_coords :233-251)
+ *     -> d_noisy_frac[N,3], d_target_eps[N,3] (the wrapped fractional noise, in [0,1));
+ *   D3PM.get_xt / q_sample (d3pm.py:119-143) -> d_noisy_types[N];
+ *   matrix_to_params (lattice_helpers.py:16-35) -> d_lengths[B,3], d_angles[B,3];
+ *   VP_lattice.forward (diffusion_helpers.py:156-163) -> d_noisy_lengths[B,3].
+ * d_inv_lattice[B,3,3] receives the inverse cells (scratch the caller owns). */
+int arreau_diffusion_noise(const arreau_model* model, const float* d_frac0, const int32_t* d_types0,
+                           const float* d_lattice0, const int32_t* d_t, const int32_t* d_crystal_offsets,
+                           int32_t B, int32_t N, const float* d_z_frac, const float* d_u_types,
+                           const float* d_z_lengths, float* d_noisy_frac, float* d_target_eps,
+                           int32_t* d_noisy_types, float* d_noisy_lengths, float* d_lengths, float* d_angles,
+                           float* d_inv_lattice, void* stream);
+
+/* The three errors of DiffusionLoss.__call__ (diffusion_loss.py:250-274) from the network outputs on the noised state:
+ * compute_frac_x_error (:95-110), D3PM.calculate_loss (d3pm.py:146-163: vb * 0.001 + cross entropy) and
+ * mse(pred_lengths, lengths / num_atoms) (:264-267); loss weights 1, 1, 1 (:91-93).
+ *   d_losses[6] = {loss, error_frac_x, error_atomic_type, error_lattice, vb, ce};  d_terms[N,3] = per-atom scratch.
+ * Optional (may be NULL): the gradients of `loss` with respect to the network outputs -- d_grad_eps[N,3],
+ * d_grad_logits[N,S], d_grad_lengths[B,3] -- the seeds of the backward pass (what autograd hands to the model in
+ * lightning_wrappers/diffusion.py:108-118). */
+int arreau_diffusion_losses(const arreau_model* model, const float* d_pred_eps, const float* d_target_eps,
+                            const float* d_logits, const int32_t* d_types0, const int32_t* d_noisy_types,
+                            const int32_t* d_t, const float* d_pred_lengths, const float* d_lengths,
+                            const int32_t* d_crystal_offsets, int32_t B, int32_t N, float* d_terms,
+                            float* d_losses, float* d_grad_eps, float* d_grad_logits, float* d_grad_lengths,
+                            void* stream);
+
 /* Timing hook used by bench.py: records hipEvents around the dominant kernel of
  * arreau_predict_scores (the edge kernel) on the stream it is launched on.
  * enable=1 starts collecting; arreau_edge_kernel_time_ms returns the mean over the launches

@@ -631,8 +631,9 @@ def test_rotation_equivariance_through_the_kernels(dev, rot):
     from arreau_amd.checkpoint import make_synthetic_model
     R = _rotation([1, 0, 0], np.pi / 2) if rot == "x90" else _rotation([0.3, -1.0, 0.5], 1.1)
     m = make_synthetic_model(S=12, seed=1234, num_timesteps=100)
-    grid = m.model.ori_grid.clone()
-    m_rot = make_synthetic_model(S=12, seed=1234, num_timesteps=100, ori_grid=grid @ R)
+    import copy
+    m_rot = copy.deepcopy(m)  # same weights, co-rotated orientation grid
+    m_rot.model.ori_grid = m.model.ori_grid.clone() @ R
     assert torch.equal(m.state_dict()["model.x_embedder.weight"], m_rot.state_dict()["model.x_embedder.weight"])
     m, m_rot = m.to(dev), m_rot.to(dev)
     om32 = oracle_from_module(m, torch.float32)

@@ -184,3 +184,56 @@ def test_ori_grid_generator_matches_reference(O):
     grid = s2grid.uniform_grid_s2(O)
     np.testing.assert_allclose(grid.numpy(), z[f"ori_grid_{O}"], rtol=0, atol=2e-6)
     np.testing.assert_allclose(np.linalg.norm(grid.numpy(), axis=-1), 1.0, atol=1e-6)
+
+
+# ------------------------------------------------------------------------------------------- training (config 5)
+@pytest.mark.parametrize("tag,dtype", [("f64", torch.float64), ("f32", torch.float32)])
+def test_training_noising_and_d3pm_loss_match_reference(tag, dtype):
+    """oracle/training.py against tests/golden/training.npz (reference: VE_pbc.forward, min_distance_sqr_pbc,
+    cart_to_frac_coords, VP_lattice.forward, matrix_to_params, D3PM.get_xt / q_posterior_logits / vb /
+    calculate_loss), bit for bit in both dtypes."""
+    from oracle import training as TR
+    torch.set_default_dtype(dtype)
+    z = load("training.npz")
+    p = tag + "_"
+    na = T(z["num_atoms"])
+    lattice, frac0, types0 = T(z[p + "lattice"]), T(z[p + "frac0"]), T(z[p + "types0"])
+    timestep = T(z[p + "timestep"])
+    t_feat = timestep.repeat_interleave(na)
+    lengths, angles = G.matrix_to_params(lattice)
+    assert np.array_equal(lengths.numpy(), z[p + "m2p_lengths"]) and np.array_equal(angles.numpy(), z[p + "m2p_angles"])
+    # VE forward noising
+    fn, weps, used = TR.ve_forward(T(z[p + "ve_sigmas"]), frac0, t_feat, lattice, na, T(z[p + "ve_z"]))
+    assert np.array_equal(fn.numpy(), z[p + "ve_frac_noisy"])
+    assert np.array_equal(weps.numpy(), z[p + "ve_wrapped_eps"])
+    assert np.array_equal(used.numpy(), z[p + "ve_used_sigmas"])
+    dsq, vec = TR.min_distance_sqr_pbc(T(z[p + "md_c1"]), T(z[p + "md_c2"]), lattice, na)
+    assert np.array_equal(dsq.numpy(), z[p + "md_dsq"]) and np.array_equal(vec.numpy(), z[p + "md_vec"])
+    assert np.array_equal(TR.cart_to_frac_coords(T(z[p + "md_c1"]), lattice, na).numpy(), z[p + "c2f"])
+    # VP forward noising of the lengths
+    ht = TR.vp_forward(T(z[p + "vp_alpha_bars"]), lengths, timestep, T(z[p + "vp_eps"]))
+    assert np.array_equal(ht.numpy(), z[p + "vp_ht"])
+    # D3PM
+    Tn, S = int(z["T"]), int(z["S"])
+    q1t, qm = D.d3pm_buffers(Tn, S)
+    x_t = TR.d3pm_q_sample(qm, types0, t_feat, T(z[p + "d3_u"]))
+    assert np.array_equal(x_t.numpy(), z[p + "d3_xt"])
+    pred_logits = T(z[p + "d3_pred_logits"])
+    true_post = TR.d3pm_q_posterior_logits(q1t, qm, types0, x_t, t_feat)
+    pred_post = TR.d3pm_q_posterior_logits(q1t, qm, pred_logits, x_t, t_feat)
+    assert np.array_equal(true_post.numpy(), z[p + "d3_true_post"])
+    assert np.array_equal(pred_post.numpy(), z[p + "d3_pred_post"])
+    assert np.array_equal(TR.d3pm_vb(true_post, pred_post).numpy(), z[p + "d3_vb"])
+    loss, _, _ = TR.d3pm_calculate_loss(q1t, qm, types0, pred_logits, x_t, t_feat)
+    assert np.array_equal(loss.numpy(), z[p + "d3_loss"])
+
+
+def test_training_frac_error_wraps_mod_one():
+    """compute_frac_x_error (diffusion_loss.py:95-110; restated from source, its module needs torch_geometric):
+    the distance between 0.1 and 0.9 is 0.2, not 0.8."""
+    from oracle import training as TR
+    pred = torch.tensor([[0.1, 0.5, 0.0], [0.25, 0.25, 0.25]])
+    target = torch.tensor([[0.9, 0.5, 1.0], [0.75, 1.5, -0.25]])
+    e = TR.compute_frac_x_error(pred, target)
+    want = ((0.2 ** 2 + 0 + 0) + (0.5 ** 2 + 0.25 ** 2 + 0.5 ** 2)) / 2
+    assert abs(float(e) - want) < 1e-6
