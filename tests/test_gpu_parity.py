@@ -22,6 +22,23 @@ GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 TOL = 1e-5
 
 
+def assert_scores_close(got, want, tag=""):
+    """The north-star bound -- per-step scores, type logits and lattice predictions within 1e-5 of the fp32 CPU path --
+    as plain absolute 1e-5 wherever the quantity is of order one.  Measured (profiles/parity_r02.json, S = 90 model):
+    eps <= 2.3e-7, logits <= 2.6e-6 at |logits| ~ 6, len0 <= 1.2e-5 at |len0| ~ 58 (2 fp32 ulps of a sum over the
+    crystal's atoms; the fp32 oracle itself is that far from fp64).  A quantity larger than order one is allowed the
+    same RELATIVE error, each against its own magnitude only: logits 1e-5 * max(1, |logits|max / 8),
+    len0 1e-5 * max(1, |len0|max), eps 1e-5 * max(1, |eps|max)."""
+    (eps, logits, len0), (eps_o, logits_o, len0_o) = got, want
+    e = float((eps.detach().cpu() - eps_o).abs().max())
+    l = float((logits.detach().cpu() - logits_o).abs().max())
+    g = float((len0.detach().cpu() - len0_o).abs().max())
+    assert e <= TOL * max(1.0, float(eps_o.abs().max())), (tag, "eps", e)
+    assert l <= TOL * max(1.0, float(logits_o.abs().max()) / 8.0), (tag, "logits", l, float(logits_o.abs().max()))
+    assert g <= TOL * max(1.0, float(len0_o.abs().max())), (tag, "len0", g, float(len0_o.abs().max()))
+    return e, l, g
+
+
 @pytest.fixture(scope="module")
 def dev():
     assert torch.cuda.is_available(), "GPU tests need a GPU"
@@ -160,10 +177,7 @@ def test_predict_scores_teacher_forced_edges(dev, small_model, num_atoms, sample
     edges = tuple(x.to(dev).contiguous() for x in (deg, src, sdir, sdist))
     t_c = torch.full((B,), t, device=dev, dtype=torch.int32)
     eps, logits, len0 = eng.predict_scores(f, ty, le, an, t_c, off, edges=edges)
-    scale = max(1.0, float(logits_o.abs().max()), float(len0_o.abs().max()))
-    assert (eps.cpu() - eps_o).abs().max() <= TOL * scale
-    assert (logits.cpu() - logits_o).abs().max() <= TOL * scale
-    assert (len0.cpu() - len0_o).abs().max() <= TOL * scale * max(num_atoms)
+    assert_scores_close((eps, logits, len0), (eps_o, logits_o, len0_o))
     # informational: distance to the float64 reference path (same edges)
     e64 = (ei, dists.double(), direction.double())
     eps64, logits64, len064, _ = _oracle_scores(om64, *state, t, edges=e64, dtype=torch.float64)
@@ -193,10 +207,7 @@ def test_predict_scores_own_neighbor_list(dev, small_model, num_atoms, sampler_l
     f, ty, le, an, off = _to_dev(dev, *state)
     t_c = torch.full((len(num_atoms),), t, device=dev, dtype=torch.int32)
     eps, logits, len0 = m.engine().predict_scores(f, ty, le, an, t_c, off)
-    scale = max(1.0, float(logits_o.abs().max()), float(len0_o.abs().max()))
-    assert (eps.cpu() - eps_o).abs().max() <= TOL * scale
-    assert (logits.cpu() - logits_o).abs().max() <= TOL * scale
-    assert (len0.cpu() - len0_o).abs().max() <= TOL * scale * max(num_atoms)
+    assert_scores_close((eps, logits, len0), (eps_o, logits_o, len0_o))
 
 
 def test_forward_operator_seam(dev, small_model):
@@ -290,11 +301,25 @@ def test_full_size_architecture_parity(dev, full_model):
     f, ty, le, an, off = _to_dev(dev, *state)
     edges = tuple(x.to(dev).contiguous() for x in (deg, src, sdir, sdist))
     t_c = torch.full((2,), t, device=dev, dtype=torch.int32)
-    eps, logits, len0 = m.engine().predict_scores(f, ty, le, an, t_c, off, edges=edges)
-    scale = max(1.0, float(logits_o.abs().max()), float(len0_o.abs().max()))
-    assert (eps.cpu() - eps_o).abs().max() <= TOL * scale
-    assert (logits.cpu() - logits_o).abs().max() <= TOL * scale
-    assert (len0.cpu() - len0_o).abs().max() <= TOL * scale * 20
+    eng = m.engine()
+    eps, logits, len0 = eng.predict_scores(f, ty, le, an, t_c, off, edges=edges)
+    assert_scores_close((eps, logits, len0), (eps_o, logits_o, len0_o))
+    # The split-precision arithmetic must not cost accuracy: against the float64 path (the dtype the reference really
+    # runs, main_diffusion_generate.py:27) the default fp16x3 kernels are no further away than twice the exact
+    # fp32-MFMA kernels (plus one fp32 ulp of slack on quantities of this size).
+    om64 = oracle_from_module(m, torch.float64)
+    e64 = (ei, dists.double(), direction.double())
+    eps64, logits64, len064, _ = _oracle_scores(om64, *state, t, edges=e64, dtype=torch.float64)
+    eng.set_variant(0, 0)
+    eps_x, logits_x, len0_x = eng.predict_scores(f, ty, le, an, t_c, off, edges=edges)
+    st = eng.check_status()
+    eng.set_variant(4, 3)
+    assert st["edge_kernel"] == "fp32-mfma" and st["mlp_kernel"] == "fp32-mfma"
+    for name, a, b, ref, ulp in (("eps", eps, eps_x, eps64, 1e-8), ("logits", logits, logits_x, logits64, 5e-7),
+                                 ("len0", len0, len0_x, len064, 4e-6)):
+        err_split = float((a.cpu().double() - ref).abs().max())
+        err_exact = float((b.cpu().double() - ref).abs().max())
+        assert err_split <= 2 * err_exact + ulp, (name, err_split, err_exact)
 
 
 # ------------------------------------------------------------------------------------------- reverse updates
@@ -364,10 +389,7 @@ def test_teacher_forced_trajectory(dev, small_model):
         t_c = torch.full((B,), t, device=dev, dtype=torch.int32)
         f, ty, le, an = d(rec["frac"]), d(rec["types"].to(torch.int32)), d(rec["lengths"]), d(angles)
         eps, logits, len0 = eng.predict_scores(f, ty, le, an, t_c, off)
-        scale = max(1.0, float(logits_o.abs().max()), float(len0_o.abs().max()))
-        assert (eps.cpu() - eps_o).abs().max() <= TOL * scale, t
-        assert (logits.cpu() - logits_o).abs().max() <= TOL * scale, t
-        assert (len0.cpu() - len0_o).abs().max() <= TOL * scale * n_per, t
+        assert_scores_close((eps, logits, len0), (eps_o, logits_o, len0_o))
 
 
 def test_sample_end_to_end_properties(dev, small_model):
@@ -440,10 +462,7 @@ def test_ragged_batch_trajectory_parity(dev, small_model):
         # (1) teacher-forced from the oracle's state
         f, ty, le = d(frac.clone()), d(types.to(torch.int32)), d(lengths.clone())
         eps, logits, len0 = eng.predict_scores(f, ty, le, an, t_c, off)
-        scale = max(1.0, float(scores[1].abs().max()))
-        assert (eps.cpu() - scores[0]).abs().max() <= TOL * max(1.0, float(scores[0].abs().max())), t
-        assert (logits.cpu() - scores[1]).abs().max() <= TOL * scale, t
-        assert (len0.cpu() - scores[2]).abs().max() <= TOL * max(counts) * max(1.0, float(scores[2].abs().max())), t
+        assert_scores_close((eps, logits, len0), scores, tag=t)
         # (2) free-running HIP state, same noise
         eps_h, logits_h, len0_h = eng.predict_scores(f_h, ty_h, le_h, an, t_c, off)
         eng.reverse_step(f_h, ty_h, le_h, an, t_c, off, eps_h, logits_h, len0_h, d(noise.z_lattice), d(noise.z_frac),
@@ -540,10 +559,7 @@ def test_large_cell_regime_vs_oracle(dev, small_model):
     eps_o, logits_o, len0_o, (ei, _d, _dr, _c, _l) = _oracle_scores(om32, *state, 40)
     assert ei.shape[1] == 8 * 128  # saturated graph
     eps, logits, len0 = _engine_scores(m, dev, state, 40)
-    scale = max(1.0, float(logits_o.abs().max()), float(len0_o.abs().max()))
-    assert (eps.cpu() - eps_o).abs().max() <= TOL * scale
-    assert (logits.cpu() - logits_o).abs().max() <= TOL * scale
-    assert (len0.cpu() - len0_o).abs().max() <= TOL * scale * 64
+    assert_scores_close((eps, logits, len0), (eps_o, logits_o, len0_o))
 
 
 @pytest.mark.parametrize("B,n", [(256, 20), (64, 64)])
@@ -568,10 +584,7 @@ def test_full_size_batch_independence_and_determinism(dev, full_model, B, n):
         eps1, logits1, len01 = _engine_scores(m, dev, one, t)
         assert torch.equal(eps1, a[0][sl]) and torch.equal(logits1, a[1][sl]) and torch.equal(len01, a[2][ci:ci + 1])
     eps_o, logits_o, len0_o, _ = _oracle_scores(om32, *one, t)
-    scale = max(1.0, float(logits_o.abs().max()), float(len0_o.abs().max()))
-    assert (eps1.cpu() - eps_o).abs().max() <= TOL * scale
-    assert (logits1.cpu() - logits_o).abs().max() <= TOL * scale
-    assert (len01.cpu() - len0_o).abs().max() <= TOL * scale * n
+    assert_scores_close((eps1, logits1, len01), (eps_o, logits_o, len0_o))
 
 
 def test_atom_permutation_equivariance(dev, small_model):
@@ -583,10 +596,7 @@ def test_atom_permutation_equivariance(dev, small_model):
                       9 + torch.randperm(7, generator=torch.Generator().manual_seed(2))])
     a = _engine_scores(m, dev, (frac, types, lengths, angles, na), 30)
     b = _engine_scores(m, dev, (frac[perm], types[perm], lengths, angles, na), 30)
-    scale = max(1.0, float(a[1].abs().max()))
-    assert (a[0][perm] - b[0]).abs().max() <= TOL * scale
-    assert (a[1][perm] - b[1]).abs().max() <= TOL * scale
-    assert (a[2] - b[2]).abs().max() <= TOL * scale * 9
+    assert_scores_close((b[0], b[1], b[2]), (a[0][perm].cpu(), a[1][perm].cpu(), a[2].cpu()))
 
 
 def test_many_ragged_crystals_persistent_edge_workgroups(dev, small_model):
@@ -605,10 +615,7 @@ def test_many_ragged_crystals_persistent_edge_workgroups(dev, small_model):
     # where the reference's unstable sort and the kernel's (d2, index) rule may keep different ones
     edges = tuple(x.to(dev).contiguous() for x in (deg, src, sdir, sdist))
     eps, logits, len0 = _engine_scores(m, dev, state, 60, edges=edges)
-    scale = max(1.0, float(logits_o.abs().max()), float(len0_o.abs().max()))
-    assert (eps.cpu() - eps_o).abs().max() <= TOL * scale
-    assert (logits.cpu() - logits_o).abs().max() <= TOL * scale
-    assert (len0.cpu() - len0_o).abs().max() <= TOL * scale * max(num_atoms)
+    assert_scores_close((eps, logits, len0), (eps_o, logits_o, len0_o))
 
 
 def _rotation(axis, angle):
@@ -682,9 +689,7 @@ def test_alternative_arithmetic_variants_agree(dev, small_model, edge_variant, m
             path = os.path.join(d, tag + ".pt")
             subprocess.run([sys.executable, "-c", code, path], check=True, env={**os.environ, **env}, timeout=300)
             outs[tag] = torch.load(path)
-    scale = max(1.0, float(outs["default"][1].abs().max()))
-    for x, y in zip(outs["default"], outs["alt"]):
-        assert (x - y).abs().max() <= TOL * scale * 8
+    assert_scores_close(outs["alt"], outs["default"])  # two roundings of the same fp32 computation
 
 
 def test_launch_geometry_switches_and_counted_waits_are_bitwise_neutral(dev):
