@@ -19,7 +19,7 @@ EXPORTS = [
     "arreau_radius_graph_pbc", "arreau_compact_edges", "arreau_edges_to_slots", "arreau_predict_scores",
     "arreau_reverse_step", "arreau_profile_edge_kernel", "arreau_edge_kernel_time_ms",
     "arreau_model_status", "arreau_model_set_variant", "arreau_ponita_forward",
-    "arreau_diffusion_noise", "arreau_diffusion_losses",
+    "arreau_diffusion_noise", "arreau_diffusion_losses", "arreau_sample_loop", "arreau_philox_fill",
 ]
 
 STATUS_NONFINITE, STATUS_BAD_TIMESTEP, STATUS_BAD_TYPE = 1, 2, 4
@@ -92,6 +92,9 @@ def lib():
                                         [c_void_p, c_size_t, c_void_p])
     L.arreau_diffusion_noise.argtypes = [c_void_p] * 6 + [c_int32, c_int32] + [c_void_p] * 11
     L.arreau_diffusion_losses.argtypes = [c_void_p] * 10 + [c_int32, c_int32] + [c_void_p] * 6
+    L.arreau_sample_loop.argtypes = ([c_void_p] * 6 + [c_int32, c_int32, c_int32, c_int32, ctypes.c_uint64] +
+                                     [c_void_p, c_void_p, c_void_p, c_size_t, c_int32, c_void_p])
+    L.arreau_philox_fill.argtypes = [ctypes.c_uint64, c_int32, c_int32, c_int64, c_void_p, c_void_p, c_void_p]
     L.arreau_profile_edge_kernel.argtypes = [c_int32]
     L.arreau_edge_kernel_time_ms.argtypes = [POINTER(c_double), POINTER(c_int64)]
     for name in EXPORTS:

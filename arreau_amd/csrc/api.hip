@@ -21,7 +21,8 @@ struct Carver {
 
 struct Workspace {
     float *lattice, *cart, *cvec, *dir, *dist, *kbuf, *xa, *xb, *xc, *xbar, *vsum, *gs;
-    int32_t *batch, *deg, *src, *cell;
+    float *eps, *logits, *len0;  // network outputs of the sampling loop (arreau_sample_loop)
+    int32_t *batch, *deg, *src, *cell, *t_next, *t_cur;
     size_t bytes;
 };
 
@@ -45,6 +46,11 @@ Workspace carve(const arreau_config* cfg, int64_t N, int64_t B, void* base, size
     w.xbar = c.take<float>(L * N * C);
     w.vsum = c.take<float>(N * O);
     w.gs = c.take<float>(N * 3);
+    w.eps = c.take<float>(N * 3);
+    w.logits = c.take<float>(N * (size_t)cfg->num_atomic_states);
+    w.len0 = c.take<float>(B * 3);
+    w.t_next = c.take<int32_t>(B);
+    w.t_cur = c.take<int32_t>(B);
     w.bytes = (c.off + 255) & ~(size_t)255;
     return w;
 }
@@ -187,4 +193,83 @@ extern "C" int arreau_ponita_forward(const arreau_model* m, const float* d_x, co
     if ((rc = run_edge_kernel(m, d_dir, d_dist, d_deg, w, N, s))) return rc;
     if ((rc = arreau_launch_embed_general(m, d_x, d_vec, N, w.xa, s))) return rc;
     return run_layers_and_readout(m, w, d_deg, d_src, d_off, B, N, d_vec_out, d_logits, d_global_scalar, s);
+}
+
+// ---------------------------------------------------------------------------------------------
+// The hot loop of DiffusionLoss.sample (diffusion/diffusion_loss.py:318-347), enqueued in one call.
+// ---------------------------------------------------------------------------------------------
+namespace {
+__global__ void fill_i32_kernel(int32_t* __restrict__ p, int32_t v, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = v;
+}
+
+int enqueue_sample_step(const arreau_model* m, float* d_frac, int32_t* d_types, float* d_lengths, const float* d_angles,
+                        const int32_t* d_off, int B, int N, uint64_t seed, const int32_t* d_const_types, float* d_lattice,
+                        const Workspace& w, hipStream_t s) {
+    int rc;
+    if ((rc = arreau_launch_prep(m, d_frac, d_lengths, d_angles, nullptr, d_off, B, N, w.lattice, w.cart, w.batch, w.cvec, s,
+                                 w.t_next, w.t_cur)))
+        return rc;
+    if ((rc = arreau_launch_neighbor(w.cart, w.lattice, d_off, w.batch, B, N, m->cfg.radius, m->k, w.deg, w.src, w.cell,
+                                     w.dir, w.dist, s)))
+        return rc;
+    if ((rc = run_edge_kernel(m, w.dir, w.dist, w.deg, w, N, s))) return rc;
+    if ((rc = arreau_launch_embed(m, d_frac, d_types, w.lattice, w.batch, w.cvec, N, w.xa, s))) return rc;
+    if ((rc = run_layers_and_readout(m, w, w.deg, w.src, d_off, B, N, w.eps, w.logits, w.len0, s))) return rc;
+    return arreau_launch_reverse(m, d_frac, d_types, d_lengths, d_angles, w.t_cur, d_off, B, N, w.eps, w.logits, w.len0,
+                                 StepNoiseSrc{nullptr, nullptr, nullptr, seed}, d_const_types, d_lattice, s);
+}
+}  // namespace
+
+extern "C" int arreau_sample_loop(arreau_model* m, float* d_frac, int32_t* d_types, float* d_lengths,
+                                  const float* d_angles, const int32_t* d_off, int32_t B, int32_t N, int32_t t_start,
+                                  int32_t n_steps, uint64_t seed, const int32_t* d_const_types, float* d_lattice,
+                                  void* d_workspace, size_t workspace_bytes, int32_t use_graph, void* stream) {
+    ARREAU_REQUIRE(m && d_frac && d_types && d_lengths && d_angles && d_off && d_lattice, "arreau_sample_loop: null pointer");
+    ARREAU_REQUIRE(B >= 1 && N >= 0 && n_steps >= 0, "arreau_sample_loop: bad size");
+    ARREAU_REQUIRE(t_start <= m->T && t_start - n_steps >= 0, "arreau_sample_loop: timesteps t_start .. t_start-n_steps+1 must lie in 1..T");
+    ARREAU_REQUIRE(d_workspace != nullptr, "arreau_sample_loop: null workspace");
+    Workspace w = carve(&m->cfg, N, B, d_workspace, workspace_bytes);
+    if (w.bytes > workspace_bytes) {
+        arreau_set_error("arreau_sample_loop: workspace too small");
+        return ARREAU_ECAPACITY;
+    }
+    if (n_steps == 0) return ARREAU_OK;
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(fill_i32_kernel, dim3((B + 255) / 256), dim3(256), 0, s, w.t_next, t_start, B);
+    ARREAU_CHECK_HIP(hipGetLastError());
+    int rc;
+    if (!use_graph || n_steps < 3) {
+        for (int i = 0; i < n_steps; ++i)
+            if ((rc = enqueue_sample_step(m, d_frac, d_types, d_lengths, d_angles, d_off, B, N, seed, d_const_types, d_lattice, w, s)))
+                return rc;
+        return ARREAU_OK;
+    }
+    // One step captured into a hipGraph and replayed: the timestep lives on the device (prep_kernel advances it), the noise
+    // is a function of (seed, timestep, element), so every replay is the next step of the same trajectory as the eager loop.
+    // The first step runs eagerly (it also forces lazy module loading, which must not happen inside a capture).
+    if ((rc = enqueue_sample_step(m, d_frac, d_types, d_lengths, d_angles, d_off, B, N, seed, d_const_types, d_lattice, w, s)))
+        return rc;
+    hipGraph_t graph = nullptr;
+    ARREAU_CHECK_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+    rc = enqueue_sample_step(m, d_frac, d_types, d_lengths, d_angles, d_off, B, N, seed, d_const_types, d_lattice, w, s);
+    hipError_t e = hipStreamEndCapture(s, &graph);
+    if (rc) {
+        if (graph) (void)hipGraphDestroy(graph);
+        return rc;
+    }
+    ARREAU_CHECK_HIP(e);
+    hipGraphExec_t exec = nullptr;
+    e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(graph);
+    ARREAU_CHECK_HIP(e);
+    for (int i = 1; i < n_steps; ++i) {
+        e = hipGraphLaunch(exec, s);
+        if (e != hipSuccess) break;
+    }
+    // the executable graph must outlive its launches: it is kept with the model and released at the next loop / destroy
+    arreau_model_retire_graph(m, (void*)exec, (void*)s);
+    ARREAU_CHECK_HIP(e);
+    return ARREAU_OK;
 }

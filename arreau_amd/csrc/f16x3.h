@@ -233,10 +233,12 @@ struct MmaStream16 {
 };
 
 // Closed form of the above for register-starved kernels: steps [ST0, ST1) with their own fragment prefetch, nothing
-// carried across the call (no fragment registers live over a barrier).
-template <int NKB, int ST0, int ST1>
-__device__ __forceinline__ void mma16_range(f32x4v (&am)[2][2], f32x4v (&ax)[2][2], const u32x4* __restrict__ buf,
-                                            const u32x4 (&b)[2][NKB][2], int lane) {
+// carried across the call (no fragment registers live over a barrier).  NB = 16-column blocks per wave (2 = the wave's
+// 32 rows; 1 = a 16-row tile for batches too small to fill the chip with 32-row tiles -- every output row is computed by
+// the same instruction sequence either way, so the two geometries agree bit for bit).
+template <int NKB, int ST0, int ST1, int NB = 2>
+__device__ __forceinline__ void mma16_range(f32x4v (&am)[2][NB], f32x4v (&ax)[2][NB], const u32x4* __restrict__ buf,
+                                            const u32x4 (&b)[NB][NKB][2], int lane) {
     const u32x4* f = buf + lane;
     u32x4 a1[2], a2[2];
     a1[ST0 & 1] = f[(size_t)ST0 * 128];
@@ -250,7 +252,7 @@ __device__ __forceinline__ void mma16_range(f32x4v (&am)[2][2], f32x4v (&ax)[2][
         }
         const int kb = st >> 1, mt = st & 1;
 #pragma unroll
-        for (int nb = 0; nb < 2; ++nb) {
+        for (int nb = 0; nb < NB; ++nb) {
             am[mt][nb] = mfma16_f16(a1[slot], b[nb][kb][0], am[mt][nb]);
             ax[mt][nb] = mfma16_f16(a1[slot], b[nb][kb][1], ax[mt][nb]);
             ax[mt][nb] = mfma16_f16(a2[slot], b[nb][kb][0], ax[mt][nb]);
@@ -260,7 +262,7 @@ __device__ __forceinline__ void mma16_range(f32x4v (&am)[2][2], f32x4v (&ax)[2][
 #pragma unroll
     for (int st = ST0; st < ST1; ++st) {
         if (st + 1 < ST1) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, 6, 0);
+        __builtin_amdgcn_sched_group_barrier(0x008, 3 * NB, 0);
     }
 }
 

@@ -54,6 +54,8 @@ struct arreau_model {
     // arreau_model_set_variant overrides) and what the last arreau_predict_scores actually launched.
     int edge_variant, mlp_variant, conv_variant, readout_variant;
     mutable int ran_edge, ran_mlp, ran_conv;
+    void* retired_graph;     // hipGraphExec_t of the last arreau_sample_loop (+ the stream it was launched on): destroyed,
+    void* retired_stream;    //   after that stream has drained, by the next loop or by arreau_model_destroy
     int32_t* status;         // device word of sticky ARREAU_STATUS_* bits (written by the kernels with atomicOr)
     float* fk;               // [L][O(o)][O(p)][C] fiber kernels / O (written once by the precompute kernel)
     const float* conv_bias;  // [L][C]
@@ -179,6 +181,17 @@ __device__ __forceinline__ float arreau_gelu(float x) {
     return 0.5f * x * (1.0f + arreau_erf(x * 0.70710678118654752440f));
 }
 
+// Noise of one reverse step: either the caller's arrays (parity mode: the reference's draws injected) or drawn in the
+// kernel from Philox4x32-10 keyed by (seed, timestep, draw kind, element) -- no RNG launches, no noise arrays in HBM.
+struct StepNoiseSrc {
+    const float* z_lattice;  // [B,3]  or null
+    const float* z_frac;     // [N,3]  or null
+    const float* u_types;    // [N,S]  or null
+    uint64_t seed;           // used when the arrays are null
+};
+
+void arreau_model_retire_graph(arreau_model* m, void* exec, void* stream);  // takes ownership; frees the previous one
+
 // launchers implemented in the other translation units ------------------------------------------
 int arreau_launch_fiber_precompute(arreau_model* m, hipStream_t s);
 int arreau_launch_neighbor(const float* cart, const float* lattice, const int32_t* offsets, const int32_t* batch, int B, int N,
@@ -186,7 +199,11 @@ int arreau_launch_neighbor(const float* cart, const float* lattice, const int32_
                            hipStream_t s);
 int arreau_launch_prep(const arreau_model* m, const float* frac, const float* lengths, const float* angles,
                        const int32_t* t, const int32_t* offsets, int B, int N, float* lattice, float* cart,
-                       int32_t* batch, float* cvec, hipStream_t s);
+                       int32_t* batch, float* cvec, hipStream_t s, int32_t* t_next = nullptr, int32_t* t_cur = nullptr);
+int arreau_launch_reverse(const arreau_model* m, float* d_frac, int32_t* d_types, float* d_lengths, const float* d_angles,
+                          const int32_t* d_t, const int32_t* d_off, int B, int N, const float* d_eps,
+                          const float* d_logits, const float* d_len0, StepNoiseSrc noise, const int32_t* d_const_types,
+                          float* d_lattice, hipStream_t s);
 int arreau_launch_edge(const arreau_model* m, const float* dir, const float* dist, const int32_t* deg,
                        const int32_t* batch, const float* lattice, int N, float* kbuf, hipStream_t s);
 int arreau_launch_edge_bf16x6(const arreau_model* m, const float* dir, const float* dist, const int32_t* deg,

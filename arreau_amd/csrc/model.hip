@@ -459,8 +459,18 @@ extern "C" int arreau_model_create(const arreau_config* cfg, const arreau_state_
     return ARREAU_OK;
 }
 
+void arreau_model_retire_graph(arreau_model* m, void* exec, void* stream) {
+    if (m->retired_graph) {
+        (void)hipStreamSynchronize((hipStream_t)m->retired_stream);  // its launches have long finished; make it certain
+        (void)hipGraphExecDestroy((hipGraphExec_t)m->retired_graph);
+    }
+    m->retired_graph = exec;
+    m->retired_stream = stream;
+}
+
 extern "C" void arreau_model_destroy(arreau_model* model) {
     if (!model) return;
+    arreau_model_retire_graph(model, nullptr, nullptr);
     if (model->blob) (void)hipFree(model->blob);
     delete model;
 }

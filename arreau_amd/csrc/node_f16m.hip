@@ -49,7 +49,7 @@ __device__ __forceinline__ void split8(const float (&v)[8], u32x4& hi, u32x4& lo
 }
 }  // namespace
 
-template <int C, int H, int NW>
+template <int C, int H, int NW, int NB>
 __global__ __launch_bounds__(64 * NW, 2) void mlp_kernel_f16x3_m16(
     const float* __restrict__ x_conv,    // [N][16][C]  conv output (pre-LayerNorm)
     const float* __restrict__ x_in, float* __restrict__ x_out,
@@ -72,12 +72,12 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_kernel_f16x3_m16(
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int cp = lane & 15, gp = lane >> 4;  // prologue / matrix-phase copies
     const long long tile = (long long)blockIdx.x * NW + wave;
-    const bool active = 2 * tile < N;  // wave-uniform; idle waves still copy weights and meet the barriers
-    int nrow[2];                       // node of column block nb (padding: a valid node, nothing written)
-    bool valid[2];
+    const bool active = NB * tile < N;  // wave-uniform; idle waves still copy weights and meet the barriers
+    int nrow[NB];                      // node of column block nb (padding: a valid node, nothing written)
+    bool valid[NB];
 #pragma unroll
-    for (int nb = 0; nb < 2; ++nb) {
-        const long long n_ll = 2 * tile + nb;
+    for (int nb = 0; nb < NB; ++nb) {
+        const long long n_ll = NB * tile + nb;
         valid[nb] = n_ll < N;
         nrow[nb] = valid[nb] ? (int)n_ll : N - 1;
     }
@@ -90,9 +90,9 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_kernel_f16x3_m16(
     for (int i = threadIdx.x; i < H; i += 64 * NW) bias_s[i] = mb1[i];
 
     // ---- load the rows in B-operand layout, LayerNorm them (eps 1e-5, biased variance), split ---------------
-    u32x4 xn[2][KC][2];  // [column block][k-block][plane]
+    u32x4 xn[NB][KC][2];  // [column block][k-block][plane]
 #pragma unroll
-    for (int nb = 0; nb < 2; ++nb) {
+    for (int nb = 0; nb < NB; ++nb) {
         const float* rowp = x_conv + ((size_t)nrow[nb] * 16 + cp) * C + 4 * gp;
         float x[KC][8];
         float sum = 0.f;
@@ -131,13 +131,13 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_kernel_f16x3_m16(
     dma_wait();
     __syncthreads();
 
-    f32x4v acc_o[KC][2][2];  // [output chunk u][16-row tile mt][column block nb]
+    f32x4v acc_o[KC][2][NB];  // [output chunk u][16-row tile mt][column block nb]
 #pragma unroll
     for (int u = 0; u < KC; ++u)
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-            for (int nb = 0; nb < 2; ++nb) acc_o[u][mt][nb] = f32x4v{0.f, 0.f, 0.f, 0.f};
+            for (int nb = 0; nb < NB; ++nb) acc_o[u][mt][nb] = f32x4v{0.f, 0.f, 0.f, 0.f};
 
     // 32 chunks per layer: per quarter 4 chunks of W1 rows (32 hidden units each) then 4 chunks of W2 columns (32
     // outputs each).  Chunk q sits in ring slot q % 3; SYNC_q in the middle of its MFMA stream (edge_f16.hip).
@@ -153,25 +153,25 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_kernel_f16x3_m16(
     constexpr int ST = KC;  // step (of 2 KC) at which the barrier is taken
 #pragma unroll 1
     for (int w = 0; w < 4; ++w) {
-        u32x4 hid[2][KH][2];  // [column block][k-block = hidden chunk][plane]
+        u32x4 hid[NB][KH][2];  // [column block][k-block = hidden chunk][plane]
 #pragma unroll
         for (int u = 0; u < KH; ++u) {  // ---- hidden chunk u = GELU(W1q[u] . xn + b1q[u]) ----
-            Acc16 acc;
+            struct { f32x4v m[2][NB], x[2][NB]; } acc;
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt) {
                 const f32x4 b = *reinterpret_cast<const f32x4*>(bias_s + w * HQ + 32 * u + 16 * mt + 4 * gp);
 #pragma unroll
-                for (int nb = 0; nb < 2; ++nb) {
+                for (int nb = 0; nb < NB; ++nb) {
                     acc.m[mt][nb] = f32x4v{b[0], b[1], b[2], b[3]};
                     acc.x[mt][nb] = f32x4v{0.f, 0.f, 0.f, 0.f};
                 }
             }
-            if (active) mma16_range<KC, 0, ST>(acc.m, acc.x, lds[sl], xn, lane);
+            if (active) mma16_range<KC, 0, ST, NB>(acc.m, acc.x, lds[sl], xn, lane);
             sync(true);  // a W1 chunk is always followed by at least four more
             if (active) {
-                mma16_range<KC, ST, 2 * KC>(acc.m, acc.x, lds[sl], xn, lane);
+                mma16_range<KC, ST, 2 * KC, NB>(acc.m, acc.x, lds[sl], xn, lane);
 #pragma unroll
-                for (int nb = 0; nb < 2; ++nb) {
+                for (int nb = 0; nb < NB; ++nb) {
                     float v[8];
 #pragma unroll
                     for (int mt = 0; mt < 2; ++mt)
@@ -190,19 +190,19 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_kernel_f16x3_m16(
         }
 #pragma unroll
         for (int u = 0; u < KC; ++u) {  // ---- output chunk u += W2[:, quarter][u] . hid ----
-            f32x4v cross[2][2];  // acc_o[u] itself is the main accumulator
+            f32x4v cross[2][NB];  // acc_o[u] itself is the main accumulator
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-                for (int nb = 0; nb < 2; ++nb) cross[mt][nb] = f32x4v{0.f, 0.f, 0.f, 0.f};
-            if (active) mma16_range<KH, 0, ST>(acc_o[u], cross, lds[sl], hid, lane);
+                for (int nb = 0; nb < NB; ++nb) cross[mt][nb] = f32x4v{0.f, 0.f, 0.f, 0.f};
+            if (active) mma16_range<KH, 0, ST, NB>(acc_o[u], cross, lds[sl], hid, lane);
             sync(!(w == 3 && u >= KC - 2));
             if (active) {
-                mma16_range<KH, ST, 2 * KH>(acc_o[u], cross, lds[sl], hid, lane);
+                mma16_range<KH, ST, 2 * KH, NB>(acc_o[u], cross, lds[sl], hid, lane);
 #pragma unroll
                 for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
-                    for (int nb = 0; nb < 2; ++nb)
+                    for (int nb = 0; nb < NB; ++nb)
 #pragma unroll
                         for (int r = 0; r < 4; ++r) acc_o[u][mt][nb][r] = fmaf(cross[mt][nb][r], F16X3_INV_SCALE, acc_o[u][mt][nb][r]);
             }
@@ -218,7 +218,9 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_kernel_f16x3_m16(
     asm volatile("" : "+v"(lane_e));
     const int c = lane_e & 15, g = lane_e >> 4;
     const float inv16 = 1.0f / 16.0f;
-    float vdot[2] = {0.f, 0.f};
+    float vdot[NB];
+#pragma unroll
+    for (int nb = 0; nb < NB; ++nb) vdot[nb] = 0.f;
 #pragma unroll
     for (int u = 0; u < KC; ++u)
 #pragma unroll
@@ -228,7 +230,7 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_kernel_f16x3_m16(
             const f32x4 lsv = *reinterpret_cast<const f32x4*>(ls + c0);
             const f32x4 wvv = *reinterpret_cast<const f32x4*>(wv + c0);
 #pragma unroll
-            for (int nb = 0; nb < 2; ++nb) {
+            for (int nb = 0; nb < NB; ++nb) {
                 const size_t off = ((size_t)nrow[nb] * 16 + c) * C + c0;
                 const f32x4 xi = *reinterpret_cast<const f32x4*>(x_in + off);
                 f32x4 xo;
@@ -247,7 +249,7 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_kernel_f16x3_m16(
             }
         }
 #pragma unroll
-    for (int nb = 0; nb < 2; ++nb) {
+    for (int nb = 0; nb < NB; ++nb) {
         const float tot = group4_sum(vdot[nb]);
         if (valid[nb] && g == 0) {
             const size_t o = (size_t)nrow[nb] * 16 + c;
@@ -266,13 +268,33 @@ int arreau_launch_mlp_f16x3_m16(const arreau_model* m, int layer, const float* x
     }
     constexpr int NW = 4;
     const size_t layer_u32x4 = (size_t)2 * H * C * 2 * 2 / 16;  // bytes of W1 + W2 as 2 fp16 planes, in 16-byte units
-    const long long tiles = ((long long)N + 1) / 2;
-    hipLaunchKernelGGL((mlp_kernel_f16x3_m16<128, 512, NW>), dim3((unsigned)((tiles + NW - 1) / NW)), dim3(64 * NW), 0, s,
-                       x_conv, x_in, x_out, m->ln_w + (size_t)layer * C, m->ln_b + (size_t)layer * C,
-                       reinterpret_cast<const u32x4*>(m->mlp_f16m) + (size_t)layer * layer_u32x4,
-                       m->mb1 + (size_t)layer * H, m->mb2 + (size_t)layer * C, m->ls + (size_t)layer * C,
-                       m->ro_wv + (size_t)layer * C, m->ro_bv_host[layer], N, layer == 0 ? 1 : 0,
-                       xbar + (size_t)layer * N * C, vsum);
+    // Tile geometry: one wave = 2 nodes (32 rows) normally; 1 node (16 rows) while that still leaves wave slots idle
+    // (2 workgroups x 4 waves on each of the CUs) -- twice the waves, half the work each, bit-identical rows.
+    // ARREAU_MLP_NB = 1 / 2 forces a geometry (tests).
+    static const int nb_env = [] { const char* e = getenv("ARREAU_MLP_NB"); return e ? atoi(e) : 0; }();
+    static const int wave_slots = [] {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+            return 8 * (int)prop.multiProcessorCount;
+        return 2048;
+    }();
+    const int nb = nb_env == 1 || nb_env == 2 ? nb_env : (((long long)N + 1) / 2 < wave_slots ? 1 : 2);
+    const long long tiles = ((long long)N + nb - 1) / nb;
+    const dim3 grid((unsigned)((tiles + NW - 1) / NW)), block(64 * NW);
+    const float* lnw = m->ln_w + (size_t)layer * C;
+    const float* lnb = m->ln_b + (size_t)layer * C;
+    const u32x4* stream = reinterpret_cast<const u32x4*>(m->mlp_f16m) + (size_t)layer * layer_u32x4;
+    if (nb == 1)
+        hipLaunchKernelGGL((mlp_kernel_f16x3_m16<128, 512, NW, 1>), grid, block, 0, s, x_conv, x_in, x_out, lnw, lnb, stream,
+                           m->mb1 + (size_t)layer * H, m->mb2 + (size_t)layer * C, m->ls + (size_t)layer * C,
+                           m->ro_wv + (size_t)layer * C, m->ro_bv_host[layer], N, layer == 0 ? 1 : 0,
+                           xbar + (size_t)layer * N * C, vsum);
+    else
+        hipLaunchKernelGGL((mlp_kernel_f16x3_m16<128, 512, NW, 2>), grid, block, 0, s, x_conv, x_in, x_out, lnw, lnb, stream,
+                           m->mb1 + (size_t)layer * H, m->mb2 + (size_t)layer * C, m->ls + (size_t)layer * C,
+                           m->ro_wv + (size_t)layer * C, m->ro_bv_host[layer], N, layer == 0 ? 1 : 0,
+                           xbar + (size_t)layer * N * C, vsum);
     ARREAU_CHECK_HIP(hipGetLastError());
     return ARREAU_OK;
 }

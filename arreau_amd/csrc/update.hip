@@ -1,17 +1,20 @@
 // K6: the reverse updates of one denoising step (diffusion/diffusion_loss.py:338-347).
 #include "internal.h"
+#include "philox.h"
 
 #define D3PM_EPS 1e-6f  // d3pm.py:23
+
 
 // VP_lattice.reverse_given_x0 (diffusion_helpers.py:185-199) on lengths, then lattice_from_params.
 // Note the reference adds `variance * z` (not sqrt(variance)) and zeroes z when t <= 1.
 __global__ void reverse_lattice_kernel(float* __restrict__ lengths, const float* __restrict__ angles,
                                        const int32_t* __restrict__ tstep, const int32_t* __restrict__ offsets,
-                                       const float* __restrict__ len0, const float* __restrict__ z,
+                                       const float* __restrict__ len0, StepNoiseSrc noise,
                                        const float* __restrict__ alpha_bars, const float* __restrict__ betas, int B,
                                        int T, float* __restrict__ lattice, int32_t* __restrict__ status) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
+    const float* __restrict__ z = noise.z_lattice;
     int t = tstep[b];
     if (t < 1 || t > T) atomicOr(status, ARREAU_STATUS_BAD_TIMESTEP);  // clamped, but flagged
     t = t < 1 ? 1 : (t > T ? T : t);
@@ -28,7 +31,8 @@ __global__ void reverse_lattice_kernel(float* __restrict__ lengths, const float*
         const float x0 = len0[3 * b + i] * n;  // pred_lengths_0 * num_atoms (diffusion_loss.py:338)
         const float xt = lengths[3 * b + i];
         const float mean = (c0 * x0 + c1 * xt) / denom;
-        const float zz = t > 1 ? z[3 * b + i] : 0.0f;
+        const float zdraw = z ? z[3 * b + i] : philox_normal(noise.seed, (uint32_t)t, ARREAU_DRAW_Z_LATTICE, 3u * b + i);
+        const float zz = t > 1 ? zdraw : 0.0f;
         newlen[i] = mean + variance * zz;
         lengths[3 * b + i] = newlen[i];
     }
@@ -58,9 +62,11 @@ __device__ __forceinline__ float remainder_one(float x) {
 __global__ __launch_bounds__(256) void reverse_atoms_kernel(
     float* __restrict__ frac, int32_t* __restrict__ types, const int32_t* __restrict__ tstep,
     const int32_t* __restrict__ offsets, int B, int N, const float* __restrict__ eps,
-    const float* __restrict__ logits, const float* __restrict__ z_frac, const float* __restrict__ u_types,
+    const float* __restrict__ logits, StepNoiseSrc noise,
     const float* __restrict__ ve_sigmas, const float* __restrict__ q1t, const float* __restrict__ qmats, int S,
-    int T, int32_t* __restrict__ status) {
+    int T, const int32_t* __restrict__ const_types, int32_t* __restrict__ status) {
+    const float* __restrict__ z_frac = noise.z_frac;
+    const float* __restrict__ u_types = noise.u_types;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int i = blockIdx.x * 4 + wave;
     if (i >= N) return;  // wave-uniform; no block-level barrier below
@@ -85,7 +91,8 @@ __global__ __launch_bounds__(256) void reverse_atoms_kernel(
         const size_t g = 3 * (size_t)i + lane;
         const float mean = frac[g] - eps[g] * (s2 - sp2);
         const float stdv = sqrtf((sp2 * (s2 - sp2)) / s2);
-        frac[g] = remainder_one(mean + stdv * z_frac[g]);
+        const float zf = z_frac ? z_frac[g] : philox_normal(noise.seed, (uint32_t)t, ARREAU_DRAW_Z_FRAC, (uint32_t)g);
+        frac[g] = remainder_one(mean + stdv * zf);
     }
 
     // ---- D3PM posterior logits ------------------------------------------------------------------
@@ -135,16 +142,19 @@ __global__ __launch_bounds__(256) void reverse_atoms_kernel(
     }
     // ---- Gumbel arg-max (d3pm.py:206-214) ----------------------------------------------------------
     const float scale = (t != 1) ? 1.0f : 0.2f;
-    const float* un = u_types + (size_t)i * S;
+    const float* un = u_types ? u_types + (size_t)i * S : nullptr;
+    auto draw_u = [&](int s_) {
+        return un ? un[s_] : philox_uniform(noise.seed, (uint32_t)t, ARREAU_DRAW_U_TYPES, (uint32_t)((size_t)i * S + s_));
+    };
     float best = -INFINITY;
     int besti = 0x7fffffff;
     if (v0) {
-        const float u = fminf(fmaxf(un[s0], D3PM_EPS), 1.0f);
+        const float u = fminf(fmaxf(draw_u(s0), D3PM_EPS), 1.0f);
         best = post0 + (-logf(-logf(u))) * scale;
         besti = s0;
     }
     if (v1) {
-        const float u = fminf(fmaxf(un[s1], D3PM_EPS), 1.0f);
+        const float u = fminf(fmaxf(draw_u(s1), D3PM_EPS), 1.0f);
         const float val = post1 + (-logf(-logf(u))) * scale;
         if (val > best) { best = val; besti = s1; }
     }
@@ -154,7 +164,23 @@ __global__ __launch_bounds__(256) void reverse_atoms_kernel(
         const int oi = __shfl_xor(besti, off, 64);
         if (ob > best || (ob == best && oi < besti)) { best = ob; besti = oi; }  // first index wins ties
     }
-    if (lane == 0) types[i] = besti;
+    // use_constant_atomic_symbols (lightning_wrappers/diffusion.py:231-236): the fixed species are re-imposed each step
+    if (lane == 0) types[i] = const_types ? const_types[i] : besti;
+}
+
+int arreau_launch_reverse(const arreau_model* m, float* d_frac, int32_t* d_types, float* d_lengths, const float* d_angles,
+                          const int32_t* d_t, const int32_t* d_off, int B, int N, const float* d_eps,
+                          const float* d_logits, const float* d_len0, StepNoiseSrc noise, const int32_t* d_const_types,
+                          float* d_lattice, hipStream_t s) {
+    hipLaunchKernelGGL(reverse_lattice_kernel, dim3((B + 127) / 128), dim3(128), 0, s, d_lengths, d_angles, d_t, d_off,
+                       d_len0, noise, m->vp_alpha_bars, m->vp_betas, B, m->T, d_lattice, m->status);
+    ARREAU_CHECK_HIP(hipGetLastError());
+    if (N > 0) {
+        hipLaunchKernelGGL(reverse_atoms_kernel, dim3((N + 3) / 4), dim3(256), 0, s, d_frac, d_types, d_t, d_off, B, N,
+                           d_eps, d_logits, noise, m->ve_sigmas, m->q1t, m->qmats, m->S, m->T, d_const_types, m->status);
+        ARREAU_CHECK_HIP(hipGetLastError());
+    }
+    return ARREAU_OK;
 }
 
 extern "C" int arreau_reverse_step(const arreau_model* m, float* d_frac, int32_t* d_types, float* d_lengths,
@@ -165,14 +191,31 @@ extern "C" int arreau_reverse_step(const arreau_model* m, float* d_frac, int32_t
     ARREAU_REQUIRE(m && d_frac && d_types && d_lengths && d_angles && d_t && d_off && d_eps && d_logits && d_len0 &&
                        d_z_lattice && d_z_frac && d_u_types && d_lattice, "arreau_reverse_step: null pointer");
     ARREAU_REQUIRE(B >= 1 && N >= 0, "arreau_reverse_step: bad size");
-    hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(reverse_lattice_kernel, dim3((B + 127) / 128), dim3(128), 0, s, d_lengths, d_angles, d_t, d_off,
-                       d_len0, d_z_lattice, m->vp_alpha_bars, m->vp_betas, B, m->T, d_lattice, m->status);
-    ARREAU_CHECK_HIP(hipGetLastError());
-    if (N > 0) {
-        hipLaunchKernelGGL(reverse_atoms_kernel, dim3((N + 3) / 4), dim3(256), 0, s, d_frac, d_types, d_t, d_off, B, N,
-                           d_eps, d_logits, d_z_frac, d_u_types, m->ve_sigmas, m->q1t, m->qmats, m->S, m->T, m->status);
-        ARREAU_CHECK_HIP(hipGetLastError());
+    return arreau_launch_reverse(m, d_frac, d_types, d_lengths, d_angles, d_t, d_off, B, N, d_eps, d_logits, d_len0,
+                                 StepNoiseSrc{d_z_lattice, d_z_frac, d_u_types, 0}, nullptr, d_lattice, (hipStream_t)stream);
+}
+
+// The sampler's in-kernel noise, written out: out[i] = the draw (seed, timestep, kind, element i) -- standard normal for
+// kinds 0/1, uniform [0,1) for kind 2.  For tests (known-answer / statistics) and for reproducing a Philox trajectory
+// through arreau_reverse_step.
+__global__ void philox_fill_kernel(uint64_t seed, uint32_t timestep, uint32_t kind, int64_t n, float* __restrict__ out,
+                                   uint32_t* __restrict__ raw) {
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if (raw) {
+        const Philox4 r = philox4x32_10((uint32_t)i, timestep, kind, 0u, (uint32_t)seed, (uint32_t)(seed >> 32));
+        for (int j = 0; j < 4; ++j) raw[4 * i + j] = r.x[j];
     }
+    if (out) out[i] = kind == ARREAU_DRAW_U_TYPES ? philox_uniform(seed, timestep, kind, (uint32_t)i)
+                                                  : philox_normal(seed, timestep, kind, (uint32_t)i);
+}
+
+extern "C" int arreau_philox_fill(uint64_t seed, int32_t timestep, int32_t kind, int64_t n, float* d_out, uint32_t* d_raw,
+                                  void* stream) {
+    ARREAU_REQUIRE((d_out || d_raw) && n >= 0 && kind >= 0 && kind <= 2, "arreau_philox_fill: bad argument");
+    if (n == 0) return ARREAU_OK;
+    hipLaunchKernelGGL(philox_fill_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, seed,
+                       (uint32_t)timestep, (uint32_t)kind, n, d_out, d_raw);
+    ARREAU_CHECK_HIP(hipGetLastError());
     return ARREAU_OK;
 }

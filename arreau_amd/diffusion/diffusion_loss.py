@@ -126,21 +126,24 @@ class DiffusionLoss(nn.Module):
     @torch.no_grad()
     def sample(self, *, model, z_table: AtomicNumberTable, t_emb_weights=None, num_atoms_per_sample,
                num_samples_in_batch: int, vis_name: str = "", visualization_setting=VisualizationSetting.NONE,
-               show_bonds: bool = False, constant_atoms: Optional[torch.Tensor] = None, noise: str = "device",
-               max_steps: Optional[int] = None, use_graph: Optional[bool] = None) -> SampleResult:
-        """diffusion_loss.py:276-377.  The initial state is drawn on the host exactly like the
-        reference (numpy uniforms for the angles, then randn lengths, randn fractional coordinates
-        from torch's global CPU generator).  Per-step noise: `noise="device"` draws on the GPU
-        (fast path); `noise="reference"` draws randn[B,3], randn[N,3], rand[N,S] from the global
-        CPU generator in the reference's order and uploads it.  `use_graph=True` (device noise only) captures the
-        whole step (score network, three noise draws, reverse updates, timestep decrement: ~25 kernel launches)
-        once into a HIP graph and replays it T-1 times.  Measured on MI355X it does not change the step time (even
-        one crystal of 8 atoms, 0.43 ms/step, is bound by the dependent chain of small kernels, not by host
-        launches), so it is off by default."""
+               show_bonds: bool = False, constant_atoms: Optional[torch.Tensor] = None, noise: str = "philox",
+               max_steps: Optional[int] = None, use_graph: Optional[bool] = None, seed: Optional[int] = None) -> SampleResult:
+        """diffusion_loss.py:276-377.  The initial state is drawn on the host exactly like the reference (numpy
+        uniforms for the angles, then randn lengths, randn fractional coordinates from torch's global CPU generator).
+        Per-step noise:
+          noise="philox" (default): the whole loop is ONE library call (arreau_sample_loop): the three draws of a step are
+              generated inside the update kernels from Philox4x32-10 keyed by (seed, timestep, draw, element), the
+              timestep lives on the device, nothing happens on the host between steps.  `seed` defaults to a draw from
+              torch's global CPU generator (so torch.manual_seed makes runs repeatable).  `use_graph=True` replays one
+              captured step as a hipGraph (same trajectory bit for bit; default: on for batches of at most 64 atoms,
+              where the step is launch-bound, off otherwise).
+          noise="reference": randn[B,3], randn[N,3], rand[N,S] from the global CPU generator in the reference's order
+              (diffusion_helpers.py:193-197, :79; d3pm.py:206), uploaded every step -- the parity mode.
+          noise="device": the same loop with torch's device generator (three RNG launches per step)."""
         if visualization_setting != VisualizationSetting.NONE:
             raise NotImplementedError("per-step visualisation is outside this build; use VisualizationSetting.NONE")
-        if noise not in ("device", "reference"):
-            raise ValueError("noise must be 'device' or 'reference'")
+        if noise not in ("philox", "device", "reference"):
+            raise ValueError("noise must be 'philox', 'device' or 'reference'")
         eng = model.engine()
         dev = eng.device
         S = len(z_table)
@@ -173,44 +176,23 @@ class DiffusionLoss(nn.Module):
         const_d = types_d.clone() if constant_atoms is not None else None
         off_d = crystal_offsets(num_atoms, dev)
         lattice_d = torch.zeros((B, 3, 3), **f32)
-        t_d = torch.empty(B, device=dev, dtype=torch.int32)
         n_steps = self.T - 1 if max_steps is None else min(self.T - 1, int(max_steps))
-        if use_graph is None:
-            use_graph = False
-        if use_graph and noise != "device":
-            raise ValueError("graph replay needs device-side noise")
+        if use_graph and noise != "philox":
+            raise ValueError("graph replay needs noise='philox' (the in-kernel generator)")
 
-        def one_step():
-            eps, logits, len0 = eng.predict_scores(frac_d, types_d, len_d, ang_d, t_d, off_d)
-            z_l = torch.randn((B, 3), **f32)
-            z_f = torch.randn((N, 3), **f32)
-            u_t = torch.rand((N, S), **f32)
-            eng.reverse_step(frac_d, types_d, len_d, ang_d, t_d, off_d, eps, logits, len0, z_l, z_f, u_t, lattice_d)
-            if const_d is not None:
-                types_d.copy_(const_d)
-            t_d.sub_(1)  # next (lower) timestep; part of the captured graph
-
-        if use_graph and n_steps > 2:
-            eng.workspace(N, B)  # size the workspace before capture (no allocation may happen inside)
-            t_d.fill_(self.T - 1)
-            state0 = [x.clone() for x in (frac_d, types_d, len_d, lattice_d)]
-            side = torch.cuda.Stream(device=dev)
-            side.wait_stream(torch.cuda.current_stream(dev))
-            with torch.cuda.stream(side):  # warm-up outside capture (lazy module loads, allocator pools)
-                one_step()
-            torch.cuda.current_stream(dev).wait_stream(side)
-            for dst, src in zip((frac_d, types_d, len_d, lattice_d), state0):
-                dst.copy_(src)
-            graph = torch.cuda.CUDAGraph()
-            t_d.fill_(self.T - 1)
-            with torch.cuda.graph(graph):
-                one_step()
-            # the capture itself does not run the kernels: state and timestep are still at their start values
-            for _ in range(n_steps):
-                graph.replay()
+        if noise == "philox":
+            if seed is None:
+                seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+            if use_graph is None:
+                use_graph = N <= 64
+            eng.sample_loop(frac_d, types_d, len_d, ang_d, off_d, self.T - 1, n_steps, seed, const_d, lattice_d,
+                            use_graph=bool(use_graph))
         else:
+            t_d = torch.empty(B, device=dev, dtype=torch.int32)
             done = 0
             for timestep in reversed(range(1, self.T)):
+                if done >= n_steps:
+                    break
                 t_d.fill_(timestep)
                 eps, logits, len0 = eng.predict_scores(frac_d, types_d, len_d, ang_d, t_d, off_d)
                 if noise == "device":
@@ -225,8 +207,6 @@ class DiffusionLoss(nn.Module):
                 if const_d is not None:
                     types_d.copy_(const_d)
                 done += 1
-                if done >= n_steps:
-                    break
         eng.check_status()  # sticky device flags (non-finite outputs, clamped indices): raise instead of returning them
         atomic_numbers = atomic_number_indexes_to_atomic_numbers(z_table, types_d.cpu().numpy())
         return SampleResult(num_atoms=num_atoms.numpy(), frac_x=frac_d.cpu().numpy().astype(np.float64),

@@ -136,6 +136,25 @@ class HipEngine:
             _hip.ptr(ws), ws.numel(), _hip.stream_ptr(dev)), "arreau_ponita_forward")
         return logits, vec_out, gscalar
 
+    def sample_loop(self, frac, types, lengths, angles, offsets, t_start, n_steps, seed, const_types, lattice_out,
+                    use_graph=False):
+        """n_steps iterations of the sampling loop in one library call (arreau_sample_loop): in-place update of
+        (frac, types, lengths); Philox noise keyed by (seed, timestep, draw, element)."""
+        N, B = frac.shape[0], lengths.shape[0]
+        ws = self.workspace(N, B)
+        _hip.check(_hip.lib().arreau_sample_loop(
+            self._handle, _hip.ptr(frac), _hip.ptr(types), _hip.ptr(lengths), _hip.ptr(angles), _hip.ptr(offsets), B, N,
+            int(t_start), int(n_steps), int(seed) & (2 ** 64 - 1), _hip.ptr(const_types), _hip.ptr(lattice_out), _hip.ptr(ws),
+            ws.numel(), int(bool(use_graph)), _hip.stream_ptr(self.device)), "arreau_sample_loop")
+
+    def philox_fill(self, seed, timestep, kind, n, raw=False):
+        """The sampler's in-kernel noise written out (arreau_philox_fill): kind 0/1 standard normal, 2 uniform [0,1)."""
+        out = torch.empty(n, device=self.device, dtype=torch.float32)
+        words = torch.empty((n, 4), device=self.device, dtype=torch.int32) if raw else None
+        _hip.check(_hip.lib().arreau_philox_fill(int(seed) & (2 ** 64 - 1), int(timestep), int(kind), int(n), _hip.ptr(out),
+                                                 _hip.ptr(words), _hip.stream_ptr(self.device)), "arreau_philox_fill")
+        return (out, words) if raw else out
+
     def diffusion_noise(self, frac0, types0, lattice0, t_crystal, offsets, z_frac, u_types, z_lengths):
         """Forward noising of a clean batch (arreau_diffusion_noise).  Returns dict(noisy_frac, target_eps, noisy_types,
         noisy_lengths, lengths, angles)."""

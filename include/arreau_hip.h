@@ -228,6 +228,27 @@ int arreau_reverse_step(const arreau_model* model,
                         const float* d_z_lattice, const float* d_z_frac, const float* d_u_types,
                         float* d_lattice, void* stream);
 
+/* The hot loop of DiffusionLoss.sample (diffusion/diffusion_loss.py:318-347) enqueued in ONE call: for timestep
+ * t_start, t_start-1, ..., t_start-n_steps+1 (the reference runs T-1 .. 1): arreau_predict_scores, then the reverse
+ * updates with the three draws of the step (diffusion_helpers.py:193-197, :79; d3pm.py:206) generated INSIDE the update
+ * kernels from Philox4x32-10 keyed by (seed, timestep, draw, element) -- no RNG launches, no noise arrays, no host work
+ * between steps; the timestep lives on the device.  State (d_frac, d_types, d_lengths) is updated in place, d_lattice
+ * [B,3,3] receives the final cell.  d_const_types (may be NULL): species re-imposed after every step
+ * (use_constant_atomic_symbols, lightning_wrappers/diffusion.py:231-236).  use_graph != 0 captures one step into a
+ * hipGraph and replays it (same trajectory; pays for itself only on small, launch-bound batches).
+ * Does not synchronise. */
+int arreau_sample_loop(arreau_model* model, float* d_frac, int32_t* d_types, float* d_lengths, const float* d_angles,
+                       const int32_t* d_crystal_offsets, int32_t B, int32_t N, int32_t t_start, int32_t n_steps,
+                       uint64_t seed, const int32_t* d_const_types, float* d_lattice,
+                       void* d_workspace, size_t workspace_bytes, int32_t use_graph, void* stream);
+
+/* The sampler's in-kernel noise written out: d_out[i] = draw (seed, timestep, kind, element i) -- standard normal for
+ * kind 0 (z_lattice) and 1 (z_frac), uniform [0,1) for kind 2 (u_types); d_raw[4 i .. 4 i + 3] (may be NULL) = the raw
+ * Philox4x32-10 words of counter (i, timestep, kind, 0), key = seed.  Feeding these arrays to arreau_reverse_step
+ * reproduces arreau_sample_loop's update bit for bit. */
+int arreau_philox_fill(uint64_t seed, int32_t timestep, int32_t kind, int64_t n, float* d_out, uint32_t* d_raw,
+                       void* stream);
+
 /* ---- score-matching training loss, forward part (BASELINE config 5) ------------------------------------------ */
 
 /* The forward-noising half of DiffusionLoss.__call__ (diffusion/diffusion_loss.py:222-234), random draws supplied by

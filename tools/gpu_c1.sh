@@ -17,3 +17,10 @@ import shutil; shutil.copy(f, "gpurun_out/${tag}_kernel_stats_c1.csv")
 for r in list(csv.DictReader(open(f)))[:24]:
     print(r["Name"][:48].ljust(48), r["Calls"].rjust(5), "%9.1f us" % (float(r["AverageNs"])/1e3), r["Percentage"])
 PY
+timeout -k 10 300 python bench.py --no-cpu-baseline > gpurun_out/${tag}_bench_c2.json 2> gpurun_out/${tag}_bench_c2.err || { tail -n 30 gpurun_out/${tag}_bench_c2.err; exit 1; }
+python - <<PY
+import json
+for c in ("c1", "c2"):
+    d = json.load(open("gpurun_out/${tag}_bench_%s.json" % c))
+    print(c, "ms_per_step", round(d["ms_per_step"], 4), "free_loop", d.get("free_running_loop"), "edge_ms", round(d["roofline"]["avg_launch_ms"], 4))
+PY
