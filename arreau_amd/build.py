@@ -19,7 +19,7 @@ LIB = os.path.join(CSRC, "libarreau_hip.so")
 # Its outputs must be bit-identical to the product library's (test_counted_waits_match_full_waits); only the sources
 # that contain counted waits are recompiled for it.
 LIB_DEBUG_WAIT = os.path.join(CSRC, "libarreau_hip_dbgwait.so")
-DEBUG_WAIT_SOURCES = ["edge_f16.hip", "node.hip"]
+DEBUG_WAIT_SOURCES = ["edge_f16.hip", "node.hip", "node_f16m.hip"]
 STAMP = os.path.join(CSRC, ".build_stamp")
 # Kernels that hand-count s_waitcnt vmcnt(N) or drain LDS-DMA copies with asm waits hipcc cannot see: a register spill
 # would put scratch loads/stores into the same in-order queue and silently break the protocol, so the build fails if

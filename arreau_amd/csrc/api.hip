@@ -248,6 +248,21 @@ extern "C" int arreau_sample_loop(arreau_model* m, float* d_frac, int32_t* d_typ
     }
     // One step captured into a hipGraph and replayed: the timestep lives on the device (prep_kernel advances it), the noise
     // is a function of (seed, timestep, element), so every replay is the next step of the same trajectory as the eager loop.
+    // Capture is not allowed on the legacy default stream (which is what callers usually pass), so the loop runs on a
+    // stream of the model's own, joined to the caller's stream by events on both sides: still no host synchronisation.
+    if (!m->loop_stream) {
+        hipStream_t ls = nullptr;
+        ARREAU_CHECK_HIP(hipStreamCreateWithFlags(&ls, hipStreamNonBlocking));
+        hipEvent_t ev = nullptr;
+        ARREAU_CHECK_HIP(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        m->loop_stream = (void*)ls;
+        m->loop_event = (void*)ev;
+    }
+    hipStream_t user = s;
+    hipEvent_t ev = (hipEvent_t)m->loop_event;
+    s = (hipStream_t)m->loop_stream;
+    ARREAU_CHECK_HIP(hipEventRecord(ev, user));
+    ARREAU_CHECK_HIP(hipStreamWaitEvent(s, ev, 0));
     // The first step runs eagerly (it also forces lazy module loading, which must not happen inside a capture).
     if ((rc = enqueue_sample_step(m, d_frac, d_types, d_lengths, d_angles, d_off, B, N, seed, d_const_types, d_lattice, w, s)))
         return rc;
@@ -268,6 +283,8 @@ extern "C" int arreau_sample_loop(arreau_model* m, float* d_frac, int32_t* d_typ
         e = hipGraphLaunch(exec, s);
         if (e != hipSuccess) break;
     }
+    if (e == hipSuccess) e = hipEventRecord(ev, s);
+    if (e == hipSuccess) e = hipStreamWaitEvent(user, ev, 0);  // the caller's stream continues after the loop
     // the executable graph must outlive its launches: it is kept with the model and released at the next loop / destroy
     arreau_model_retire_graph(m, (void*)exec, (void*)s);
     ARREAU_CHECK_HIP(e);

@@ -54,6 +54,8 @@ struct arreau_model {
     // arreau_model_set_variant overrides) and what the last arreau_predict_scores actually launched.
     int edge_variant, mlp_variant, conv_variant, readout_variant;
     mutable int ran_edge, ran_mlp, ran_conv;
+    void* loop_stream;       // hipStream_t / hipEvent_t of arreau_sample_loop's graph mode (capture is not allowed on the
+    void* loop_event;        //   legacy default stream callers usually pass); created on first use
     void* retired_graph;     // hipGraphExec_t of the last arreau_sample_loop (+ the stream it was launched on): destroyed,
     void* retired_stream;    //   after that stream has drained, by the next loop or by arreau_model_destroy
     int32_t* status;         // device word of sticky ARREAU_STATUS_* bits (written by the kernels with atomicOr)

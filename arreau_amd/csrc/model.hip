@@ -471,6 +471,11 @@ void arreau_model_retire_graph(arreau_model* m, void* exec, void* stream) {
 extern "C" void arreau_model_destroy(arreau_model* model) {
     if (!model) return;
     arreau_model_retire_graph(model, nullptr, nullptr);
+    if (model->loop_stream) {
+        (void)hipStreamSynchronize((hipStream_t)model->loop_stream);
+        (void)hipStreamDestroy((hipStream_t)model->loop_stream);
+        (void)hipEventDestroy((hipEvent_t)model->loop_event);
+    }
     if (model->blob) (void)hipFree(model->blob);
     delete model;
 }

@@ -49,7 +49,7 @@ __device__ __forceinline__ void split8(const float (&v)[8], u32x4& hi, u32x4& lo
 }
 }  // namespace
 
-template <int C, int H, int NW, int NB>
+template <int C, int H, int NW, int NB, int NSLOT>
 __global__ __launch_bounds__(64 * NW, 2) void mlp_kernel_f16x3_m16(
     const float* __restrict__ x_conv,    // [N][16][C]  conv output (pre-LayerNorm)
     const float* __restrict__ x_in, float* __restrict__ x_out,
@@ -66,7 +66,14 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_kernel_f16x3_m16(
     constexpr int HQ = H / 4, KH = HQ / 32;  // hidden quarter, its k-blocks
     constexpr int NF = KC * 4;            // 16 fragments (16 KiB) per chunk = 32 output rows
     static_assert(KH == KC, "W1 and W2 quarter chunks have the same size");
-    __shared__ u32x4 lds[3][NF * 64];                              // 3 x 16 KiB ring of weight chunks
+    // Ring of NSLOT x 16 KiB weight chunks; the copy of a chunk is issued P = NSLOT - 1 chunks ahead of its use.  With
+    // three slots (P = 2) a copy has one chunk of matrix work (about 1.2 us at two waves per SIMD) to cross L2 -> LDS,
+    // which is the order of the L2 latency itself; the fourth slot doubles that slack (2 x 66 KiB still fits two
+    // workgroups per CU).
+    static_assert(NSLOT == 3 || NSLOT == 4, "ring depth");
+    constexpr int P = NSLOT - 1;
+    constexpr int PER = NF / NW;                                      // DMA instructions per wave and chunk
+    __shared__ u32x4 lds[NSLOT][NF * 64];
     __shared__ __attribute__((aligned(16))) float bias_s[H];      // mb1: no global loads while a DMA is in flight
 
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
@@ -87,6 +94,10 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_kernel_f16x3_m16(
     dma_src += (size_t)NF * 64;
     dma_chunk<NF, NW>(dma_src, lds[1], wave, lane);
     dma_src += (size_t)NF * 64;
+    if constexpr (P == 3) {
+        dma_chunk<NF, NW>(dma_src, lds[2], wave, lane);
+        dma_src += (size_t)NF * 64;
+    }
     for (int i = threadIdx.x; i < H; i += 64 * NW) bias_s[i] = mb1[i];
 
     // ---- load the rows in B-operand layout, LayerNorm them (eps 1e-5, biased variance), split ---------------
@@ -144,11 +155,19 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_kernel_f16x3_m16(
     int sl = 0;
     const unsigned lane16 = 16u * lane;
     const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)&lds[0][0]) + 1024u * wave;
-    auto sync = [&](bool more2) {
-        dma_wait();
+    // SYNC of chunk q (mid-chunk): chunk q + 1 must have landed for every wave; this wave's younger copies (chunks
+    // q + 2 .. q + P - 1, as far as they exist) stay in flight -- vmcnt retires in issue order.  Then the copy of chunk
+    // q + P starts into the slot chunk q - 1 just left.
+    int q = 0;  // chunk index within the layer (32 chunks)
+    constexpr int NCHUNK = 8 * 4;
+    auto sync = [&]() {
+        const int younger = min(max(NCHUNK - 2 - q, 0), P - 2);
+        if (P == 3 && younger == 1) dma_wait_but<PER>();
+        else dma_wait();
         __syncthreads();
-        if (more2) dma_chunk_lean<NF, NW>(dma_src, lane16, wave, lds0 + (sl == 0 ? 2u : (unsigned)sl - 1u) * (NF * 1024u));
+        if (q + P < NCHUNK) dma_chunk_lean<NF, NW>(dma_src, lane16, wave, lds0 + (unsigned)(sl == 0 ? NSLOT - 1 : sl - 1) * (NF * 1024u));
         dma_src += (size_t)NF * 64;
+        ++q;
     };
     constexpr int ST = KC;  // step (of 2 KC) at which the barrier is taken
 #pragma unroll 1
@@ -167,7 +186,7 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_kernel_f16x3_m16(
                 }
             }
             if (active) mma16_range<KC, 0, ST, NB>(acc.m, acc.x, lds[sl], xn, lane);
-            sync(true);  // a W1 chunk is always followed by at least four more
+            sync();
             if (active) {
                 mma16_range<KC, ST, 2 * KC, NB>(acc.m, acc.x, lds[sl], xn, lane);
 #pragma unroll
@@ -186,7 +205,7 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_kernel_f16x3_m16(
                     split8<false>(v, hid[nb][u][0], hid[nb][u][1]);
                 }
             }
-            sl = sl == 2 ? 0 : sl + 1;
+            sl = sl == NSLOT - 1 ? 0 : sl + 1;
         }
 #pragma unroll
         for (int u = 0; u < KC; ++u) {  // ---- output chunk u += W2[:, quarter][u] . hid ----
@@ -196,7 +215,7 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_kernel_f16x3_m16(
 #pragma unroll
                 for (int nb = 0; nb < NB; ++nb) cross[mt][nb] = f32x4v{0.f, 0.f, 0.f, 0.f};
             if (active) mma16_range<KH, 0, ST, NB>(acc_o[u], cross, lds[sl], hid, lane);
-            sync(!(w == 3 && u >= KC - 2));
+            sync();
             if (active) {
                 mma16_range<KH, ST, 2 * KH, NB>(acc_o[u], cross, lds[sl], hid, lane);
 #pragma unroll
@@ -206,7 +225,7 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_kernel_f16x3_m16(
 #pragma unroll
                         for (int r = 0; r < 4; ++r) acc_o[u][mt][nb][r] = fmaf(cross[mt][nb][r], F16X3_INV_SCALE, acc_o[u][mt][nb][r]);
             }
-            sl = sl == 2 ? 0 : sl + 1;
+            sl = sl == NSLOT - 1 ? 0 : sl + 1;
         }
     }
     if (!active) return;
@@ -285,16 +304,17 @@ int arreau_launch_mlp_f16x3_m16(const arreau_model* m, int layer, const float* x
     const float* lnw = m->ln_w + (size_t)layer * C;
     const float* lnb = m->ln_b + (size_t)layer * C;
     const u32x4* stream = reinterpret_cast<const u32x4*>(m->mlp_f16m) + (size_t)layer * layer_u32x4;
-    if (nb == 1)
-        hipLaunchKernelGGL((mlp_kernel_f16x3_m16<128, 512, NW, 1>), grid, block, 0, s, x_conv, x_in, x_out, lnw, lnb, stream,
-                           m->mb1 + (size_t)layer * H, m->mb2 + (size_t)layer * C, m->ls + (size_t)layer * C,
-                           m->ro_wv + (size_t)layer * C, m->ro_bv_host[layer], N, layer == 0 ? 1 : 0,
-                           xbar + (size_t)layer * N * C, vsum);
-    else
-        hipLaunchKernelGGL((mlp_kernel_f16x3_m16<128, 512, NW, 2>), grid, block, 0, s, x_conv, x_in, x_out, lnw, lnb, stream,
-                           m->mb1 + (size_t)layer * H, m->mb2 + (size_t)layer * C, m->ls + (size_t)layer * C,
-                           m->ro_wv + (size_t)layer * C, m->ro_bv_host[layer], N, layer == 0 ? 1 : 0,
-                           xbar + (size_t)layer * N * C, vsum);
+    // ring depth: 4 slots by default (ARREAU_MLP_SLOTS=3 selects the three-slot ring for A/B timing)
+    static const int slots = [] { const char* e = getenv("ARREAU_MLP_SLOTS"); return e && atoi(e) == 3 ? 3 : 4; }();
+    auto launch = [&](auto kernel) {
+        hipLaunchKernelGGL(kernel, grid, block, 0, s, x_conv, x_in, x_out, lnw, lnb, stream, m->mb1 + (size_t)layer * H,
+                           m->mb2 + (size_t)layer * C, m->ls + (size_t)layer * C, m->ro_wv + (size_t)layer * C,
+                           m->ro_bv_host[layer], N, layer == 0 ? 1 : 0, xbar + (size_t)layer * N * C, vsum);
+    };
+    if (nb == 1 && slots == 4) launch(mlp_kernel_f16x3_m16<128, 512, NW, 1, 4>);
+    else if (nb == 1) launch(mlp_kernel_f16x3_m16<128, 512, NW, 1, 3>);
+    else if (slots == 4) launch(mlp_kernel_f16x3_m16<128, 512, NW, 2, 4>);
+    else launch(mlp_kernel_f16x3_m16<128, 512, NW, 2, 3>);
     ARREAU_CHECK_HIP(hipGetLastError());
     return ARREAU_OK;
 }

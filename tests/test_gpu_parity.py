@@ -721,12 +721,13 @@ def test_launch_geometry_switches_and_counted_waits_are_bitwise_neutral(dev):
     with tempfile.TemporaryDirectory() as d:
         for tag, env in (("default", {}), ("conv0", {"ARREAU_CONV_VARIANT": "0"}), ("wgs", {"ARREAU_EDGE_WGS": "100000"}),
                          ("dbgwait", {"ARREAU_HIP_LIB": LIB_DEBUG_WAIT}), ("nb1", {"ARREAU_MLP_NB": "1"}),
-                         ("nb2", {"ARREAU_MLP_NB": "2"})):
+                         ("nb2", {"ARREAU_MLP_NB": "2"}), ("slots3", {"ARREAU_MLP_SLOTS": "3"})):
             path = os.path.join(d, tag + ".pt")
             subprocess.run([sys.executable, "-c", code, path], check=True, env={**os.environ, **env}, timeout=300)
             outs[tag] = torch.load(path)
     # nb1 / nb2: the MLP kernel on 16-row (one node) and 32-row (two nodes) wave tiles -- the small-batch geometry
-    for tag in ("conv0", "wgs", "dbgwait", "nb1", "nb2"):
+    # slots3: the MLP kernel's weight ring with three slots instead of four (another set of counted waits)
+    for tag in ("conv0", "wgs", "dbgwait", "nb1", "nb2", "slots3"):
         for x, y in zip(outs["default"], outs[tag]):
             assert torch.equal(x, y), tag
 
