@@ -93,7 +93,7 @@ def lib():
     L.arreau_diffusion_noise.argtypes = [c_void_p] * 6 + [c_int32, c_int32] + [c_void_p] * 11
     L.arreau_diffusion_losses.argtypes = [c_void_p] * 10 + [c_int32, c_int32] + [c_void_p] * 6
     L.arreau_sample_loop.argtypes = ([c_void_p] * 6 + [c_int32, c_int32, c_int32, c_int32, ctypes.c_uint64] +
-                                     [c_void_p, c_void_p, c_void_p, c_size_t, c_int32, c_void_p])
+                                     [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int32, c_void_p])
     L.arreau_philox_fill.argtypes = [ctypes.c_uint64, c_int32, c_int32, c_int64, c_void_p, c_void_p, c_void_p]
     L.arreau_profile_edge_kernel.argtypes = [c_int32]
     L.arreau_edge_kernel_time_ms.argtypes = [POINTER(c_double), POINTER(c_int64)]

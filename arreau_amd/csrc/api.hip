@@ -205,8 +205,8 @@ __global__ void fill_i32_kernel(int32_t* __restrict__ p, int32_t v, int n) {
 }
 
 int enqueue_sample_step(const arreau_model* m, float* d_frac, int32_t* d_types, float* d_lengths, const float* d_angles,
-                        const int32_t* d_off, int B, int N, uint64_t seed, const int32_t* d_const_types, float* d_lattice,
-                        const Workspace& w, hipStream_t s) {
+                        const int32_t* d_off, int B, int N, uint64_t seed, const int32_t* d_const_types,
+                        const float* d_fixed_lengths, float* d_lattice, const Workspace& w, hipStream_t s) {
     int rc;
     if ((rc = arreau_launch_prep(m, d_frac, d_lengths, d_angles, nullptr, d_off, B, N, w.lattice, w.cart, w.batch, w.cvec, s,
                                  w.t_next, w.t_cur)))
@@ -218,14 +218,14 @@ int enqueue_sample_step(const arreau_model* m, float* d_frac, int32_t* d_types, 
     if ((rc = arreau_launch_embed(m, d_frac, d_types, w.lattice, w.batch, w.cvec, N, w.xa, s))) return rc;
     if ((rc = run_layers_and_readout(m, w, w.deg, w.src, d_off, B, N, w.eps, w.logits, w.len0, s))) return rc;
     return arreau_launch_reverse(m, d_frac, d_types, d_lengths, d_angles, w.t_cur, d_off, B, N, w.eps, w.logits, w.len0,
-                                 StepNoiseSrc{nullptr, nullptr, nullptr, seed}, d_const_types, d_lattice, s);
+                                 StepNoiseSrc{nullptr, nullptr, nullptr, seed}, d_const_types, d_lattice, s, d_fixed_lengths);
 }
 }  // namespace
 
 extern "C" int arreau_sample_loop(arreau_model* m, float* d_frac, int32_t* d_types, float* d_lengths,
                                   const float* d_angles, const int32_t* d_off, int32_t B, int32_t N, int32_t t_start,
-                                  int32_t n_steps, uint64_t seed, const int32_t* d_const_types, float* d_lattice,
-                                  void* d_workspace, size_t workspace_bytes, int32_t use_graph, void* stream) {
+                                  int32_t n_steps, uint64_t seed, const int32_t* d_const_types,
+                                  const float* d_fixed_lengths, float* d_lattice, void* d_workspace, size_t workspace_bytes, int32_t use_graph, void* stream) {
     ARREAU_REQUIRE(m && d_frac && d_types && d_lengths && d_angles && d_off && d_lattice, "arreau_sample_loop: null pointer");
     ARREAU_REQUIRE(B >= 1 && N >= 0 && n_steps >= 0, "arreau_sample_loop: bad size");
     ARREAU_REQUIRE(t_start <= m->T && t_start - n_steps >= 0, "arreau_sample_loop: timesteps t_start .. t_start-n_steps+1 must lie in 1..T");
@@ -242,7 +242,7 @@ extern "C" int arreau_sample_loop(arreau_model* m, float* d_frac, int32_t* d_typ
     int rc;
     if (!use_graph || n_steps < 3) {
         for (int i = 0; i < n_steps; ++i)
-            if ((rc = enqueue_sample_step(m, d_frac, d_types, d_lengths, d_angles, d_off, B, N, seed, d_const_types, d_lattice, w, s)))
+            if ((rc = enqueue_sample_step(m, d_frac, d_types, d_lengths, d_angles, d_off, B, N, seed, d_const_types, d_fixed_lengths, d_lattice, w, s)))
                 return rc;
         return ARREAU_OK;
     }
@@ -264,11 +264,11 @@ extern "C" int arreau_sample_loop(arreau_model* m, float* d_frac, int32_t* d_typ
     ARREAU_CHECK_HIP(hipEventRecord(ev, user));
     ARREAU_CHECK_HIP(hipStreamWaitEvent(s, ev, 0));
     // The first step runs eagerly (it also forces lazy module loading, which must not happen inside a capture).
-    if ((rc = enqueue_sample_step(m, d_frac, d_types, d_lengths, d_angles, d_off, B, N, seed, d_const_types, d_lattice, w, s)))
+    if ((rc = enqueue_sample_step(m, d_frac, d_types, d_lengths, d_angles, d_off, B, N, seed, d_const_types, d_fixed_lengths, d_lattice, w, s)))
         return rc;
     hipGraph_t graph = nullptr;
     ARREAU_CHECK_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
-    rc = enqueue_sample_step(m, d_frac, d_types, d_lengths, d_angles, d_off, B, N, seed, d_const_types, d_lattice, w, s);
+    rc = enqueue_sample_step(m, d_frac, d_types, d_lengths, d_angles, d_off, B, N, seed, d_const_types, d_fixed_lengths, d_lattice, w, s);
     hipError_t e = hipStreamEndCapture(s, &graph);
     if (rc) {
         if (graph) (void)hipGraphDestroy(graph);

@@ -304,8 +304,9 @@ int arreau_launch_mlp_f16x3_m16(const arreau_model* m, int layer, const float* x
     const float* lnw = m->ln_w + (size_t)layer * C;
     const float* lnb = m->ln_b + (size_t)layer * C;
     const u32x4* stream = reinterpret_cast<const u32x4*>(m->mlp_f16m) + (size_t)layer * layer_u32x4;
-    // ring depth: 4 slots by default (ARREAU_MLP_SLOTS=3 selects the three-slot ring for A/B timing)
-    static const int slots = [] { const char* e = getenv("ARREAU_MLP_SLOTS"); return e && atoi(e) == 3 ? 3 : 4; }();
+    // ring depth: 3 slots; ARREAU_MLP_SLOTS=4 selects the four-slot ring (measured on MI355X at 256 x 20: 1.77 vs 1.77 ms
+    // per step, no gain -- the L2 -> LDS latency is already covered by one chunk of matrix work -- so the smaller one stays)
+    static const int slots = [] { const char* e = getenv("ARREAU_MLP_SLOTS"); return e && atoi(e) == 4 ? 4 : 3; }();
     auto launch = [&](auto kernel) {
         hipLaunchKernelGGL(kernel, grid, block, 0, s, x_conv, x_in, x_out, lnw, lnb, stream, m->mb1 + (size_t)layer * H,
                            m->mb2 + (size_t)layer * C, m->ls + (size_t)layer * C, m->ro_wv + (size_t)layer * C,

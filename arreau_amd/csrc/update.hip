@@ -11,7 +11,8 @@ __global__ void reverse_lattice_kernel(float* __restrict__ lengths, const float*
                                        const int32_t* __restrict__ tstep, const int32_t* __restrict__ offsets,
                                        const float* __restrict__ len0, StepNoiseSrc noise,
                                        const float* __restrict__ alpha_bars, const float* __restrict__ betas, int B,
-                                       int T, float* __restrict__ lattice, int32_t* __restrict__ status) {
+                                       int T, float* __restrict__ lattice, const float* __restrict__ fixed_lengths,
+                                       int32_t* __restrict__ status) {
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= B) return;
     const float* __restrict__ z = noise.z_lattice;
@@ -33,7 +34,8 @@ __global__ void reverse_lattice_kernel(float* __restrict__ lengths, const float*
         const float mean = (c0 * x0 + c1 * xt) / denom;
         const float zdraw = z ? z[3 * b + i] : philox_normal(noise.seed, (uint32_t)t, ARREAU_DRAW_Z_LATTICE, 3u * b + i);
         const float zz = t > 1 ? zdraw : 0.0f;
-        newlen[i] = mean + variance * zz;
+        // fixed-cell sampling (arreau_sample_loop, d_fixed_lengths): the given lengths are re-imposed after the update
+        newlen[i] = fixed_lengths ? fixed_lengths[3 * b + i] : mean + variance * zz;
         lengths[3 * b + i] = newlen[i];
     }
     // lattice_from_params (lattice_helpers.py:55-105)
@@ -171,9 +173,9 @@ __global__ __launch_bounds__(256) void reverse_atoms_kernel(
 int arreau_launch_reverse(const arreau_model* m, float* d_frac, int32_t* d_types, float* d_lengths, const float* d_angles,
                           const int32_t* d_t, const int32_t* d_off, int B, int N, const float* d_eps,
                           const float* d_logits, const float* d_len0, StepNoiseSrc noise, const int32_t* d_const_types,
-                          float* d_lattice, hipStream_t s) {
+                          float* d_lattice, hipStream_t s, const float* d_fixed_lengths) {
     hipLaunchKernelGGL(reverse_lattice_kernel, dim3((B + 127) / 128), dim3(128), 0, s, d_lengths, d_angles, d_t, d_off,
-                       d_len0, noise, m->vp_alpha_bars, m->vp_betas, B, m->T, d_lattice, m->status);
+                       d_len0, noise, m->vp_alpha_bars, m->vp_betas, B, m->T, d_lattice, d_fixed_lengths, m->status);
     ARREAU_CHECK_HIP(hipGetLastError());
     if (N > 0) {
         hipLaunchKernelGGL(reverse_atoms_kernel, dim3((N + 3) / 4), dim3(256), 0, s, d_frac, d_types, d_t, d_off, B, N,

@@ -137,14 +137,14 @@ class HipEngine:
         return logits, vec_out, gscalar
 
     def sample_loop(self, frac, types, lengths, angles, offsets, t_start, n_steps, seed, const_types, lattice_out,
-                    use_graph=False):
+                    use_graph=False, fixed_lengths=None):
         """n_steps iterations of the sampling loop in one library call (arreau_sample_loop): in-place update of
         (frac, types, lengths); Philox noise keyed by (seed, timestep, draw, element)."""
         N, B = frac.shape[0], lengths.shape[0]
         ws = self.workspace(N, B)
         _hip.check(_hip.lib().arreau_sample_loop(
             self._handle, _hip.ptr(frac), _hip.ptr(types), _hip.ptr(lengths), _hip.ptr(angles), _hip.ptr(offsets), B, N,
-            int(t_start), int(n_steps), int(seed) & (2 ** 64 - 1), _hip.ptr(const_types), _hip.ptr(lattice_out), _hip.ptr(ws),
+            int(t_start), int(n_steps), int(seed) & (2 ** 64 - 1), _hip.ptr(const_types), _hip.ptr(fixed_lengths), _hip.ptr(lattice_out), _hip.ptr(ws),
             ws.numel(), int(bool(use_graph)), _hip.stream_ptr(self.device)), "arreau_sample_loop")
 
     def philox_fill(self, seed, timestep, kind, n, raw=False):

@@ -248,22 +248,25 @@ def run_rank(args, rank, local_rank, world):
     lat_d = torch.zeros(B, 3, 3, **f32)
     t_d = torch.empty(B, device=dev, dtype=torch.int32)
 
-    # Random-init weights predict unphysical cell lengths, so a free-running state drifts to huge, sparse
-    # cells within a few steps (E/N falls from 8 to ~4), which would shrink the timed work.  A trained model
-    # keeps the cell compact (E/N = 8.00 in the sampler regime, SURVEY.md symbol table), so every step re-imposes
-    # the sampler-start lengths; coordinates and atom types evolve freely.  edges_per_atom_* reports the result.
+    # Random-init weights predict unphysical cell lengths, so a free-running state drifts to huge, sparse cells within a
+    # few steps (E/N falls from 8 to ~4), which would shrink the timed work.  A trained model keeps the cell compact
+    # (E/N = 8.00 in the sampler regime, SURVEY.md symbol table), so the bench samples at FIXED cell lengths (the
+    # sampler-start ones; arreau_sample_loop's d_fixed_lengths); coordinates and atom types evolve freely.
+    # edges_per_atom_* reports the density actually processed.
     len_start = len_d.clone()
+    seed = 77 + rank
     timestep = [T - 1]
 
-    seed = 77 + rank
-
-    def one_step():
-        # one iteration of the product's sampling loop (arreau_sample_loop with n_steps = 1: score network, in-kernel
-        # Philox noise, reverse updates), preceded by the bench-only reset of the cell lengths explained above
-        t = timestep[0]
-        len_d.copy_(len_start)
-        eng.sample_loop(frac_d, types_d, len_d, ang_d, off_d, t, 1, seed, None, lat_d)
-        timestep[0] = t - 1 if t > 1 else T - 1
+    def run_steps(k, use_graph=False):
+        """k iterations of the product's sampling loop (score network, in-kernel Philox noise, reverse updates), enqueued
+        by ONE arreau_sample_loop call per stretch of consecutive timesteps (the loop wraps from t = 1 back to T - 1)."""
+        while k > 0:
+            t = timestep[0]
+            n = min(k, t)
+            eng.sample_loop(frac_d, types_d, len_d, ang_d, off_d, t, n, seed, None, lat_d, use_graph=use_graph,
+                            fixed_lengths=len_start)
+            k -= n
+            timestep[0] = t - n if t - n >= 1 else T - 1
 
     def sync():
         torch.cuda.synchronize(dev)
@@ -272,27 +275,25 @@ def run_rank(args, rank, local_rank, world):
             torch.cuda.synchronize(dev)
 
     def degree_sum():
+        t_d.fill_(timestep[0])
         _, _, _, edges = eng.predict_scores(frac_d, types_d, len_d, ang_d, t_d, off_d, return_edges=True)
         return int(edges[0].sum().item())
 
     local_elapsed = [0.0]
 
-    def timed_loop(steps):
+    def timed_loop(steps, use_graph=False):
         sync()
         t0 = time.perf_counter()
-        for _ in range(steps):
-            one_step()
+        run_steps(steps, use_graph)
         torch.cuda.synchronize(dev)
         local_elapsed[0] = time.perf_counter() - t0  # this rank's own work, before it waits for the others
         sync()
         return time.perf_counter() - t0
 
     log(f"rank {rank}: model packed, state ready (B={B}, n={n}, T={T}); warm-up {args.warmup} steps")
-    for _ in range(args.warmup):
-        one_step()
+    run_steps(args.warmup)
     torch.cuda.synchronize(dev)
     log("warm-up done; timing")
-    t_d.fill_(timestep[0])
     e_start = degree_sum()
     _hip.check(_hip.lib().arreau_profile_edge_kernel(1), "profile on")
     elapsed = timed_loop(args.steps)
@@ -310,27 +311,14 @@ def run_rank(args, rank, local_rank, world):
         per_rank = [float(g[0]) for g in gathered]
         elapsed = max(float(g[1]) for g in gathered)  # barrier-to-barrier time, MAX over ranks
 
-    # The product's own loop, free-running: ONE arreau_sample_loop call for all the steps (no host work between steps;
-    # hipGraph replay when the batch is launch-bound), state drifting freely -- reported beside `value`, which keeps
-    # the per-step form with the cell reset so that the edge density stays the sampler's.
-    free_loop = None
+    # The same K steps as a hipGraph replay of one captured step (arreau_sample_loop use_graph = 1): what small,
+    # launch-bound batches gain from it; `value` stays the eager loop above.
+    graph_loop = None
     if world == 1:
-        k_free = min(args.steps, T - 1)
-        use_graph = N <= 64
-        state0 = [x.clone() for x in (frac_d, types_d, len_d)]
-        eng.sample_loop(frac_d, types_d, len_d, ang_d, off_d, T - 1, min(3, k_free), seed, None, lat_d, use_graph=use_graph)
-        for dst, src in zip((frac_d, types_d, len_d), state0):
-            dst.copy_(src)
-        sync()
-        t0 = time.perf_counter()
-        eng.sample_loop(frac_d, types_d, len_d, ang_d, off_d, T - 1, k_free, seed, None, lat_d, use_graph=use_graph)
-        sync()
-        el_free = time.perf_counter() - t0
-        t_d.fill_(T - 1 - k_free if T - 1 - k_free >= 1 else 1)
-        free_loop = {"steps": k_free, "ms_per_step": 1e3 * el_free / k_free, "hip_graph": bool(use_graph),
-                     "edges_per_atom_end": degree_sum() / N}
-        for dst, src in zip((frac_d, types_d, len_d), state0):
-            dst.copy_(src)
+        run_steps(3, use_graph=True)  # warm-up of the graph path (stream / event creation)
+        el_g = timed_loop(args.steps, use_graph=True)
+        graph_loop = {"steps": args.steps, "ms_per_step": 1e3 * el_g / args.steps,
+                      "note": "hipGraph replay of the captured step; includes one capture + instantiation per call"}
         eng.check_status()
 
     # second, short timed loop on the exact fp32-MFMA kernels (v_mfma_f32_32x32x2_f32): what the same step costs
@@ -339,8 +327,7 @@ def run_rank(args, rank, local_rank, world):
     if not args.no_fp32_variant and world == 1:
         eng.set_variant(0, 0)
         k32 = max(3, min(10, args.steps))
-        for _ in range(2):
-            one_step()
+        run_steps(2)
         _hip.check(_hip.lib().arreau_profile_edge_kernel(1), "profile on")
         el32 = timed_loop(k32)
         m32, l32 = ctypes.c_double(), ctypes.c_int64()
@@ -406,7 +393,7 @@ def run_rank(args, rank, local_rank, world):
                 "edges_per_atom_start": e_start / N, "edges_per_atom_end": e_end / N,
                 "parallelism": f"replicas x{world}, disjoint sub-batches, no data-path collective",
             },
-            "free_running_loop": free_loop,
+            "graph_loop": graph_loop,
             "batch_steps_per_sec": world * args.steps / elapsed,
             "crystals_per_min": 60.0 * crystal_steps_per_s / (T - 1),
             "step_tflops_algorithmic": world * step_flops / (ms_per_step * 1e-3) / 1e12,

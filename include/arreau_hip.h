@@ -234,12 +234,15 @@ int arreau_reverse_step(const arreau_model* model,
  * kernels from Philox4x32-10 keyed by (seed, timestep, draw, element) -- no RNG launches, no noise arrays, no host work
  * between steps; the timestep lives on the device.  State (d_frac, d_types, d_lengths) is updated in place, d_lattice
  * [B,3,3] receives the final cell.  d_const_types (may be NULL): species re-imposed after every step
- * (use_constant_atomic_symbols, lightning_wrappers/diffusion.py:231-236).  use_graph != 0 captures one step into a
+ * (use_constant_atomic_symbols, lightning_wrappers/diffusion.py:231-236).  d_fixed_lengths[B,3] (may be NULL): the
+ * same idea for the cell -- fixed-cell sampling, the given lengths re-imposed after every step (an extension; the
+ * reference has no counterpart; bench.py uses it to keep the synthetic checkpoint's cells at the sampler's density).
+ * use_graph != 0 captures one step into a
  * hipGraph and replays it (same trajectory; pays for itself only on small, launch-bound batches).
  * Does not synchronise. */
 int arreau_sample_loop(arreau_model* model, float* d_frac, int32_t* d_types, float* d_lengths, const float* d_angles,
                        const int32_t* d_crystal_offsets, int32_t B, int32_t N, int32_t t_start, int32_t n_steps,
-                       uint64_t seed, const int32_t* d_const_types, float* d_lattice,
+                       uint64_t seed, const int32_t* d_const_types, const float* d_fixed_lengths, float* d_lattice,
                        void* d_workspace, size_t workspace_bytes, int32_t use_graph, void* stream);
 
 /* The sampler's in-kernel noise written out: d_out[i] = draw (seed, timestep, kind, element i) -- standard normal for

@@ -721,13 +721,13 @@ def test_launch_geometry_switches_and_counted_waits_are_bitwise_neutral(dev):
     with tempfile.TemporaryDirectory() as d:
         for tag, env in (("default", {}), ("conv0", {"ARREAU_CONV_VARIANT": "0"}), ("wgs", {"ARREAU_EDGE_WGS": "100000"}),
                          ("dbgwait", {"ARREAU_HIP_LIB": LIB_DEBUG_WAIT}), ("nb1", {"ARREAU_MLP_NB": "1"}),
-                         ("nb2", {"ARREAU_MLP_NB": "2"}), ("slots3", {"ARREAU_MLP_SLOTS": "3"})):
+                         ("nb2", {"ARREAU_MLP_NB": "2"}), ("slots4", {"ARREAU_MLP_SLOTS": "4"})):
             path = os.path.join(d, tag + ".pt")
             subprocess.run([sys.executable, "-c", code, path], check=True, env={**os.environ, **env}, timeout=300)
             outs[tag] = torch.load(path)
     # nb1 / nb2: the MLP kernel on 16-row (one node) and 32-row (two nodes) wave tiles -- the small-batch geometry
-    # slots3: the MLP kernel's weight ring with three slots instead of four (another set of counted waits)
-    for tag in ("conv0", "wgs", "dbgwait", "nb1", "nb2", "slots3"):
+    # slots4: the MLP kernel's weight ring with four slots instead of three (another set of counted waits)
+    for tag in ("conv0", "wgs", "dbgwait", "nb1", "nb2", "slots4"):
         for x, y in zip(outs["default"], outs[tag]):
             assert torch.equal(x, y), tag
 
@@ -810,6 +810,12 @@ def test_sample_loop_is_the_per_step_path_with_philox_noise(dev, small_model):
     const = ty2.clone()
     eng.sample_loop(f2, ty2, le2, an, off, T - 1, 4, seed, const, lat2, use_graph=True)
     assert torch.equal(ty2, const) and torch.isfinite(f2).all()
+    # fixed-cell sampling: the given lengths are re-imposed after every step, the cell follows from them
+    f2, ty2, le2, lat2 = fresh()
+    fixed = le2.clone()
+    eng.sample_loop(f2, ty2, le2, an, off, T - 1, 3, seed, None, lat2, fixed_lengths=fixed)
+    assert torch.equal(le2, fixed)
+    np.testing.assert_allclose(lat2.cpu().numpy(), OG.lattice_from_params(lengths, angles).numpy(), atol=2e-6, rtol=0)
     eng.check_status()
     with pytest.raises(Exception):
         eng.sample_loop(f2, ty2, le2, an, off, 3, 5, seed, None, lat2)  # would run past timestep 1

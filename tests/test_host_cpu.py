@@ -81,3 +81,46 @@ def test_crystals_hdf5_when_h5py_is_present(tmp_path):
         assert sorted(fh["crystals"].keys()) == sorted(KEYS)
     back = load_sample_results_from_hdf5(path)
     np.testing.assert_array_equal(back.frac_x, res.frac_x)
+
+
+# ------------------------------------------------------------------------------------------- training data path (f3)
+def test_crystal_dataset_layout_round_trip_and_collate(tmp_path):
+    """prep_datasets.py:67-79 layout -> lattice_dataset.py:23-113: file round trip (numeric group order, not
+    lexicographic), class table with the mask state last, Data fields, PyG-style collation."""
+    from arreau_amd.diffusion.lattice_dataset import (CrystalDataset, collate, iterate_batches, load_data, save_dataset,
+                                                      synthetic_alexandria_like)
+    configs = synthetic_alexandria_like(23, seed=3, num_species=20)
+    path = save_dataset(str(tmp_path / "datasets" / "alexandria_hdf5" / "alexandria_ps_000.npz"),
+                        [c.atomic_numbers for c in configs], np.stack([c.L0 for c in configs]), [c.X0 for c in configs])
+    zs, lattice, fc = load_data(path)
+    assert len(zs) == 23 and lattice.shape == (23, 3, 3)
+    for i, c in enumerate(configs):  # crystal 10 must follow crystal 9, not crystal 1
+        assert np.array_equal(zs[i], c.atomic_numbers) and np.array_equal(fc[i], c.X0) and np.array_equal(lattice[i], c.L0)
+    ds = CrystalDataset([path])
+    assert len(ds) == 23 and ds.z_table.zs[-1] == 2001 and ds.z_table.zs[:-1] == sorted(ds.unique_atomic_numbers)
+    it = ds[5]
+    assert it.X0.dtype == torch.float64 and it.L0.shape == (3, 3) and it.A0.dtype == torch.long
+    assert it.num_atoms == len(configs[5].atomic_numbers)
+    np.testing.assert_allclose(it.pos.numpy(), configs[5].X0 @ configs[5].L0)
+    assert [ds.z_table.zs[int(a)] for a in it.A0] == [int(z) for z in configs[5].atomic_numbers]
+    b = collate([ds[0], ds[1], ds[2]])
+    n = [len(configs[i].atomic_numbers) for i in range(3)]
+    assert b.num_atoms.tolist() == n and b.X0.shape == (sum(n), 3) and b.L0.shape == (9, 3)
+    assert b.batch.tolist() == sum(([i] * k for i, k in enumerate(n)), []) and b.ptr.tolist() == [0] + list(np.cumsum(n))
+    assert torch.equal(b.L0.view(-1, 3, 3)[1], ds[1].L0)  # the view DiffusionLoss.__call__ takes (diffusion_loss.py:208)
+    # data-parallel sharding: the ranks' batches partition the epoch
+    seen = []
+    for r in range(2):
+        for bt in iterate_batches(ds, 4, shuffle=True, seed=9, rank=r, world_size=2):
+            assert bt.num_graphs <= 4
+            seen += [tuple(x) for x in bt.L0.view(-1, 9).tolist()]
+    assert len(seen) == 23 and len(set(seen)) == 23
+
+
+def test_synthetic_alexandria_statistics():
+    from arreau_amd.diffusion.lattice_dataset import synthetic_alexandria_like
+    cs = synthetic_alexandria_like(2000, seed=1)
+    n = np.array([len(c.atomic_numbers) for c in cs])
+    dens = np.array([len(c.atomic_numbers) / abs(np.linalg.det(c.L0)) for c in cs])
+    assert 7.0 < n.mean() < 9.5 and n.max() <= 64 and n.min() >= 1
+    np.testing.assert_allclose(dens, 0.05539856, rtol=1e-9)  # exploration/find_avg_density_of_dataset.py:40
