@@ -13,7 +13,7 @@ import csv,glob,collections
 acc=collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob("gpurun_out/pmc_${tag}_*/*/*counter_collection.csv"):
     for r in csv.DictReader(open(f)):
-        k=r["Kernel_Name"].split("(")[0][-34:]
+        k=r["Kernel_Name"].split("(")[0].replace("void ","")[:40]
         acc[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k in acc:
     if "edge" in k or "mlp" in k or "conv" in k:
