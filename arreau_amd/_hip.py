@@ -20,6 +20,7 @@ EXPORTS = [
     "arreau_reverse_step", "arreau_profile_edge_kernel", "arreau_edge_kernel_time_ms",
     "arreau_model_status", "arreau_model_set_variant", "arreau_ponita_forward",
     "arreau_diffusion_noise", "arreau_diffusion_losses", "arreau_sample_loop", "arreau_philox_fill",
+    "arreau_train_forward", "arreau_train_backward", "arreau_train_conv_stats",
 ]
 
 STATUS_NONFINITE, STATUS_BAD_TIMESTEP, STATUS_BAD_TYPE = 1, 2, 4
@@ -95,6 +96,9 @@ def lib():
     L.arreau_sample_loop.argtypes = ([c_void_p] * 6 + [c_int32, c_int32, c_int32, c_int32, ctypes.c_uint64] +
                                      [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int32, c_void_p])
     L.arreau_philox_fill.argtypes = [ctypes.c_uint64, c_int32, c_int32, c_int64, c_void_p, c_void_p, c_void_p]
+    L.arreau_train_forward.argtypes = [c_void_p] * 7 + [c_int32, c_int32] + [c_void_p] * 4
+    L.arreau_train_backward.argtypes = [c_void_p] * 4 + [POINTER(StateDict), c_void_p]
+    L.arreau_train_conv_stats.argtypes = [c_void_p, c_void_p, c_void_p]
     L.arreau_profile_edge_kernel.argtypes = [c_int32]
     L.arreau_edge_kernel_time_ms.argtypes = [POINTER(c_double), POINTER(c_int64)]
     for name in EXPORTS:

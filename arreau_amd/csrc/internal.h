@@ -13,6 +13,7 @@
 #define ARREAU_POLY_COLS 258   // 6 + 36 + 216 columns of PolynomialFeatures(3)  (nn/embedding.py:10-14)
 #define ARREAU_ORI 16
 
+struct arreau_train_ctx;
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -54,6 +55,10 @@ struct arreau_model {
     // arreau_model_set_variant overrides) and what the last arreau_predict_scores actually launched.
     int edge_variant, mlp_variant, conv_variant, readout_variant;
     mutable int ran_edge, ran_mlp, ran_conv;
+    // training (train_net.hip): plain row-major fp32 copies of the weights the sampling kernels hold only in packed
+    // form, and the step's activation buffers (created on first use)
+    const float *t_w1f, *t_w2, *t_wk, *t_lin1, *t_lin2, *t_ro_w;
+    struct arreau_train_ctx* train;
     void* loop_stream;       // hipStream_t / hipEvent_t of arreau_sample_loop's graph mode (capture is not allowed on the
     void* loop_event;        //   legacy default stream callers usually pass); created on first use
     void* retired_graph;     // hipGraphExec_t of the last arreau_sample_loop (+ the stream it was launched on): destroyed,
@@ -192,6 +197,7 @@ struct StepNoiseSrc {
     uint64_t seed;           // used when the arrays are null
 };
 
+void arreau_train_ctx_destroy(struct arreau_train_ctx* t);
 void arreau_model_retire_graph(arreau_model* m, void* exec, void* stream);  // takes ownership; frees the previous one
 
 // launchers implemented in the other translation units ------------------------------------------

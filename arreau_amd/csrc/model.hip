@@ -402,6 +402,13 @@ extern "C" int arreau_model_create(const arreau_config* cfg, const arreau_state_
     const size_t off_fw2 = bb.put(sd->fiber_w2, (size_t)D * C);
     const size_t off_fb2 = bb.put(sd->fiber_b2, D);
     const size_t off_fwk = bb.put(sd->conv_fiber_w, (size_t)L * C * D);
+    // plain row-major copies for the training path (train_net.hip)
+    const size_t off_t_w1f = bb.put(w1f.data(), (size_t)C * ARREAU_MONO_PAD);
+    const size_t off_t_w2 = bb.put(sd->basis_w2, (size_t)D * C);
+    const size_t off_t_wk = bb.put(sd->conv_kernel_w, (size_t)L * C * D);
+    const size_t off_t_lin1 = bb.put(sd->linear1_w, (size_t)L * H * C);
+    const size_t off_t_lin2 = bb.put(sd->linear2_w, (size_t)L * C * H);
+    const size_t off_t_ro_w = bb.put(sd->readout_w, (size_t)L * RO * C);
     const size_t off_status = bb.reserve(64);  // zero-initialised sticky status word (+ pad)
 
     arreau_model* m = new arreau_model();
@@ -435,6 +442,8 @@ extern "C" int arreau_model_create(const arreau_config* cfg, const arreau_state_
     m->fiber_w1 = b + off_fw1; m->fiber_b1 = b + off_fb1; m->fiber_w2 = b + off_fw2; m->fiber_b2 = b + off_fb2;
     m->fiber_wk = b + off_fwk;
     m->status = reinterpret_cast<int32_t*>(b + off_status);
+    m->t_w1f = b + off_t_w1f; m->t_w2 = b + off_t_w2; m->t_wk = b + off_t_wk; m->t_lin1 = b + off_t_lin1;
+    m->t_lin2 = b + off_t_lin2; m->t_ro_w = b + off_t_ro_w;
     auto env_int = [](const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; };
     m->edge_variant = env_int("ARREAU_EDGE_VARIANT", 4);
     m->mlp_variant = env_int("ARREAU_MLP_VARIANT", 3);
@@ -471,6 +480,10 @@ void arreau_model_retire_graph(arreau_model* m, void* exec, void* stream) {
 extern "C" void arreau_model_destroy(arreau_model* model) {
     if (!model) return;
     arreau_model_retire_graph(model, nullptr, nullptr);
+    if (model->train) {
+        (void)hipDeviceSynchronize();
+        arreau_train_ctx_destroy(model->train);
+    }
     if (model->loop_stream) {
         (void)hipStreamSynchronize((hipStream_t)model->loop_stream);
         (void)hipStreamDestroy((hipStream_t)model->loop_stream);

@@ -1,0 +1,738 @@
+// Training-mode score network (BASELINE config 5): forward with saved activations and the backward pass, fp32.
+//
+// The sampling kernels (edge_f16.hip, node*.hip) keep nothing: activations live in registers and only K_l reaches HBM.
+// A training step needs every layer's inputs again, so this file evaluates the same network in the textbook form --
+// one dense product per Linear (sgemm_kernel below, fp32 FMA, split-K for the weight gradients), small elementwise /
+// gather / reduce kernels between them, every intermediate in HBM -- and walks it backwards.  At config-5 sizes (64
+// crystals, about 540 atoms, 69 k (edge, orientation) rows per GPU) the whole step moves a few hundred MB; clarity
+// and exact fp32 arithmetic matter more here than the last factor of two.
+//
+// Reference: PonitaFiberBundle.forward (ponita/models/ponita.py:88-123), FiberBundleConv.forward / message
+// (ponita/nn/conv.py:105-138; PyG sum aggregation onto edge_index[1]), ConvNext.forward (ponita/nn/convnext.py:20-33),
+// the read-outs (ponita.py:126-155); the backward is what autograd derives from those (training_step,
+// lightning_wrappers/diffusion.py:108-118).  Gradients are returned in the state_dict layout (arreau_state_dict with
+// DEVICE pointers; non-trainable entries are ignored).
+#include <vector>
+
+#include "internal.h"
+
+namespace {
+constexpr int TILE = 64, BK = 16;
+
+// C[m,n] = alpha * sum_k A(m,k) B(k,n) + beta * C[m,n];  A(m,k) = A[m*as0 + k*as1], B(k,n) = B[k*bs0 + n*bs1].
+// gridDim.z > 1: split-K, partial sums to `partial[z][M][N]` (reduced in z order by splitk_reduce_kernel: deterministic).
+__global__ __launch_bounds__(256) void sgemm_kernel(int M, int N, int K, const float* __restrict__ A, long as0, long as1,
+                                                    const float* __restrict__ B, long bs0, long bs1, float* __restrict__ C,
+                                                    int ldc, float alpha, float beta, int kchunk,
+                                                    float* __restrict__ partial) {
+    __shared__ float As[BK][TILE + 4], Bs[BK][TILE + 4];
+    const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+    const int m0 = blockIdx.y * TILE, n0 = blockIdx.x * TILE;
+    const int kbeg = blockIdx.z * kchunk, kend = min(K, kbeg + kchunk);
+    float acc[4][4] = {};
+    for (int k0 = kbeg; k0 < kend; k0 += BK) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int idx = tid + 256 * i;
+            int mm, kk;
+            if (as1 == 1) { kk = idx & 15; mm = idx >> 4; } else { mm = idx & 63; kk = idx >> 6; }
+            const int m = m0 + mm, k = k0 + kk;
+            As[kk][mm] = (m < M && k < kend) ? A[(long)m * as0 + (long)k * as1] : 0.f;
+            int nn;
+            if (bs1 == 1) { nn = idx & 63; kk = idx >> 6; } else { kk = idx & 15; nn = idx >> 4; }
+            const int n = n0 + nn;
+            const int kb = k0 + kk;
+            Bs[kk][nn] = (n < N && kb < kend) ? B[(long)kb * bs0 + (long)n * bs1] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < BK; ++kk) {
+            float a[4], b[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { a[i] = As[kk][ty * 4 + i]; b[i] = Bs[kk][tx * 4 + i]; }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(a[i], b[j], acc[i][j]);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int m = m0 + ty * 4 + i, n = n0 + tx * 4 + j;
+            if (m < M && n < N) {
+                if (gridDim.z > 1) partial[((size_t)blockIdx.z * M + m) * N + n] = acc[i][j];
+                else C[(size_t)m * ldc + n] = alpha * acc[i][j] + (beta != 0.f ? beta * C[(size_t)m * ldc + n] : 0.f);
+            }
+        }
+}
+__global__ void splitk_reduce_kernel(const float* __restrict__ partial, int Z, int M, int N, float* __restrict__ C, int ldc,
+                                     float alpha, float beta) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)M * N) return;
+    float s = 0.f;
+    for (int z = 0; z < Z; ++z) s += partial[(size_t)z * M * N + i];
+    const int m = (int)(i / N), n = (int)(i % N);
+    C[(size_t)m * ldc + n] = alpha * s + (beta != 0.f ? beta * C[(size_t)m * ldc + n] : 0.f);
+}
+
+// out[c] = scale * sum_r a[r][c] * (b ? b[r][c] : 1)  (+ out[c] if accumulate): one thread column, 4 row phases, fixed order
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ a, const float* __restrict__ b, int rows,
+                                                     int cols, float scale, int accumulate, float* __restrict__ out) {
+    __shared__ float part[4][64];
+    const int c = blockIdx.x * 64 + (threadIdx.x & 63), ph = threadIdx.x >> 6;
+    float s = 0.f;
+    if (c < cols)
+        for (int r = ph; r < rows; r += 4) s += a[(size_t)r * cols + c] * (b ? b[(size_t)r * cols + c] : 1.0f);
+    part[ph][threadIdx.x & 63] = s;
+    __syncthreads();
+    if (ph == 0 && c < cols) {
+        const float t = ((part[0][threadIdx.x] + part[1][threadIdx.x]) + part[2][threadIdx.x]) + part[3][threadIdx.x];
+        out[c] = scale * t + (accumulate ? out[c] : 0.f);
+    }
+}
+
+__device__ __forceinline__ float gelu_exact(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float gelu_grad(float x) {
+    return 0.5f * (1.0f + erff(x * 0.70710678118654752440f)) + x * 0.39894228040143267794f * expf(-0.5f * x * x);
+}
+
+// pre[r][c] += bias[c]; act[r][c] = gelu(pre) * (rowscale ? rowscale[r] : 1)
+__global__ void bias_gelu_kernel(float* __restrict__ pre, const float* __restrict__ bias, const float* __restrict__ rowscale,
+                                 long rows, int cols, float* __restrict__ act) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * cols) return;
+    const long r = i / cols;
+    const int c = (int)(i % cols);
+    const float v = pre[i] + bias[c];
+    pre[i] = v;
+    act[i] = gelu_exact(v) * (rowscale ? rowscale[r] : 1.0f);
+}
+// g[r][c] = g[r][c] * gelu'(pre[r][c]) * (rowscale ? rowscale[r] : 1)
+__global__ void gelu_backward_kernel(float* __restrict__ g, const float* __restrict__ pre, const float* __restrict__ rowscale,
+                                     long rows, int cols) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * cols) return;
+    g[i] = g[i] * gelu_grad(pre[i]) * (rowscale ? rowscale[i / cols] : 1.0f);
+}
+__global__ void add_bias_kernel(float* __restrict__ x, const float* __restrict__ bias, long rows, int cols) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < rows * cols) x[i] += bias[i % cols];
+}
+
+// (edge slot, orientation) rows: pair invariants + edge scalars (transforms/invariants.py:82-88, geometry/invariants.py:
+// 10-31), cut-off window (windowing.py:21-29; 0 for unused slots) and the 83 distinct monomials (columns 83..95 zero).
+__global__ void edge_rows_kernel(const float* __restrict__ dir, const float* __restrict__ dist, const int32_t* __restrict__ deg,
+                                 const int32_t* __restrict__ batch, const float* __restrict__ lattice,
+                                 const float* __restrict__ ori, float r_max, int N, int k, float* __restrict__ mono,
+                                 float* __restrict__ window) {
+    const long r = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= (long)N * k * 16) return;
+    const int o = (int)(r & 15);
+    const long e = r >> 4;
+    const int n = (int)(e / k), s = (int)(e % k);
+    const float dx = dir[3 * e], dy = dir[3 * e + 1], dz = dir[3 * e + 2], d = dist[e];
+    const float ox = ori[3 * o], oy = ori[3 * o + 1], oz = ori[3 * o + 2];
+    float a[6];
+    a[0] = (dx * ox + dy * oy) + dz * oz;
+    const float rx = dx - a[0] * ox, ry = dy - a[0] * oy, rz = dz - a[0] * oz;
+    a[1] = sqrtf((rx * rx + ry * ry) + rz * rz);
+    a[2] = d;
+    const float* Lm = lattice + 9 * (size_t)batch[n];
+    const float dn = fmaxf(sqrtf((dx * dx + dy * dy) + dz * dz), 1e-8f);
+    for (int i = 0; i < 3; ++i) {
+        const float lx = Lm[3 * i], ly = Lm[3 * i + 1], lz = Lm[3 * i + 2];
+        const float ln = fmaxf(sqrtf((lx * lx + ly * ly) + lz * lz), 1e-8f);
+        a[3 + i] = ((dx / dn) * (lx / ln) + (dy / dn) * (ly / ln)) + (dz / dn) * (lz / ln);
+    }
+    const float u = d / r_max, u2 = u * u, u6 = u2 * u2 * u2;
+    window[r] = (s < deg[n] && d < r_max) ? 1.0f - 28.0f * u6 + 48.0f * u6 * u - 21.0f * u6 * u2 : 0.0f;
+    float* mrow = mono + r * ARREAU_MONO_PAD;
+    int p = 0;
+    for (int i = 0; i < 6; ++i) mrow[p++] = a[i];
+    for (int i = 0; i < 6; ++i)
+        for (int j = i; j < 6; ++j) mrow[p++] = a[i] * a[j];
+    for (int i = 0; i < 6; ++i)
+        for (int j = i; j < 6; ++j)
+            for (int q = j; q < 6; ++q) mrow[p++] = (a[i] * a[j]) * a[q];
+    for (; p < ARREAU_MONO_PAD; ++p) mrow[p] = 0.f;
+}
+
+// fiber attributes: poly3(ori_o . ori_p)  [256][3]  (geometry/invariants.py:24; embedding.py:10-14 with one input)
+__global__ void fiber_poly_kernel(const float* __restrict__ ori, float* __restrict__ fpoly) {
+    const int i = threadIdx.x;  // 256 threads
+    const int o = i >> 4, p = i & 15;
+    const float a = (ori[3 * o] * ori[3 * p] + ori[3 * o + 1] * ori[3 * p + 1]) + ori[3 * o + 2] * ori[3 * p + 2];
+    fpoly[3 * i] = a;
+    fpoly[3 * i + 1] = a * a;
+    fpoly[3 * i + 2] = (a * a) * a;
+}
+
+// dense input features of x_embedder, one row per (atom, orientation):  [one_hot(type) S | t_emb 64 | n | lengths 3 |
+// angles 3 | |lengths/n| 3 | vec . ori 4]   (diffusion_loss.py:124-158, position_orientation_graph.py:82-86)
+__global__ void features_kernel(const float* __restrict__ frac, const int32_t* __restrict__ types,
+                                const float* __restrict__ lengths, const float* __restrict__ angles,
+                                const int32_t* __restrict__ tstep, const int32_t* __restrict__ offsets,
+                                const int32_t* __restrict__ batch, const float* __restrict__ lattice,
+                                const float* __restrict__ betas, const float* __restrict__ t_emb_w,
+                                const float* __restrict__ ori, int S, int T, int N, float* __restrict__ F) {
+    const int row = blockIdx.x;  // (n, o)
+    const int n = row >> 4, o = row & 15;
+    const int b = batch[n];
+    const int FW = S + 78;
+    float* f = F + (size_t)row * FW;
+    const float nat = (float)(offsets[b + 1] - offsets[b]);
+    int t = tstep[b];
+    t = t < 0 ? 0 : (t > T ? T : t);
+    const int ty = min(max(types[n], 0), S - 1);
+    for (int i = threadIdx.x; i < FW; i += blockDim.x) {
+        float v;
+        if (i < S) v = i == ty ? 1.0f : 0.0f;
+        else if (i < S + 64) {
+            const int j = i - S;
+            const float proj = ((betas[t] * t_emb_w[j & 31]) * 2.0f) * 3.14159265358979323846f;
+            v = j < 32 ? sinf(proj) : cosf(proj);
+        } else if (i == S + 64) v = nat;
+        else if (i < S + 68) v = lengths[3 * b + (i - S - 65)];
+        else if (i < S + 71) v = angles[3 * b + (i - S - 68)];
+        else if (i < S + 74) v = fabsf(lengths[3 * b + (i - S - 71)] / nat);
+        else {
+            const int q = i - S - 74;
+            const float* vv = q == 0 ? frac + 3 * (size_t)n : lattice + 9 * (size_t)b + 3 * (q - 1);
+            v = (vv[0] * ori[3 * o] + vv[1] * ori[3 * o + 1]) + vv[2] * ori[3 * o + 2];
+        }
+        f[i] = v;
+    }
+}
+
+// x1[n,o,c] = sum_{s < deg[n]} kern[(n,s,o),c] * x[src(n,s),o,c]   (conv.py:111,131-133 + sum aggregation)
+__global__ void conv_forward_kernel(const float* __restrict__ kern, const float* __restrict__ x, const int32_t* __restrict__ deg,
+                                    const int32_t* __restrict__ src, int N, int k, int C, float* __restrict__ x1) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)N * 16 * C) return;
+    const int c = (int)(i % C);
+    const long row = i / C;
+    const int o = (int)(row & 15), n = (int)(row >> 4);
+    const int nd = min(deg[n], k);
+    float acc = 0.f;
+    for (int s = 0; s < nd; ++s) {
+        const int j = src[(size_t)n * k + s];
+        acc += kern[(((size_t)n * k + s) * 16 + o) * C + c] * x[((size_t)j * 16 + o) * C + c];
+    }
+    x1[i] = acc;
+}
+// dkern[(n,s,o),c] = dx1[n,o,c] * x[src,o,c];  dx[src,o,c] += kern[(n,s,o),c] * dx1[n,o,c]  (atomic: several receivers
+// share a sender)
+__global__ void conv_backward_kernel(const float* __restrict__ kern, const float* __restrict__ x, const float* __restrict__ dx1,
+                                     const int32_t* __restrict__ deg, const int32_t* __restrict__ src, int N, int k, int C,
+                                     float* __restrict__ dkern, float* __restrict__ dx) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)N * k * 16 * C) return;
+    const int c = (int)(i % C);
+    const long row = i / C;
+    const int o = (int)(row & 15);
+    const long e = row >> 4;
+    const int n = (int)(e / k), s = (int)(e % k);
+    if (s >= min(deg[n], k)) { dkern[i] = 0.f; return; }
+    const int j = src[e];
+    const float g = dx1[((size_t)n * 16 + o) * C + c];
+    dkern[i] = g * x[((size_t)j * 16 + o) * C + c];
+    atomicAdd(dx + ((size_t)j * 16 + o) * C + c, kern[i] * g);
+}
+// x2[n,p,c] = sum_o x1[n,o,c] fk[o,p,c] / 16 + bias[c]   (conv.py:113-127)
+__global__ void mix_forward_kernel(const float* __restrict__ x1, const float* __restrict__ fk, const float* __restrict__ bias,
+                                   int N, int C, float* __restrict__ x2) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)N * 16 * C) return;
+    const int c = (int)(i % C);
+    const long row = i / C;
+    const int p = (int)(row & 15), n = (int)(row >> 4);
+    float acc = 0.f;
+    for (int o = 0; o < 16; ++o) acc += x1[((size_t)n * 16 + o) * C + c] * fk[((size_t)o * 16 + p) * C + c];
+    x2[i] = acc * (1.0f / 16.0f) + bias[c];
+}
+// dx1[n,o,c] = sum_p dx2[n,p,c] fk[o,p,c] / 16
+__global__ void mix_backward_x_kernel(const float* __restrict__ dx2, const float* __restrict__ fk, int N, int C,
+                                      float* __restrict__ dx1) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)N * 16 * C) return;
+    const int c = (int)(i % C);
+    const long row = i / C;
+    const int o = (int)(row & 15), n = (int)(row >> 4);
+    float acc = 0.f;
+    for (int p = 0; p < 16; ++p) acc += dx2[((size_t)n * 16 + p) * C + c] * fk[((size_t)o * 16 + p) * C + c];
+    dx1[i] = acc * (1.0f / 16.0f);
+}
+// dfk[o,p,c] = sum_n x1[n,o,c] dx2[n,p,c] / 16   (atoms in order: deterministic)
+__global__ void mix_backward_fk_kernel(const float* __restrict__ x1, const float* __restrict__ dx2, int N, int C,
+                                       float* __restrict__ dfk) {
+    const int op = blockIdx.x, o = op >> 4, p = op & 15;
+    for (int c = threadIdx.x; c < C; c += blockDim.x) {
+        float acc = 0.f;
+        for (int n = 0; n < N; ++n) acc += x1[((size_t)n * 16 + o) * C + c] * dx2[((size_t)n * 16 + p) * C + c];
+        dfk[(size_t)op * C + c] = acc * (1.0f / 16.0f);
+    }
+}
+// LayerNorm over C (eps 1e-5, biased variance; convnext.py:25): xhat, rstd saved; y = xhat g + b.  One wave per row.
+__global__ __launch_bounds__(256) void ln_forward_kernel(const float* __restrict__ x, const float* __restrict__ g,
+                                                         const float* __restrict__ b, long rows, int C,
+                                                         float* __restrict__ xhat, float* __restrict__ rstd_out,
+                                                         float* __restrict__ y) {
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    const float* xr = x + (size_t)row * C;
+    float s = 0.f;
+    for (int c = lane; c < C; c += 64) s += xr[c];
+    for (int off = 32; off >= 1; off >>= 1) s += __shfl_xor(s, off, 64);
+    const float mean = s / (float)C;
+    float q = 0.f;
+    for (int c = lane; c < C; c += 64) { const float d = xr[c] - mean; q += d * d; }
+    for (int off = 32; off >= 1; off >>= 1) q += __shfl_xor(q, off, 64);
+    const float rstd = 1.0f / sqrtf(q / (float)C + 1e-5f);
+    if (lane == 0) rstd_out[row] = rstd;
+    for (int c = lane; c < C; c += 64) {
+        const float h = (xr[c] - mean) * rstd;
+        xhat[(size_t)row * C + c] = h;
+        y[(size_t)row * C + c] = h * g[c] + b[c];
+    }
+}
+// dx = rstd * (dy - mean(dy) - xhat mean(dy xhat)),  dy = dyn * g
+__global__ __launch_bounds__(256) void ln_backward_kernel(const float* __restrict__ dyn, const float* __restrict__ xhat,
+                                                          const float* __restrict__ rstd, const float* __restrict__ g,
+                                                          long rows, int C, float* __restrict__ dx) {
+    const long row = (long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    float s1 = 0.f, s2 = 0.f;
+    for (int c = lane; c < C; c += 64) {
+        const float dy = dyn[(size_t)row * C + c] * g[c];
+        s1 += dy;
+        s2 += dy * xhat[(size_t)row * C + c];
+    }
+    for (int off = 32; off >= 1; off >>= 1) { s1 += __shfl_xor(s1, off, 64); s2 += __shfl_xor(s2, off, 64); }
+    const float m1 = s1 / (float)C, m2 = s2 / (float)C, r = rstd[row];
+    for (int c = lane; c < C; c += 64) {
+        const float dy = dyn[(size_t)row * C + c] * g[c];
+        dx[(size_t)row * C + c] = r * (dy - m1 - xhat[(size_t)row * C + c] * m2);
+    }
+}
+// x_next = out * ls + x   (convnext.py:30-32)
+__global__ void scale_residual_kernel(const float* __restrict__ out, const float* __restrict__ ls, const float* __restrict__ x,
+                                      long rows, int C, float* __restrict__ xn) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < rows * C) xn[i] = out[i] * ls[i % C] + x[i];
+}
+__global__ void scale_cols_kernel(const float* __restrict__ a, const float* __restrict__ colscale, long rows, int C,
+                                  float* __restrict__ out) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < rows * C) out[i] = a[i] * colscale[i % C];
+}
+// read-outs from rbar[(n,o)][S+4] = mean over layers (bias added here): logits = mean_o, eps = sum_o vec * ori / 16,
+// gs = mean_o (ponita.py:108-117,126-155); len0 by readout_crystals-style ordered sums
+__global__ void train_outputs_kernel(const float* __restrict__ rbar, const float* __restrict__ ro_b, const float* __restrict__ ori,
+                                     int S, int L, int N, float* __restrict__ eps, float* __restrict__ logits,
+                                     float* __restrict__ gs) {
+    const int n = blockIdx.x, RO = S + 4;
+    for (int j = threadIdx.x; j < RO + 2; j += blockDim.x) {
+        if (j < S || (j > S && j < RO)) {
+            float bsum = 0.f;
+            for (int l = 0; l < L; ++l) bsum += ro_b[l * RO + j];
+            float acc = 0.f;
+            for (int o = 0; o < 16; ++o) acc += rbar[((size_t)n * 16 + o) * RO + j];
+            const float v = acc * (1.0f / 16.0f) + bsum / (float)L;
+            if (j < S) logits[(size_t)n * S + j] = v;
+            else gs[(size_t)n * 3 + (j - S - 1)] = v;
+        } else {  // j == S, RO, RO+1 -> the three components of the vector read-out
+            const int d = j == S ? 0 : (j - RO + 1);
+            float bsum = 0.f;
+            for (int l = 0; l < L; ++l) bsum += ro_b[l * RO + S];
+            bsum /= (float)L;
+            float acc = 0.f;
+            for (int o = 0; o < 16; ++o) acc += (rbar[((size_t)n * 16 + o) * RO + S] + bsum) * ori[3 * o + d];
+            eps[(size_t)n * 3 + d] = acc * (1.0f / 16.0f);
+        }
+    }
+}
+__global__ void pool_crystals_kernel(const float* __restrict__ gs, const int32_t* __restrict__ offsets, int B,
+                                     float* __restrict__ len0) {
+    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= 3 * B) return;
+    const int b = idx / 3, g = idx - 3 * b;
+    float acc = 0.f;
+    for (int n = offsets[b]; n < offsets[b + 1]; ++n) acc += gs[(size_t)n * 3 + g];
+    len0[idx] = acc;
+}
+// d rbar[(n,o)][j] from the gradient seeds
+__global__ void train_outputs_backward_kernel(const float* __restrict__ g_eps, const float* __restrict__ g_logits,
+                                              const float* __restrict__ g_len0, const int32_t* __restrict__ batch,
+                                              const float* __restrict__ ori, int S, int N, float* __restrict__ drbar) {
+    const int row = blockIdx.x, n = row >> 4, o = row & 15, RO = S + 4;
+    const int b = batch[n];
+    for (int j = threadIdx.x; j < RO; j += blockDim.x) {
+        float v;
+        if (j < S) v = g_logits[(size_t)n * S + j] * (1.0f / 16.0f);
+        else if (j == S)
+            v = ((g_eps[3 * (size_t)n] * ori[3 * o] + g_eps[3 * (size_t)n + 1] * ori[3 * o + 1]) +
+                 g_eps[3 * (size_t)n + 2] * ori[3 * o + 2]) * (1.0f / 16.0f);
+        else v = g_len0[3 * (size_t)b + (j - S - 1)] * (1.0f / 16.0f);
+        drbar[(size_t)row * RO + j] = v;
+    }
+}
+// basis_fn.1.weight gradient [C][258] from the gradient of the folded weight [C][96]: every permutation column of a
+// monomial receives that monomial's gradient (embedding.py:10-14 column order)
+__global__ void unfold_poly_grad_kernel(const float* __restrict__ dw1f, int C, float* __restrict__ dw1) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= C * ARREAU_POLY_COLS) return;
+    const int c = i / ARREAU_POLY_COLS, col = i % ARREAU_POLY_COLS;
+    int a[3], n;
+    if (col < 6) { n = 1; a[0] = col; }
+    else if (col < 42) { n = 2; a[0] = (col - 6) / 6; a[1] = (col - 6) % 6; }
+    else { n = 3; a[0] = (col - 42) / 36; a[1] = ((col - 42) / 6) % 6; a[2] = (col - 42) % 6; }
+    for (int x = 0; x < n; ++x)  // sort the multiset
+        for (int y = x + 1; y < n; ++y)
+            if (a[y] < a[x]) { const int t = a[x]; a[x] = a[y]; a[y] = t; }
+    int p = 0, found = -1;  // index in the canonical monomial order (same enumeration as edge_rows_kernel)
+    for (int i1 = 0; i1 < 6 && found < 0; ++i1, ++p)
+        if (n == 1 && a[0] == i1) found = p;
+    for (int i1 = 0; i1 < 6; ++i1)
+        for (int j1 = i1; j1 < 6; ++j1, ++p)
+            if (found < 0 && n == 2 && a[0] == i1 && a[1] == j1) found = p;
+    for (int i1 = 0; i1 < 6; ++i1)
+        for (int j1 = i1; j1 < 6; ++j1)
+            for (int k1 = j1; k1 < 6; ++k1, ++p)
+                if (found < 0 && n == 3 && a[0] == i1 && a[1] == j1 && a[2] == k1) found = p;
+    dw1[i] = dw1f[c * ARREAU_MONO_PAD + found];
+}
+__global__ void transpose_kernel(const float* __restrict__ in, int rows, int cols, float* __restrict__ out) {  // out[c][r]
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < rows * cols) out[(size_t)(i % cols) * rows + i / cols] = in[i];
+}
+
+inline unsigned blocks(long n, int per = 256) { return (unsigned)((n + per - 1) / per); }
+}  // namespace
+
+// ---------------------------------------------------------------------------------------------
+// context: buffers of one training step, owned by the model, grown on demand
+// ---------------------------------------------------------------------------------------------
+struct arreau_train_ctx {
+    int N = 0, B = 0, capN = 0, capB = 0;
+    float* buf = nullptr;
+    size_t buf_floats = 0;
+    // plain row-major weights (in the model blob): [C][96], [D][C], [L][C][D], [L][H][C], [L][C][H], [L][S+4][C]
+    const float *w1f, *w2, *wk, *lin1, *lin2, *ro_w;
+    // forward state
+    int32_t *batch, *deg, *src, *cell;
+    float *lattice, *cart, *cvec, *dir, *dist;
+    float *mono, *window, *h1pre, *h1, *h2pre, *kb, *fpoly, *fh1pre, *fh1, *fh2pre, *fkb, *F;
+    float *x, *x1, *xhat, *rstd, *xn, *hpre, *h, *out, *fk, *rbar, *gs, *kern;
+    // backward temporaries
+    float *dx, *dtmp, *dh, *drbar, *dx1, *dkern, *dkb, *dh1, *dfk, *dfkb, *dfh1, *dw1f, *partial, *scratch_cols;
+    const int32_t *tstep, *offsets, *types;
+    const float *frac, *lengths, *angles;
+};
+
+namespace {
+struct Carve {
+    float* base;
+    size_t off = 0;
+    template <typename T>
+    T* take(size_t n) {
+        off = (off + 63) & ~(size_t)63;
+        T* r = base ? reinterpret_cast<T*>(base + off) : nullptr;
+        off += (n * sizeof(T) + 3) / 4;
+        return r;
+    }
+};
+constexpr size_t PARTIAL_FLOATS = (size_t)64 * 512 * 512;  // split-K partial sums (64 slices of the largest weight)
+
+size_t layout(arreau_train_ctx& t, const arreau_model* m, int N, int B, float* base) {
+    Carve c{base};
+    const size_t C = m->C, D = m->D, L = m->L, H = m->H, k = m->k, S = m->S, RO = S + 4;
+    const size_t R = (size_t)N * k * 16, M = (size_t)N * 16;
+    t.w1f = m->t_w1f; t.w2 = m->t_w2; t.wk = m->t_wk; t.lin1 = m->t_lin1; t.lin2 = m->t_lin2; t.ro_w = m->t_ro_w;
+    t.batch = c.take<int32_t>(N); t.deg = c.take<int32_t>(N); t.src = c.take<int32_t>(N * k); t.cell = c.take<int32_t>(N * k);
+    t.lattice = c.take<float>(B * 9); t.cart = c.take<float>(N * 3); t.cvec = c.take<float>(B * C);
+    t.dir = c.take<float>(N * k * 3); t.dist = c.take<float>(N * k);
+    t.mono = c.take<float>(R * ARREAU_MONO_PAD); t.window = c.take<float>(R);
+    t.h1pre = c.take<float>(R * C); t.h1 = c.take<float>(R * C); t.h2pre = c.take<float>(R * D); t.kb = c.take<float>(R * D);
+    t.fpoly = c.take<float>(256 * 3); t.fh1pre = c.take<float>(256 * C); t.fh1 = c.take<float>(256 * C);
+    t.fh2pre = c.take<float>(256 * D); t.fkb = c.take<float>(256 * D); t.F = c.take<float>(M * (S + 78));
+    t.x = c.take<float>((L + 1) * M * C); t.x1 = c.take<float>(L * M * C); t.xhat = c.take<float>(L * M * C);
+    t.rstd = c.take<float>(L * M); t.xn = c.take<float>(M * C); t.hpre = c.take<float>(L * M * H); t.h = c.take<float>(L * M * H);
+    t.out = c.take<float>(L * M * C); t.fk = c.take<float>(L * 256 * C); t.rbar = c.take<float>(M * RO); t.gs = c.take<float>(N * 3);
+    t.kern = c.take<float>(R * C);
+    t.dx = c.take<float>(M * C); t.dtmp = c.take<float>(M * C); t.dh = c.take<float>(M * H); t.drbar = c.take<float>(M * RO);
+    t.dx1 = c.take<float>(M * C); t.dkern = c.take<float>(R * C); t.dkb = c.take<float>(R * D); t.dh1 = c.take<float>(R * C);
+    t.dfk = c.take<float>(256 * C); t.dfkb = c.take<float>(256 * D); t.dfh1 = c.take<float>(256 * C);
+    t.dw1f = c.take<float>(C * ARREAU_MONO_PAD); t.partial = c.take<float>(PARTIAL_FLOATS); t.scratch_cols = c.take<float>(1024);
+    return c.off;
+}
+
+int gemm(hipStream_t s, arreau_train_ctx& t, int M, int N, int K, const float* A, long as0, long as1, const float* B, long bs0,
+         long bs1, float* C, int ldc, float alpha = 1.f, float beta = 0.f) {
+    if (M == 0 || N == 0) return ARREAU_OK;
+    const int gm = (M + TILE - 1) / TILE, gn = (N + TILE - 1) / TILE;
+    int Z = 1;
+    if (K >= 4096 && gm * gn < 256) {  // weight gradients: few output tiles, long reduction -> split K
+        Z = min(64, (K + 1023) / 1024);
+        while (Z > 1 && (size_t)Z * M * N > PARTIAL_FLOATS) --Z;
+    }
+    const int kchunk = ((K + Z - 1) / Z + BK - 1) / BK * BK;
+    Z = (K + kchunk - 1) / kchunk;
+    hipLaunchKernelGGL(sgemm_kernel, dim3(gn, gm, Z), dim3(256), 0, s, M, N, K, A, as0, as1, B, bs0, bs1, C, ldc, alpha, beta,
+                       kchunk, t.partial);
+    ARREAU_CHECK_HIP(hipGetLastError());
+    if (Z > 1) {
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks((long)M * N)), dim3(256), 0, s, t.partial, Z, M, N, C, ldc, alpha, beta);
+        ARREAU_CHECK_HIP(hipGetLastError());
+    }
+    return ARREAU_OK;
+}
+// Y[rows][out] = X[rows][in] . W[out][in]^T
+int linear(hipStream_t s, arreau_train_ctx& t, long rows, int in, int out, const float* X, const float* W, float* Y,
+           float alpha = 1.f, float beta = 0.f) {
+    return gemm(s, t, (int)rows, out, in, X, in, 1, W, 1, in, Y, out, alpha, beta);
+}
+// dX[rows][in] (+)= dY[rows][out] . W[out][in]
+int linear_dx(hipStream_t s, arreau_train_ctx& t, long rows, int in, int out, const float* dY, const float* W, float* dX,
+              float alpha = 1.f, float beta = 0.f) {
+    return gemm(s, t, (int)rows, in, out, dY, out, 1, W, in, 1, dX, in, alpha, beta);
+}
+// dW[out][in] = alpha * dY[rows][out]^T . X[rows][in]
+int linear_dw(hipStream_t s, arreau_train_ctx& t, long rows, int in, int out, const float* dY, const float* X, float* dW,
+              float alpha = 1.f) {
+    return gemm(s, t, out, in, (int)rows, dY, 1, out, X, in, 1, dW, in, alpha, 0.f);
+}
+int colsum(hipStream_t s, const float* a, const float* b, long rows, int cols, float scale, float* out, int accumulate = 0) {
+    hipLaunchKernelGGL(colsum_kernel, dim3((cols + 63) / 64), dim3(256), 0, s, a, b, (int)rows, cols, scale, accumulate, out);
+    ARREAU_CHECK_HIP(hipGetLastError());
+    return ARREAU_OK;
+}
+#define TRY(expr) do { int rc_ = (expr); if (rc_) return rc_; } while (0)
+#define LAUNCH(kernel, grid, block, ...)                                  \
+    do {                                                                  \
+        hipLaunchKernelGGL(kernel, grid, block, 0, s, __VA_ARGS__);       \
+        ARREAU_CHECK_HIP(hipGetLastError());                              \
+    } while (0)
+}  // namespace
+
+void arreau_train_ctx_destroy(arreau_train_ctx* t) {
+    if (!t) return;
+    if (t->buf) (void)hipFree(t->buf);
+    delete t;
+}
+
+static int ensure_ctx(arreau_model* m, int N, int B, hipStream_t s) {
+    arreau_train_ctx* t = m->train;
+    if (t && N <= t->capN && B <= t->capB) {
+        layout(*t, m, t->capN, t->capB, t->buf);
+        t->N = N; t->B = B;
+        return ARREAU_OK;
+    }
+    if (t) {
+        ARREAU_CHECK_HIP(hipStreamSynchronize(s));
+        arreau_train_ctx_destroy(t);
+        m->train = nullptr;
+    }
+    t = new arreau_train_ctx();
+    t->capN = N; t->capB = B;
+    arreau_train_ctx probe;
+    t->buf_floats = layout(probe, m, N, B, nullptr);
+    hipError_t e = hipMalloc((void**)&t->buf, t->buf_floats * sizeof(float));
+    if (e != hipSuccess) {
+        delete t;
+        arreau_set_error(std::string("hipMalloc(training buffers): ") + hipGetErrorString(e));
+        return ARREAU_EHIP;
+    }
+    layout(*t, m, N, B, t->buf);
+    t->N = N; t->B = B;
+    m->train = t;
+    ARREAU_CHECK_HIP(hipMemsetAsync(t->scratch_cols, 0, 1024 * sizeof(float), s));
+    return ARREAU_OK;
+}
+
+extern "C" int arreau_train_forward(arreau_model* m, const float* d_frac, const int32_t* d_types, const float* d_lengths,
+                                    const float* d_angles, const int32_t* d_t, const int32_t* d_off, int32_t B, int32_t N,
+                                    float* d_eps, float* d_logits, float* d_len0, void* stream) {
+    ARREAU_REQUIRE(m && d_frac && d_types && d_lengths && d_angles && d_t && d_off && d_eps && d_logits && d_len0,
+                   "arreau_train_forward: null pointer");
+    ARREAU_REQUIRE(B >= 1 && N >= 1, "arreau_train_forward: bad size");
+    hipStream_t s = (hipStream_t)stream;
+    TRY(ensure_ctx(m, N, B, s));
+    arreau_train_ctx& t = *m->train;
+    const int C = m->C, D = m->D, L = m->L, H = m->H, k = m->k, S = m->S, RO = S + 4;
+    const long R = (long)N * k * 16, M = (long)N * 16;
+    t.tstep = d_t; t.offsets = d_off; t.types = d_types; t.frac = d_frac; t.lengths = d_lengths; t.angles = d_angles;
+    // geometry and graph: the sampling path's own kernels (prep, neighbour list)
+    TRY(arreau_launch_prep(m, d_frac, d_lengths, d_angles, d_t, d_off, B, N, t.lattice, t.cart, t.batch, t.cvec, s));
+    TRY(arreau_launch_neighbor(t.cart, t.lattice, d_off, t.batch, B, N, m->cfg.radius, k, t.deg, t.src, t.cell, t.dir, t.dist, s));
+    // edge basis: kb = gelu(W2 gelu(W1 poly + b1) + b2) * window   (ponita.py:65,94)
+    LAUNCH(edge_rows_kernel, dim3(blocks(R)), dim3(256), t.dir, t.dist, t.deg, t.batch, t.lattice, m->ori, m->cfg.radius, N, k,
+           t.mono, t.window);
+    TRY(linear(s, t, R, ARREAU_MONO_PAD, C, t.mono, t.w1f, t.h1pre));
+    LAUNCH(bias_gelu_kernel, dim3(blocks(R * C)), dim3(256), t.h1pre, m->b1, (const float*)nullptr, R, C, t.h1);
+    TRY(linear(s, t, R, C, D, t.h1, t.w2, t.h2pre));
+    LAUNCH(bias_gelu_kernel, dim3(blocks(R * D)), dim3(256), t.h2pre, m->b2, (const float*)t.window, R, D, t.kb);
+    // fiber basis (ponita.py:66,95)
+    LAUNCH(fiber_poly_kernel, dim3(1), dim3(256), m->ori, t.fpoly);
+    TRY(linear(s, t, 256, 3, C, t.fpoly, m->fiber_w1, t.fh1pre));
+    LAUNCH(bias_gelu_kernel, dim3(blocks(256L * C)), dim3(256), t.fh1pre, m->fiber_b1, (const float*)nullptr, 256L, C, t.fh1);
+    TRY(linear(s, t, 256, C, D, t.fh1, m->fiber_w2, t.fh2pre));
+    LAUNCH(bias_gelu_kernel, dim3(blocks(256L * D)), dim3(256), t.fh2pre, m->fiber_b2, (const float*)nullptr, 256L, D, t.fkb);
+    // embedding (ponita.py:98): x_0 = F . W_emb^T, embT = W_emb^T [S+78][C]
+    LAUNCH(features_kernel, dim3((unsigned)M), dim3(64), d_frac, d_types, d_lengths, d_angles, d_t, d_off, t.batch, t.lattice,
+           m->vp_betas, m->t_emb_w, m->ori, S, m->T, N, t.F);
+    TRY(gemm(s, t, (int)M, C, S + 78, t.F, S + 78, 1, m->embT, C, 1, t.x, C));
+    ARREAU_CHECK_HIP(hipMemsetAsync(t.rbar, 0, (size_t)M * RO * sizeof(float), s));
+    for (int l = 0; l < L; ++l) {
+        const float* xl = t.x + (size_t)l * M * C;
+        float* xnext = t.x + (size_t)(l + 1) * M * C;
+        float* x1 = t.x1 + (size_t)l * M * C;
+        float* fk = t.fk + (size_t)l * 256 * C;
+        TRY(linear(s, t, R, D, C, t.kb, t.wk + (size_t)l * C * D, t.kern));
+        LAUNCH(conv_forward_kernel, dim3(blocks(M * C)), dim3(256), t.kern, xl, t.deg, t.src, N, k, C, x1);
+        TRY(linear(s, t, 256, D, C, t.fkb, m->fiber_wk + (size_t)l * C * D, fk));
+        LAUNCH(mix_forward_kernel, dim3(blocks(M * C)), dim3(256), x1, fk, m->conv_bias + (size_t)l * C, N, C, t.dtmp);
+        LAUNCH(ln_forward_kernel, dim3(blocks(M, 4)), dim3(256), t.dtmp, m->ln_w + (size_t)l * C, m->ln_b + (size_t)l * C, M, C,
+               t.xhat + (size_t)l * M * C, t.rstd + (size_t)l * M, t.xn);
+        float* hpre = t.hpre + (size_t)l * M * H;
+        float* h = t.h + (size_t)l * M * H;
+        float* out = t.out + (size_t)l * M * C;
+        TRY(linear(s, t, M, C, H, t.xn, t.lin1 + (size_t)l * H * C, hpre));
+        LAUNCH(bias_gelu_kernel, dim3(blocks(M * H)), dim3(256), hpre, m->mb1 + (size_t)l * H, (const float*)nullptr, M, H, h);
+        TRY(linear(s, t, M, H, C, h, t.lin2 + (size_t)l * C * H, out));
+        LAUNCH(add_bias_kernel, dim3(blocks(M * C)), dim3(256), out, m->mb2 + (size_t)l * C, M, C);
+        LAUNCH(scale_residual_kernel, dim3(blocks(M * C)), dim3(256), out, m->ls + (size_t)l * C, xl, M, C, xnext);
+        // read-out of this layer, averaged over layers (ponita.py:105,108); biases are added in train_outputs_kernel
+        TRY(linear(s, t, M, C, RO, xnext, t.ro_w + (size_t)l * RO * C, t.rbar, 1.0f / (float)L, 1.0f));
+    }
+    LAUNCH(train_outputs_kernel, dim3(N), dim3(128), t.rbar, m->ro_b, m->ori, S, L, N, d_eps, d_logits, t.gs);
+    LAUNCH(pool_crystals_kernel, dim3(blocks(3 * B, 128)), dim3(128), t.gs, d_off, B, d_len0);
+    return ARREAU_OK;
+}
+
+extern "C" int arreau_train_backward(arreau_model* m, const float* d_g_eps, const float* d_g_logits, const float* d_g_len0,
+                                     const arreau_state_dict* g, void* stream) {
+    ARREAU_REQUIRE(m && d_g_eps && d_g_logits && d_g_len0 && g, "arreau_train_backward: null pointer");
+    ARREAU_REQUIRE(m->train && m->train->N > 0, "arreau_train_backward: call arreau_train_forward first");
+    const float* need[] = {g->basis_w1, g->basis_b1, g->basis_w2, g->basis_b2, g->fiber_w1, g->fiber_b1, g->fiber_w2, g->fiber_b2,
+                           g->x_embedder_w, g->conv_kernel_w, g->conv_fiber_w, g->conv_bias, g->norm_w, g->norm_b, g->linear1_w,
+                           g->linear1_b, g->linear2_w, g->linear2_b, g->readout_w, g->readout_b};
+    for (const float* p : need) ARREAU_REQUIRE(p != nullptr, "arreau_train_backward: missing gradient buffer");
+    ARREAU_REQUIRE(!m->cfg.has_layer_scale || g->layer_scale, "arreau_train_backward: missing layer_scale gradient buffer");
+    hipStream_t s = (hipStream_t)stream;
+    arreau_train_ctx& t = *m->train;
+    const int N = t.N, C = m->C, D = m->D, L = m->L, H = m->H, k = m->k, S = m->S, RO = S + 4;
+    const long R = (long)N * k * 16, M = (long)N * 16;
+    auto W = [](const float* p) { return const_cast<float*>(p); };  // the gradient struct reuses the const state_dict type
+    LAUNCH(train_outputs_backward_kernel, dim3((unsigned)M), dim3(128), d_g_eps, d_g_logits, d_g_len0, t.batch, m->ori, S, N, t.drbar);
+    ARREAU_CHECK_HIP(hipMemsetAsync(t.dx, 0, (size_t)M * C * sizeof(float), s));
+    ARREAU_CHECK_HIP(hipMemsetAsync(t.dkb, 0, (size_t)R * D * sizeof(float), s));
+    ARREAU_CHECK_HIP(hipMemsetAsync(t.dfkb, 0, (size_t)256 * D * sizeof(float), s));
+    const float invL = 1.0f / (float)L;
+    for (int l = L - 1; l >= 0; --l) {
+        const float* xl = t.x + (size_t)l * M * C;
+        const float* xnext = t.x + (size_t)(l + 1) * M * C;
+        const float* x1 = t.x1 + (size_t)l * M * C;
+        const float* xhat = t.xhat + (size_t)l * M * C;
+        const float* fk = t.fk + (size_t)l * 256 * C;
+        const float* hpre = t.hpre + (size_t)l * M * H;
+        const float* h = t.h + (size_t)l * M * H;
+        const float* out = t.out + (size_t)l * M * C;
+        // read-out (ponita.py:105,108)
+        TRY(linear_dw(s, t, M, C, RO, t.drbar, xnext, W(g->readout_w) + (size_t)l * RO * C, invL));
+        TRY(colsum(s, t.drbar, nullptr, M, RO, invL, W(g->readout_b) + (size_t)l * RO));
+        TRY(linear_dx(s, t, M, C, RO, t.drbar, t.ro_w + (size_t)l * RO * C, t.dx, invL, 1.0f));   // dx = d x_{l+1}
+        // ConvNext tail: x_{l+1} = out * ls + x_l
+        if (m->cfg.has_layer_scale) TRY(colsum(s, t.dx, out, M, C, 1.0f, W(g->layer_scale) + (size_t)l * C));
+        LAUNCH(scale_cols_kernel, dim3(blocks(M * C)), dim3(256), t.dx, m->ls + (size_t)l * C, M, C, t.dtmp);   // dout
+        TRY(linear_dw(s, t, M, H, C, t.dtmp, h, W(g->linear2_w) + (size_t)l * C * H));
+        TRY(colsum(s, t.dtmp, nullptr, M, C, 1.0f, W(g->linear2_b) + (size_t)l * C));
+        TRY(linear_dx(s, t, M, H, C, t.dtmp, t.lin2 + (size_t)l * C * H, t.dh));
+        LAUNCH(gelu_backward_kernel, dim3(blocks(M * H)), dim3(256), t.dh, hpre, (const float*)nullptr, M, H);      // dhpre
+        // xn = xhat * g + b (recomputed)
+        LAUNCH(scale_cols_kernel, dim3(blocks(M * C)), dim3(256), xhat, m->ln_w + (size_t)l * C, M, C, t.xn);
+        LAUNCH(add_bias_kernel, dim3(blocks(M * C)), dim3(256), t.xn, m->ln_b + (size_t)l * C, M, C);
+        TRY(linear_dw(s, t, M, C, H, t.dh, t.xn, W(g->linear1_w) + (size_t)l * H * C));
+        TRY(colsum(s, t.dh, nullptr, M, H, 1.0f, W(g->linear1_b) + (size_t)l * H));
+        TRY(linear_dx(s, t, M, C, H, t.dh, t.lin1 + (size_t)l * H * C, t.dtmp));                                     // dxn
+        TRY(colsum(s, t.dtmp, xhat, M, C, 1.0f, W(g->norm_w) + (size_t)l * C));
+        TRY(colsum(s, t.dtmp, nullptr, M, C, 1.0f, W(g->norm_b) + (size_t)l * C));
+        LAUNCH(ln_backward_kernel, dim3(blocks(M, 4)), dim3(256), t.dtmp, xhat, t.rstd + (size_t)l * M, m->ln_w + (size_t)l * C, M, C,
+               t.xn);                                                                                                // dx2 (in xn)
+        // spherical conv: x2 = mix(x1, fk) / 16 + bias
+        TRY(colsum(s, t.xn, nullptr, M, C, 1.0f, W(g->conv_bias) + (size_t)l * C));
+        LAUNCH(mix_backward_x_kernel, dim3(blocks(M * C)), dim3(256), t.xn, fk, N, C, t.dx1);
+        LAUNCH(mix_backward_fk_kernel, dim3(256), dim3(128), x1, t.xn, N, C, t.dfk);
+        TRY(linear_dw(s, t, 256, D, C, t.dfk, t.fkb, W(g->conv_fiber_w) + (size_t)l * C * D));
+        TRY(linear_dx(s, t, 256, D, C, t.dfk, m->fiber_wk + (size_t)l * C * D, t.dfkb, 1.0f, 1.0f));
+        // spatial conv: x1 = sum_s kern * x_l[src]; the residual path already sits in dx (= d x_l so far)
+        TRY(linear(s, t, R, D, C, t.kb, t.wk + (size_t)l * C * D, t.kern));
+        LAUNCH(conv_backward_kernel, dim3(blocks(R * C)), dim3(256), t.kern, xl, t.dx1, t.deg, t.src, N, k, C, t.dkern, t.dx);
+        TRY(linear_dw(s, t, R, D, C, t.dkern, t.kb, W(g->conv_kernel_w) + (size_t)l * C * D));
+        TRY(linear_dx(s, t, R, D, C, t.dkern, t.wk + (size_t)l * C * D, t.dkb, 1.0f, 1.0f));
+    }
+    // embedding: x_0 = F . W_emb^T  -> dW_emb[c][i] = sum_rows dx[row][c] F[row][i]
+    TRY(linear_dw(s, t, M, S + 78, C, t.dx, t.F, W(g->x_embedder_w)));
+    // edge basis MLP
+    LAUNCH(gelu_backward_kernel, dim3(blocks(R * D)), dim3(256), t.dkb, t.h2pre, (const float*)t.window, R, D);      // dh2pre
+    TRY(linear_dw(s, t, R, C, D, t.dkb, t.h1, W(g->basis_w2)));
+    TRY(colsum(s, t.dkb, nullptr, R, D, 1.0f, W(g->basis_b2)));
+    TRY(linear_dx(s, t, R, C, D, t.dkb, t.w2, t.dh1));
+    LAUNCH(gelu_backward_kernel, dim3(blocks(R * C)), dim3(256), t.dh1, t.h1pre, (const float*)nullptr, R, C);       // dh1pre
+    TRY(linear_dw(s, t, R, ARREAU_MONO_PAD, C, t.dh1, t.mono, t.dw1f));
+    LAUNCH(unfold_poly_grad_kernel, dim3(blocks((long)C * ARREAU_POLY_COLS)), dim3(256), t.dw1f, C, W(g->basis_w1));
+    TRY(colsum(s, t.dh1, nullptr, R, C, 1.0f, W(g->basis_b1)));
+    // fiber basis MLP
+    LAUNCH(gelu_backward_kernel, dim3(blocks(256L * D)), dim3(256), t.dfkb, t.fh2pre, (const float*)nullptr, 256L, D);
+    TRY(linear_dw(s, t, 256, C, D, t.dfkb, t.fh1, W(g->fiber_w2)));
+    TRY(colsum(s, t.dfkb, nullptr, 256, D, 1.0f, W(g->fiber_b2)));
+    TRY(linear_dx(s, t, 256, C, D, t.dfkb, m->fiber_w2, t.dfh1));
+    LAUNCH(gelu_backward_kernel, dim3(blocks(256L * C)), dim3(256), t.dfh1, t.fh1pre, (const float*)nullptr, 256L, C);
+    TRY(linear_dw(s, t, 256, 3, C, t.dfh1, t.fpoly, W(g->fiber_w1)));
+    TRY(colsum(s, t.dfh1, nullptr, 256, C, 1.0f, W(g->fiber_b1)));
+    return ARREAU_OK;
+}
+
+// activation statistics of the first training forward for FiberBundleConv.callibrate (conv.py:121-123,140-146): the
+// unbiased standard deviations of x (layer input), x_1 (after the spatial conv) and x_2 (after the spherical conv,
+// before the bias) of every layer, as torch.std() computes them.   d_stats[L][3]
+namespace {
+__global__ __launch_bounds__(256) void std_kernel(const float* __restrict__ a, long n, float* __restrict__ out) {
+    __shared__ double s1[256], s2[256];
+    double p = 0.0, q = 0.0;
+    for (long i = threadIdx.x; i < n; i += 256) { const double v = a[i]; p += v; q += v * v; }
+    s1[threadIdx.x] = p; s2[threadIdx.x] = q;
+    __syncthreads();
+    for (int st = 128; st >= 1; st >>= 1) {
+        if ((int)threadIdx.x < st) { s1[threadIdx.x] += s1[threadIdx.x + st]; s2[threadIdx.x] += s2[threadIdx.x + st]; }
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const double mean = s1[0] / (double)n;
+        out[0] = (float)sqrt(fmax((s2[0] - (double)n * mean * mean) / (double)(n - 1), 0.0));
+    }
+}
+}  // namespace
+
+extern "C" int arreau_train_conv_stats(arreau_model* m, float* d_stats, void* stream) {
+    ARREAU_REQUIRE(m && d_stats, "arreau_train_conv_stats: null pointer");
+    ARREAU_REQUIRE(m->train && m->train->N > 0, "arreau_train_conv_stats: call arreau_train_forward first");
+    hipStream_t s = (hipStream_t)stream;
+    arreau_train_ctx& t = *m->train;
+    const int N = t.N, C = m->C, L = m->L;
+    const long M = (long)N * 16;
+    for (int l = 0; l < L; ++l) {
+        const float* xl = t.x + (size_t)l * M * C;
+        const float* x1 = t.x1 + (size_t)l * M * C;
+        LAUNCH(std_kernel, dim3(1), dim3(256), xl, M * C, d_stats + 3 * l);
+        LAUNCH(std_kernel, dim3(1), dim3(256), x1, M * C, d_stats + 3 * l + 1);
+        // x_2 without the bias: recompute the mix into scratch
+        LAUNCH(mix_forward_kernel, dim3(blocks(M * C)), dim3(256), x1, t.fk + (size_t)l * 256 * C, (const float*)t.scratch_cols, N, C, t.dtmp);
+        LAUNCH(std_kernel, dim3(1), dim3(256), t.dtmp, M * C, d_stats + 3 * l + 2);
+    }
+    return ARREAU_OK;
+}

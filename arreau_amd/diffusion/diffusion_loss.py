@@ -43,7 +43,8 @@ class DiffusionLoss(nn.Module):
         self.lattice_diffusion = VP_lattice(num_steps=self.T, power=lattice_power, clipmax=lattice_clipmax)
         self.num_atomic_states = num_atomic_states
 
-    def __call__(self, model, batch, t_emb_weights=None, timestep=None, noise=None, return_parts=False):
+    def __call__(self, model, batch, t_emb_weights=None, timestep=None, noise=None, return_parts=False,
+                 training=False):
         """diffusion_loss.py:204-274: sample a timestep per crystal, noise (coordinates, atom types, cell lengths),
         evaluate the score network on the noised batch and return `coord + atom-type + lattice` error (weights 1).
 
@@ -53,6 +54,9 @@ class DiffusionLoss(nn.Module):
         rand(N,S) (D3PM.get_xt), randn_like(lengths) (VP_lattice.forward), from torch's global CPU generator;
         `noise=(z_frac, u_types, z_lengths)` injects them instead (parity tests).  Everything else runs in
         libarreau_hip.so (arreau_diffusion_noise -> arreau_predict_scores -> arreau_diffusion_losses).
+
+        `training=True` evaluates the network with arreau_train_forward (fp32, activations kept) instead of the fused
+        sampling kernels, so that HipEngine.train_backward can follow.
 
         Returns the scalar loss (a 0-d float32 CUDA tensor); with return_parts=True also a dict of the three errors,
         the noised inputs, the network outputs and d(loss)/d(outputs)."""
@@ -86,8 +90,8 @@ class DiffusionLoss(nn.Module):
         types0 = i32(batch.A0)
         nz = eng.diffusion_noise(f32(frac0), types0, f32(torch.as_tensor(batch.L0).reshape(-1, 3, 3)), t_d, off,
                                  f32(z_frac), f32(u_types), f32(z_len))
-        eps, logits, len0 = eng.predict_scores(nz["noisy_frac"], nz["noisy_types"], nz["noisy_lengths"], nz["angles"],
-                                               t_d, off)
+        evaluate = eng.train_forward if training else eng.predict_scores
+        eps, logits, len0 = evaluate(nz["noisy_frac"], nz["noisy_types"], nz["noisy_lengths"], nz["angles"], t_d, off)
         losses, grads = eng.diffusion_losses(eps, nz["target_eps"], logits, types0, nz["noisy_types"], t_d, len0,
                                              nz["lengths"], off, with_grads=True)
         eng.check_status()

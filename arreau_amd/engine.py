@@ -191,6 +191,66 @@ class HipEngine:
             "arreau_diffusion_losses")
         return (losses, g) if with_grads else losses
 
+    # ---- training (BASELINE config 5) ---------------------------------------------------------------
+    def train_forward(self, frac, types, lengths, angles, t_crystal, offsets):
+        """Training-mode network evaluation (arreau_train_forward): fp32, activations kept for train_backward.
+        Same inputs / outputs as predict_scores."""
+        dev = self.device
+        N, B = frac.shape[0], lengths.shape[0]
+        eps = torch.empty((N, 3), device=dev, dtype=torch.float32)
+        logits = torch.empty((N, self.S), device=dev, dtype=torch.float32)
+        len0 = torch.empty((B, 3), device=dev, dtype=torch.float32)
+        _hip.check(_hip.lib().arreau_train_forward(
+            self._handle, _hip.ptr(frac), _hip.ptr(types), _hip.ptr(lengths), _hip.ptr(angles), _hip.ptr(t_crystal),
+            _hip.ptr(offsets), B, N, _hip.ptr(eps), _hip.ptr(logits), _hip.ptr(len0), _hip.stream_ptr(dev)),
+            "arreau_train_forward")
+        return eps, logits, len0
+
+    def train_backward(self, grad_eps, grad_logits, grad_len0):
+        """Backward pass of the last train_forward (arreau_train_backward).  Returns {state_dict key: gradient} for every
+        trainable tensor of the score network, on the device, in the reference's parameter names and shapes."""
+        dev = self.device
+        cfg = self.cfg
+        S, C, D, L, W = self.S, cfg.hidden_dim, cfg.basis_dim, cfg.num_layers, cfg.widening_factor
+        H = W * C
+        z = lambda *shape: torch.zeros(shape, device=dev, dtype=torch.float32)
+        g = {"basis_w1": z(C, 258), "basis_b1": z(C), "basis_w2": z(D, C), "basis_b2": z(D), "fiber_w1": z(C, 3),
+             "fiber_b1": z(C), "fiber_w2": z(D, C), "fiber_b2": z(D), "x_embedder_w": z(C, S + 78),
+             "conv_kernel_w": z(L, C, D), "conv_fiber_w": z(L, C, D), "conv_bias": z(L, C), "norm_w": z(L, C),
+             "norm_b": z(L, C), "linear1_w": z(L, H, C), "linear1_b": z(L, H), "linear2_w": z(L, C, H),
+             "linear2_b": z(L, C), "layer_scale": z(L, C), "readout_w": z(L, S + 4, C), "readout_b": z(L, S + 4)}
+        csd = _hip.StateDict()
+        for name in _hip._SD_FIELDS:
+            t = g.get(name)
+            setattr(csd, name, t.data_ptr() if t is not None else None)
+        _hip.check(_hip.lib().arreau_train_backward(self._handle, _hip.ptr(grad_eps), _hip.ptr(grad_logits),
+                                                    _hip.ptr(grad_len0), ctypes.byref(csd), _hip.stream_ptr(dev)),
+                   "arreau_train_backward")
+        out = {"model.basis_fn.1.weight": g["basis_w1"], "model.basis_fn.1.bias": g["basis_b1"],
+               "model.basis_fn.3.weight": g["basis_w2"], "model.basis_fn.3.bias": g["basis_b2"],
+               "model.fiber_basis_fn.1.weight": g["fiber_w1"], "model.fiber_basis_fn.1.bias": g["fiber_b1"],
+               "model.fiber_basis_fn.3.weight": g["fiber_w2"], "model.fiber_basis_fn.3.bias": g["fiber_b2"],
+               "model.x_embedder.weight": g["x_embedder_w"]}
+        il = "model.interaction_layers.{}."
+        per_layer = {"conv.kernel.weight": "conv_kernel_w", "conv.fiber_kernel.weight": "conv_fiber_w", "conv.bias": "conv_bias",
+                     "norm.weight": "norm_w", "norm.bias": "norm_b", "linear_1.weight": "linear1_w",
+                     "linear_1.bias": "linear1_b", "linear_2.weight": "linear2_w", "linear_2.bias": "linear2_b"}
+        if cfg.has_layer_scale:
+            per_layer["layer_scale"] = "layer_scale"
+        for l in range(L):
+            for key, field in per_layer.items():
+                out[il.format(l) + key] = g[field][l]
+            out[f"model.read_out_layers.{l}.weight"] = g["readout_w"][l]
+            out[f"model.read_out_layers.{l}.bias"] = g["readout_b"][l]
+        return out
+
+    def conv_stats(self):
+        """[L,3] unbiased std of (x, x_1, x_2) per layer from the last train_forward (FiberBundleConv.callibrate)."""
+        st = torch.empty((self.cfg.num_layers, 3), device=self.device, dtype=torch.float32)
+        _hip.check(_hip.lib().arreau_train_conv_stats(self._handle, _hip.ptr(st), _hip.stream_ptr(self.device)),
+                   "arreau_train_conv_stats")
+        return st
+
     def workspace(self, N, B):
         if self._ws is None or N > self._ws_cap[0] or B > self._ws_cap[1]:
             capN, capB = max(N, self._ws_cap[0]), max(B, self._ws_cap[1])

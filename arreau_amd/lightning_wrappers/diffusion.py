@@ -90,6 +90,68 @@ class PONITA_DIFFUSION(nn.Module):
             model = model.to(map_location if map_location is not None else "cuda")
         return model
 
+    # ---- training (BASELINE config 5) --------------------------------------------------------------
+    def training_step(self, graph, timestep=None, noise=None):
+        """lightning_wrappers/diffusion.py:108-118: one forward + backward of the score-matching loss on a collated batch
+        (fields X0, A0, L0, num_atoms).  Leaves d(loss)/d(parameter) in `.grad` of every trainable parameter of
+        `self.model` (what loss.backward() does in the reference) and returns the loss as a 0-d CUDA tensor.
+        On the first training forward the conv weights are rescaled by the activation std ratios
+        (FiberBundleConv.callibrate, ponita/nn/conv.py:121-123,140-146) -- after this step's gradients were taken."""
+        loss, parts = self.diffusion_loss(self, graph, self.t_emb, timestep=timestep, noise=noise, return_parts=True,
+                                          training=True)
+        eng = self.engine()
+        grads = eng.train_backward(parts["grad_eps"], parts["grad_logits"], parts["grad_lengths"])
+        params = dict(self.named_parameters())
+        for name, g in grads.items():
+            p = params.get(name)
+            if p is not None and p.requires_grad:
+                p.grad = g.to(device=p.device, dtype=p.dtype).reshape(p.shape)
+        self._callibrate_if_needed(eng)
+        return loss
+
+    def _callibrate_if_needed(self, eng):
+        layers = self.model.interaction_layers
+        if all(bool(layer.conv.callibrated) for layer in layers):
+            return
+        st = eng.conv_stats().cpu().double()
+        with torch.no_grad():
+            for l, layer in enumerate(layers):
+                if bool(layer.conv.callibrated):
+                    continue
+                std_in, std_1, std_2 = (float(v) for v in st[l])
+                layer.conv.kernel.weight.mul_(std_in / std_1)
+                layer.conv.fiber_kernel.weight.mul_(std_1 / std_2)
+                layer.conv.callibrated.fill_(True)
+        self._engine = None  # weights changed: repack on next use
+
+    def notify_parameters_changed(self):
+        """Call after an optimizer step: the HIP engine holds packed copies of the weights."""
+        self._engine = None
+
+    def configure_optimizers(self, max_epochs=None):
+        """lightning_wrappers/diffusion.py:152-218: Adam with weight decay on Linear weights only (biases, LayerNorm
+        weights, layer_scale and the Fourier projection are not decayed) + the cosine warm-up schedule."""
+        from .scheduler import CosineWarmupScheduler
+        decay, no_decay = set(), set()
+        for mn, mod in self.named_modules():
+            for pn, _p in mod.named_parameters(recurse=False):
+                fpn = f"{mn}.{pn}" if mn else pn
+                if pn.endswith("bias"):
+                    no_decay.add(fpn)
+                elif pn.endswith("weight") and isinstance(mod, torch.nn.Linear):
+                    decay.add(fpn)
+                elif pn.endswith("weight") and isinstance(mod, (torch.nn.LayerNorm, torch.nn.Embedding)):
+                    no_decay.add(fpn)
+                elif pn.endswith("layer_scale") or pn.endswith("gaussian_fourier_proj_w"):
+                    no_decay.add(fpn)
+        param_dict = dict(self.named_parameters())
+        assert not (decay & no_decay) and not (param_dict.keys() - (decay | no_decay)), "parameter grouping is not a partition"
+        groups = [{"params": [param_dict[pn] for pn in sorted(decay)], "weight_decay": self.weight_decay},
+                  {"params": [param_dict[pn] for pn in sorted(no_decay)], "weight_decay": 0.0}]
+        optimizer = torch.optim.Adam(groups, lr=self.lr)
+        scheduler = CosineWarmupScheduler(optimizer, self.warmup, max_epochs if max_epochs is not None else self.epochs)
+        return {"optimizer": optimizer, "lr_scheduler": scheduler, "monitor": "val_loss"}
+
     # ---- operator seam ----------------------------------------------------------------------------
     def forward(self, graph):
         """model(batch) of diffusion_loss.py:183-189 / PonitaFiberBundle.forward (ponita.py:88-123).

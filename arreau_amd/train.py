@@ -1,0 +1,108 @@
+"""Data-parallel training driver for the score-matching step (BASELINE config 5: global batch 512 over 8 GPUs).
+
+The role of main_diffusion.py:293-310 + Lightning's DDP, without pytorch_lightning: one process per GPU, every rank
+takes a disjoint slice of each global batch (arreau_amd.diffusion.lattice_dataset.iterate_batches), runs
+PONITA_DIFFUSION.training_step (forward + backward in libarreau_hip.so), the gradients are averaged with ONE all-reduce
+of a flat fp32 bucket (1.17 M parameters = 4.7 MB; RCCL when the process group is "nccl"), clipped to norm 0.5
+(main_diffusion.py:297) and applied by Adam (decay / no-decay groups) with the cosine warm-up schedule stepped per epoch.
+
+    python -m torch.distributed.run --nproc-per-node 8 -m arreau_amd.train --epochs 2 --batch_size 64
+"""
+import argparse
+import os
+from typing import Iterable, Optional
+
+import torch
+
+GRAD_CLIP = 0.5  # main_diffusion.py:297 gradient_clip_val
+
+
+def all_reduce_gradients(parameters: Iterable[torch.nn.Parameter], world_size: int, group=None):
+    """Average `.grad` over the ranks with one collective on a flat bucket (what DDP does with its single 4.7 MB bucket
+    for this model).  Parameters without a gradient on this rank contribute zeros.  Returns the number of elements."""
+    params = [p for p in parameters if p.requires_grad and p.numel() > 0]
+    if not params:
+        return 0
+    dev, dt = params[0].device, torch.float32
+    flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1).to(dt) for p in params])
+    if world_size > 1:
+        import torch.distributed as dist
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=group)
+        flat /= world_size
+    off = 0
+    for p in params:
+        n = p.numel()
+        p.grad = flat[off:off + n].reshape(p.shape).to(device=dev, dtype=p.dtype)
+        off += n
+    return off
+
+
+def optimizer_step(model, optimizer, world_size: int = 1, clip: Optional[float] = GRAD_CLIP):
+    """all-reduce -> clip -> Adam step -> invalidate the engine's packed weights.  Returns the gradient norm."""
+    all_reduce_gradients(model.parameters(), world_size)
+    norm = torch.nn.utils.clip_grad_norm_([p for p in model.parameters() if p.grad is not None], clip) if clip else None
+    optimizer.step()
+    optimizer.zero_grad(set_to_none=True)
+    model.notify_parameters_changed()
+    return norm
+
+
+def train_epochs(model, dataset, epochs: int, batch_size: int, rank: int = 0, world_size: int = 1, seed: int = 0,
+                 log=print):
+    """`batch_size` is per rank (global batch = batch_size * world_size).  Returns the list of per-step losses."""
+    from .diffusion.lattice_dataset import iterate_batches
+    opt = model.configure_optimizers(max_epochs=epochs)
+    optimizer, scheduler = opt["optimizer"], opt["lr_scheduler"]
+    losses = []
+    for epoch in range(epochs):
+        for step, batch in enumerate(iterate_batches(dataset, batch_size, shuffle=True, seed=seed + epoch, rank=rank,
+                                                     world_size=world_size, drop_last=True)):
+            loss = model.training_step(batch)
+            optimizer_step(model, optimizer, world_size)
+            losses.append(float(loss))
+        scheduler.step()
+        if rank == 0:
+            log(f"epoch {epoch}: {len(losses)} steps, last loss {losses[-1] if losses else float('nan'):.5f}, "
+                f"lr {scheduler.get_last_lr()[0]:.3e}")
+    return losses
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--data", nargs="*", default=None, help="dataset files (lattice_dataset layout); synthetic if omitted")
+    ap.add_argument("--num_synthetic", type=int, default=2048)
+    ap.add_argument("--epochs", type=int, default=1)
+    ap.add_argument("--batch_size", type=int, default=64, help="crystals per rank")
+    ap.add_argument("--lr", type=float, default=3e-4)
+    ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--out", type=str, default=None, help="write a Lightning-format checkpoint here (rank 0)")
+    args = ap.parse_args()
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if os.environ.get("ARREAU_TRAIN_ONE_DEVICE", "0") == "1":
+        local_rank = 0
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        backend = os.environ.get("ARREAU_TRAIN_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
+    from .checkpoint import default_args, save_lightning_checkpoint
+    from .diffusion.lattice_dataset import CrystalDataset, synthetic_alexandria_like
+    from .lightning_wrappers.diffusion import PONITA_DIFFUSION
+    ds = CrystalDataset(args.data) if args.data else CrystalDataset(configs=synthetic_alexandria_like(args.num_synthetic, args.seed))
+    torch.manual_seed(args.seed)  # same initial weights on every rank
+    model = PONITA_DIFFUSION(default_args(lr=args.lr, epochs=args.epochs), ds.z_table).to(f"cuda:{local_rank}")
+    torch.manual_seed(args.seed + 1000 + rank)  # different noise per rank
+    train_epochs(model, ds, args.epochs, args.batch_size, rank, world, args.seed)
+    if rank == 0 and args.out:
+        print("wrote", save_lightning_checkpoint(args.out, model))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

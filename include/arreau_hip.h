@@ -284,6 +284,24 @@ int arreau_diffusion_losses(const arreau_model* model, const float* d_pred_eps, 
                             float* d_losses, float* d_grad_eps, float* d_grad_logits, float* d_grad_lengths,
                             void* stream);
 
+/* Training-mode evaluation of the score network on a (noised) batch -- same inputs and outputs as
+ * arreau_predict_scores, fp32 throughout, every layer's activations kept for the backward pass (the sampling kernels
+ * keep none).  PonitaFiberBundle.forward in train mode (ponita/models/ponita.py:88-123). */
+int arreau_train_forward(arreau_model* model, const float* d_frac, const int32_t* d_types, const float* d_lengths,
+                         const float* d_angles, const int32_t* d_t, const int32_t* d_crystal_offsets, int32_t B,
+                         int32_t N, float* d_eps, float* d_logits, float* d_len0, void* stream);
+
+/* Backward pass of the last arreau_train_forward: given d(loss)/d(eps, logits, len0) (arreau_diffusion_losses), the
+ * gradient of every trainable tensor, written to the DEVICE arrays `d_grads` points to, in the state_dict layout
+ * of arreau_state_dict (entries for buffers -- ori_grid, t_emb_w, schedules, D3PM matrices -- are ignored).  What
+ * loss.backward() leaves in .grad in the reference's training_step (lightning_wrappers/diffusion.py:108-118). */
+int arreau_train_backward(arreau_model* model, const float* d_grad_eps, const float* d_grad_logits,
+                          const float* d_grad_len0, const arreau_state_dict* d_grads, void* stream);
+
+/* FiberBundleConv.callibrate's inputs (ponita/nn/conv.py:121-123,140-146) from the last arreau_train_forward:
+ * d_stats[L][3] = unbiased std of x (layer input), x_1 (after the spatial conv), x_2 (after the spherical conv). */
+int arreau_train_conv_stats(arreau_model* model, float* d_stats, void* stream);
+
 /* Timing hook used by bench.py: records hipEvents around the dominant kernel of
  * arreau_predict_scores (the edge kernel) on the stream it is launched on.
  * enable=1 starts collecting; arreau_edge_kernel_time_ms returns the mean over the launches

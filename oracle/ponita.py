@@ -92,7 +92,7 @@ def _basis_mlp(sd, prefix, attr, degree):
     return F.gelu(F.linear(h, sd[prefix + ".3.weight"], sd[prefix + ".3.bias"]))
 
 
-def fiber_bundle_conv(sd, prefix, x, edge_index, kernel_basis, fiber_kernel_basis):
+def fiber_bundle_conv(sd, prefix, x, edge_index, kernel_basis, fiber_kernel_basis, stats=None):
     """Separable depth-wise conv: spatial message passing then spherical conv.
 
     ponita/nn/conv.py:105-129 with message :131-133 and the PyG propagate
@@ -104,6 +104,8 @@ def fiber_bundle_conv(sd, prefix, x, edge_index, kernel_basis, fiber_kernel_basi
     x_1 = torch.zeros_like(x).index_add_(0, edge_index[1], messages)
     fiber_kernel = F.linear(fiber_kernel_basis, sd[prefix + ".fiber_kernel.weight"])  # [O,O,C]
     x_2 = torch.einsum("boc,opc->bpc", x_1, fiber_kernel) / fiber_kernel.shape[-2]
+    if stats is not None:  # what FiberBundleConv.callibrate reads (conv.py:121-123): x.std(), x_1.std(), x_2.std()
+        stats.append((x, x_1, x_2))
     return x_2 + sd[prefix + ".bias"], messages
 
 
@@ -141,12 +143,12 @@ def ponita_forward(sd, hp, x, vec, edge_index, dists, direction, lattice, batch,
     fiber_kernel_basis = _basis_mlp(sd, "fiber_basis_fn", fiber_attr, degree)
 
     h = F.linear(xs, sd["x_embedder.weight"])
-    internals = {"attr": attr, "kernel_basis": kernel_basis, "x0": h, "x": []}
+    internals = {"attr": attr, "kernel_basis": kernel_basis, "x0": h, "x": [], "conv_stats": []}
     readouts = []
     for i in range(L):
         pre = f"interaction_layers.{i}"
         conv_out, _messages = fiber_bundle_conv(sd, pre + ".conv", h, edge_index, kernel_basis,
-                                                fiber_kernel_basis)
+                                                fiber_kernel_basis, stats=internals["conv_stats"])
         h = convnext_block(sd, pre, h, conv_out)
         internals["x"].append(h)
         readouts.append(F.linear(h, sd[f"read_out_layers.{i}.weight"], sd[f"read_out_layers.{i}.bias"]))

@@ -74,3 +74,58 @@ def test_concat_results_single_rank_matches_reference_layout():
     res = generate_n_crystals(_fake_sampler(0), 5, 2, num_crystals_per_batch=2)
     assert res.idx_start.tolist() == [0, 2, 4, 6, 8] and res.lattice.shape == (5, 3, 3)
     assert concat_results([]).frac_x.shape == (0, 3)
+
+
+# ------------------------------------------------------------------------------------------- training collective
+def _grad_worker(rank, world, port, outfile):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from arreau_amd.train import all_reduce_gradients
+    torch.manual_seed(0)
+    params = [torch.nn.Parameter(torch.zeros(4, 3)), torch.nn.Parameter(torch.zeros(5)), torch.nn.Parameter(torch.zeros(0, 7)),
+              torch.nn.Parameter(torch.zeros(2), requires_grad=False)]
+    params[0].grad = torch.full((4, 3), float(rank + 1))
+    params[1].grad = torch.arange(5.0) * (rank + 1) if rank == 0 else None  # a rank without this gradient sends zeros
+    n = all_reduce_gradients(params, world)
+    assert n == 17
+    if rank == 0:
+        torch.save([p.grad for p in params[:2]], outfile)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_gradient_all_reduce_averages_one_flat_bucket():
+    """The config-5 collective (one all-reduce of the flattened gradient, mean over ranks), world_size 2 over gloo."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    with tempfile.TemporaryDirectory() as d:
+        out = os.path.join(d, "g.pt")
+        mp.spawn(_grad_worker, args=(2, port, out), nprocs=2, join=True)
+        g0, g1 = torch.load(out)
+        assert torch.equal(g0, torch.full((4, 3), 1.5))            # (1 + 2) / 2
+        assert torch.equal(g1, torch.arange(5.0) * 0.5)            # (1 * arange + 0) / 2
+
+
+def test_optimizer_groups_and_cosine_warmup_schedule():
+    """configure_optimizers (lightning_wrappers/diffusion.py:152-218): Linear weights decay, everything else does not;
+    CosineWarmupScheduler (scheduler.py:5-19) factors."""
+    from arreau_amd.checkpoint import make_synthetic_model
+    m = make_synthetic_model(S=12, seed=7, num_timesteps=50, lr=3e-4, weight_decay=1e-10, warmup=10)
+    opt = m.configure_optimizers(max_epochs=100)
+    g_decay, g_plain = opt["optimizer"].param_groups
+    assert g_decay["weight_decay"] == 1e-10 and g_plain["weight_decay"] == 0.0
+    names = {id(p): n for n, p in m.named_parameters()}
+    decay_names = {names[id(p)] for p in g_decay["params"]}
+    plain_names = {names[id(p)] for p in g_plain["params"]}
+    assert "model.interaction_layers.0.linear_1.weight" in decay_names and "model.x_embedder.weight" in decay_names
+    assert "model.interaction_layers.0.conv.kernel.weight" in decay_names
+    for n in ("model.interaction_layers.0.linear_1.bias", "model.interaction_layers.0.norm.weight",
+              "model.interaction_layers.0.layer_scale", "model.interaction_layers.0.conv.bias", "t_emb.gaussian_fourier_proj_w"):
+        assert n in plain_names
+    assert decay_names.isdisjoint(plain_names) and len(decay_names | plain_names) == len(names)
+    sch = opt["lr_scheduler"]
+    for epoch in (0, 5, 10, 50, 100):
+        want = 0.5 * (1 + np.cos(np.pi * epoch / 100)) * ((epoch + 1e-6) / (10 + 1e-6) if epoch <= 10 else 1.0)
+        assert abs(sch.get_lr_factor(epoch) - want) < 1e-12
