@@ -54,6 +54,20 @@ class PONITA_DIFFUSION(nn.Module):
         self._engine = None
         self._device = torch.device("cpu")
 
+    def __deepcopy__(self, memo):
+        """copy.deepcopy(module): weights, buffers and the grid are copied; the HIP engine (a handle into the library)
+        is not -- the copy packs its own on first use."""
+        import copy
+        eng, self._engine = self._engine, None
+        try:
+            new = self.__class__.__new__(self.__class__)
+            memo[id(self)] = new
+            for k, v in self.__dict__.items():
+                new.__dict__[k] = copy.deepcopy(v, memo)
+        finally:
+            self._engine = eng
+        return new
+
     # ---- device / engine management --------------------------------------------------------------
     def _apply(self, fn, *a, **kw):
         out = super()._apply(fn, *a, **kw)
