@@ -144,6 +144,8 @@ extern "C" int arreau_predict_scores(const arreau_model* m, const float* d_frac,
     ARREAU_REQUIRE(m && d_frac && d_types && d_lengths && d_angles && d_t && d_off && d_eps && d_logits && d_len0,
                    "arreau_predict_scores: null pointer");
     ARREAU_REQUIRE(B >= 1 && N >= 0, "arreau_predict_scores: bad size");
+    ARREAU_REQUIRE(!m->packed_stale, "arreau_predict_scores: weights were updated for training only "
+                                     "(arreau_model_update_train_weights); re-create the model before sampling");
     ARREAU_REQUIRE(d_workspace != nullptr, "arreau_predict_scores: null workspace");
     Workspace w = carve(&m->cfg, N, B, d_workspace, workspace_bytes);
     if (w.bytes > workspace_bytes) {
@@ -180,6 +182,7 @@ extern "C" int arreau_ponita_forward(const arreau_model* m, const float* d_x, co
     ARREAU_REQUIRE(m && d_x && d_vec && d_lattice && d_off && d_deg && d_src && d_dir && d_dist && d_logits && d_vec_out &&
                        d_global_scalar, "arreau_ponita_forward: null pointer");
     ARREAU_REQUIRE(B >= 1 && N >= 0, "arreau_ponita_forward: bad size");
+    ARREAU_REQUIRE(!m->packed_stale, "arreau_ponita_forward: weights were updated for training only; re-create the model");
     ARREAU_REQUIRE(d_workspace != nullptr, "arreau_ponita_forward: null workspace");
     Workspace w = carve(&m->cfg, N, B, d_workspace, workspace_bytes);
     if (w.bytes > workspace_bytes) {
@@ -228,6 +231,7 @@ extern "C" int arreau_sample_loop(arreau_model* m, float* d_frac, int32_t* d_typ
                                   const float* d_fixed_lengths, float* d_lattice, void* d_workspace, size_t workspace_bytes, int32_t use_graph, void* stream) {
     ARREAU_REQUIRE(m && d_frac && d_types && d_lengths && d_angles && d_off && d_lattice, "arreau_sample_loop: null pointer");
     ARREAU_REQUIRE(B >= 1 && N >= 0 && n_steps >= 0, "arreau_sample_loop: bad size");
+    ARREAU_REQUIRE(!m->packed_stale, "arreau_sample_loop: weights were updated for training only; re-create the model");
     ARREAU_REQUIRE(t_start <= m->T && t_start - n_steps >= 0, "arreau_sample_loop: timesteps t_start .. t_start-n_steps+1 must lie in 1..T");
     ARREAU_REQUIRE(d_workspace != nullptr, "arreau_sample_loop: null workspace");
     Workspace w = carve(&m->cfg, N, B, d_workspace, workspace_bytes);

@@ -59,6 +59,7 @@ struct arreau_model {
     // form, and the step's activation buffers (created on first use)
     const float *t_w1f, *t_w2, *t_wk, *t_lin1, *t_lin2, *t_ro_w;
     struct arreau_train_ctx* train;
+    int packed_stale;        // 1 after arreau_model_update_train_weights: the sampling kernels' packed planes are out of date
     void* loop_stream;       // hipStream_t / hipEvent_t of arreau_sample_loop's graph mode (capture is not allowed on the
     void* loop_event;        //   legacy default stream callers usually pass); created on first use
     void* retired_graph;     // hipGraphExec_t of the last arreau_sample_loop (+ the stream it was launched on): destroyed,

@@ -381,12 +381,10 @@ __global__ void train_outputs_backward_kernel(const float* __restrict__ g_eps, c
         drbar[(size_t)row * RO + j] = v;
     }
 }
-// basis_fn.1.weight gradient [C][258] from the gradient of the folded weight [C][96]: every permutation column of a
-// monomial receives that monomial's gradient (embedding.py:10-14 column order)
-__global__ void unfold_poly_grad_kernel(const float* __restrict__ dw1f, int C, float* __restrict__ dw1) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= C * ARREAU_POLY_COLS) return;
-    const int c = i / ARREAU_POLY_COLS, col = i % ARREAU_POLY_COLS;
+// index, in the canonical monomial order of edge_rows_kernel, of the monomial that column `col` of
+// PolynomialFeatures(3) over 6 attributes holds (embedding.py:10-14: x_i at i, x_i x_j at 6 + 6 i + j, x_i x_j x_k at
+// 42 + 36 i + 6 j + k)
+__device__ int mono_of_poly_column(int col) {
     int a[3], n;
     if (col < 6) { n = 1; a[0] = col; }
     else if (col < 42) { n = 2; a[0] = (col - 6) / 6; a[1] = (col - 6) % 6; }
@@ -404,7 +402,27 @@ __global__ void unfold_poly_grad_kernel(const float* __restrict__ dw1f, int C, f
         for (int j1 = i1; j1 < 6; ++j1)
             for (int k1 = j1; k1 < 6; ++k1, ++p)
                 if (found < 0 && n == 3 && a[0] == i1 && a[1] == j1 && a[2] == k1) found = p;
-    dw1[i] = dw1f[c * ARREAU_MONO_PAD + found];
+    return found;
+}
+// basis_fn.1.weight gradient [C][258] from the gradient of the folded weight [C][96]: every permutation column of a
+// monomial receives that monomial's gradient
+__global__ void unfold_poly_grad_kernel(const float* __restrict__ dw1f, int C, float* __restrict__ dw1) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= C * ARREAU_POLY_COLS) return;
+    const int c = i / ARREAU_POLY_COLS, col = i % ARREAU_POLY_COLS;
+    dw1[i] = dw1f[c * ARREAU_MONO_PAD + mono_of_poly_column(col)];
+}
+// the forward direction: fold basis_fn.1.weight [C][258] onto the 83 monomials (columns of one monomial summed in
+// column order), padding columns zero -- the device twin of fold_poly_weight in model.hip
+__global__ void fold_poly_weight_kernel(const float* __restrict__ w1, int C, float* __restrict__ w1f) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= C * ARREAU_MONO_PAD) return;
+    const int c = i / ARREAU_MONO_PAD, mi = i % ARREAU_MONO_PAD;
+    float acc = 0.f;
+    if (mi < ARREAU_NUM_MONO)
+        for (int col = 0; col < ARREAU_POLY_COLS; ++col)
+            if (mono_of_poly_column(col) == mi) acc += w1[c * ARREAU_POLY_COLS + col];
+    w1f[i] = acc;
 }
 __global__ void transpose_kernel(const float* __restrict__ in, int rows, int cols, float* __restrict__ out) {  // out[c][r]
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -734,5 +752,46 @@ extern "C" int arreau_train_conv_stats(arreau_model* m, float* d_stats, void* st
         LAUNCH(mix_forward_kernel, dim3(blocks(M * C)), dim3(256), x1, t.fk + (size_t)l * 256 * C, (const float*)t.scratch_cols, N, C, t.dtmp);
         LAUNCH(std_kernel, dim3(1), dim3(256), t.dtmp, M * C, d_stats + 3 * l + 2);
     }
+    return ARREAU_OK;
+}
+
+// After an optimizer step: refresh the plain fp32 weights the TRAINING path reads (this file, prep_kernel's embT, the
+// biases / LayerNorm / layer-scale vectors) from the caller's DEVICE tensors -- device-to-device copies, one fold and one
+// transpose kernel, no host work.  The packed operand planes of the sampling kernels are NOT rebuilt: the model is marked
+// stale for sampling (arreau_predict_scores & co. then fail loudly) until it is re-created from the new state_dict.
+extern "C" int arreau_model_update_train_weights(arreau_model* m, const arreau_state_dict* d, void* stream) {
+    ARREAU_REQUIRE(m && d, "arreau_model_update_train_weights: null pointer");
+    const float* need[] = {d->basis_w1, d->basis_b1, d->basis_w2, d->basis_b2, d->fiber_w1, d->fiber_b1, d->fiber_w2, d->fiber_b2,
+                           d->x_embedder_w, d->conv_kernel_w, d->conv_fiber_w, d->conv_bias, d->norm_w, d->norm_b, d->linear1_w,
+                           d->linear1_b, d->linear2_w, d->linear2_b, d->readout_w, d->readout_b};
+    for (const float* p : need) ARREAU_REQUIRE(p != nullptr, "arreau_model_update_train_weights: missing state_dict entry");
+    hipStream_t s = (hipStream_t)stream;
+    const size_t C = m->C, D = m->D, L = m->L, H = m->H, S = m->S, RO = S + 4;
+    auto W = [](const float* p) { return const_cast<float*>(p); };
+    auto cp = [&](const float* dst, const float* src, size_t n) {
+        return hipMemcpyAsync(W(dst), src, n * sizeof(float), hipMemcpyDeviceToDevice, s);
+    };
+    m->packed_stale = 1;
+    LAUNCH(fold_poly_weight_kernel, dim3(blocks((long)C * ARREAU_MONO_PAD)), dim3(256), d->basis_w1, (int)C, W(m->t_w1f));
+    ARREAU_CHECK_HIP(cp(m->b1, d->basis_b1, C));
+    ARREAU_CHECK_HIP(cp(m->t_w2, d->basis_w2, D * C));
+    ARREAU_CHECK_HIP(cp(m->b2, d->basis_b2, D));
+    ARREAU_CHECK_HIP(cp(m->fiber_w1, d->fiber_w1, C * 3));
+    ARREAU_CHECK_HIP(cp(m->fiber_b1, d->fiber_b1, C));
+    ARREAU_CHECK_HIP(cp(m->fiber_w2, d->fiber_w2, D * C));
+    ARREAU_CHECK_HIP(cp(m->fiber_b2, d->fiber_b2, D));
+    LAUNCH(transpose_kernel, dim3(blocks((long)C * (S + 78))), dim3(256), d->x_embedder_w, (int)C, (int)(S + 78), W(m->embT));
+    ARREAU_CHECK_HIP(cp(m->t_wk, d->conv_kernel_w, L * C * D));
+    ARREAU_CHECK_HIP(cp(m->fiber_wk, d->conv_fiber_w, L * C * D));
+    ARREAU_CHECK_HIP(cp(m->conv_bias, d->conv_bias, L * C));
+    ARREAU_CHECK_HIP(cp(m->ln_w, d->norm_w, L * C));
+    ARREAU_CHECK_HIP(cp(m->ln_b, d->norm_b, L * C));
+    ARREAU_CHECK_HIP(cp(m->t_lin1, d->linear1_w, L * H * C));
+    ARREAU_CHECK_HIP(cp(m->mb1, d->linear1_b, L * H));
+    ARREAU_CHECK_HIP(cp(m->t_lin2, d->linear2_w, L * C * H));
+    ARREAU_CHECK_HIP(cp(m->mb2, d->linear2_b, L * C));
+    if (m->cfg.has_layer_scale && d->layer_scale) ARREAU_CHECK_HIP(cp(m->ls, d->layer_scale, L * C));
+    ARREAU_CHECK_HIP(cp(m->t_ro_w, d->readout_w, L * RO * C));
+    ARREAU_CHECK_HIP(cp(m->ro_b, d->readout_b, L * RO));
     return ARREAU_OK;
 }

@@ -60,7 +60,7 @@ class DiffusionLoss(nn.Module):
 
         Returns the scalar loss (a 0-d float32 CUDA tensor); with return_parts=True also a dict of the three errors,
         the noised inputs, the network outputs and d(loss)/d(outputs)."""
-        eng = model.engine()
+        eng = model.engine(for_training=training)
         dev = eng.device
         S = self.num_atomic_states
         n_cpu = torch.as_tensor(batch.num_atoms).to("cpu", torch.int64)

@@ -72,6 +72,7 @@ class HipEngine:
         self._ws = None
         self._ws_cap = (0, 0)
         self.S, self.k = S, cfg.max_neighbors
+        self.stale_for_sampling = False
 
     def close(self):
         if getattr(self, "_handle", None) is not None and self._handle.value:
@@ -243,6 +244,37 @@ class HipEngine:
             out[f"model.read_out_layers.{l}.weight"] = g["readout_w"][l]
             out[f"model.read_out_layers.{l}.bias"] = g["readout_b"][l]
         return out
+
+    def update_train_weights(self, module):
+        """After an optimizer step: push the module's updated parameters (device tensors) into the plain fp32 weights the
+        training entry points read (arreau_model_update_train_weights; device-to-device, no host repack).  The engine is
+        then `stale_for_sampling` until it is rebuilt."""
+        dev = self.device
+        sd = module.state_dict()
+        L = self.cfg.num_layers
+        f = lambda t: t.detach().to(device=dev, dtype=torch.float32).contiguous()
+        il = "model.interaction_layers.{}."
+        stack = lambda fmt: torch.stack([f(sd[fmt.format(i)]) for i in range(L)], 0).contiguous()
+        d = {"basis_w1": f(sd["model.basis_fn.1.weight"]), "basis_b1": f(sd["model.basis_fn.1.bias"]),
+             "basis_w2": f(sd["model.basis_fn.3.weight"]), "basis_b2": f(sd["model.basis_fn.3.bias"]),
+             "fiber_w1": f(sd["model.fiber_basis_fn.1.weight"]), "fiber_b1": f(sd["model.fiber_basis_fn.1.bias"]),
+             "fiber_w2": f(sd["model.fiber_basis_fn.3.weight"]), "fiber_b2": f(sd["model.fiber_basis_fn.3.bias"]),
+             "x_embedder_w": f(sd["model.x_embedder.weight"]),
+             "conv_kernel_w": stack(il + "conv.kernel.weight"), "conv_fiber_w": stack(il + "conv.fiber_kernel.weight"),
+             "conv_bias": stack(il + "conv.bias"), "norm_w": stack(il + "norm.weight"), "norm_b": stack(il + "norm.bias"),
+             "linear1_w": stack(il + "linear_1.weight"), "linear1_b": stack(il + "linear_1.bias"),
+             "linear2_w": stack(il + "linear_2.weight"), "linear2_b": stack(il + "linear_2.bias"),
+             "readout_w": stack("model.read_out_layers.{}.weight"), "readout_b": stack("model.read_out_layers.{}.bias")}
+        if self.cfg.has_layer_scale:
+            d["layer_scale"] = stack(il + "layer_scale")
+        csd = _hip.StateDict()
+        for name in _hip._SD_FIELDS:
+            t = d.get(name)
+            setattr(csd, name, t.data_ptr() if t is not None else None)
+        _hip.check(_hip.lib().arreau_model_update_train_weights(self._handle, ctypes.byref(csd), _hip.stream_ptr(dev)),
+                   "arreau_model_update_train_weights")
+        self._keep = d  # alive until the copies have been enqueued and run (stream-ordered; freed at the next update)
+        self.stale_for_sampling = True
 
     def conv_stats(self):
         """[L,3] unbiased std of (x, x_1, x_2) per layer from the last train_forward (FiberBundleConv.callibrate)."""

@@ -84,8 +84,12 @@ class PONITA_DIFFUSION(nn.Module):
         self._engine = None
         return out
 
-    def engine(self):
-        """The HIP engine for the module's current (cuda) device; packs the weights on first use."""
+    def engine(self, for_training: bool = False):
+        """The HIP engine for the module's current (cuda) device; packs the weights on first use.  After optimizer
+        steps the engine only holds refreshed TRAINING weights (HipEngine.update_train_weights); any other use
+        re-creates it from the current parameters."""
+        if self._engine is not None and self._engine.stale_for_sampling and not for_training:
+            self._engine = None
         if self._engine is None:
             from ..engine import HipEngine
             dev = self._device if self._device.type == "cuda" else torch.device("cuda", 0)
@@ -113,7 +117,7 @@ class PONITA_DIFFUSION(nn.Module):
         (FiberBundleConv.callibrate, ponita/nn/conv.py:121-123,140-146) -- after this step's gradients were taken."""
         loss, parts = self.diffusion_loss(self, graph, self.t_emb, timestep=timestep, noise=noise, return_parts=True,
                                           training=True)
-        eng = self.engine()
+        eng = self.engine(for_training=True)
         grads = eng.train_backward(parts["grad_eps"], parts["grad_logits"], parts["grad_lengths"])
         params = dict(self.named_parameters())
         for name, g in grads.items():
@@ -136,11 +140,13 @@ class PONITA_DIFFUSION(nn.Module):
                 layer.conv.kernel.weight.mul_(std_in / std_1)
                 layer.conv.fiber_kernel.weight.mul_(std_1 / std_2)
                 layer.conv.callibrated.fill_(True)
-        self._engine = None  # weights changed: repack on next use
+        self.notify_parameters_changed()
 
     def notify_parameters_changed(self):
-        """Call after an optimizer step: the HIP engine holds packed copies of the weights."""
-        self._engine = None
+        """Call after an optimizer step: the HIP engine holds copies of the weights.  An engine that exists is refreshed
+        for training in place (device-to-device copies, no host repack); sampling re-creates it on next use."""
+        if self._engine is not None:
+            self._engine.update_train_weights(self)
 
     def configure_optimizers(self, max_epochs=None):
         """lightning_wrappers/diffusion.py:152-218: Adam with weight decay on Linear weights only (biases, LayerNorm

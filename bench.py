@@ -37,8 +37,8 @@ BF16X6_EQUIV_PEAK_TFLOPS = MFMA_BF16_PEAK_TFLOPS / 6.0
 # default kernels: three fp16 MFMA products per fp32 product (two 11-bit operand planes) -> fp16 peak / 3
 F16X3_EQUIV_PEAK_TFLOPS = MFMA_BF16_PEAK_TFLOPS / 3.0
 
-CONFIGS = {  # name -> (crystals per GPU, atoms per crystal, num_timesteps)
-    "c1": (1, 8, 100), "c2": (256, 20, 1000), "c3": (1024, 20, 1000), "c4": (1024, 64, 1000)}
+CONFIGS = {  # name -> (crystals per GPU, atoms per crystal, num_timesteps); c5 = the training step (run_rank_c5)
+    "c1": (1, 8, 100), "c2": (256, 20, 1000), "c3": (1024, 20, 1000), "c4": (1024, 64, 1000), "c5": (64, 0, 1000)}
 
 
 def edge_kernel_flops_per_row(C=128, D=256, L=5):
@@ -162,6 +162,8 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     if stub:
         return run_stub(args, rank, world)
+    if args.config == "c5":
+        return run_rank_c5(args, rank, local_rank, world)
     return run_rank(args, rank, local_rank, world)
 
 
@@ -409,6 +411,107 @@ def run_rank(args, rank, local_rank, world):
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(model, B, n, T, args.cpu_steps)
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def run_rank_c5(args, rank, local_rank, world):
+    """BASELINE configs[4]: the score-matching training step, data parallel (global batch = 64 x n_gpus; the reference's
+    512 at 8 GPUs).  A step = forward noising + score network forward + losses + backward (all in libarreau_hip.so) +
+    ONE all-reduce of the flat fp32 gradient bucket + clip + Adam + refresh of the library's training weights.  Data:
+    synthetic crystals with Alexandria-PBE's statistics (arreau_amd.diffusion.lattice_dataset.synthetic_alexandria_like)."""
+    import numpy as np
+    import torch
+
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
+    backend = os.environ.get("ARREAU_BENCH_BACKEND", "nccl")
+    one_device = os.environ.get("ARREAU_BENCH_ONE_DEVICE", "0") == "1"
+    dev = torch.device("cuda", 0 if one_device else local_rank)
+    torch.cuda.set_device(dev)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
+    from arreau_amd import build
+    build.build(verbose=False)
+    from arreau_amd.checkpoint import default_args
+    from arreau_amd.diffusion.lattice_dataset import CrystalDataset, collate, synthetic_alexandria_like
+    from arreau_amd.lightning_wrappers.diffusion import PONITA_DIFFUSION
+    from arreau_amd.train import optimizer_step
+
+    B = args.batch_per_gpu
+    ds = CrystalDataset(configs=synthetic_alexandria_like(4096, seed=0))  # same table (S = 90) on every rank
+    torch.manual_seed(1234)
+    model = PONITA_DIFFUSION(default_args(lr=3e-4, epochs=10), ds.z_table).to(dev)
+    optimizer = model.configure_optimizers(max_epochs=10)["optimizer"]
+    rng = np.random.RandomState(100 + rank)
+    batches = [collate([ds[int(i)] for i in rng.choice(len(ds), B, replace=False)]) for _ in range(8)]
+    torch.manual_seed(2000 + rank)
+    n_atoms = float(np.mean([int(b.num_atoms.sum()) for b in batches]))
+
+    def one_step(i):
+        loss = model.training_step(batches[i % len(batches)])
+        optimizer_step(model, optimizer, world)
+        return loss
+
+    def sync():
+        torch.cuda.synchronize(dev)
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize(dev)
+
+    log(f"rank {rank}: training bench, {B} crystals / GPU, mean {n_atoms:.0f} atoms per batch; warm-up {args.warmup} steps")
+    for i in range(max(args.warmup, 2)):  # the first step also callibrates the conv weights
+        one_step(i)
+    sync()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        loss = one_step(i)
+    torch.cuda.synchronize(dev)
+    local = time.perf_counter() - t0
+    sync()
+    elapsed = time.perf_counter() - t0
+    per_rank = [local]
+    if dist is not None:
+        tt = torch.tensor([local, elapsed], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
+        gathered = [torch.zeros_like(tt) for _ in range(world)]
+        dist.all_gather(gathered, tt)
+        per_rank = [float(g[0]) for g in gathered]
+        elapsed = max(float(g[1]) for g in gathered)
+    # device-only part (forward + backward, no optimizer / collective), for the roofline line
+    torch.cuda.synchronize(dev)
+    t1 = time.perf_counter()
+    for i in range(args.steps):
+        model.training_step(batches[i % len(batches)])
+    torch.cuda.synchronize(dev)
+    fb_ms = 1e3 * (time.perf_counter() - t1) / args.steps
+    if rank == 0:
+        ms = 1e3 * elapsed / args.steps
+        flops = 3.0 * step_flops_per_atom() * n_atoms  # forward + backward ~ 3 x forward (SURVEY.md 8a, row a22)
+        out = {
+            "metric": "training steps/sec (crystal-steps, whole node) -- BASELINE configs[4]",
+            "value": world * B * args.steps / elapsed, "unit": "crystal-steps/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": ms, "per_rank_ms": [1e3 * e / args.steps for e in per_rank],
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": f"BASELINE configs[4]: score-matching training step, global batch {B * world} = {B} crystals x "
+                                   f"{world} GPUs, Alexandria-like synthetic crystals (mean {n_atoms / B:.1f} atoms), T=1000, fp32",
+                       "crystals_per_gpu": B, "mean_atoms_per_batch": n_atoms,
+                       "parallelism": f"data parallel x{world}: one all-reduce of the 1.17M-parameter fp32 gradient per step"},
+            "last_loss": float(loss),
+            "forward_backward_ms": fb_ms,
+            "roofline": {"kernel": "training step, forward + backward (sgemm_kernel + elementwise kernels of train_net.hip)",
+                         "bound": "mfma", "achieved": flops / (fb_ms * 1e-3) / 1e12, "peak": MFMA_F32_PEAK_TFLOPS,
+                         "unit": "TFLOP/s", "frac": flops / (fb_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, "traffic": None,
+                         "peak_note": "fp32 vector / fp32-MFMA peak; the training kernels are plain fp32 FMA code (first "
+                                      "correct version, not tuned)"},
+        }
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()

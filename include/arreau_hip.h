@@ -298,6 +298,13 @@ int arreau_train_forward(arreau_model* model, const float* d_frac, const int32_t
 int arreau_train_backward(arreau_model* model, const float* d_grad_eps, const float* d_grad_logits,
                           const float* d_grad_len0, const arreau_state_dict* d_grads, void* stream);
 
+/* After an optimizer step: refresh the fp32 weights the TRAINING entry points read (arreau_train_forward / backward)
+ * from the caller's updated tensors -- `d_sd` holds DEVICE pointers in the state_dict layout (buffers ignored).  Only
+ * device-to-device copies: no host repacking between steps.  The sampling kernels' packed operand planes are NOT
+ * rebuilt; until the model is re-created from the new state_dict, arreau_predict_scores / arreau_ponita_forward /
+ * arreau_sample_loop return ARREAU_EINVAL. */
+int arreau_model_update_train_weights(arreau_model* model, const arreau_state_dict* d_sd, void* stream);
+
 /* FiberBundleConv.callibrate's inputs (ponita/nn/conv.py:121-123,140-146) from the last arreau_train_forward:
  * d_stats[L][3] = unbiased std of x (layer input), x_1 (after the spatial conv), x_2 (after the spherical conv). */
 int arreau_train_conv_stats(arreau_model* model, float* d_stats, void* stream);

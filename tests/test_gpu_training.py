@@ -185,6 +185,38 @@ def test_first_training_forward_callibrates_conv_weights(setup):
         assert torch.equal(layer.conv.kernel.weight, k1[l])
 
 
+def test_optimizer_step_refreshes_training_weights_without_repacking(setup):
+    """After an optimizer step the engine is refreshed in place for training (device-to-device copies,
+    arreau_model_update_train_weights): the next training forward equals a freshly packed engine's, the stale engine
+    refuses to sample, and asking for a sampling engine re-creates it."""
+    import copy
+    from arreau_amd import _hip
+    from arreau_amd.diffusion.diffusion_helpers import crystal_offsets
+    from arreau_amd.train import optimizer_step
+    m, om, batch, lattice0, timestep, noise = setup
+    mm = copy.deepcopy(m)
+    opt = mm.configure_optimizers(max_epochs=10)["optimizer"]
+    for g in opt.param_groups:
+        g["lr"] = 1e-3
+    mm.training_step(batch, timestep=timestep, noise=noise)
+    w_before = mm.model.interaction_layers[0].linear_1.weight.detach().clone()
+    norm = optimizer_step(mm, opt, world_size=1)
+    assert float(norm) > 0 and not torch.equal(w_before, mm.model.interaction_layers[0].linear_1.weight)
+    eng = mm._engine
+    assert eng is not None and eng.stale_for_sampling
+    _, parts = mm.diffusion_loss(mm, batch, None, timestep=timestep, noise=noise, return_parts=True, training=True)
+    assert mm._engine is eng  # training keeps using the refreshed engine
+    off = crystal_offsets(batch.num_atoms, eng.device)
+    args = (parts["noisy_frac"], parts["noisy_types"], parts["noisy_lengths"], parts["angles"], parts["timestep"], off)
+    with pytest.raises(_hip.ArreauHipError):
+        eng.predict_scores(*args)
+    fresh = copy.deepcopy(mm).engine()  # packs everything from the updated parameters
+    a, b = eng.train_forward(*args), fresh.train_forward(*args)
+    for x, y in zip(a, b):
+        assert (x - y).abs().max() <= 1e-6 * max(1.0, float(x.abs().max()))
+    assert mm.engine() is not eng and not mm.engine().stale_for_sampling  # a sampling engine is rebuilt on demand
+
+
 def test_two_rank_training_loop_reduces_the_loss(tmp_path):
     """arreau_amd.train end to end: two data-parallel ranks (gloo, sharing this box's GPU), synthetic Alexandria-like
     crystals, forward + backward in the library, one flat all-reduce per step, Adam with the cosine warm-up schedule;
