@@ -2,7 +2,7 @@
 //
 // The sampling kernels (edge_f16.hip, node*.hip) keep nothing: activations live in registers and only K_l reaches HBM.
 // A training step needs every layer's inputs again, so this file evaluates the same network in the textbook form --
-// one dense product per Linear (sgemm_kernel below, fp32 FMA, split-K for the weight gradients), small elementwise /
+// one dense product per Linear (sgemm_kernel below, exact fp32 on the matrix pipe, split-K for the weight gradients), small elementwise /
 // gather / reduce kernels between them, every intermediate in HBM -- and walks it backwards.  At config-5 sizes (64
 // crystals, about 540 atoms, 69 k (edge, orientation) rows per GPU) the whole step moves a few hundred MB; clarity
 // and exact fp32 arithmetic matter more here than the last factor of two.
@@ -17,56 +17,67 @@
 #include "internal.h"
 
 namespace {
-constexpr int TILE = 64, BK = 16;
+constexpr int TILE = 128, BK = 16;
 
 // C[m,n] = alpha * sum_k A(m,k) B(k,n) + beta * C[m,n];  A(m,k) = A[m*as0 + k*as1], B(k,n) = B[k*bs0 + n*bs1].
+// Exact fp32 on the matrix pipe (v_mfma_f32_32x32x2_f32): a 128 x 128 output tile per workgroup, four waves of 64 x 64
+// (2 x 2 MFMA tiles, 64 accumulator registers), operands staged k-major in LDS (a lane reads A(m0 + lane % 32,
+// k + lane / 32) and B(k + lane / 32, n0 + lane % 32): conflict-free rows).  Accumulator register r of lane (h, j) is
+// C[m0 + (r & 3) + 8 (r >> 2) + 4 h][n0 + j] (internal.h), so stores are coalesced along n.
 // gridDim.z > 1: split-K, partial sums to `partial[z][M][N]` (reduced in z order by splitk_reduce_kernel: deterministic).
 __global__ __launch_bounds__(256) void sgemm_kernel(int M, int N, int K, const float* __restrict__ A, long as0, long as1,
                                                     const float* __restrict__ B, long bs0, long bs1, float* __restrict__ C,
                                                     int ldc, float alpha, float beta, int kchunk,
                                                     float* __restrict__ partial) {
     __shared__ float As[BK][TILE + 4], Bs[BK][TILE + 4];
-    const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int h = lane >> 5, j = lane & 31, wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
     const int m0 = blockIdx.y * TILE, n0 = blockIdx.x * TILE;
     const int kbeg = blockIdx.z * kchunk, kend = min(K, kbeg + kchunk);
-    float acc[4][4] = {};
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
     for (int k0 = kbeg; k0 < kend; k0 += BK) {
 #pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const int idx = tid + 256 * i;
+        for (int i = 0; i < 8; ++i) {
+            const int idx = tid + 256 * i;  // 0 .. 2047
             int mm, kk;
-            if (as1 == 1) { kk = idx & 15; mm = idx >> 4; } else { mm = idx & 63; kk = idx >> 6; }
+            if (as1 == 1) { kk = idx & 15; mm = idx >> 4; } else { mm = idx & 127; kk = idx >> 7; }
             const int m = m0 + mm, k = k0 + kk;
             As[kk][mm] = (m < M && k < kend) ? A[(long)m * as0 + (long)k * as1] : 0.f;
             int nn;
-            if (bs1 == 1) { nn = idx & 63; kk = idx >> 6; } else { kk = idx & 15; nn = idx >> 4; }
-            const int n = n0 + nn;
-            const int kb = k0 + kk;
+            if (bs1 == 1) { nn = idx & 127; kk = idx >> 7; } else { kk = idx & 15; nn = idx >> 4; }
+            const int n = n0 + nn, kb = k0 + kk;
             Bs[kk][nn] = (n < N && kb < kend) ? B[(long)kb * bs0 + (long)n * bs1] : 0.f;
         }
         __syncthreads();
 #pragma unroll
-        for (int kk = 0; kk < BK; ++kk) {
-            float a[4], b[4];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) { a[i] = As[kk][ty * 4 + i]; b[i] = Bs[kk][tx * 4 + i]; }
-#pragma unroll
-            for (int i = 0; i < 4; ++i)
-#pragma unroll
-                for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(a[i], b[j], acc[i][j]);
+        for (int kk = 0; kk < BK; kk += 2) {
+            const float a0 = As[kk + h][wm + j], a1 = As[kk + h][wm + 32 + j];
+            const float b0 = Bs[kk + h][wn + j], b1 = Bs[kk + h][wn + 32 + j];
+            acc[0][0] = arreau_mfma(a0, b0, acc[0][0]);
+            acc[0][1] = arreau_mfma(a0, b1, acc[0][1]);
+            acc[1][0] = arreau_mfma(a1, b0, acc[1][0]);
+            acc[1][1] = arreau_mfma(a1, b1, acc[1][1]);
         }
         __syncthreads();
     }
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+    for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int m = m0 + ty * 4 + i, n = n0 + tx * 4 + j;
-            if (m < M && n < N) {
-                if (gridDim.z > 1) partial[((size_t)blockIdx.z * M + m) * N + n] = acc[i][j];
-                else C[(size_t)m * ldc + n] = alpha * acc[i][j] + (beta != 0.f ? beta * C[(size_t)m * ldc + n] : 0.f);
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * h, n = n0 + wn + 32 * b + j;
+                if (m < M && n < N) {
+                    if (gridDim.z > 1) partial[((size_t)blockIdx.z * M + m) * N + n] = acc[a][b][r];
+                    else C[(size_t)m * ldc + n] = alpha * acc[a][b][r] + (beta != 0.f ? beta * C[(size_t)m * ldc + n] : 0.f);
+                }
             }
-        }
 }
 __global__ void splitk_reduce_kernel(const float* __restrict__ partial, int Z, int M, int N, float* __restrict__ C, int ldc,
                                      float alpha, float beta) {

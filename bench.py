@@ -512,10 +512,44 @@ def run_rank_c5(args, rank, local_rank, world):
                          "peak_note": "fp32 vector / fp32-MFMA peak; the training kernels are plain fp32 FMA code (first "
                                       "correct version, not tuned)"},
         }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline_training(model, batches[0], args.cpu_steps)
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def cpu_baseline_training(model, batch, steps):
+    """The oracle's training step on the host cores: DiffusionLoss.__call__ restated in plain torch (oracle/training.py),
+    forward + torch autograd backward, fp32, on one of the bench's own batches."""
+    import torch
+    from oracle import training as TR
+    from tests.helpers import oracle_from_module
+
+    cores = host_cores()
+    torch.set_num_threads(cores)
+    om = oracle_from_module(model, torch.float32)
+    for v in om.sd.values():
+        if v.is_floating_point() and v.numel() > 0:
+            v.requires_grad_(True)
+    B, N, S = int(batch.num_atoms.numel()), int(batch.num_atoms.sum()), om.hp["S"]
+    lattice0 = batch.L0.reshape(-1, 3, 3).float()
+    times = []
+    for it in range(steps + 1):
+        t = torch.randint(1, om.hp["T"] + 1, (B,))
+        noise = (torch.randn(N, 3), torch.rand(N, S), torch.randn(B, 3))
+        t0 = time.perf_counter()
+        loss = TR.diffusion_loss(om, batch.X0.float(), batch.A0, lattice0, batch.num_atoms, t, *noise)
+        loss.backward()
+        times.append(time.perf_counter() - t0)
+        for v in om.sd.values():
+            v.grad = None
+        log(f"cpu baseline (training) step {it}: {times[-1]:.2f} s")
+    per_step = sum(times[1:]) / max(1, len(times) - 1)
+    return {"value": B / per_step, "unit": "crystal-steps/s", "cores": cores, "kind": "port",
+            "sample": f"{steps} forward + backward steps of one {B}-crystal batch ({N} atoms) after 1 warm-up "
+                      f"(oracle + torch autograd, fp32, {cores} threads)"}
 
 
 def cpu_baseline(model, B, n, T, steps):
