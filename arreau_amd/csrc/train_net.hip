@@ -12,6 +12,7 @@
 // the read-outs (ponita.py:126-155); the backward is what autograd derives from those (training_step,
 // lightning_wrappers/diffusion.py:108-118).  Gradients are returned in the state_dict layout (arreau_state_dict with
 // DEVICE pointers; non-trainable entries are ignored).
+#include <algorithm>
 #include <vector>
 
 #include "internal.h"
@@ -25,11 +26,16 @@ constexpr int TILE = 128, BK = 16;
 // k + lane / 32) and B(k + lane / 32, n0 + lane % 32): conflict-free rows).  Accumulator register r of lane (h, j) is
 // C[m0 + (r & 3) + 8 (r >> 2) + 4 h][n0 + j] (internal.h), so stores are coalesced along n.
 // gridDim.z > 1: split-K, partial sums to `partial[z][M][N]` (reduced in z order by splitk_reduce_kernel: deterministic).
+// Operand staging: each thread fetches two 16-byte pieces of the A tile (128 x 16) and two of the B tile (16 x 128)
+// into registers -- along whichever dimension is contiguous in memory -- BEFORE the matrix work of the current tile, and
+// writes them to LDS after it (register double buffering: the global latency hides behind 32 MFMAs per wave).
+// VEC = 0: element-wise path for shapes that are not multiples of four (K = 3, M = 94 ...).
+template <int VEC>
 __global__ __launch_bounds__(256) void sgemm_kernel(int M, int N, int K, const float* __restrict__ A, long as0, long as1,
                                                     const float* __restrict__ B, long bs0, long bs1, float* __restrict__ C,
                                                     int ldc, float alpha, float beta, int kchunk,
                                                     float* __restrict__ partial) {
-    __shared__ float As[BK][TILE + 4], Bs[BK][TILE + 4];
+    __shared__ __attribute__((aligned(16))) float As[BK][TILE + 4], Bs[BK][TILE + 4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int h = lane >> 5, j = lane & 31, wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
     const int m0 = blockIdx.y * TILE, n0 = blockIdx.x * TILE;
@@ -41,20 +47,74 @@ __global__ __launch_bounds__(256) void sgemm_kernel(int M, int N, int K, const f
         for (int b = 0; b < 2; ++b)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
-    for (int k0 = kbeg; k0 < kend; k0 += BK) {
+    const bool a_kmajor = as1 == 1, b_nmajor = bs1 == 1;  // which dimension is contiguous
+    f32x4 ra[2], rb[2];
+    float sa[8], sb[8];
+    auto fetch = [&](int k0) {
+        if (VEC) {
 #pragma unroll
-        for (int i = 0; i < 8; ++i) {
-            const int idx = tid + 256 * i;  // 0 .. 2047
-            int mm, kk;
-            if (as1 == 1) { kk = idx & 15; mm = idx >> 4; } else { mm = idx & 127; kk = idx >> 7; }
-            const int m = m0 + mm, k = k0 + kk;
-            As[kk][mm] = (m < M && k < kend) ? A[(long)m * as0 + (long)k * as1] : 0.f;
-            int nn;
-            if (bs1 == 1) { nn = idx & 127; kk = idx >> 7; } else { kk = idx & 15; nn = idx >> 4; }
-            const int n = n0 + nn, kb = k0 + kk;
-            Bs[kk][nn] = (n < N && kb < kend) ? B[(long)kb * bs0 + (long)n * bs1] : 0.f;
+            for (int i = 0; i < 2; ++i) {
+                const int idx = tid + 256 * i;  // 512 pieces per operand
+                {
+                    const int mm = a_kmajor ? idx >> 2 : (idx & 31) * 4, kk = a_kmajor ? (idx & 3) * 4 : idx >> 5;
+                    const int m = m0 + mm, k = k0 + kk;
+                    ra[i] = (m < M && k < kend) ? *reinterpret_cast<const f32x4*>(A + (long)m * as0 + (long)k * as1) : f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+                {
+                    const int nn = b_nmajor ? (idx & 31) * 4 : idx >> 2, kk = b_nmajor ? idx >> 5 : (idx & 3) * 4;
+                    const int n = n0 + nn, k = k0 + kk;
+                    rb[i] = (n < N && k < kend) ? *reinterpret_cast<const f32x4*>(B + (long)k * bs0 + (long)n * bs1) : f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int idx = tid + 256 * i;  // 2048 elements per operand
+                int mm, kk;
+                if (a_kmajor) { kk = idx & 15; mm = idx >> 4; } else { mm = idx & 127; kk = idx >> 7; }
+                const int m = m0 + mm, k = k0 + kk;
+                sa[i] = (m < M && k < kend) ? A[(long)m * as0 + (long)k * as1] : 0.f;
+                int nn;
+                if (b_nmajor) { nn = idx & 127; kk = idx >> 7; } else { kk = idx & 15; nn = idx >> 4; }
+                const int n = n0 + nn, kb = k0 + kk;
+                sb[i] = (n < N && kb < kend) ? B[(long)kb * bs0 + (long)n * bs1] : 0.f;
+            }
         }
+    };
+    auto stage = [&]() {
+        if (VEC) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int idx = tid + 256 * i;
+                if (a_kmajor) {
+                    const int mm = idx >> 2, kk = (idx & 3) * 4;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) As[kk + q][mm] = ra[i][q];
+                } else {
+                    *reinterpret_cast<f32x4*>(&As[idx >> 5][(idx & 31) * 4]) = ra[i];
+                }
+                if (b_nmajor) {
+                    *reinterpret_cast<f32x4*>(&Bs[idx >> 5][(idx & 31) * 4]) = rb[i];
+                } else {
+                    const int nn = idx >> 2, kk = (idx & 3) * 4;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) Bs[kk + q][nn] = rb[i][q];
+                }
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int idx = tid + 256 * i;
+                if (a_kmajor) As[idx & 15][idx >> 4] = sa[i]; else As[idx >> 7][idx & 127] = sa[i];
+                if (b_nmajor) Bs[idx >> 7][idx & 127] = sb[i]; else Bs[idx & 15][idx >> 4] = sb[i];
+            }
+        }
+    };
+    fetch(kbeg);
+    for (int k0 = kbeg; k0 < kend; k0 += BK) {
+        stage();
         __syncthreads();
+        if (k0 + BK < kend) fetch(k0 + BK);
 #pragma unroll
         for (int kk = 0; kk < BK; kk += 2) {
             const float a0 = As[kk + h][wm + j], a1 = As[kk + h][wm + 32 + j];
@@ -89,20 +149,29 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ partial, int Z, i
     C[(size_t)m * ldc + n] = alpha * s + (beta != 0.f ? beta * C[(size_t)m * ldc + n] : 0.f);
 }
 
-// out[c] = scale * sum_r a[r][c] * (b ? b[r][c] : 1)  (+ out[c] if accumulate): one thread column, 4 row phases, fixed order
-__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ a, const float* __restrict__ b, int rows,
-                                                     int cols, float scale, int accumulate, float* __restrict__ out) {
-    __shared__ float part[4][64];
+// out[c] = scale * sum_r a[r][c] * (b ? b[r][c] : 1)  (+ out[c] if accumulate), in two deterministic stages: each
+// workgroup of stage 1 sums one chunk of rows (four row phases added in a fixed order), stage 2 adds the chunks in order.
+constexpr int COLSUM_MAX_CHUNKS = 256;
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ a, const float* __restrict__ b, long rows,
+                                                             int cols, long rows_per_chunk, float* __restrict__ part) {
+    __shared__ float sh[4][64];
     const int c = blockIdx.x * 64 + (threadIdx.x & 63), ph = threadIdx.x >> 6;
+    const long r0 = (long)blockIdx.y * rows_per_chunk, r1 = min(rows, r0 + rows_per_chunk);
     float s = 0.f;
     if (c < cols)
-        for (int r = ph; r < rows; r += 4) s += a[(size_t)r * cols + c] * (b ? b[(size_t)r * cols + c] : 1.0f);
-    part[ph][threadIdx.x & 63] = s;
+        for (long r = r0 + ph; r < r1; r += 4) s += a[(size_t)r * cols + c] * (b ? b[(size_t)r * cols + c] : 1.0f);
+    sh[ph][threadIdx.x & 63] = s;
     __syncthreads();
-    if (ph == 0 && c < cols) {
-        const float t = ((part[0][threadIdx.x] + part[1][threadIdx.x]) + part[2][threadIdx.x]) + part[3][threadIdx.x];
-        out[c] = scale * t + (accumulate ? out[c] : 0.f);
-    }
+    if (ph == 0 && c < cols)
+        part[(size_t)blockIdx.y * cols + c] = ((sh[0][threadIdx.x] + sh[1][threadIdx.x]) + sh[2][threadIdx.x]) + sh[3][threadIdx.x];
+}
+__global__ void colsum_final_kernel(const float* __restrict__ part, int chunks, int cols, float scale, int accumulate,
+                                    float* __restrict__ out) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= cols) return;
+    float s = 0.f;
+    for (int i = 0; i < chunks; ++i) s += part[(size_t)i * cols + c];
+    out[c] = scale * s + (accumulate ? out[c] : 0.f);
 }
 
 __device__ __forceinline__ float gelu_exact(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
@@ -458,7 +527,7 @@ struct arreau_train_ctx {
     float *mono, *window, *h1pre, *h1, *h2pre, *kb, *fpoly, *fh1pre, *fh1, *fh2pre, *fkb, *F;
     float *x, *x1, *xhat, *rstd, *xn, *hpre, *h, *out, *fk, *rbar, *gs, *kern;
     // backward temporaries
-    float *dx, *dtmp, *dh, *drbar, *dx1, *dkern, *dkb, *dh1, *dfk, *dfkb, *dfh1, *dw1f, *partial, *scratch_cols;
+    float *dx, *dtmp, *dh, *drbar, *dx1, *dkern, *dkb, *dh1, *dfk, *dfkb, *dfh1, *dw1f, *partial, *scratch_cols, *colpart;
     const int32_t *tstep, *offsets, *types;
     const float *frac, *lengths, *angles;
 };
@@ -497,6 +566,7 @@ size_t layout(arreau_train_ctx& t, const arreau_model* m, int N, int B, float* b
     t.dx1 = c.take<float>(M * C); t.dkern = c.take<float>(R * C); t.dkb = c.take<float>(R * D); t.dh1 = c.take<float>(R * C);
     t.dfk = c.take<float>(256 * C); t.dfkb = c.take<float>(256 * D); t.dfh1 = c.take<float>(256 * C);
     t.dw1f = c.take<float>(C * ARREAU_MONO_PAD); t.partial = c.take<float>(PARTIAL_FLOATS); t.scratch_cols = c.take<float>(1024);
+    t.colpart = c.take<float>((size_t)COLSUM_MAX_CHUNKS * 1024);
     return c.off;
 }
 
@@ -511,8 +581,16 @@ int gemm(hipStream_t s, arreau_train_ctx& t, int M, int N, int K, const float* A
     }
     const int kchunk = ((K + Z - 1) / Z + BK - 1) / BK * BK;
     Z = (K + kchunk - 1) / kchunk;
-    hipLaunchKernelGGL(sgemm_kernel, dim3(gn, gm, Z), dim3(256), 0, s, M, N, K, A, as0, as1, B, bs0, bs1, C, ldc, alpha, beta,
-                       kchunk, t.partial);
+    // 16-byte operand fetches need the contiguous dimension and the leading dimension to be multiples of four floats
+    const bool a_ok = (as1 == 1 && as0 % 4 == 0 && K % 4 == 0) || (as0 == 1 && as1 % 4 == 0 && M % 4 == 0);
+    const bool b_ok = (bs1 == 1 && bs0 % 4 == 0 && N % 4 == 0) || (bs0 == 1 && bs1 % 4 == 0 && K % 4 == 0);
+    const bool vec = a_ok && b_ok && ((size_t)A % 16 == 0) && ((size_t)B % 16 == 0);
+    if (vec)
+        hipLaunchKernelGGL(sgemm_kernel<1>, dim3(gn, gm, Z), dim3(256), 0, s, M, N, K, A, as0, as1, B, bs0, bs1, C, ldc, alpha,
+                           beta, kchunk, t.partial);
+    else
+        hipLaunchKernelGGL(sgemm_kernel<0>, dim3(gn, gm, Z), dim3(256), 0, s, M, N, K, A, as0, as1, B, bs0, bs1, C, ldc, alpha,
+                           beta, kchunk, t.partial);
     ARREAU_CHECK_HIP(hipGetLastError());
     if (Z > 1) {
         hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks((long)M * N)), dim3(256), 0, s, t.partial, Z, M, N, C, ldc, alpha, beta);
@@ -535,8 +613,17 @@ int linear_dw(hipStream_t s, arreau_train_ctx& t, long rows, int in, int out, co
               float alpha = 1.f) {
     return gemm(s, t, out, in, (int)rows, dY, 1, out, X, in, 1, dW, in, alpha, 0.f);
 }
-int colsum(hipStream_t s, const float* a, const float* b, long rows, int cols, float scale, float* out, int accumulate = 0) {
-    hipLaunchKernelGGL(colsum_kernel, dim3((cols + 63) / 64), dim3(256), 0, s, a, b, (int)rows, cols, scale, accumulate, out);
+int colsum(hipStream_t s, arreau_train_ctx& t, const float* a, const float* b, long rows, int cols, float scale, float* out,
+           int accumulate = 0) {
+    if (cols > 1024) {
+        arreau_set_error("colsum: more than 1024 columns");
+        return ARREAU_EINVAL;
+    }
+    const int chunks = (int)std::min<long>(COLSUM_MAX_CHUNKS, std::max<long>(1, rows / 256));
+    const long rpc = (rows + chunks - 1) / chunks;
+    hipLaunchKernelGGL(colsum_partial_kernel, dim3((cols + 63) / 64, chunks), dim3(256), 0, s, a, b, rows, cols, rpc, t.colpart);
+    ARREAU_CHECK_HIP(hipGetLastError());
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((cols + 127) / 128), dim3(128), 0, s, t.colpart, chunks, cols, scale, accumulate, out);
     ARREAU_CHECK_HIP(hipGetLastError());
     return ARREAU_OK;
 }
@@ -673,27 +760,27 @@ extern "C" int arreau_train_backward(arreau_model* m, const float* d_g_eps, cons
         const float* out = t.out + (size_t)l * M * C;
         // read-out (ponita.py:105,108)
         TRY(linear_dw(s, t, M, C, RO, t.drbar, xnext, W(g->readout_w) + (size_t)l * RO * C, invL));
-        TRY(colsum(s, t.drbar, nullptr, M, RO, invL, W(g->readout_b) + (size_t)l * RO));
+        TRY(colsum(s, t, t.drbar, nullptr, M, RO, invL, W(g->readout_b) + (size_t)l * RO));
         TRY(linear_dx(s, t, M, C, RO, t.drbar, t.ro_w + (size_t)l * RO * C, t.dx, invL, 1.0f));   // dx = d x_{l+1}
         // ConvNext tail: x_{l+1} = out * ls + x_l
-        if (m->cfg.has_layer_scale) TRY(colsum(s, t.dx, out, M, C, 1.0f, W(g->layer_scale) + (size_t)l * C));
+        if (m->cfg.has_layer_scale) TRY(colsum(s, t, t.dx, out, M, C, 1.0f, W(g->layer_scale) + (size_t)l * C));
         LAUNCH(scale_cols_kernel, dim3(blocks(M * C)), dim3(256), t.dx, m->ls + (size_t)l * C, M, C, t.dtmp);   // dout
         TRY(linear_dw(s, t, M, H, C, t.dtmp, h, W(g->linear2_w) + (size_t)l * C * H));
-        TRY(colsum(s, t.dtmp, nullptr, M, C, 1.0f, W(g->linear2_b) + (size_t)l * C));
+        TRY(colsum(s, t, t.dtmp, nullptr, M, C, 1.0f, W(g->linear2_b) + (size_t)l * C));
         TRY(linear_dx(s, t, M, H, C, t.dtmp, t.lin2 + (size_t)l * C * H, t.dh));
         LAUNCH(gelu_backward_kernel, dim3(blocks(M * H)), dim3(256), t.dh, hpre, (const float*)nullptr, M, H);      // dhpre
         // xn = xhat * g + b (recomputed)
         LAUNCH(scale_cols_kernel, dim3(blocks(M * C)), dim3(256), xhat, m->ln_w + (size_t)l * C, M, C, t.xn);
         LAUNCH(add_bias_kernel, dim3(blocks(M * C)), dim3(256), t.xn, m->ln_b + (size_t)l * C, M, C);
         TRY(linear_dw(s, t, M, C, H, t.dh, t.xn, W(g->linear1_w) + (size_t)l * H * C));
-        TRY(colsum(s, t.dh, nullptr, M, H, 1.0f, W(g->linear1_b) + (size_t)l * H));
+        TRY(colsum(s, t, t.dh, nullptr, M, H, 1.0f, W(g->linear1_b) + (size_t)l * H));
         TRY(linear_dx(s, t, M, C, H, t.dh, t.lin1 + (size_t)l * H * C, t.dtmp));                                     // dxn
-        TRY(colsum(s, t.dtmp, xhat, M, C, 1.0f, W(g->norm_w) + (size_t)l * C));
-        TRY(colsum(s, t.dtmp, nullptr, M, C, 1.0f, W(g->norm_b) + (size_t)l * C));
+        TRY(colsum(s, t, t.dtmp, xhat, M, C, 1.0f, W(g->norm_w) + (size_t)l * C));
+        TRY(colsum(s, t, t.dtmp, nullptr, M, C, 1.0f, W(g->norm_b) + (size_t)l * C));
         LAUNCH(ln_backward_kernel, dim3(blocks(M, 4)), dim3(256), t.dtmp, xhat, t.rstd + (size_t)l * M, m->ln_w + (size_t)l * C, M, C,
                t.xn);                                                                                                // dx2 (in xn)
         // spherical conv: x2 = mix(x1, fk) / 16 + bias
-        TRY(colsum(s, t.xn, nullptr, M, C, 1.0f, W(g->conv_bias) + (size_t)l * C));
+        TRY(colsum(s, t, t.xn, nullptr, M, C, 1.0f, W(g->conv_bias) + (size_t)l * C));
         LAUNCH(mix_backward_x_kernel, dim3(blocks(M * C)), dim3(256), t.xn, fk, N, C, t.dx1);
         LAUNCH(mix_backward_fk_kernel, dim3(256), dim3(128), x1, t.xn, N, C, t.dfk);
         TRY(linear_dw(s, t, 256, D, C, t.dfk, t.fkb, W(g->conv_fiber_w) + (size_t)l * C * D));
@@ -709,20 +796,20 @@ extern "C" int arreau_train_backward(arreau_model* m, const float* d_g_eps, cons
     // edge basis MLP
     LAUNCH(gelu_backward_kernel, dim3(blocks(R * D)), dim3(256), t.dkb, t.h2pre, (const float*)t.window, R, D);      // dh2pre
     TRY(linear_dw(s, t, R, C, D, t.dkb, t.h1, W(g->basis_w2)));
-    TRY(colsum(s, t.dkb, nullptr, R, D, 1.0f, W(g->basis_b2)));
+    TRY(colsum(s, t, t.dkb, nullptr, R, D, 1.0f, W(g->basis_b2)));
     TRY(linear_dx(s, t, R, C, D, t.dkb, t.w2, t.dh1));
     LAUNCH(gelu_backward_kernel, dim3(blocks(R * C)), dim3(256), t.dh1, t.h1pre, (const float*)nullptr, R, C);       // dh1pre
     TRY(linear_dw(s, t, R, ARREAU_MONO_PAD, C, t.dh1, t.mono, t.dw1f));
     LAUNCH(unfold_poly_grad_kernel, dim3(blocks((long)C * ARREAU_POLY_COLS)), dim3(256), t.dw1f, C, W(g->basis_w1));
-    TRY(colsum(s, t.dh1, nullptr, R, C, 1.0f, W(g->basis_b1)));
+    TRY(colsum(s, t, t.dh1, nullptr, R, C, 1.0f, W(g->basis_b1)));
     // fiber basis MLP
     LAUNCH(gelu_backward_kernel, dim3(blocks(256L * D)), dim3(256), t.dfkb, t.fh2pre, (const float*)nullptr, 256L, D);
     TRY(linear_dw(s, t, 256, C, D, t.dfkb, t.fh1, W(g->fiber_w2)));
-    TRY(colsum(s, t.dfkb, nullptr, 256, D, 1.0f, W(g->fiber_b2)));
+    TRY(colsum(s, t, t.dfkb, nullptr, 256, D, 1.0f, W(g->fiber_b2)));
     TRY(linear_dx(s, t, 256, C, D, t.dfkb, m->fiber_w2, t.dfh1));
     LAUNCH(gelu_backward_kernel, dim3(blocks(256L * C)), dim3(256), t.dfh1, t.fh1pre, (const float*)nullptr, 256L, C);
     TRY(linear_dw(s, t, 256, 3, C, t.dfh1, t.fpoly, W(g->fiber_w1)));
-    TRY(colsum(s, t.dfh1, nullptr, 256, C, 1.0f, W(g->fiber_b1)));
+    TRY(colsum(s, t, t.dfh1, nullptr, 256, C, 1.0f, W(g->fiber_b1)));
     return ARREAU_OK;
 }
 
