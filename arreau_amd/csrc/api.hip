@@ -1,5 +1,7 @@
 // arreau_predict_scores: one evaluation of the score network on the current sampler state, plus the
 // workspace carve-up and the hipEvent timing hook for the dominant (edge) kernel.
+#include <string.h>
+
 #include <mutex>
 #include <vector>
 
@@ -267,30 +269,43 @@ extern "C" int arreau_sample_loop(arreau_model* m, float* d_frac, int32_t* d_typ
     s = (hipStream_t)m->loop_stream;
     ARREAU_CHECK_HIP(hipEventRecord(ev, user));
     ARREAU_CHECK_HIP(hipStreamWaitEvent(s, ev, 0));
-    // The first step runs eagerly (it also forces lazy module loading, which must not happen inside a capture).
-    if ((rc = enqueue_sample_step(m, d_frac, d_types, d_lengths, d_angles, d_off, B, N, seed, d_const_types, d_fixed_lengths, d_lattice, w, s)))
-        return rc;
-    hipGraph_t graph = nullptr;
-    ARREAU_CHECK_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
-    rc = enqueue_sample_step(m, d_frac, d_types, d_lengths, d_angles, d_off, B, N, seed, d_const_types, d_fixed_lengths, d_lattice, w, s);
-    hipError_t e = hipStreamEndCapture(s, &graph);
-    if (rc) {
-        if (graph) (void)hipGraphDestroy(graph);
-        return rc;
+    // The executable graph is kept with the model and reused while the next call names the same buffers, sizes and seed
+    // (a sampler drawing sub-batch after sub-batch through the caching allocator does): capture + instantiation, about
+    // 2 ms, are then paid once.  The timestep is not part of the graph (it lives in t_next, set above).
+    const uint64_t key[12] = {(uint64_t)d_frac, (uint64_t)d_types, (uint64_t)d_lengths, (uint64_t)d_angles, (uint64_t)d_off,
+                              ((uint64_t)(uint32_t)B << 32) | (uint32_t)N, seed, (uint64_t)d_const_types, (uint64_t)d_fixed_lengths,
+                              (uint64_t)d_lattice, (uint64_t)d_workspace,
+                              ((uint64_t)(uint32_t)m->edge_variant << 32) | (uint32_t)m->mlp_variant};
+    hipGraphExec_t exec = (hipGraphExec_t)m->retired_graph;
+    int first_replay = 0;
+    hipError_t e = hipSuccess;
+    if (!exec || memcmp(key, m->graph_key, sizeof(key)) != 0) {
+        // The first step runs eagerly (it also forces lazy module loading, which must not happen inside a capture).
+        if ((rc = enqueue_sample_step(m, d_frac, d_types, d_lengths, d_angles, d_off, B, N, seed, d_const_types, d_fixed_lengths, d_lattice, w, s)))
+            return rc;
+        first_replay = 1;
+        hipGraph_t graph = nullptr;
+        ARREAU_CHECK_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+        rc = enqueue_sample_step(m, d_frac, d_types, d_lengths, d_angles, d_off, B, N, seed, d_const_types, d_fixed_lengths, d_lattice, w, s);
+        e = hipStreamEndCapture(s, &graph);
+        if (rc) {
+            if (graph) (void)hipGraphDestroy(graph);
+            return rc;
+        }
+        ARREAU_CHECK_HIP(e);
+        exec = nullptr;
+        e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(graph);
+        ARREAU_CHECK_HIP(e);
+        arreau_model_retire_graph(m, (void*)exec, (void*)s);  // takes ownership; frees the previous one after its stream drained
+        memcpy(m->graph_key, key, sizeof(key));
     }
-    ARREAU_CHECK_HIP(e);
-    hipGraphExec_t exec = nullptr;
-    e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
-    (void)hipGraphDestroy(graph);
-    ARREAU_CHECK_HIP(e);
-    for (int i = 1; i < n_steps; ++i) {
+    for (int i = first_replay; i < n_steps; ++i) {
         e = hipGraphLaunch(exec, s);
         if (e != hipSuccess) break;
     }
     if (e == hipSuccess) e = hipEventRecord(ev, s);
     if (e == hipSuccess) e = hipStreamWaitEvent(user, ev, 0);  // the caller's stream continues after the loop
-    // the executable graph must outlive its launches: it is kept with the model and released at the next loop / destroy
-    arreau_model_retire_graph(m, (void*)exec, (void*)s);
     ARREAU_CHECK_HIP(e);
     return ARREAU_OK;
 }

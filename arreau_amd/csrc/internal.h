@@ -62,6 +62,7 @@ struct arreau_model {
     int packed_stale;        // 1 after arreau_model_update_train_weights: the sampling kernels' packed planes are out of date
     void* loop_stream;       // hipStream_t / hipEvent_t of arreau_sample_loop's graph mode (capture is not allowed on the
     void* loop_event;        //   legacy default stream callers usually pass); created on first use
+    uint64_t graph_key[12];  // what the cached executable graph of arreau_sample_loop was captured for
     void* retired_graph;     // hipGraphExec_t of the last arreau_sample_loop (+ the stream it was launched on): destroyed,
     void* retired_stream;    //   after that stream has drained, by the next loop or by arreau_model_destroy
     int32_t* status;         // device word of sticky ARREAU_STATUS_* bits (written by the kernels with atomicOr)

@@ -5,7 +5,8 @@
 // one dense product per Linear (sgemm_kernel below, exact fp32 on the matrix pipe, split-K for the weight gradients), small elementwise /
 // gather / reduce kernels between them, every intermediate in HBM -- and walks it backwards.  At config-5 sizes (64
 // crystals, about 540 atoms, 69 k (edge, orientation) rows per GPU) the whole step moves a few hundred MB; clarity
-// and exact fp32 arithmetic matter more here than the last factor of two.
+// and exact fp32 arithmetic matter more here than the last factor of two.  Measured on MI355X (profiles/r02i_*): 9.6 ms
+// forward + backward for 64 crystals / 532 atoms (first version with FMA GEMMs and single-workgroup column sums: 38 ms).
 //
 // Reference: PonitaFiberBundle.forward (ponita/models/ponita.py:88-123), FiberBundleConv.forward / message
 // (ponita/nn/conv.py:105-138; PyG sum aggregation onto edge_index[1]), ConvNext.forward (ponita/nn/convnext.py:20-33),
@@ -345,15 +346,25 @@ __global__ void mix_backward_x_kernel(const float* __restrict__ dx2, const float
     for (int p = 0; p < 16; ++p) acc += dx2[((size_t)n * 16 + p) * C + c] * fk[((size_t)o * 16 + p) * C + c];
     dx1[i] = acc * (1.0f / 16.0f);
 }
-// dfk[o,p,c] = sum_n x1[n,o,c] dx2[n,p,c] / 16   (atoms in order: deterministic)
-__global__ void mix_backward_fk_kernel(const float* __restrict__ x1, const float* __restrict__ dx2, int N, int C,
-                                       float* __restrict__ dfk) {
+// dfk[o,p,c] = sum_n x1[n,o,c] dx2[n,p,c] / 16: chunks of 32 atoms summed by separate workgroups, then the chunks in
+// order (deterministic)
+constexpr int MIX_CHUNK = 32;
+__global__ void mix_backward_fk_partial_kernel(const float* __restrict__ x1, const float* __restrict__ dx2, int N, int C,
+                                               float* __restrict__ part /*[chunks][256][C]*/) {
     const int op = blockIdx.x, o = op >> 4, p = op & 15;
+    const int n0 = blockIdx.y * MIX_CHUNK, n1 = min(N, n0 + MIX_CHUNK);
     for (int c = threadIdx.x; c < C; c += blockDim.x) {
         float acc = 0.f;
-        for (int n = 0; n < N; ++n) acc += x1[((size_t)n * 16 + o) * C + c] * dx2[((size_t)n * 16 + p) * C + c];
-        dfk[(size_t)op * C + c] = acc * (1.0f / 16.0f);
+        for (int n = n0; n < n1; ++n) acc += x1[((size_t)n * 16 + o) * C + c] * dx2[((size_t)n * 16 + p) * C + c];
+        part[((size_t)blockIdx.y * 256 + op) * C + c] = acc;
     }
+}
+__global__ void mix_backward_fk_final_kernel(const float* __restrict__ part, int chunks, int C, float* __restrict__ dfk) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= 256 * C) return;
+    float acc = 0.f;
+    for (int q = 0; q < chunks; ++q) acc += part[(size_t)q * 256 * C + i];
+    dfk[i] = acc * (1.0f / 16.0f);
 }
 // LayerNorm over C (eps 1e-5, biased variance; convnext.py:25): xhat, rstd saved; y = xhat g + b.  One wave per row.
 __global__ __launch_bounds__(256) void ln_forward_kernel(const float* __restrict__ x, const float* __restrict__ g,
@@ -495,13 +506,16 @@ __global__ void unfold_poly_grad_kernel(const float* __restrict__ dw1f, int C, f
 // the forward direction: fold basis_fn.1.weight [C][258] onto the 83 monomials (columns of one monomial summed in
 // column order), padding columns zero -- the device twin of fold_poly_weight in model.hip
 __global__ void fold_poly_weight_kernel(const float* __restrict__ w1, int C, float* __restrict__ w1f) {
+    __shared__ int mono_of[ARREAU_POLY_COLS];
+    for (int col = threadIdx.x; col < ARREAU_POLY_COLS; col += blockDim.x) mono_of[col] = mono_of_poly_column(col);
+    __syncthreads();
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= C * ARREAU_MONO_PAD) return;
     const int c = i / ARREAU_MONO_PAD, mi = i % ARREAU_MONO_PAD;
     float acc = 0.f;
     if (mi < ARREAU_NUM_MONO)
         for (int col = 0; col < ARREAU_POLY_COLS; ++col)
-            if (mono_of_poly_column(col) == mi) acc += w1[c * ARREAU_POLY_COLS + col];
+            if (mono_of[col] == mi) acc += w1[c * ARREAU_POLY_COLS + col];
     w1f[i] = acc;
 }
 __global__ void transpose_kernel(const float* __restrict__ in, int rows, int cols, float* __restrict__ out) {  // out[c][r]
@@ -782,7 +796,15 @@ extern "C" int arreau_train_backward(arreau_model* m, const float* d_g_eps, cons
         // spherical conv: x2 = mix(x1, fk) / 16 + bias
         TRY(colsum(s, t, t.xn, nullptr, M, C, 1.0f, W(g->conv_bias) + (size_t)l * C));
         LAUNCH(mix_backward_x_kernel, dim3(blocks(M * C)), dim3(256), t.xn, fk, N, C, t.dx1);
-        LAUNCH(mix_backward_fk_kernel, dim3(256), dim3(128), x1, t.xn, N, C, t.dfk);
+        {
+            const int chunks = (N + MIX_CHUNK - 1) / MIX_CHUNK;  // partial sums live in the split-K scratch (free here)
+            if ((size_t)chunks * 256 * C > PARTIAL_FLOATS) {
+                arreau_set_error("arreau_train_backward: batch too large for the fiber-kernel gradient scratch");
+                return ARREAU_ECAPACITY;
+            }
+            LAUNCH(mix_backward_fk_partial_kernel, dim3(256, chunks), dim3(128), x1, t.xn, N, C, t.partial);
+            LAUNCH(mix_backward_fk_final_kernel, dim3(blocks(256L * C)), dim3(256), t.partial, chunks, C, t.dfk);
+        }
         TRY(linear_dw(s, t, 256, D, C, t.dfk, t.fkb, W(g->conv_fiber_w) + (size_t)l * C * D));
         TRY(linear_dx(s, t, 256, D, C, t.dfk, m->fiber_wk + (size_t)l * C * D, t.dfkb, 1.0f, 1.0f));
         // spatial conv: x1 = sum_s kern * x_l[src]; the residual path already sits in dx (= d x_l so far)

@@ -139,8 +139,9 @@ class DiffusionLoss(nn.Module):
               generated inside the update kernels from Philox4x32-10 keyed by (seed, timestep, draw, element), the
               timestep lives on the device, nothing happens on the host between steps.  `seed` defaults to a draw from
               torch's global CPU generator (so torch.manual_seed makes runs repeatable).  `use_graph=True` replays one
-              captured step as a hipGraph (same trajectory bit for bit; default: on for batches of at most 64 atoms,
-              where the step is launch-bound, off otherwise).
+              captured step as a hipGraph (same trajectory bit for bit; measured on MI355X: 1.70 vs 1.765 ms per step at
+              256 x 20, nothing at 1 x 8 where the step is the sum of its kernels' durations; default: on for runs of at
+              least 200 steps, which amortise the capture).
           noise="reference": randn[B,3], randn[N,3], rand[N,S] from the global CPU generator in the reference's order
               (diffusion_helpers.py:193-197, :79; d3pm.py:206), uploaded every step -- the parity mode.
           noise="device": the same loop with torch's device generator (three RNG launches per step)."""
@@ -188,7 +189,7 @@ class DiffusionLoss(nn.Module):
             if seed is None:
                 seed = int(torch.randint(0, 2 ** 62, (1,)).item())
             if use_graph is None:
-                use_graph = N <= 64
+                use_graph = n_steps >= 200  # capture + instantiation (about 2 ms) against ~4 us saved per kernel boundary
             eng.sample_loop(frac_d, types_d, len_d, ang_d, off_d, self.T - 1, n_steps, seed, const_d, lattice_d,
                             use_graph=bool(use_graph))
         else:

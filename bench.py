@@ -320,7 +320,7 @@ def run_rank(args, rank, local_rank, world):
         run_steps(3, use_graph=True)  # warm-up of the graph path (stream / event creation)
         el_g = timed_loop(args.steps, use_graph=True)
         graph_loop = {"steps": args.steps, "ms_per_step": 1e3 * el_g / args.steps,
-                      "note": "hipGraph replay of the captured step; includes one capture + instantiation per call"}
+                      "note": "hipGraph replay of the captured step (executable graph cached from the warm-up call)"}
         eng.check_status()
 
     # second, short timed loop on the exact fp32-MFMA kernels (v_mfma_f32_32x32x2_f32): what the same step costs
