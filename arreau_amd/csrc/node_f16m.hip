@@ -287,9 +287,12 @@ int arreau_launch_mlp_f16x3_m16(const arreau_model* m, int layer, const float* x
     }
     constexpr int NW = 4;
     const size_t layer_u32x4 = (size_t)2 * H * C * 2 * 2 / 16;  // bytes of W1 + W2 as 2 fp16 planes, in 16-byte units
-    // Tile geometry: one wave = 2 nodes (32 rows) normally; 1 node (16 rows) while that still leaves wave slots idle
-    // (2 workgroups x 4 waves on each of the CUs) -- twice the waves, half the work each, bit-identical rows.
-    // ARREAU_MLP_NB = 1 / 2 forces a geometry (tests).
+    // Tile geometry: one wave = 2 nodes (32 rows, each weight fragment read from LDS serves six MFMAs) or 1 node (16 rows:
+    // twice the tiles, a little more than half the time each -- 0.6 measured) -- bit-identical rows either way.  The launch
+    // takes whole rounds of tiles over the chip's wave slots (2 workgroups x 4 waves per CU), so pick the geometry whose
+    // rounds cost less: 16-row tiles while a batch leaves slots idle (1 x 8: -20 % step time) or has an expensive tail
+    // (256 x 20: 2.5 rounds of 0.6 against 1.25 rounds -> 2 of 1.0: 1.70 vs 1.73 ms per step), 32-row tiles for large
+    // batches (1024 x 20: 5 full rounds).  ARREAU_MLP_NB = 1 / 2 forces a geometry (tests).
     static const int nb_env = [] { const char* e = getenv("ARREAU_MLP_NB"); return e ? atoi(e) : 0; }();
     static const int wave_slots = [] {
         int dev = 0;
@@ -298,7 +301,9 @@ int arreau_launch_mlp_f16x3_m16(const arreau_model* m, int layer, const float* x
             return 8 * (int)prop.multiProcessorCount;
         return 2048;
     }();
-    const int nb = nb_env == 1 || nb_env == 2 ? nb_env : (((long long)N + 1) / 2 < wave_slots ? 1 : 2);
+    const long long rounds1 = ((long long)N + wave_slots - 1) / wave_slots;
+    const long long rounds2 = (((long long)N + 1) / 2 + wave_slots - 1) / wave_slots;
+    const int nb = nb_env == 1 || nb_env == 2 ? nb_env : (6 * rounds1 < 10 * rounds2 ? 1 : 2);
     const long long tiles = ((long long)N + nb - 1) / nb;
     const dim3 grid((unsigned)((tiles + NW - 1) / NW)), block(64 * NW);
     const float* lnw = m->ln_w + (size_t)layer * C;

@@ -289,8 +289,10 @@ __global__ void features_kernel(const float* __restrict__ frac, const int32_t* _
 }
 
 // x1[n,o,c] = sum_{s < deg[n]} kern[(n,s,o),c] * x[src(n,s),o,c]   (conv.py:111,131-133 + sum aggregation)
-__global__ void conv_forward_kernel(const float* __restrict__ kern, const float* __restrict__ x, const int32_t* __restrict__ deg,
-                                    const int32_t* __restrict__ src, int N, int k, int C, float* __restrict__ x1) {
+// (kern is one layer's column block of the all-layer kernel matrix [R][L*C]: row stride ldk)
+__global__ void conv_forward_kernel(const float* __restrict__ kern, int ldk, const float* __restrict__ x,
+                                    const int32_t* __restrict__ deg, const int32_t* __restrict__ src, int N, int k, int C,
+                                    float* __restrict__ x1) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (long)N * 16 * C) return;
     const int c = (int)(i % C);
@@ -300,15 +302,16 @@ __global__ void conv_forward_kernel(const float* __restrict__ kern, const float*
     float acc = 0.f;
     for (int s = 0; s < nd; ++s) {
         const int j = src[(size_t)n * k + s];
-        acc += kern[(((size_t)n * k + s) * 16 + o) * C + c] * x[((size_t)j * 16 + o) * C + c];
+        acc += kern[(((size_t)n * k + s) * 16 + o) * ldk + c] * x[((size_t)j * 16 + o) * C + c];
     }
     x1[i] = acc;
 }
 // dkern[(n,s,o),c] = dx1[n,o,c] * x[src,o,c];  dx[src,o,c] += kern[(n,s,o),c] * dx1[n,o,c]  (atomic: several receivers
 // share a sender)
-__global__ void conv_backward_kernel(const float* __restrict__ kern, const float* __restrict__ x, const float* __restrict__ dx1,
-                                     const int32_t* __restrict__ deg, const int32_t* __restrict__ src, int N, int k, int C,
-                                     float* __restrict__ dkern, float* __restrict__ dx) {
+__global__ void conv_backward_kernel(const float* __restrict__ kern, int ldk, const float* __restrict__ x,
+                                     const float* __restrict__ dx1, const int32_t* __restrict__ deg,
+                                     const int32_t* __restrict__ src, int N, int k, int C, float* __restrict__ dkern,
+                                     float* __restrict__ dx) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (long)N * k * 16 * C) return;
     const int c = (int)(i % C);
@@ -316,11 +319,12 @@ __global__ void conv_backward_kernel(const float* __restrict__ kern, const float
     const int o = (int)(row & 15);
     const long e = row >> 4;
     const int n = (int)(e / k), s = (int)(e % k);
-    if (s >= min(deg[n], k)) { dkern[i] = 0.f; return; }
+    const size_t ik = (size_t)row * ldk + c;  // same position in the [R][L*C] matrices
+    if (s >= min(deg[n], k)) { dkern[ik] = 0.f; return; }
     const int j = src[e];
     const float g = dx1[((size_t)n * 16 + o) * C + c];
-    dkern[i] = g * x[((size_t)j * 16 + o) * C + c];
-    atomicAdd(dx + ((size_t)j * 16 + o) * C + c, kern[i] * g);
+    dkern[ik] = g * x[((size_t)j * 16 + o) * C + c];
+    atomicAdd(dx + ((size_t)j * 16 + o) * C + c, kern[ik] * g);
 }
 // x2[n,p,c] = sum_o x1[n,o,c] fk[o,p,c] / 16 + bias[c]   (conv.py:113-127)
 __global__ void mix_forward_kernel(const float* __restrict__ x1, const float* __restrict__ fk, const float* __restrict__ bias,
@@ -575,9 +579,9 @@ size_t layout(arreau_train_ctx& t, const arreau_model* m, int N, int B, float* b
     t.x = c.take<float>((L + 1) * M * C); t.x1 = c.take<float>(L * M * C); t.xhat = c.take<float>(L * M * C);
     t.rstd = c.take<float>(L * M); t.xn = c.take<float>(M * C); t.hpre = c.take<float>(L * M * H); t.h = c.take<float>(L * M * H);
     t.out = c.take<float>(L * M * C); t.fk = c.take<float>(L * 256 * C); t.rbar = c.take<float>(M * RO); t.gs = c.take<float>(N * 3);
-    t.kern = c.take<float>(R * C);
+    t.kern = c.take<float>(R * L * C);   // all layers' spatial kernels, [R][L*C] (one GEMM: the basis is layer-independent)
     t.dx = c.take<float>(M * C); t.dtmp = c.take<float>(M * C); t.dh = c.take<float>(M * H); t.drbar = c.take<float>(M * RO);
-    t.dx1 = c.take<float>(M * C); t.dkern = c.take<float>(R * C); t.dkb = c.take<float>(R * D); t.dh1 = c.take<float>(R * C);
+    t.dx1 = c.take<float>(M * C); t.dkern = c.take<float>(R * L * C); t.dkb = c.take<float>(R * D); t.dh1 = c.take<float>(R * C);
     t.dfk = c.take<float>(256 * C); t.dfkb = c.take<float>(256 * D); t.dfh1 = c.take<float>(256 * C);
     t.dw1f = c.take<float>(C * ARREAU_MONO_PAD); t.partial = c.take<float>(PARTIAL_FLOATS); t.scratch_cols = c.take<float>(1024);
     t.colpart = c.take<float>((size_t)COLSUM_MAX_CHUNKS * 1024);
@@ -717,13 +721,14 @@ extern "C" int arreau_train_forward(arreau_model* m, const float* d_frac, const 
            m->vp_betas, m->t_emb_w, m->ori, S, m->T, N, t.F);
     TRY(gemm(s, t, (int)M, C, S + 78, t.F, S + 78, 1, m->embT, C, 1, t.x, C));
     ARREAU_CHECK_HIP(hipMemsetAsync(t.rbar, 0, (size_t)M * RO * sizeof(float), s));
+    // kernel_l = kb . Wk_l^T for all layers in one product (conv.py:110; conv.kernel.weight stacked [L*C][D])
+    TRY(linear(s, t, R, D, L * C, t.kb, t.wk, t.kern));
     for (int l = 0; l < L; ++l) {
         const float* xl = t.x + (size_t)l * M * C;
         float* xnext = t.x + (size_t)(l + 1) * M * C;
         float* x1 = t.x1 + (size_t)l * M * C;
         float* fk = t.fk + (size_t)l * 256 * C;
-        TRY(linear(s, t, R, D, C, t.kb, t.wk + (size_t)l * C * D, t.kern));
-        LAUNCH(conv_forward_kernel, dim3(blocks(M * C)), dim3(256), t.kern, xl, t.deg, t.src, N, k, C, x1);
+        LAUNCH(conv_forward_kernel, dim3(blocks(M * C)), dim3(256), t.kern + (size_t)l * C, L * C, xl, t.deg, t.src, N, k, C, x1);
         TRY(linear(s, t, 256, D, C, t.fkb, m->fiber_wk + (size_t)l * C * D, fk));
         LAUNCH(mix_forward_kernel, dim3(blocks(M * C)), dim3(256), x1, fk, m->conv_bias + (size_t)l * C, N, C, t.dtmp);
         LAUNCH(ln_forward_kernel, dim3(blocks(M, 4)), dim3(256), t.dtmp, m->ln_w + (size_t)l * C, m->ln_b + (size_t)l * C, M, C,
@@ -760,7 +765,6 @@ extern "C" int arreau_train_backward(arreau_model* m, const float* d_g_eps, cons
     auto W = [](const float* p) { return const_cast<float*>(p); };  // the gradient struct reuses the const state_dict type
     LAUNCH(train_outputs_backward_kernel, dim3((unsigned)M), dim3(128), d_g_eps, d_g_logits, d_g_len0, t.batch, m->ori, S, N, t.drbar);
     ARREAU_CHECK_HIP(hipMemsetAsync(t.dx, 0, (size_t)M * C * sizeof(float), s));
-    ARREAU_CHECK_HIP(hipMemsetAsync(t.dkb, 0, (size_t)R * D * sizeof(float), s));
     ARREAU_CHECK_HIP(hipMemsetAsync(t.dfkb, 0, (size_t)256 * D * sizeof(float), s));
     const float invL = 1.0f / (float)L;
     for (int l = L - 1; l >= 0; --l) {
@@ -808,11 +812,12 @@ extern "C" int arreau_train_backward(arreau_model* m, const float* d_g_eps, cons
         TRY(linear_dw(s, t, 256, D, C, t.dfk, t.fkb, W(g->conv_fiber_w) + (size_t)l * C * D));
         TRY(linear_dx(s, t, 256, D, C, t.dfk, m->fiber_wk + (size_t)l * C * D, t.dfkb, 1.0f, 1.0f));
         // spatial conv: x1 = sum_s kern * x_l[src]; the residual path already sits in dx (= d x_l so far)
-        TRY(linear(s, t, R, D, C, t.kb, t.wk + (size_t)l * C * D, t.kern));
-        LAUNCH(conv_backward_kernel, dim3(blocks(R * C)), dim3(256), t.kern, xl, t.dx1, t.deg, t.src, N, k, C, t.dkern, t.dx);
-        TRY(linear_dw(s, t, R, D, C, t.dkern, t.kb, W(g->conv_kernel_w) + (size_t)l * C * D));
-        TRY(linear_dx(s, t, R, D, C, t.dkern, t.wk + (size_t)l * C * D, t.dkb, 1.0f, 1.0f));
+        LAUNCH(conv_backward_kernel, dim3(blocks(R * C)), dim3(256), t.kern + (size_t)l * C, L * C, xl, t.dx1, t.deg, t.src, N, k, C,
+               t.dkern + (size_t)l * C, t.dx);
     }
+    // kernel projections of all layers at once: dWk [L*C][D] = dkern^T . kb,  dkb = dkern . Wk
+    TRY(linear_dw(s, t, R, D, L * C, t.dkern, t.kb, W(g->conv_kernel_w)));
+    TRY(linear_dx(s, t, R, D, L * C, t.dkern, t.wk, t.dkb));
     // embedding: x_0 = F . W_emb^T  -> dW_emb[c][i] = sum_rows dx[row][c] F[row][i]
     TRY(linear_dw(s, t, M, S + 78, C, t.dx, t.F, W(g->x_embedder_w)));
     // edge basis MLP

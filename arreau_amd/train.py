@@ -23,6 +23,8 @@ def all_reduce_gradients(parameters: Iterable[torch.nn.Parameter], world_size: i
     params = [p for p in parameters if p.requires_grad and p.numel() > 0]
     if not params:
         return 0
+    if world_size <= 1:  # nothing to exchange: leave the gradients where they are
+        return sum(p.numel() for p in params)
     dev, dt = params[0].device, torch.float32
     flat = torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).reshape(-1).to(dt) for p in params])
     if world_size > 1:

@@ -3,7 +3,7 @@
 # -> gpurun_out/hbm_traffic_pmc.json in the layout bench.py reads from profiles/hbm_traffic_pmc.json.
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout -k 10 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d gpurun_out/pmc_traffic_$c -- python bench.py --steps 6 --warmup 2 --no-cpu-baseline > gpurun_out/pmc_traffic_$c.json 2> gpurun_out/pmc_traffic_$c.err || exit 1
+  timeout -k 10 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d gpurun_out/pmc_traffic_$c -- python bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-fp32-variant > gpurun_out/pmc_traffic_$c.json 2> gpurun_out/pmc_traffic_$c.err || exit 1
 done
 python - <<'PY'
 import csv, glob, json, collections
@@ -22,7 +22,7 @@ for k, v in acc.items():
     f = sum(v["FETCH_SIZE"]) / max(1, len(v["FETCH_SIZE"]))
     w = sum(v["WRITE_SIZE"]) / max(1, len(v["WRITE_SIZE"]))
     out["kernels"][k] = {"FETCH_SIZE_KB": f, "WRITE_SIZE_KB": w, "hbm_bytes_corrected": (2 * f + w) * 1024}
-    if "edge_kernel" in k:
+    if "edge_kernel_f16x3" in k:
         edge = k
 out["edge_kernel"] = edge
 out["edge_kernel_hbm_bytes_per_launch"] = out["kernels"][edge]["hbm_bytes_corrected"]
