@@ -90,6 +90,7 @@ struct arreau_model {
     const float* vp_betas;   // [T+1]
     const float* q1t;        // [T][S][S]
     const float* qmats;      // [T][S][S]
+    int qmats_absorbing;     // 1 when every Qbar_t is diagonal + last ("mask") column: the D3PM update skips the dense S x S read
     // raw fiber-basis MLP (only used by the one-time precompute kernel)
     const float* fiber_w1;   // [C][3]
     const float* fiber_b1;   // [C]

@@ -439,6 +439,17 @@ extern "C" int arreau_model_create(const arreau_config* cfg, const arreau_state_
     for (int l = 0; l < L; ++l) m->ro_bv_host[l] = sd->readout_b[(size_t)l * RO + S];
     m->t_emb_w = b + off_temb; m->ve_sigmas = b + off_ve; m->vp_alpha_bars = b + off_ab; m->vp_betas = b + off_be;
     m->q1t = b + off_q1t; m->qmats = b + off_qm;
+    {   // structure of the cumulative D3PM matrices (d3pm.py:33-54, forward_type "mask"): nonzeros only on the diagonal and in
+        // the last column?  (A "uniform" chain, or any other buffer a checkpoint may hold, keeps the dense path.)
+        int absorbing = 1;
+        const float* q = sd->q_mats;
+        for (size_t t = 0; t < (size_t)T && absorbing; ++t)
+            for (int c = 0; c < S && absorbing; ++c)
+                for (int s2 = 0; s2 < S - 1; ++s2)
+                    if (s2 != c && q[(t * S + c) * S + s2] != 0.0f) { absorbing = 0; break; }
+        if (getenv("ARREAU_D3PM_DENSE")) absorbing = 0;  // force the general path (tests)
+        m->qmats_absorbing = absorbing;
+    }
     m->fiber_w1 = b + off_fw1; m->fiber_b1 = b + off_fb1; m->fiber_w2 = b + off_fw2; m->fiber_b2 = b + off_fb2;
     m->fiber_wk = b + off_fwk;
     m->status = reinterpret_cast<int32_t*>(b + off_status);

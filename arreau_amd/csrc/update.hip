@@ -66,7 +66,7 @@ __global__ __launch_bounds__(256) void reverse_atoms_kernel(
     const int32_t* __restrict__ offsets, int B, int N, const float* __restrict__ eps,
     const float* __restrict__ logits, StepNoiseSrc noise,
     const float* __restrict__ ve_sigmas, const float* __restrict__ q1t, const float* __restrict__ qmats, int S,
-    int T, const int32_t* __restrict__ const_types, int32_t* __restrict__ status) {
+    int T, const int32_t* __restrict__ const_types, int absorbing, int32_t* __restrict__ status) {
     const float* __restrict__ z_frac = noise.z_frac;
     const float* __restrict__ u_types = noise.u_types;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -120,6 +120,25 @@ __global__ __launch_bounds__(256) void reverse_atoms_kernel(
         const float* q1row = q1t + ((size_t)(t - 1) * S + xt) * S;  // fact1 = Q_t^T[x_t, :]
         const float* qm = qmats + (size_t)(t - 2) * S * S;          // Qbar_{t-1} (reference index t-2)
         float f2a = 0.f, f2b = 0.f;
+        if (absorbing) {
+            // Absorbing ("mask") chain: Qbar_t is diagonal plus the mask column (checked on the host for every t at model
+            // creation).  The dense loop below adds exact zeros everywhere else, so these are bit for bit its sums: for an
+            // ordinary class s only the term c = s, for the mask class the whole column in class order -- without the
+            // S x S read per atom.
+            const int mask = S - 1;
+            const float d0 = v0 ? qm[(size_t)s0 * S + s0] : 0.f, d1 = v1 ? qm[(size_t)s1 * S + s1] : 0.f;
+            const float c0 = v0 ? qm[(size_t)s0 * S + mask] : 0.f, c1 = v1 ? qm[(size_t)s1 * S + mask] : 0.f;
+            f2a = fmaf(p0, d0, 0.f);
+            f2b = fmaf(p1, d1, 0.f);
+            float fm = 0.f;
+            for (int c = 0; c < S; ++c) {  // wave-uniform
+                const float pc = c < 64 ? __shfl(p0, c, 64) : __shfl(p1, c - 64, 64);
+                const float qc = c < 64 ? __shfl(c0, c, 64) : __shfl(c1, c - 64, 64);
+                fm = fmaf(pc, qc, fm);
+            }
+            if (s0 == mask) f2a = fm;
+            if (s1 == mask) f2b = fm;
+        } else
         // fact2 = softmax . Qbar: rows of Qbar are fetched 16 at a time (independent loads in flight), then the
         // softmax entries are broadcast from the lanes that hold them
         for (int c0 = 0; c0 < S; c0 += 16) {
@@ -135,8 +154,8 @@ __global__ __launch_bounds__(256) void reverse_atoms_kernel(
                 const int c = c0 + i;  // wave-uniform
                 float sc = c < 64 ? __shfl(p0, c, 64) : __shfl(p1, c - 64, 64);
                 sc = c < S ? sc : 0.f;
-                f2a += sc * qa[i];
-                f2b += sc * qb[i];
+                f2a = fmaf(sc, qa[i], f2a);
+                f2b = fmaf(sc, qb[i], f2b);
             }
         }
         post0 = v0 ? logf(q1row[s0] + D3PM_EPS) + logf(f2a + D3PM_EPS) : -INFINITY;
@@ -179,7 +198,7 @@ int arreau_launch_reverse(const arreau_model* m, float* d_frac, int32_t* d_types
     ARREAU_CHECK_HIP(hipGetLastError());
     if (N > 0) {
         hipLaunchKernelGGL(reverse_atoms_kernel, dim3((N + 3) / 4), dim3(256), 0, s, d_frac, d_types, d_t, d_off, B, N,
-                           d_eps, d_logits, noise, m->ve_sigmas, m->q1t, m->qmats, m->S, m->T, d_const_types, m->status);
+                           d_eps, d_logits, noise, m->ve_sigmas, m->q1t, m->qmats, m->S, m->T, d_const_types, m->qmats_absorbing, m->status);
         ARREAU_CHECK_HIP(hipGetLastError());
     }
     return ARREAU_OK;

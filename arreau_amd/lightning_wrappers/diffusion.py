@@ -127,6 +127,13 @@ class PONITA_DIFFUSION(nn.Module):
         self._callibrate_if_needed(eng)
         return loss
 
+    @torch.no_grad()
+    def validation_step(self, graph, timestep=None, noise=None):
+        """lightning_wrappers/diffusion.py:126-137: the same loss without a backward pass (fused sampling kernels)."""
+        return self.diffusion_loss(self, graph, self.t_emb, timestep=timestep, noise=noise)
+
+    test_step = validation_step  # :139-150
+
     def _callibrate_if_needed(self, eng):
         layers = self.model.interaction_layers
         if all(bool(layer.conv.callibrated) for layer in layers):

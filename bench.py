@@ -119,7 +119,7 @@ def launch_ranks(n, argv, stub=False):
     """Start `n` copies of this script as ranks 0..n-1 (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their
     environment) BEFORE this process touches a GPU; rank 0's stdout (the JSON line) is passed through.  Returns the
     exit code (non-zero if any rank failed; the others are then stopped by PID)."""
-    if not stub:
+    if not stub and os.environ.get("ARREAU_BENCH_ONE_DEVICE", "0") != "1":  # (rehearsal mode shares one GPU)
         import torch
         have = torch.cuda.device_count()  # does not initialise the GPU runtime in this process
         if have < n:

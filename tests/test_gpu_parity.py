@@ -361,6 +361,57 @@ def test_reverse_step_matches_oracle(dev, small_model, t):
     assert torch.equal(ty.cpu().long()[decided], ty_o[decided])
 
 
+def test_d3pm_absorbing_chain_shortcut_is_bitwise_the_dense_product(dev, small_model):
+    """The reverse kernel skips the S x S read of Qbar when the buffers have the absorbing chain's structure (diagonal +
+    mask column, d3pm.py:33-54).  It must give bit for bit what the dense softmax . Qbar product gives (the dense loop
+    only adds exact zeros elsewhere), and a buffer without that structure must take the dense path and match the oracle."""
+    import copy
+    from arreau_amd.diffusion.diffusion_helpers import crystal_offsets
+    m, om32, _ = small_model
+    S, t = 12, 40
+    frac, types, lengths, angles, na = random_state(S, [6, 9, 3], 61, sampler_like=True)
+    frac = frac % 1
+    N, B = frac.shape[0], 3
+    g = torch.Generator().manual_seed(9)
+    eps, logits, len0 = torch.randn(N, 3, generator=g), torch.randn(N, S, generator=g) * 3, torch.randn(B, 3, generator=g)
+    noise = OS.StepNoise(torch.randn(B, 3, generator=g), torch.randn(N, 3, generator=g), torch.rand(N, S, generator=g))
+    d = lambda v: v.to(dev).contiguous()
+    off = crystal_offsets(na, dev)
+    t_c = torch.full((B,), t, device=dev, dtype=torch.int32)
+
+    def run(engine):
+        f, ty, le = d(frac.clone()), d(types.to(torch.int32)), d(lengths.clone())
+        lat = torch.zeros(B, 3, 3, device=dev)
+        engine.reverse_step(f, ty, le, d(angles), t_c, off, d(eps), d(logits), d(len0), d(noise.z_lattice), d(noise.z_frac),
+                            d(noise.u_types), lat)
+        return f, ty, le
+
+    a = run(m.engine())
+    os.environ["ARREAU_D3PM_DENSE"] = "1"
+    try:
+        dense_engine = copy.deepcopy(m).engine()
+    finally:
+        del os.environ["ARREAU_D3PM_DENSE"]
+    b = run(dense_engine)
+    for x, y in zip(a, b):
+        assert torch.equal(x, y)
+    # a chain that is not absorbing (mass leaks into class 0 as well): general path, against the oracle
+    m2 = copy.deepcopy(m)
+    with torch.no_grad():
+        q = m2.diffusion_loss.d3pm.q_mats
+        q[:, :, 0] += 0.01
+        q /= q.sum(dim=-1, keepdim=True)
+    om2 = oracle_from_module(m2, torch.float32)
+    f_o, ty_o, _len_o, _lat = OS.reverse_step(om2, frac, types, lengths, angles, na, (eps, logits, len0), t, noise)
+    f2, ty2, _ = run(m2.engine())
+    post = OD.d3pm_q_posterior_logits(om2.q_one_step_transposed, om2.q_mats, logits, types, torch.full((N,), t))
+    val = post + (-torch.log(-torch.log(torch.clip(noise.u_types, 1e-6, 1.0))))
+    top2 = val.topk(2, dim=-1).values
+    decided = (top2[:, 0] - top2[:, 1]) > 1e-4
+    assert torch.equal(ty2.cpu().long()[decided], ty_o[decided]) and decided.float().mean() > 0.8
+    assert not torch.equal(ty2.cpu(), a[1].cpu())  # the leak really changes the update
+
+
 # ------------------------------------------------------------------------------------------- sampler
 def test_teacher_forced_trajectory(dev, small_model):
     """Per-step parity along a real sampler trajectory (T=100): at t in {99, 75, 50, 25, 2, 1} feed the
