@@ -1,5 +1,6 @@
 // arreau_predict_scores: one evaluation of the score network on the current sampler state, plus the
 // workspace carve-up and the hipEvent timing hook for the dominant (edge) kernel.
+#include <stdlib.h>
 #include <string.h>
 
 #include <mutex>
@@ -57,6 +58,63 @@ Workspace carve(const arreau_config* cfg, int64_t N, int64_t B, void* base, size
     return w;
 }
 
+constexpr int MAX_GROUPS = 8;
+}  // namespace
+
+// Crystal-aligned slices of a batch (host copy of the CSR offsets -> G ranges of about N / G atoms each) and the streams
+// / events the slices run on.  Crystals are independent and every kernel of the network takes a node range over
+// whole-batch arrays (NodeRange), so slice g computes bit for bit what the whole-batch launches compute for its atoms;
+// what changes is WHEN: slices in different phases overlap the HBM-bound message-passing kernel of one with the
+// matrix-bound edge / MLP kernels of another.
+struct arreau_partition {
+    int B = 0, N = 0, G = 1;
+    int nb[MAX_GROUPS + 1], bb[MAX_GROUPS + 1];
+    hipStream_t stream[MAX_GROUPS] = {};
+    hipEvent_t fork = nullptr, join[MAX_GROUPS] = {};
+};
+void arreau_partition_destroy(arreau_partition* p) {
+    if (!p) return;
+    for (int g = 0; g < MAX_GROUPS; ++g) {
+        if (p->stream[g]) { (void)hipStreamSynchronize(p->stream[g]); (void)hipStreamDestroy(p->stream[g]); }
+        if (p->join[g]) (void)hipEventDestroy(p->join[g]);
+    }
+    if (p->fork) (void)hipEventDestroy(p->fork);
+    delete p;
+}
+
+extern "C" int arreau_model_set_batch_layout(arreau_model* m, const int32_t* h_off, int32_t B, int32_t groups) {
+    ARREAU_REQUIRE(m && (B == 0 || h_off), "arreau_model_set_batch_layout: null pointer");
+    static const int env_groups = [] { const char* e = getenv("ARREAU_GROUPS"); return e ? atoi(e) : 0; }();
+    int G = groups > 0 ? groups : (env_groups > 0 ? env_groups : 1);
+    G = G > MAX_GROUPS ? MAX_GROUPS : G;
+    if (B <= 0 || G <= 1 || B < 2 * G) {  // nothing to slice
+        if (m->part) m->part->G = 1, m->part->B = -1;
+        return ARREAU_OK;
+    }
+    arreau_partition* p = m->part ? m->part : new arreau_partition();
+    m->part = p;
+    const int N = h_off[B];
+    p->B = B; p->N = N; p->G = G;
+    p->bb[0] = 0; p->nb[0] = 0;
+    int b = 0;
+    for (int g = 1; g < G; ++g) {  // cut at the crystal boundary nearest to g N / G (at least one crystal per slice)
+        const long long target = (long long)N * g / G;
+        while (b < B - (G - g) && h_off[b + 1] <= target) ++b;
+        if (b < B - (G - g) && b + 1 <= B && (target - h_off[b]) > (h_off[b + 1] - target)) ++b;
+        if (b <= p->bb[g - 1]) b = p->bb[g - 1] + 1;
+        p->bb[g] = b;
+        p->nb[g] = h_off[b];
+    }
+    p->bb[G] = B; p->nb[G] = N;
+    for (int g = 0; g < G; ++g) {
+        if (!p->stream[g]) ARREAU_CHECK_HIP(hipStreamCreateWithFlags(&p->stream[g], hipStreamNonBlocking));
+        if (!p->join[g]) ARREAU_CHECK_HIP(hipEventCreateWithFlags(&p->join[g], hipEventDisableTiming));
+    }
+    if (!p->fork) ARREAU_CHECK_HIP(hipEventCreateWithFlags(&p->fork, hipEventDisableTiming));
+    return ARREAU_OK;
+}
+
+namespace {
 // hipEvent pairs around the edge kernel, on the stream it is launched on
 struct EdgeProfile {
     std::mutex mu;
@@ -101,7 +159,7 @@ extern "C" int arreau_edge_kernel_time_ms(double* mean_ms, int64_t* launches) {
 namespace {
 // the edge kernel, bracketed by hipEvents on its own stream when bench.py asked for its launch time
 int run_edge_kernel(const arreau_model* m, const float* dir, const float* dist, const int32_t* deg, const Workspace& w,
-                    int N, hipStream_t s) {
+                    int N, hipStream_t s, NodeRange r = NodeRange()) {
     hipEvent_t e0 = nullptr, e1 = nullptr;
     bool prof = false;
     {
@@ -113,7 +171,7 @@ int run_edge_kernel(const arreau_model* m, const float* dir, const float* dist, 
         ARREAU_CHECK_HIP(hipEventCreate(&e1));
         ARREAU_CHECK_HIP(hipEventRecord(e0, s));
     }
-    const int rc = arreau_launch_edge(m, dir, dist, deg, w.batch, w.lattice, N, w.kbuf, s);
+    const int rc = arreau_launch_edge(m, dir, dist, deg, w.batch, w.lattice, N, w.kbuf, s, r);
     if (prof) {
         ARREAU_CHECK_HIP(hipEventRecord(e1, s));
         std::lock_guard<std::mutex> lock(g_prof.mu);
@@ -125,15 +183,57 @@ int run_edge_kernel(const arreau_model* m, const float* dir, const float* dist, 
 // interaction layers (conv.py:105-129 + convnext.py:20-33) on the embedded features in w.xa, then the read-outs
 int run_layers_and_readout(const arreau_model* m, const Workspace& w, const int32_t* deg, const int32_t* src,
                            const int32_t* d_off, int B, int N, float* d_eps, float* d_logits, float* d_len0,
-                           hipStream_t s) {
+                           hipStream_t s, NodeRange r = NodeRange()) {
     int rc;
     float* xin = w.xa;
     float* xout = w.xb;
     for (int l = 0; l < m->L; ++l) {
-        if ((rc = arreau_launch_node_layer(m, l, w.kbuf, deg, src, xin, w.xc, xout, w.xbar, w.vsum, N, s))) return rc;
+        if ((rc = arreau_launch_node_layer(m, l, w.kbuf, deg, src, xin, w.xc, xout, w.xbar, w.vsum, N, s, r))) return rc;
         float* tmp = xin; xin = xout; xout = tmp;
     }
-    return arreau_launch_readout(m, w.xbar, w.vsum, d_off, B, N, w.gs, d_eps, d_logits, d_len0, s);
+    return arreau_launch_readout(m, w.xbar, w.vsum, d_off, B, N, w.gs, d_eps, d_logits, d_len0, s, r);
+}
+
+// The score network after prep_kernel: neighbour list (unless given), edge kernel, embedding, interaction layers,
+// read-outs -- for the whole batch on `s`, or slice by slice on the partition's streams (forked from / joined to `s`
+// by events, so the caller's stream order is kept and nothing synchronises with the host).
+int run_network(const arreau_model* m, const Workspace& w, bool given, int32_t* deg, int32_t* src, float* dir, float* dist,
+                const float* d_frac, const int32_t* d_types, const int32_t* d_off, int B, int N, float* d_eps,
+                float* d_logits, float* d_len0, hipStream_t s) {
+    int rc;
+    arreau_partition* p = m->part;
+    const bool sliced = p && p->G > 1 && p->B == B && p->N == N && arreau_range_launches_supported(m);
+    if (!sliced) {
+        if (!given && (rc = arreau_launch_neighbor(w.cart, w.lattice, d_off, w.batch, B, N, m->cfg.radius, m->k, deg, src, w.cell, dir, dist, s)))
+            return rc;
+        if ((rc = run_edge_kernel(m, dir, dist, deg, w, N, s))) return rc;
+        if ((rc = arreau_launch_embed(m, d_frac, d_types, w.lattice, w.batch, w.cvec, N, w.xa, s))) return rc;
+        return run_layers_and_readout(m, w, deg, src, d_off, B, N, d_eps, d_logits, d_len0, s);
+    }
+    static const int n_cu = [] {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+            return (int)prop.multiProcessorCount;
+        return 256;
+    }();
+    static const int cap_env = [] { const char* e = getenv("ARREAU_GROUP_WGS"); return e ? atoi(e) : 0; }();
+    const int cap = cap_env > 0 ? cap_env : (n_cu + p->G - 1) / p->G;
+    ARREAU_CHECK_HIP(hipEventRecord(p->fork, s));
+    for (int g = 0; g < p->G; ++g) {
+        hipStream_t sg = p->stream[g];
+        ARREAU_CHECK_HIP(hipStreamWaitEvent(sg, p->fork, 0));
+        NodeRange r;
+        r.n0 = p->nb[g]; r.n1 = p->nb[g + 1]; r.b0 = p->bb[g]; r.b1 = p->bb[g + 1]; r.wg_cap = cap;
+        if (!given && (rc = arreau_launch_neighbor(w.cart, w.lattice, d_off, w.batch, B, N, m->cfg.radius, m->k, deg, src, w.cell, dir, dist, sg, r)))
+            return rc;
+        if ((rc = run_edge_kernel(m, dir, dist, deg, w, N, sg, r))) return rc;
+        if ((rc = arreau_launch_embed(m, d_frac, d_types, w.lattice, w.batch, w.cvec, N, w.xa, sg, r))) return rc;
+        if ((rc = run_layers_and_readout(m, w, deg, src, d_off, B, N, d_eps, d_logits, d_len0, sg, r))) return rc;
+        ARREAU_CHECK_HIP(hipEventRecord(p->join[g], sg));
+        ARREAU_CHECK_HIP(hipStreamWaitEvent(s, p->join[g], 0));
+    }
+    return ARREAU_OK;
 }
 }  // namespace
 
@@ -165,14 +265,7 @@ extern "C" int arreau_predict_scores(const arreau_model* m, const float* d_frac,
     int rc;
     if ((rc = arreau_launch_prep(m, d_frac, d_lengths, d_angles, d_t, d_off, B, N, w.lattice, w.cart, w.batch, w.cvec, s)))
         return rc;
-    if (!use_given_edges) {
-        if ((rc = arreau_launch_neighbor(w.cart, w.lattice, d_off, w.batch, B, N, m->cfg.radius, m->k, deg, src, w.cell, dir,
-                                         dist, s)))
-            return rc;
-    }
-    if ((rc = run_edge_kernel(m, dir, dist, deg, w, N, s))) return rc;
-    if ((rc = arreau_launch_embed(m, d_frac, d_types, w.lattice, w.batch, w.cvec, N, w.xa, s))) return rc;
-    return run_layers_and_readout(m, w, deg, src, d_off, B, N, d_eps, d_logits, d_len0, s);
+    return run_network(m, w, use_given_edges != 0, deg, src, dir, dist, d_frac, d_types, d_off, B, N, d_eps, d_logits, d_len0, s);
 }
 
 // PonitaFiberBundle.forward on the reference's own batch attributes (the inner operator seam).
@@ -216,12 +309,8 @@ int enqueue_sample_step(const arreau_model* m, float* d_frac, int32_t* d_types, 
     if ((rc = arreau_launch_prep(m, d_frac, d_lengths, d_angles, nullptr, d_off, B, N, w.lattice, w.cart, w.batch, w.cvec, s,
                                  w.t_next, w.t_cur)))
         return rc;
-    if ((rc = arreau_launch_neighbor(w.cart, w.lattice, d_off, w.batch, B, N, m->cfg.radius, m->k, w.deg, w.src, w.cell,
-                                     w.dir, w.dist, s)))
+    if ((rc = run_network(m, w, false, w.deg, w.src, w.dir, w.dist, d_frac, d_types, d_off, B, N, w.eps, w.logits, w.len0, s)))
         return rc;
-    if ((rc = run_edge_kernel(m, w.dir, w.dist, w.deg, w, N, s))) return rc;
-    if ((rc = arreau_launch_embed(m, d_frac, d_types, w.lattice, w.batch, w.cvec, N, w.xa, s))) return rc;
-    if ((rc = run_layers_and_readout(m, w, w.deg, w.src, d_off, B, N, w.eps, w.logits, w.len0, s))) return rc;
     return arreau_launch_reverse(m, d_frac, d_types, d_lengths, d_angles, w.t_cur, d_off, B, N, w.eps, w.logits, w.len0,
                                  StepNoiseSrc{nullptr, nullptr, nullptr, seed}, d_const_types, d_lattice, s, d_fixed_lengths);
 }

@@ -215,7 +215,7 @@ static void launch_variant(const arreau_model* m, const float* dir, const float*
 }
 
 int arreau_launch_edge(const arreau_model* m, const float* dir, const float* dist, const int32_t* deg,
-                       const int32_t* batch, const float* lattice, int N, float* kbuf, hipStream_t s) {
+                       const int32_t* batch, const float* lattice, int N, float* kbuf, hipStream_t s, NodeRange r) {
     if (N == 0) return ARREAU_OK;
     if (!(m->C == 128 && m->D == 256)) {
         arreau_set_error("edge kernel: unsupported (hidden_dim, basis_dim)");
@@ -228,7 +228,11 @@ int arreau_launch_edge(const arreau_model* m, const float* dir, const float* dis
     const int variant = m->edge_variant;
     if (variant == 4 && m->f16_ok) {
         m->ran_edge = 4;
-        return arreau_launch_edge_f16x3(m, dir, dist, deg, batch, lattice, N, kbuf, s);
+        return arreau_launch_edge_f16x3(m, dir, dist, deg, batch, lattice, N, kbuf, s, r);
+    }
+    if (r.n0 != 0 || (r.n1 >= 0 && r.n1 != N)) {
+        arreau_set_error("edge kernel: range launches are implemented for the fp16x3 kernel only");
+        return ARREAU_EINVAL;
     }
     if (variant >= 3) {
         m->ran_edge = 3;

@@ -80,7 +80,8 @@ __global__ __launch_bounds__(64 * EH_WAVES, 2) void edge_kernel_f16x3(
     const float* __restrict__ ori,       // [16][3]
     const u32x4* __restrict__ stream,    // fp16x3 chunks: w1 (C/32 chunks) | w2 (D/32) | wk_l (L * C/32)
     const float* __restrict__ b1, const float* __restrict__ b2, float r_max, int N, int k, int L,
-    float* __restrict__ kbuf)            // [L][N*k*16][C]
+    float* __restrict__ kbuf,            // [L][N*k*16][C]
+    int n0, int n1)                      // receivers of this launch: n0 .. n1-1 (N stays the batch size: it strides kbuf)
 {
     constexpr int TC = C / 32, TD = D / 32, TM = ARREAU_MONO_PAD / 32;
     constexpr int NF1 = TM * 4, NF2 = TC * 4, NF3 = TD * 4;  // 1 KiB fragments per chunk: 12, 16, 32
@@ -90,7 +91,7 @@ __global__ __launch_bounds__(64 * EH_WAVES, 2) void edge_kernel_f16x3(
     __shared__ __attribute__((aligned(16))) float bias_s[C + D];              // b1 | b2 (no global loads beside the DMA)
 
     const int wave0 = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane0 = threadIdx.x & 63;
-    const int npairs = (N + EH_WAVES / 4 - 1) / (EH_WAVES / 4);
+    const int npairs = (n1 - n0 + EH_WAVES / 4 - 1) / (EH_WAVES / 4);
 
 #ifdef ARREAU_EDGE_TIMING
     long long tick_ = clock64();
@@ -120,9 +121,9 @@ __global__ __launch_bounds__(64 * EH_WAVES, 2) void edge_kernel_f16x3(
         const unsigned lane16 = 16u * lane;            // per-lane byte offset inside a 1 KiB fragment
         const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)&lds[0][0]) + 1024u * wave;
         const bool has_next = pair + (int)gridDim.x < npairs;  // workgroup-uniform
-        const int node_raw = (EH_WAVES / 4) * pair + (wave >> 2);
-        const int node = min(node_raw, N - 1);
-        const int nd = node_raw < N ? min(deg[node], k) : 0;
+        const int node_raw = n0 + (EH_WAVES / 4) * pair + (wave >> 2);
+        const int node = min(node_raw, n1 - 1);
+        const int nd = node_raw < n1 ? min(deg[node], k) : 0;
         const bool active = 2 * wn < nd;               // wave-uniform; idle waves still copy weights and meet the barriers
         const u32x4* dma_src = stream + (size_t)2 * NF1 * 64;  // next chunk to copy: chunk 2 of this pair
 
@@ -392,8 +393,9 @@ __global__ __launch_bounds__(64 * EH_WAVES, 2) void edge_kernel_f16x3(
 }
 
 int arreau_launch_edge_f16x3(const arreau_model* m, const float* dir, const float* dist, const int32_t* deg,
-                             const int32_t* batch, const float* lattice, int N, float* kbuf, hipStream_t s) {
-    if (N == 0) return ARREAU_OK;
+                             const int32_t* batch, const float* lattice, int N, float* kbuf, hipStream_t s, NodeRange r) {
+    const int n0 = r.n0, n1 = r.n1 < 0 ? N : r.n1;
+    if (n1 <= n0) return ARREAU_OK;
     if (!(m->C == 128 && m->D == 256 && m->k <= 8)) {
         arreau_set_error("edge kernel (fp16x3): unsupported (hidden_dim, basis_dim, max_neighbors)");
         return ARREAU_EINVAL;
@@ -410,11 +412,12 @@ int arreau_launch_edge_f16x3(const arreau_model* m, const float* dir, const floa
             return (int)prop.multiProcessorCount;
         return 256;
     }();
-    const int npairs = (N + 1) / 2;
-    const int wgs = wgs_env > 0 ? (wgs_env < npairs ? wgs_env : npairs) : (npairs < n_cu ? npairs : n_cu);
+    const int npairs = (n1 - n0 + 1) / 2;
+    int wgs = wgs_env > 0 ? (wgs_env < npairs ? wgs_env : npairs) : (npairs < n_cu ? npairs : n_cu);
+    if (r.wg_cap > 0 && wgs > r.wg_cap) wgs = r.wg_cap;
     hipLaunchKernelGGL((edge_kernel_f16x3<128, 256, 8>), dim3(wgs), dim3(512), 0, s, dir, dist, deg, batch,
                        lattice, m->ori, reinterpret_cast<const u32x4*>(m->edge_f16), m->b1, m->b2, m->cfg.radius, N,
-                       m->k, m->L, kbuf);
+                       m->k, m->L, kbuf, n0, n1);
     ARREAU_CHECK_HIP(hipGetLastError());
     return ARREAU_OK;
 }

@@ -105,9 +105,9 @@ __device__ __forceinline__ Cand arreau_candidate(const float* __restrict__ cart,
 __global__ __launch_bounds__(256) void neighbor_kernel(
     const float* __restrict__ cart, const float* __restrict__ lattice, const int32_t* __restrict__ offsets,
     const int32_t* __restrict__ batch /* [N] crystal of atom, or null */, int B,
-    int N, float r2, int k, int32_t* __restrict__ deg, int32_t* __restrict__ src, int32_t* __restrict__ cell,
-    float* __restrict__ dir, float* __restrict__ dist) {
-    const int i = (int)((blockIdx.x * (unsigned)blockDim.x + threadIdx.x) >> 6);
+    int n0, int N /* receivers n0 .. N-1 */, float r2, int k, int32_t* __restrict__ deg, int32_t* __restrict__ src,
+    int32_t* __restrict__ cell, float* __restrict__ dir, float* __restrict__ dist) {
+    const int i = n0 + (int)((blockIdx.x * (unsigned)blockDim.x + threadIdx.x) >> 6);
     const int lane = threadIdx.x & 63;
     if (i >= N) return;  // wave-uniform
     // the crystal of the receiver: one load when the caller has the atom -> crystal map (prep_kernel writes it),
@@ -192,12 +192,13 @@ __global__ __launch_bounds__(256) void neighbor_kernel(
 
 int arreau_launch_neighbor(const float* cart, const float* lattice, const int32_t* offsets, const int32_t* batch,
                            int B, int N, float radius, int k, int32_t* deg, int32_t* src, int32_t* cell, float* dir, float* dist,
-                           hipStream_t s) {
-    if (N == 0) return ARREAU_OK;
+                           hipStream_t s, NodeRange r) {
+    const int n0 = r.n0, n1 = r.n1 < 0 ? N : r.n1;
+    if (n1 <= n0) return ARREAU_OK;
     const float r2 = (float)((double)radius * (double)radius);
     const int waves_per_block = 4;
-    hipLaunchKernelGGL(neighbor_kernel, dim3((N + waves_per_block - 1) / waves_per_block), dim3(64 * waves_per_block),
-                       0, s, cart, lattice, offsets, batch, B, N, r2, k, deg, src, cell, dir, dist);
+    hipLaunchKernelGGL(neighbor_kernel, dim3((n1 - n0 + waves_per_block - 1) / waves_per_block), dim3(64 * waves_per_block),
+                       0, s, cart, lattice, offsets, batch, B, n0, n1, r2, k, deg, src, cell, dir, dist);
     ARREAU_CHECK_HIP(hipGetLastError());
     return ARREAU_OK;
 }

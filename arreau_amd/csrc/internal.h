@@ -14,6 +14,8 @@
 #define ARREAU_ORI 16
 
 struct arreau_train_ctx;
+struct arreau_partition;
+void arreau_partition_destroy(struct arreau_partition* p);
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -59,6 +61,9 @@ struct arreau_model {
     // form, and the step's activation buffers (created on first use)
     const float *t_w1f, *t_w2, *t_wk, *t_lin1, *t_lin2, *t_ro_w;
     struct arreau_train_ctx* train;
+    // crystal-aligned slices of the batch the score network may be run in, on separate streams (api.hip: set by
+    // arreau_model_set_batch_layout; used when (B, N) of a call match and the default kernel set is selected)
+    struct arreau_partition* part;
     int packed_stale;        // 1 after arreau_model_update_train_weights: the sampling kernels' packed planes are out of date
     void* loop_stream;       // hipStream_t / hipEvent_t of arreau_sample_loop's graph mode (capture is not allowed on the
     void* loop_event;        //   legacy default stream callers usually pass); created on first use
@@ -203,11 +208,19 @@ struct StepNoiseSrc {
 void arreau_train_ctx_destroy(struct arreau_train_ctx* t);
 void arreau_model_retire_graph(arreau_model* m, void* exec, void* stream);  // takes ownership; frees the previous one
 
+// A launch over part of the batch: receivers / atoms n0 .. n1-1 (n1 < 0: all), crystals b0 .. b1-1, and for the persistent
+// kernels a cap on the workgroup count (0: one per CU).  All arrays stay whole-batch arrays with absolute indices, so a
+// range launch computes bit for bit what the whole-batch launch computes for those atoms: arreau_predict_scores uses it
+// to run crystal-aligned slices of the batch on separate streams (api.hip).
+struct NodeRange {
+    int n0 = 0, n1 = -1, b0 = 0, b1 = -1, wg_cap = 0;
+};
+
 // launchers implemented in the other translation units ------------------------------------------
 int arreau_launch_fiber_precompute(arreau_model* m, hipStream_t s);
 int arreau_launch_neighbor(const float* cart, const float* lattice, const int32_t* offsets, const int32_t* batch, int B, int N,
                            float radius, int k, int32_t* deg, int32_t* src, int32_t* cell, float* dir, float* dist,
-                           hipStream_t s);
+                           hipStream_t s, NodeRange r = NodeRange());
 int arreau_launch_prep(const arreau_model* m, const float* frac, const float* lengths, const float* angles,
                        const int32_t* t, const int32_t* offsets, int B, int N, float* lattice, float* cart,
                        int32_t* batch, float* cvec, hipStream_t s, int32_t* t_next = nullptr, int32_t* t_cur = nullptr);
@@ -216,23 +229,24 @@ int arreau_launch_reverse(const arreau_model* m, float* d_frac, int32_t* d_types
                           const float* d_logits, const float* d_len0, StepNoiseSrc noise, const int32_t* d_const_types,
                           float* d_lattice, hipStream_t s, const float* d_fixed_lengths = nullptr);
 int arreau_launch_edge(const arreau_model* m, const float* dir, const float* dist, const int32_t* deg,
-                       const int32_t* batch, const float* lattice, int N, float* kbuf, hipStream_t s);
+                       const int32_t* batch, const float* lattice, int N, float* kbuf, hipStream_t s, NodeRange r = NodeRange());
 int arreau_launch_edge_bf16x6(const arreau_model* m, const float* dir, const float* dist, const int32_t* deg,
                               const int32_t* batch, const float* lattice, int N, float* kbuf, hipStream_t s);
 int arreau_launch_edge_f16x3(const arreau_model* m, const float* dir, const float* dist, const int32_t* deg,
-                             const int32_t* batch, const float* lattice, int N, float* kbuf, hipStream_t s);
+                             const int32_t* batch, const float* lattice, int N, float* kbuf, hipStream_t s, NodeRange r = NodeRange());
 int arreau_launch_embed(const arreau_model* m, const float* frac, const int32_t* types, const float* lattice,
-                        const int32_t* batch, const float* cvec, int N, float* x0, hipStream_t s);
+                        const int32_t* batch, const float* cvec, int N, float* x0, hipStream_t s, NodeRange r = NodeRange());
 int arreau_launch_embed_general(const arreau_model* m, const float* x, const float* vec, int N, float* x0, hipStream_t s);
 int arreau_launch_batch_index(const int32_t* offsets, int B, int N, int32_t* batch, hipStream_t s);
 int arreau_launch_node_layer(const arreau_model* m, int layer, const float* kbuf, const int32_t* deg,
                              const int32_t* src, const float* x_in, float* x_conv, float* x_out, float* xbar,
-                             float* vsum, int N, hipStream_t s);
+                             float* vsum, int N, hipStream_t s, NodeRange r = NodeRange());
 int arreau_launch_mlp_bf16x6(const arreau_model* m, int layer, const float* x_conv, const float* x_in, float* x_out,
                              float* xbar, float* vsum, int N, hipStream_t s);
 int arreau_launch_mlp_f16x3_m16(const arreau_model* m, int layer, const float* x_conv, const float* x_in, float* x_out,
-                                float* xbar, float* vsum, int N, hipStream_t s);
+                                float* xbar, float* vsum, int N, hipStream_t s, NodeRange r = NodeRange());
 int arreau_launch_mlp_f16x3(const arreau_model* m, int layer, const float* x_conv, const float* x_in, float* x_out,
                             float* xbar, float* vsum, int N, hipStream_t s);
 int arreau_launch_readout(const arreau_model* m, const float* xbar, const float* vsum, const int32_t* offsets,
-                          int B, int N, float* gs, float* eps, float* logits, float* len0, hipStream_t s);
+                          int B, int N, float* gs, float* eps, float* logits, float* len0, hipStream_t s, NodeRange r = NodeRange());
+bool arreau_range_launches_supported(const arreau_model* m);  // the default kernel set (fp16x3 edge + MLP, streamed conv, MFMA read-out)

@@ -491,6 +491,7 @@ void arreau_model_retire_graph(arreau_model* m, void* exec, void* stream) {
 extern "C" void arreau_model_destroy(arreau_model* model) {
     if (!model) return;
     arreau_model_retire_graph(model, nullptr, nullptr);
+    arreau_partition_destroy(model->part);
     if (model->train) {
         (void)hipDeviceSynchronize();
         arreau_train_ctx_destroy(model->train);

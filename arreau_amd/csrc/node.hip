@@ -107,14 +107,15 @@ int arreau_launch_prep(const arreau_model* m, const float* frac, const float* le
 __global__ __launch_bounds__(256) void embed_kernel(
     const float* __restrict__ frac, const int32_t* __restrict__ types, const float* __restrict__ lattice,
     const int32_t* __restrict__ batch, const float* __restrict__ cvec, const float* __restrict__ ori,
-    const float* __restrict__ embT, int S, int C, int N, float* __restrict__ x0, int32_t* __restrict__ status) {
+    const float* __restrict__ embT, int S, int C, int n0, int N /* atoms n0 .. N-1 */, float* __restrict__ x0,
+    int32_t* __restrict__ status) {
     // thread = (atom n, float4 column c4): the atom's scalar part and the four vector-channel weight rows are
     // loaded once and serve all 16 orientations (16 coalesced 512-byte row stores per 32 lanes)
     const int C4 = C / 4;
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= (long long)N * C4) return;
+    if (idx >= (long long)(N - n0) * C4) return;
     const int c4 = (int)(idx % C4);
-    const int n = (int)(idx / C4);
+    const int n = n0 + (int)(idx / C4);
     const int b = batch[n];
     int ty = types[n];
     if ((ty < 0 || ty >= S) && c4 == 0) atomicOr(status, ARREAU_STATUS_BAD_TYPE);  // clamped, but flagged
@@ -144,11 +145,12 @@ __global__ __launch_bounds__(256) void embed_kernel(
 }
 
 int arreau_launch_embed(const arreau_model* m, const float* frac, const int32_t* types, const float* lattice,
-                        const int32_t* batch, const float* cvec, int N, float* x0, hipStream_t s) {
-    if (N == 0) return ARREAU_OK;
-    const long long total = (long long)N * (m->C / 4);
+                        const int32_t* batch, const float* cvec, int N, float* x0, hipStream_t s, NodeRange r) {
+    const int n0 = r.n0, n1 = r.n1 < 0 ? N : r.n1;
+    if (n1 <= n0) return ARREAU_OK;
+    const long long total = (long long)(n1 - n0) * (m->C / 4);
     hipLaunchKernelGGL(embed_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, frac, types, lattice, batch,
-                       cvec, m->ori, m->embT, m->S, m->C, N, x0, m->status);
+                       cvec, m->ori, m->embT, m->S, m->C, n0, n1, x0, m->status);
     ARREAU_CHECK_HIP(hipGetLastError());
     return ARREAU_OK;
 }
@@ -335,7 +337,7 @@ __global__ __launch_bounds__(512, 2) void conv_kernel_streamed(
     const int32_t* __restrict__ deg, const int32_t* __restrict__ src,
     const float* __restrict__ x_in,      // [N][16][C]
     const float* __restrict__ fk,        // [16(o)][16(p)][C]
-    const float* __restrict__ conv_bias, int N,
+    const float* __restrict__ conv_bias, int n0, int N /* receivers n0 .. n0 + N - 1 (arrays are whole-batch, indices absolute) */,
     float* __restrict__ x_conv)          // [N][16][C]
 {
     static_assert(C == 128, "thread mapping assumes C = 128");
@@ -366,9 +368,10 @@ __global__ __launch_bounds__(512, 2) void conv_kernel_streamed(
     const int xcd = blockIdx.x & 7, wg_in_xcd = blockIdx.x >> 3, wgs_per_xcd = gridDim.x >> 3;
     const int n_iter = xcd_order ? ((N + 8 * CONV_GROUP - 1) / (8 * CONV_GROUP)) * CONV_GROUP : N;
     const int m_step = xcd_order ? wgs_per_xcd : (int)gridDim.x;
-    auto node_of = [&](int m) { return xcd_order ? ((m / CONV_GROUP) * 8 + xcd) * CONV_GROUP + (m % CONV_GROUP) : m; };
-    auto next_valid = [&](int m) {  // first local index >= m with a receiver < N, or n_iter
-        while (m < n_iter && node_of(m) >= N) m += m_step;
+    auto local_of = [&](int m) { return xcd_order ? ((m / CONV_GROUP) * 8 + xcd) * CONV_GROUP + (m % CONV_GROUP) : m; };
+    auto node_of = [&](int m) { return n0 + local_of(m); };
+    auto next_valid = [&](int m) {  // first local index >= m with a receiver inside the range, or n_iter
+        while (m < n_iter && local_of(m) >= N) m += m_step;
         return m;
     };
     const unsigned kb0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)&kbuf_s[0][0]);
@@ -651,8 +654,11 @@ __global__ __launch_bounds__(256, 2) void mlp_kernel(
 
 int arreau_launch_node_layer(const arreau_model* m, int layer, const float* kbuf, const int32_t* deg,
                              const int32_t* src, const float* x_in, float* x_conv, float* x_out, float* xbar,
-                             float* vsum, int N, hipStream_t s) {
-    if (N == 0) return ARREAU_OK;
+                             float* vsum, int N, hipStream_t s, NodeRange r) {
+    const int n0 = r.n0, n1 = r.n1 < 0 ? N : r.n1;
+    const int Ng = n1 - n0;
+    if (Ng <= 0) return ARREAU_OK;
+    const bool whole = n0 == 0 && n1 == N;
     const int C = m->C, H = m->H, S = m->S;
     if (!(C == 128 && H == 512)) {
         arreau_set_error("node kernels: unsupported (hidden_dim, widening_factor)");
@@ -665,10 +671,15 @@ int arreau_launch_node_layer(const arreau_model* m, int layer, const float* kbuf
     const int conv_variant = m->conv_variant;
     m->ran_conv = (conv_variant == 1 && m->k == 8) ? 1 : 0;
     if (conv_variant == 1 && m->k == 8) {
-        const int blocks = N < 256 ? N : 256;
+        int blocks = Ng < 256 ? Ng : 256;
+        if (r.wg_cap > 0 && blocks > r.wg_cap) blocks = r.wg_cap;
         hipLaunchKernelGGL((conv_kernel_streamed<128>), dim3(blocks), dim3(512), 0, s, kbuf + (size_t)layer * layer_stride, deg,
-                           src, x_in, m->fk + (size_t)layer * 16 * 16 * C, m->conv_bias + (size_t)layer * C, N, x_conv);
+                           src, x_in, m->fk + (size_t)layer * 16 * 16 * C, m->conv_bias + (size_t)layer * C, n0, Ng, x_conv);
     } else {
+        if (!whole) {
+            arreau_set_error("conv kernel: range launches are implemented for the streamed form only");
+            return ARREAU_EINVAL;
+        }
         hipLaunchKernelGGL((conv_kernel<128>), dim3(conv_blocks), dim3(512), 0, s, kbuf + (size_t)layer * layer_stride, deg,
                            src, x_in, m->fk + (size_t)layer * 16 * 16 * C, m->conv_bias + (size_t)layer * C, N, m->k, x_conv);
     }
@@ -678,7 +689,11 @@ int arreau_launch_node_layer(const arreau_model* m, int layer, const float* kbuf
     const int mlp_variant = m->mlp_variant;
     if (mlp_variant == 3 && m->f16_ok) {
         m->ran_mlp = 3;
-        return arreau_launch_mlp_f16x3_m16(m, layer, x_conv, x_in, x_out, xbar, vsum, N, s);
+        return arreau_launch_mlp_f16x3_m16(m, layer, x_conv, x_in, x_out, xbar, vsum, N, s, r);
+    }
+    if (!whole) {
+        arreau_set_error("mlp kernel: range launches are implemented for the fp16x3 16x16x32 kernel only");
+        return ARREAU_EINVAL;
     }
     if (mlp_variant >= 2 && m->f16_ok) {
         m->ran_mlp = 2;
@@ -805,18 +820,19 @@ __global__ __launch_bounds__(512) void readout_mfma_kernel(
     const float* __restrict__ vsum,     // [N][16]
     const float* __restrict__ ro_pack,  // [L][ROT][C/32][1024]
     const float* __restrict__ ro_b,     // [L][S+4]
-    const float* __restrict__ ori, int S, int L, int N, float* __restrict__ eps, float* __restrict__ logits,
+    const float* __restrict__ ori, int S, int L, int Ntot /* batch size: strides xbar */, int nbeg,
+    int N /* atoms nbeg .. N-1 */, float* __restrict__ eps, float* __restrict__ logits,
     float* __restrict__ gs /*[N][3]*/, int32_t* __restrict__ status) {
     constexpr int TC = C / 32;
     extern __shared__ __attribute__((aligned(16))) float part[];  // [L][ROT][64 lanes][16]
     const int lane = threadIdx.x & 63, l = threadIdx.x >> 6;
     const int h = lane >> 5, j = lane & 31;
-    const int n0 = blockIdx.x * 32;
+    const int n0 = nbeg + blockIdx.x * 32;
     const int RO = S + 4;
     const float invL = 1.0f / (float)L;
     {
         const int n = min(n0 + j, N - 1);  // padding atoms read a valid row and write nothing
-        const float* rowp = xbar + ((size_t)l * N + n) * C + 4 * h;
+        const float* rowp = xbar + ((size_t)l * Ntot + n) * C + 4 * h;
         f32x16 bx[TC][1];
 #pragma unroll
         for (int t = 0; t < TC; ++t)
@@ -881,9 +897,9 @@ __global__ __launch_bounds__(512) void readout_mfma_kernel(
     if (bad) atomicOr(status, ARREAU_STATUS_NONFINITE);
 }
 
-__global__ void readout_crystals_kernel(const float* __restrict__ gs, const int32_t* __restrict__ offsets, int B,
+__global__ void readout_crystals_kernel(const float* __restrict__ gs, const int32_t* __restrict__ offsets, int b0, int B,
                                         float* __restrict__ len0) {
-    const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const int idx = 3 * b0 + blockIdx.x * blockDim.x + threadIdx.x;  // crystals b0 .. B-1
     if (idx >= 3 * B) return;
     const int b = idx / 3, g = idx - 3 * b;
     float acc = 0.f;
@@ -891,10 +907,17 @@ __global__ void readout_crystals_kernel(const float* __restrict__ gs, const int3
     len0[idx] = acc;
 }
 
+bool arreau_range_launches_supported(const arreau_model* m) {
+    return m->edge_variant == 4 && m->mlp_variant == 3 && m->f16_ok && m->conv_variant == 1 && m->k == 8 &&
+           m->readout_variant == 1 && m->S + 4 <= 96 && m->L <= 8 && m->C == 128;
+}
+
 int arreau_launch_readout(const arreau_model* m, const float* xbar, const float* vsum, const int32_t* offsets, int B,
-                          int N, float* gs, float* eps, float* logits, float* len0, hipStream_t s) {
+                          int N, float* gs, float* eps, float* logits, float* len0, hipStream_t s, NodeRange r) {
     if (B == 0) return ARREAU_OK;
-    if (N > 0) {
+    const int n0 = r.n0, n1 = r.n1 < 0 ? N : r.n1, b0 = r.b0, b1 = r.b1 < 0 ? B : r.b1;
+    const bool whole = n0 == 0 && n1 == N;
+    if (n1 > n0) {
         const size_t smem = ((size_t)RO_ATOMS * m->L * m->C + (size_t)m->L * RO_ATOMS * RO_COLS) * sizeof(float);
         if (m->L * RO_COLS > 1024 || m->S + 4 > RO_COLS) {
             arreau_set_error("readout kernel: num_layers * 128 threads must fit one workgroup");
@@ -907,15 +930,20 @@ int arreau_launch_readout(const arreau_model* m, const float* xbar, const float*
             static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&readout_mfma_kernel<128, 3>),
                                                                hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 3 * 64 * 16 * 4);
             ARREAU_CHECK_HIP(attr);
-            hipLaunchKernelGGL((readout_mfma_kernel<128, 3>), dim3((N + 31) / 32), dim3(64 * m->L), smem_m, s, xbar, vsum,
-                               m->ro_pack, m->ro_b, m->ori, m->S, m->L, N, eps, logits, gs, m->status);
+            hipLaunchKernelGGL((readout_mfma_kernel<128, 3>), dim3((n1 - n0 + 31) / 32), dim3(64 * m->L), smem_m, s, xbar, vsum,
+                               m->ro_pack, m->ro_b, m->ori, m->S, m->L, N, n0, n1, eps, logits, gs, m->status);
         } else {
+            if (!whole) {
+                arreau_set_error("read-out: range launches are implemented for the MFMA kernel only");
+                return ARREAU_EINVAL;
+            }
             hipLaunchKernelGGL(readout_nodes_kernel, dim3((N + RO_ATOMS - 1) / RO_ATOMS), dim3(RO_COLS * m->L), smem, s, xbar, vsum,
                                m->ro_wT, m->ro_b, m->ori, m->S, m->C, m->L, N, eps, logits, gs, m->status);
         }
         ARREAU_CHECK_HIP(hipGetLastError());
     }
-    hipLaunchKernelGGL(readout_crystals_kernel, dim3((3 * B + 127) / 128), dim3(128), 0, s, gs, offsets, B, len0);
+    if (b1 > b0)
+        hipLaunchKernelGGL(readout_crystals_kernel, dim3((3 * (b1 - b0) + 127) / 128), dim3(128), 0, s, gs, offsets, b0, b1, len0);
     ARREAU_CHECK_HIP(hipGetLastError());
     return ARREAU_OK;
 }

@@ -57,7 +57,7 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_kernel_f16x3_m16(
     const u32x4* __restrict__ stream,    // this layer: [4 quarters][W1 quarter: 4 chunks | W2 quarter: 4 chunks], 16 frags per chunk
     const float* __restrict__ mb1, const float* __restrict__ mb2, const float* __restrict__ ls,
     const float* __restrict__ wv,        // [C] vector read-out weights of this layer (column S of read_out_layers)
-    float bv, int N, int first_layer,
+    float bv, int n0, int N /* nodes n0 .. N-1 */, int first_layer,
     float* __restrict__ xbar,            // [N][C] this layer
     float* __restrict__ vsum)            // [N][16]
 {
@@ -79,12 +79,12 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_kernel_f16x3_m16(
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int cp = lane & 15, gp = lane >> 4;  // prologue / matrix-phase copies
     const long long tile = (long long)blockIdx.x * NW + wave;
-    const bool active = NB * tile < N;  // wave-uniform; idle waves still copy weights and meet the barriers
+    const bool active = n0 + NB * tile < N;  // wave-uniform; idle waves still copy weights and meet the barriers
     int nrow[NB];                      // node of column block nb (padding: a valid node, nothing written)
     bool valid[NB];
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
-        const long long n_ll = NB * tile + nb;
+        const long long n_ll = n0 + NB * tile + nb;
         valid[nb] = n_ll < N;
         nrow[nb] = valid[nb] ? (int)n_ll : N - 1;
     }
@@ -278,8 +278,10 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_kernel_f16x3_m16(
 }
 
 int arreau_launch_mlp_f16x3_m16(const arreau_model* m, int layer, const float* x_conv, const float* x_in, float* x_out,
-                                float* xbar, float* vsum, int N, hipStream_t s) {
-    if (N == 0) return ARREAU_OK;
+                                float* xbar, float* vsum, int Ntot, hipStream_t s, NodeRange r) {
+    const int n0 = r.n0, n1 = r.n1 < 0 ? Ntot : r.n1;
+    const int N = n1 - n0;  // nodes of this launch (tile geometry is chosen for them)
+    if (N <= 0) return ARREAU_OK;
     const int C = m->C, H = m->H;
     if (!(C == 128 && H == 512)) {
         arreau_set_error("mlp kernel (fp16x3, 16x16x32): unsupported (hidden_dim, widening_factor)");
@@ -315,7 +317,7 @@ int arreau_launch_mlp_f16x3_m16(const arreau_model* m, int layer, const float* x
     auto launch = [&](auto kernel) {
         hipLaunchKernelGGL(kernel, grid, block, 0, s, x_conv, x_in, x_out, lnw, lnb, stream, m->mb1 + (size_t)layer * H,
                            m->mb2 + (size_t)layer * C, m->ls + (size_t)layer * C, m->ro_wv + (size_t)layer * C,
-                           m->ro_bv_host[layer], N, layer == 0 ? 1 : 0, xbar + (size_t)layer * N * C, vsum);
+                           m->ro_bv_host[layer], n0, n1, layer == 0 ? 1 : 0, xbar + (size_t)layer * Ntot * C, vsum);
     };
     if (nb == 1 && slots == 4) launch(mlp_kernel_f16x3_m16<128, 512, NW, 1, 4>);
     else if (nb == 1) launch(mlp_kernel_f16x3_m16<128, 512, NW, 1, 3>);

@@ -185,6 +185,7 @@ class DiffusionLoss(nn.Module):
         if use_graph and noise != "philox":
             raise ValueError("graph replay needs noise='philox' (the in-kernel generator)")
 
+        eng.set_batch_layout(num_atoms)  # lets the library slice the batch over streams (bit-identical results)
         if noise == "philox":
             if seed is None:
                 seed = int(torch.randint(0, 2 ** 62, (1,)).item())

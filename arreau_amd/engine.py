@@ -113,6 +113,16 @@ class HipEngine:
             raise _hip.ArreauHipError("arreau_hip status flags %d: %s" % (f, "; ".join(why)))
         return st
 
+    def set_batch_layout(self, num_atoms, groups=0):
+        """Tell the library the (host-side) atom count of every crystal of the batches that follow, so that it may run
+        the score network as `groups` crystal-aligned slices on separate streams (arreau_model_set_batch_layout;
+        groups = 0: the library's default, ARREAU_GROUPS or off).  Results are bit-identical either way."""
+        n = torch.as_tensor(num_atoms).to("cpu", torch.int64).reshape(-1)
+        off = torch.zeros(n.numel() + 1, dtype=torch.int32)
+        off[1:] = torch.cumsum(n, 0).to(torch.int32)
+        _hip.check(_hip.lib().arreau_model_set_batch_layout(self._handle, ctypes.c_void_p(off.data_ptr()), int(n.numel()),
+                                                            int(groups)), "arreau_model_set_batch_layout")
+
     def set_variant(self, edge=-1, mlp=-1):
         """Select the arithmetic of the dense kernels (edge: 0 fp32 MFMA, 3 bf16x6, 4 fp16x3; mlp: 0 fp32 MFMA,
         1 bf16x6, 2/3 fp16x3); -1 keeps."""

@@ -104,6 +104,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fp32-variant", action="store_true", help="skip the second timed loop on the fp32-MFMA kernels")
     ap.add_argument("--cpu-steps", type=int, default=2)
+    ap.add_argument("--groups", type=int, default=0, help="slices of the batch run on separate streams (0: library default)")
     args = ap.parse_args(argv)
     B, n, T = CONFIGS[args.config or "c2"]
     args.batch_per_gpu = args.batch_per_gpu or B
@@ -258,6 +259,7 @@ def run_rank(args, rank, local_rank, world):
     len_start = len_d.clone()
     seed = 77 + rank
     timestep = [T - 1]
+    eng.set_batch_layout(torch.full((B,), n), groups=args.groups)  # crystal-aligned slices on separate streams (0: default)
 
     def run_steps(k, use_graph=False):
         """k iterations of the product's sampling loop (score network, in-kernel Philox noise, reverse updates), enqueued
@@ -349,7 +351,9 @@ def run_rank(args, rank, local_rank, world):
         ms_per_step = 1e3 * elapsed / args.steps
         crystal_steps_per_s = world * B * args.steps / elapsed
         e_mean = 0.5 * (e_start + e_end)
-        edge_flops = e_mean * 16 * edge_kernel_flops_per_row()
+        # one edge-kernel launch per slice of the batch and step: the algorithmic FLOPs of a launch are its share
+        launches_per_step = max(1, round(launches.value / args.steps))
+        edge_flops = e_mean * 16 * edge_kernel_flops_per_row() / launches_per_step
         edge_tflops = edge_flops / (mean_ms.value * 1e-3) / 1e12 if mean_ms.value > 0 else 0.0
         step_flops = step_flops_per_atom() * N * (e_mean / (8.0 * N))  # scaled by the edge density actually seen
         ran = status["edge_kernel"]
@@ -394,6 +398,7 @@ def run_rank(args, rank, local_rank, world):
                 "checkpoint": "synthetic 1.17M-param (S=90,C=128,O=16,D=256,L=5,k=8,R=5), seed 1234",
                 "edges_per_atom_start": e_start / N, "edges_per_atom_end": e_end / N,
                 "parallelism": f"replicas x{world}, disjoint sub-batches, no data-path collective",
+                "slices_per_gpu": launches_per_step,
             },
             "graph_loop": graph_loop,
             "batch_steps_per_sec": world * args.steps / elapsed,

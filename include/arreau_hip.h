@@ -133,6 +133,15 @@ int arreau_model_status(const arreau_model* model, arreau_status* out, int32_t r
  * bench.py to time/compare the exact fp32-MFMA kernels against the default fp16x3 ones in one process. */
 int arreau_model_set_variant(arreau_model* model, int32_t edge_variant, int32_t mlp_variant);
 
+/* Optional: tell the library how the batch is laid out (HOST copy of d_crystal_offsets[B+1]) so that the score network
+ * of subsequent arreau_predict_scores / arreau_sample_loop calls with the same (B, N) may run as `groups`
+ * crystal-aligned slices on separate internal streams (forked from and joined to the caller's stream by events; no host
+ * synchronisation).  Crystals are independent and every kernel takes a node range over whole-batch arrays, so
+ * the results are bit for bit those of the unsliced run; the slices drift into different phases and the HBM-bound
+ * message-passing kernel of one overlaps the matrix-bound edge / MLP kernels of another.  groups <= 0: the library's
+ * default (environment ARREAU_GROUPS, else 1 = off).  Used only with the default kernel set; ignored otherwise. */
+int arreau_model_set_batch_layout(arreau_model* model, const int32_t* h_crystal_offsets, int32_t B, int32_t groups);
+
 /* Scratch for one step over at most max_atoms atoms / max_crystals crystals. */
 size_t arreau_workspace_bytes(const arreau_config* cfg, int64_t max_atoms, int64_t max_crystals);
 
