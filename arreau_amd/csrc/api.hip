@@ -68,15 +68,20 @@ constexpr int MAX_GROUPS = 8;
 // matrix-bound edge / MLP kernels of another.
 struct arreau_partition {
     int B = 0, N = 0, G = 1;
+    int eager = 0;  // 1: also slice single evaluations / eager loops (fork-join per step; host-bound, for tests: ARREAU_SLICE_EAGER)
     int nb[MAX_GROUPS + 1], bb[MAX_GROUPS + 1];
     hipStream_t stream[MAX_GROUPS] = {};
-    hipEvent_t fork = nullptr, join[MAX_GROUPS] = {};
+    hipEvent_t fork = nullptr, join[MAX_GROUPS] = {}, stagger[MAX_GROUPS] = {};
+    hipGraphExec_t exec[MAX_GROUPS] = {};  // per-slice step graphs of the pipelined sampling loop (cached on graph_key)
+    uint64_t graph_key[12] = {};
 };
 void arreau_partition_destroy(arreau_partition* p) {
     if (!p) return;
     for (int g = 0; g < MAX_GROUPS; ++g) {
         if (p->stream[g]) { (void)hipStreamSynchronize(p->stream[g]); (void)hipStreamDestroy(p->stream[g]); }
         if (p->join[g]) (void)hipEventDestroy(p->join[g]);
+        if (p->stagger[g]) (void)hipEventDestroy(p->stagger[g]);
+        if (p->exec[g]) (void)hipGraphExecDestroy(p->exec[g]);
     }
     if (p->fork) (void)hipEventDestroy(p->fork);
     delete p;
@@ -95,6 +100,7 @@ extern "C" int arreau_model_set_batch_layout(arreau_model* m, const int32_t* h_o
     m->part = p;
     const int N = h_off[B];
     p->B = B; p->N = N; p->G = G;
+    p->eager = getenv("ARREAU_SLICE_EAGER") != nullptr;
     p->bb[0] = 0; p->nb[0] = 0;
     int b = 0;
     for (int g = 1; g < G; ++g) {  // cut at the crystal boundary nearest to g N / G (at least one crystal per slice)
@@ -109,7 +115,9 @@ extern "C" int arreau_model_set_batch_layout(arreau_model* m, const int32_t* h_o
     for (int g = 0; g < G; ++g) {
         if (!p->stream[g]) ARREAU_CHECK_HIP(hipStreamCreateWithFlags(&p->stream[g], hipStreamNonBlocking));
         if (!p->join[g]) ARREAU_CHECK_HIP(hipEventCreateWithFlags(&p->join[g], hipEventDisableTiming));
+        if (!p->stagger[g]) ARREAU_CHECK_HIP(hipEventCreateWithFlags(&p->stagger[g], hipEventDisableTiming));
     }
+    memset(p->graph_key, 0, sizeof(p->graph_key));  // a new layout invalidates the cached slice graphs
     if (!p->fork) ARREAU_CHECK_HIP(hipEventCreateWithFlags(&p->fork, hipEventDisableTiming));
     return ARREAU_OK;
 }
@@ -202,7 +210,11 @@ int run_network(const arreau_model* m, const Workspace& w, bool given, int32_t* 
                 float* d_logits, float* d_len0, hipStream_t s) {
     int rc;
     arreau_partition* p = m->part;
-    const bool sliced = p && p->G > 1 && p->B == B && p->N == N && arreau_range_launches_supported(m);
+    // Fork-join slicing of a single evaluation keeps the slices in lockstep (they start together and have the same work),
+    // so it overlaps nothing and costs 4 G extra host calls per step: measured 1.70 / 2.59 ms per step at G = 2 / 4 against
+    // 1.66 ms unsliced (256 x 20, eager).  It stays as the test vehicle of the range launches (ARREAU_SLICE_EAGER); the
+    // sampling loop uses the pipelined form (arreau_sample_loop).
+    const bool sliced = p && p->eager && p->G > 1 && p->B == B && p->N == N && arreau_range_launches_supported(m);
     if (!sliced) {
         if (!given && (rc = arreau_launch_neighbor(w.cart, w.lattice, d_off, w.batch, B, N, m->cfg.radius, m->k, deg, src, w.cell, dir, dist, s)))
             return rc;
@@ -302,6 +314,27 @@ __global__ void fill_i32_kernel(int32_t* __restrict__ p, int32_t v, int n) {
     if (i < n) p[i] = v;
 }
 
+// One step of ONE slice of the batch, entirely on stream `s` (prep, network and updates restricted to the slice's crystals
+// and atoms): slices are independent samplers that share the weights, so their chains need no synchronisation at all.
+int enqueue_slice_step(const arreau_model* m, float* d_frac, int32_t* d_types, float* d_lengths, const float* d_angles,
+                       const int32_t* d_off, int B, int N, uint64_t seed, const int32_t* d_const_types,
+                       const float* d_fixed_lengths, float* d_lattice, const Workspace& w, hipStream_t s, NodeRange r,
+                       hipEvent_t after_edge) {
+    int rc;
+    if ((rc = arreau_launch_prep(m, d_frac, d_lengths, d_angles, nullptr, d_off, B, N, w.lattice, w.cart, w.batch, w.cvec, s,
+                                 w.t_next, w.t_cur, r)))
+        return rc;
+    if ((rc = arreau_launch_neighbor(w.cart, w.lattice, d_off, w.batch, B, N, m->cfg.radius, m->k, w.deg, w.src, w.cell, w.dir,
+                                     w.dist, s, r)))
+        return rc;
+    if ((rc = run_edge_kernel(m, w.dir, w.dist, w.deg, w, N, s, r))) return rc;
+    if (after_edge) ARREAU_CHECK_HIP(hipEventRecord(after_edge, s));
+    if ((rc = arreau_launch_embed(m, d_frac, d_types, w.lattice, w.batch, w.cvec, N, w.xa, s, r))) return rc;
+    if ((rc = run_layers_and_readout(m, w, w.deg, w.src, d_off, B, N, w.eps, w.logits, w.len0, s, r))) return rc;
+    return arreau_launch_reverse(m, d_frac, d_types, d_lengths, d_angles, w.t_cur, d_off, B, N, w.eps, w.logits, w.len0,
+                                 StepNoiseSrc{nullptr, nullptr, nullptr, seed}, d_const_types, d_lattice, s, d_fixed_lengths, r);
+}
+
 int enqueue_sample_step(const arreau_model* m, float* d_frac, int32_t* d_types, float* d_lengths, const float* d_angles,
                         const int32_t* d_off, int B, int N, uint64_t seed, const int32_t* d_const_types,
                         const float* d_fixed_lengths, float* d_lattice, const Workspace& w, hipStream_t s) {
@@ -340,6 +373,71 @@ extern "C" int arreau_sample_loop(arreau_model* m, float* d_frac, int32_t* d_typ
             if ((rc = enqueue_sample_step(m, d_frac, d_types, d_lengths, d_angles, d_off, B, N, seed, d_const_types, d_fixed_lengths, d_lattice, w, s)))
                 return rc;
         return ARREAU_OK;
+    }
+    // Pipelined slices: when the batch has a layout with G > 1 slices (arreau_model_set_batch_layout), every slice runs its
+    // own chain of steps on its own stream -- one captured graph per slice, replayed n_steps - 1 times -- with NO
+    // synchronisation between slices until the end of the loop.  The first steps are staggered (slice g starts when slice
+    // g - 1 has finished its edge kernel), so the slices stay in different phases: while one is in its matrix-bound edge
+    // kernel another streams its K blocks from HBM.  Every slice computes exactly what it computes in the whole-batch run.
+    {
+        arreau_partition* p = m->part;
+        if (p && p->G > 1 && p->B == B && p->N == N && arreau_range_launches_supported(m)) {
+            static const int n_cu = [] {
+                int dev = 0;
+                hipDeviceProp_t prop;
+                if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+                    return (int)prop.multiProcessorCount;
+                return 256;
+            }();
+            static const int cap_env = [] { const char* e = getenv("ARREAU_GROUP_WGS"); return e ? atoi(e) : 0; }();
+            const int cap = cap_env > 0 ? cap_env : (n_cu + p->G - 1) / p->G;
+            const uint64_t key[12] = {(uint64_t)d_frac, (uint64_t)d_types, (uint64_t)d_lengths, (uint64_t)d_angles, (uint64_t)d_off,
+                                      ((uint64_t)(uint32_t)B << 32) | (uint32_t)N, seed, (uint64_t)d_const_types,
+                                      (uint64_t)d_fixed_lengths, (uint64_t)d_lattice, (uint64_t)d_workspace,
+                                      ((uint64_t)(uint32_t)p->G << 32) | (uint32_t)cap};
+            const bool cached = p->exec[0] && memcmp(key, p->graph_key, sizeof(key)) == 0;
+            ARREAU_CHECK_HIP(hipEventRecord(p->fork, s));
+            NodeRange r[MAX_GROUPS];
+            for (int g = 0; g < p->G; ++g) {
+                r[g].n0 = p->nb[g]; r[g].n1 = p->nb[g + 1]; r[g].b0 = p->bb[g]; r[g].b1 = p->bb[g + 1]; r[g].wg_cap = cap;
+                ARREAU_CHECK_HIP(hipStreamWaitEvent(p->stream[g], p->fork, 0));
+                if (g > 0) ARREAU_CHECK_HIP(hipStreamWaitEvent(p->stream[g], p->stagger[g - 1], 0));
+                // first step eagerly (stagger point + lazy module loading outside any capture)
+                if ((rc = enqueue_slice_step(m, d_frac, d_types, d_lengths, d_angles, d_off, B, N, seed, d_const_types,
+                                             d_fixed_lengths, d_lattice, w, p->stream[g], r[g], p->stagger[g])))
+                    return rc;
+            }
+            if (!cached) {
+                for (int g = 0; g < p->G; ++g) {
+                    if (p->exec[g]) {
+                        (void)hipStreamSynchronize(p->stream[g]);
+                        (void)hipGraphExecDestroy(p->exec[g]);
+                        p->exec[g] = nullptr;
+                    }
+                    hipGraph_t graph = nullptr;
+                    ARREAU_CHECK_HIP(hipStreamBeginCapture(p->stream[g], hipStreamCaptureModeThreadLocal));
+                    rc = enqueue_slice_step(m, d_frac, d_types, d_lengths, d_angles, d_off, B, N, seed, d_const_types,
+                                            d_fixed_lengths, d_lattice, w, p->stream[g], r[g], nullptr);
+                    hipError_t e = hipStreamEndCapture(p->stream[g], &graph);
+                    if (rc) {
+                        if (graph) (void)hipGraphDestroy(graph);
+                        return rc;
+                    }
+                    ARREAU_CHECK_HIP(e);
+                    e = hipGraphInstantiate(&p->exec[g], graph, nullptr, nullptr, 0);
+                    (void)hipGraphDestroy(graph);
+                    ARREAU_CHECK_HIP(e);
+                }
+                memcpy(p->graph_key, key, sizeof(key));
+            }
+            for (int i = 1; i < n_steps; ++i)
+                for (int g = 0; g < p->G; ++g) ARREAU_CHECK_HIP(hipGraphLaunch(p->exec[g], p->stream[g]));
+            for (int g = 0; g < p->G; ++g) {
+                ARREAU_CHECK_HIP(hipEventRecord(p->join[g], p->stream[g]));
+                ARREAU_CHECK_HIP(hipStreamWaitEvent(s, p->join[g], 0));
+            }
+            return ARREAU_OK;
+        }
     }
     // One step captured into a hipGraph and replayed: the timestep lives on the device (prep_kernel advances it), the noise
     // is a function of (seed, timestep, element), so every replay is the next step of the same trajectory as the eager loop.

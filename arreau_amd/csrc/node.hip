@@ -31,24 +31,24 @@ __global__ __launch_bounds__(128) void prep_kernel(
     const int32_t* __restrict__ tstep, const int32_t* __restrict__ offsets, const float* __restrict__ betas,
     const float* __restrict__ t_emb_w, const float* __restrict__ embT, int S, int C, int T,
     float* __restrict__ lattice, float* __restrict__ cart, int32_t* __restrict__ batch, float* __restrict__ cvec,
-    int32_t* __restrict__ status, int32_t* __restrict__ t_next, int32_t* __restrict__ t_cur) {
+    int32_t* __restrict__ status, int32_t* __restrict__ t_next, int32_t* __restrict__ t_cur, int b0) {
     __shared__ float feat[ARREAU_T_EMB_DIM + ARREAU_N_CRYSTAL_FEATS];
     // Sampling loop on device time (arreau_sample_loop): this workgroup is the only reader of its crystal's entry of
     // t_next in this launch; it publishes the timestep of the step in t_cur (read by the later kernels of the step) and
     // leaves the next one behind, so a captured step can be replayed without host-side bookkeeping.
     __shared__ int t_sh;
+    const int b = b0 + blockIdx.x;
     if (threadIdx.x == 0) {
         if (t_next != nullptr) {
-            t_sh = t_next[blockIdx.x];
-            t_cur[blockIdx.x] = t_sh;
-            t_next[blockIdx.x] = t_sh - 1;
+            t_sh = t_next[b];
+            t_cur[b] = t_sh;
+            t_next[b] = t_sh - 1;
         } else {
-            t_sh = tstep[blockIdx.x];
+            t_sh = tstep[b];
         }
     }
     __syncthreads();
     __shared__ float Lm[9];
-    const int b = blockIdx.x;
     const int first = offsets[b], n = offsets[b + 1] - first;
     const float* len = lengths + 3 * b;
     const float* ang = angles + 3 * b;
@@ -92,10 +92,11 @@ __global__ __launch_bounds__(128) void prep_kernel(
 
 int arreau_launch_prep(const arreau_model* m, const float* frac, const float* lengths, const float* angles,
                        const int32_t* t, const int32_t* offsets, int B, int N, float* lattice, float* cart,
-                       int32_t* batch, float* cvec, hipStream_t s, int32_t* t_next, int32_t* t_cur) {
-    if (B == 0) return ARREAU_OK;
-    hipLaunchKernelGGL(prep_kernel, dim3(B), dim3(128), 0, s, frac, lengths, angles, t, offsets, m->vp_betas,
-                       m->t_emb_w, m->embT, m->S, m->C, m->T, lattice, cart, batch, cvec, m->status, t_next, t_cur);
+                       int32_t* batch, float* cvec, hipStream_t s, int32_t* t_next, int32_t* t_cur, NodeRange r) {
+    const int b0 = r.b0, b1 = r.b1 < 0 ? B : r.b1;
+    if (b1 <= b0) return ARREAU_OK;
+    hipLaunchKernelGGL(prep_kernel, dim3(b1 - b0), dim3(128), 0, s, frac, lengths, angles, t, offsets, m->vp_betas,
+                       m->t_emb_w, m->embT, m->S, m->C, m->T, lattice, cart, batch, cvec, m->status, t_next, t_cur, b0);
     ARREAU_CHECK_HIP(hipGetLastError());
     return ARREAU_OK;
 }

@@ -12,8 +12,8 @@ __global__ void reverse_lattice_kernel(float* __restrict__ lengths, const float*
                                        const float* __restrict__ len0, StepNoiseSrc noise,
                                        const float* __restrict__ alpha_bars, const float* __restrict__ betas, int B,
                                        int T, float* __restrict__ lattice, const float* __restrict__ fixed_lengths,
-                                       int32_t* __restrict__ status) {
-    const int b = blockIdx.x * blockDim.x + threadIdx.x;
+                                       int32_t* __restrict__ status, int b0) {
+    const int b = b0 + blockIdx.x * blockDim.x + threadIdx.x;  // crystals b0 .. B-1
     if (b >= B) return;
     const float* __restrict__ z = noise.z_lattice;
     int t = tstep[b];
@@ -66,11 +66,11 @@ __global__ __launch_bounds__(256) void reverse_atoms_kernel(
     const int32_t* __restrict__ offsets, int B, int N, const float* __restrict__ eps,
     const float* __restrict__ logits, StepNoiseSrc noise,
     const float* __restrict__ ve_sigmas, const float* __restrict__ q1t, const float* __restrict__ qmats, int S,
-    int T, const int32_t* __restrict__ const_types, int absorbing, int32_t* __restrict__ status) {
+    int T, const int32_t* __restrict__ const_types, int absorbing, int32_t* __restrict__ status, int n0) {
     const float* __restrict__ z_frac = noise.z_frac;
     const float* __restrict__ u_types = noise.u_types;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int i = blockIdx.x * 4 + wave;
+    const int i = n0 + blockIdx.x * 4 + wave;  // atoms n0 .. N-1
     if (i >= N) return;  // wave-uniform; no block-level barrier below
     // crystal of this atom = largest b with offsets[b] <= i: a 64-ary search by the whole wave (each level one
     // load per lane + a ballot) instead of log2(B) dependent loads
@@ -192,13 +192,17 @@ __global__ __launch_bounds__(256) void reverse_atoms_kernel(
 int arreau_launch_reverse(const arreau_model* m, float* d_frac, int32_t* d_types, float* d_lengths, const float* d_angles,
                           const int32_t* d_t, const int32_t* d_off, int B, int N, const float* d_eps,
                           const float* d_logits, const float* d_len0, StepNoiseSrc noise, const int32_t* d_const_types,
-                          float* d_lattice, hipStream_t s, const float* d_fixed_lengths) {
-    hipLaunchKernelGGL(reverse_lattice_kernel, dim3((B + 127) / 128), dim3(128), 0, s, d_lengths, d_angles, d_t, d_off,
-                       d_len0, noise, m->vp_alpha_bars, m->vp_betas, B, m->T, d_lattice, d_fixed_lengths, m->status);
-    ARREAU_CHECK_HIP(hipGetLastError());
-    if (N > 0) {
-        hipLaunchKernelGGL(reverse_atoms_kernel, dim3((N + 3) / 4), dim3(256), 0, s, d_frac, d_types, d_t, d_off, B, N,
-                           d_eps, d_logits, noise, m->ve_sigmas, m->q1t, m->qmats, m->S, m->T, d_const_types, m->qmats_absorbing, m->status);
+                          float* d_lattice, hipStream_t s, const float* d_fixed_lengths, NodeRange r) {
+    const int n0 = r.n0, n1 = r.n1 < 0 ? N : r.n1, b0 = r.b0, b1 = r.b1 < 0 ? B : r.b1;
+    if (b1 > b0) {
+        hipLaunchKernelGGL(reverse_lattice_kernel, dim3((b1 - b0 + 127) / 128), dim3(128), 0, s, d_lengths, d_angles, d_t, d_off,
+                           d_len0, noise, m->vp_alpha_bars, m->vp_betas, b1, m->T, d_lattice, d_fixed_lengths, m->status, b0);
+        ARREAU_CHECK_HIP(hipGetLastError());
+    }
+    if (n1 > n0) {
+        hipLaunchKernelGGL(reverse_atoms_kernel, dim3((n1 - n0 + 3) / 4), dim3(256), 0, s, d_frac, d_types, d_t, d_off, B, n1,
+                           d_eps, d_logits, noise, m->ve_sigmas, m->q1t, m->qmats, m->S, m->T, d_const_types, m->qmats_absorbing,
+                           m->status, n0);
         ARREAU_CHECK_HIP(hipGetLastError());
     }
     return ARREAU_OK;

@@ -891,7 +891,11 @@ def test_sliced_multi_stream_execution_is_bitwise_the_whole_batch(dev, full_mode
     args = (d(frac), d(types.to(torch.int32)), d(lengths), d(angles), t_c, off)
     eng.set_batch_layout(na, groups=1)
     whole = eng.predict_scores(*args)
-    eng.set_batch_layout(na, groups=groups)
+    os.environ["ARREAU_SLICE_EAGER"] = "1"  # fork-join slicing of a single evaluation (read when the layout is set)
+    try:
+        eng.set_batch_layout(na, groups=groups)
+    finally:
+        del os.environ["ARREAU_SLICE_EAGER"]
     sliced = eng.predict_scores(*args)
     for x, y in zip(whole, sliced):
         assert torch.equal(x, y)
@@ -903,8 +907,8 @@ def test_sliced_multi_stream_execution_is_bitwise_the_whole_batch(dev, full_mode
 
     eng.set_batch_layout(na, groups=1)
     ref = loop(False)
-    eng.set_batch_layout(na, groups=groups)
-    for use_graph in (False, True):
+    eng.set_batch_layout(na, groups=groups)  # graph mode: pipelined slices (own chain per slice, staggered, no per-step join)
+    for use_graph in (False, True, True):    # (the second graph run reuses the cached per-slice graphs)
         for x, y in zip(ref, loop(use_graph)):
             assert torch.equal(x, y), use_graph
     eng.set_batch_layout(na, groups=1)
