@@ -241,7 +241,7 @@ __global__ __launch_bounds__(512, 4) void conv_kernel(
     const int32_t* __restrict__ deg, const int32_t* __restrict__ src,
     const float* __restrict__ x_in,      // [N][16][C]
     const float* __restrict__ fk,        // [16(o)][16(p)][C]
-    const float* __restrict__ conv_bias, int N, int k,
+    const float* __restrict__ conv_bias, int n0, int N /* receivers n0 .. n0 + N - 1 */, int k,
     float* __restrict__ x_conv)          // [N][16][C]
 {
     static_assert(C == 128, "thread mapping assumes C = 128");
@@ -265,8 +265,9 @@ __global__ __launch_bounds__(512, 4) void conv_kernel(
     const int n_iter = xcd_order ? ((N + 8 * CONV_GROUP - 1) / (8 * CONV_GROUP)) * CONV_GROUP : N;  // local node slots per XCD
     int buf = 0;
     for (int m = xcd_order ? wg_in_xcd : (int)blockIdx.x; m < n_iter; m += xcd_order ? wgs_per_xcd : (int)gridDim.x) {
-        const int n = xcd_order ? ((m / CONV_GROUP) * 8 + xcd) * CONV_GROUP + (m % CONV_GROUP) : m;
-        if (n >= N) continue;  // workgroup-uniform
+        const int nl = xcd_order ? ((m / CONV_GROUP) * 8 + xcd) * CONV_GROUP + (m % CONV_GROUP) : m;
+        if (nl >= N) continue;  // workgroup-uniform
+        const int n = n0 + nl;
         buf ^= 1;
         // ---- gather . multiply . ordered sum over the in-edges -------------------------------------
         const int nd = min(deg[n], k);
@@ -669,7 +670,7 @@ int arreau_launch_node_layer(const arreau_model* m, int layer, const float* kbuf
     const size_t mlp_layer = (size_t)2 * H * C;  // floats of W1 + W2, packed
     const int conv_blocks = N < 512 ? N : 512;   // persistent: 2 workgroups of 512 threads per CU (a multiple of 8: XCD-aware order)
     // conv variant: 1 (default, k = 8 only) = streamed form (K blocks by LDS-DMA, one workgroup per CU); 0 = register form
-    const int conv_variant = m->conv_variant;
+    const int conv_variant = r.conv_form >= 0 ? r.conv_form : m->conv_variant;
     m->ran_conv = (conv_variant == 1 && m->k == 8) ? 1 : 0;
     if (conv_variant == 1 && m->k == 8) {
         int blocks = Ng < 256 ? Ng : 256;
@@ -677,14 +678,13 @@ int arreau_launch_node_layer(const arreau_model* m, int layer, const float* kbuf
         hipLaunchKernelGGL((conv_kernel_streamed<128>), dim3(blocks), dim3(512), 0, s, kbuf + (size_t)layer * layer_stride, deg,
                            src, x_in, m->fk + (size_t)layer * 16 * 16 * C, m->conv_bias + (size_t)layer * C, n0, Ng, x_conv);
     } else {
-        if (!whole) {
-            arreau_set_error("conv kernel: range launches are implemented for the streamed form only");
-            return ARREAU_EINVAL;
-        }
-        hipLaunchKernelGGL((conv_kernel<128>), dim3(conv_blocks), dim3(512), 0, s, kbuf + (size_t)layer * layer_stride, deg,
-                           src, x_in, m->fk + (size_t)layer * 16 * 16 * C, m->conv_bias + (size_t)layer * C, N, m->k, x_conv);
+        int blocks = Ng < 512 ? Ng : 512;
+        if (r.wg_cap > 0 && blocks > r.wg_cap) blocks = r.wg_cap;
+        hipLaunchKernelGGL((conv_kernel<128>), dim3(whole ? conv_blocks : blocks), dim3(512), 0, s, kbuf + (size_t)layer * layer_stride,
+                           deg, src, x_in, m->fk + (size_t)layer * 16 * 16 * C, m->conv_bias + (size_t)layer * C, n0, Ng, m->k, x_conv);
     }
     ARREAU_CHECK_HIP(hipGetLastError());
+    if (r.after_conv) ARREAU_CHECK_HIP(hipEventRecord((hipEvent_t)r.after_conv, s));
     // variant switch: 3 (default) = fp16x3 on 16x16x32 MFMAs (node_f16m.hip); 2 = fp16x3 on 32x32x16 MFMAs (node_f16.hip) -- both
     // need weights that fit fp16; 1 = bf16x6 split-precision MLP kernel (node_bf16.hip); 0 = fp32-MFMA kernel below
     const int mlp_variant = m->mlp_variant;
