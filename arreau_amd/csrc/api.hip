@@ -215,38 +215,6 @@ int run_network(const arreau_model* m, const Workspace& w, bool given, int32_t* 
     // 1.66 ms unsliced (256 x 20, eager).  It stays as the test vehicle of the range launches (ARREAU_SLICE_EAGER); the
     // sampling loop uses the pipelined form (arreau_sample_loop).
     const bool sliced = p && p->eager && p->G > 1 && p->B == B && p->N == N && arreau_range_launches_supported(m);
-    // Experimental (ARREAU_NODE_PIPELINE=1, needs a two-slice layout): the interaction layers of the two halves of the
-    // batch on two streams, the second half one conv kernel behind the first, so that the HBM-bound conv of one half
-    // runs beside the matrix-bound MLP of the other -- on the same CUs when their footprints allow co-residence.
-    static const int node_pipe = [] { const char* e = getenv("ARREAU_NODE_PIPELINE"); return e ? atoi(e) : 0; }();
-    static const int node_pipe_conv = [] { const char* e = getenv("ARREAU_NODE_PIPELINE_CONV"); return e ? atoi(e) : 0; }();
-    if (node_pipe && !sliced && p && p->G == 2 && p->B == B && p->N == N && arreau_range_launches_supported(m)) {
-        if (!given && (rc = arreau_launch_neighbor(w.cart, w.lattice, d_off, w.batch, B, N, m->cfg.radius, m->k, deg, src, w.cell, dir, dist, s)))
-            return rc;
-        if ((rc = run_edge_kernel(m, dir, dist, deg, w, N, s))) return rc;
-        if ((rc = arreau_launch_embed(m, d_frac, d_types, w.lattice, w.batch, w.cvec, N, w.xa, s))) return rc;
-        ARREAU_CHECK_HIP(hipEventRecord(p->fork, s));
-        for (int g = 0; g < 2; ++g) {
-            hipStream_t sg = p->stream[g];
-            ARREAU_CHECK_HIP(hipStreamWaitEvent(sg, p->fork, 0));
-            if (g == 1) ARREAU_CHECK_HIP(hipStreamWaitEvent(sg, p->stagger[0], 0));
-            NodeRange r;
-            r.n0 = p->nb[g]; r.n1 = p->nb[g + 1]; r.b0 = p->bb[g]; r.b1 = p->bb[g + 1];
-            r.conv_form = node_pipe_conv;
-            float* xin = w.xa;
-            float* xout = w.xb;
-            for (int l = 0; l < m->L; ++l) {
-                NodeRange rl = r;
-                if (g == 0 && l == 0) rl.after_conv = (void*)p->stagger[0];
-                if ((rc = arreau_launch_node_layer(m, l, w.kbuf, deg, src, xin, w.xc, xout, w.xbar, w.vsum, N, sg, rl))) return rc;
-                float* tmp = xin; xin = xout; xout = tmp;
-            }
-            if ((rc = arreau_launch_readout(m, w.xbar, w.vsum, d_off, B, N, w.gs, d_eps, d_logits, d_len0, sg, r))) return rc;
-            ARREAU_CHECK_HIP(hipEventRecord(p->join[g], sg));
-            ARREAU_CHECK_HIP(hipStreamWaitEvent(s, p->join[g], 0));
-        }
-        return ARREAU_OK;
-    }
     if (!sliced) {
         if (!given && (rc = arreau_launch_neighbor(w.cart, w.lattice, d_off, w.batch, B, N, m->cfg.radius, m->k, deg, src, w.cell, dir, dist, s)))
             return rc;
@@ -413,8 +381,7 @@ extern "C" int arreau_sample_loop(arreau_model* m, float* d_frac, int32_t* d_typ
     // kernel another streams its K blocks from HBM.  Every slice computes exactly what it computes in the whole-batch run.
     {
         arreau_partition* p = m->part;
-        static const bool node_pipe = getenv("ARREAU_NODE_PIPELINE") != nullptr && atoi(getenv("ARREAU_NODE_PIPELINE")) != 0;
-        if (!node_pipe && p && p->G > 1 && p->B == B && p->N == N && arreau_range_launches_supported(m)) {
+        if (p && p->G > 1 && p->B == B && p->N == N && arreau_range_launches_supported(m)) {
             static const int n_cu = [] {
                 int dev = 0;
                 hipDeviceProp_t prop;

@@ -214,8 +214,6 @@ void arreau_model_retire_graph(arreau_model* m, void* exec, void* stream);  // t
 // to run crystal-aligned slices of the batch on separate streams (api.hip).
 struct NodeRange {
     int n0 = 0, n1 = -1, b0 = 0, b1 = -1, wg_cap = 0;
-    int conv_form = -1;          // >= 0: conv kernel form for this launch (0 register form, 1 streamed), else the model's
-    void* after_conv = nullptr;  // hipEvent_t recorded behind the conv kernel of arreau_launch_node_layer (pipelining)
 };
 
 // launchers implemented in the other translation units ------------------------------------------

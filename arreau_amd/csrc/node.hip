@@ -670,7 +670,7 @@ int arreau_launch_node_layer(const arreau_model* m, int layer, const float* kbuf
     const size_t mlp_layer = (size_t)2 * H * C;  // floats of W1 + W2, packed
     const int conv_blocks = N < 512 ? N : 512;   // persistent: 2 workgroups of 512 threads per CU (a multiple of 8: XCD-aware order)
     // conv variant: 1 (default, k = 8 only) = streamed form (K blocks by LDS-DMA, one workgroup per CU); 0 = register form
-    const int conv_variant = r.conv_form >= 0 ? r.conv_form : m->conv_variant;
+    const int conv_variant = m->conv_variant;
     m->ran_conv = (conv_variant == 1 && m->k == 8) ? 1 : 0;
     if (conv_variant == 1 && m->k == 8) {
         int blocks = Ng < 256 ? Ng : 256;
@@ -684,7 +684,6 @@ int arreau_launch_node_layer(const arreau_model* m, int layer, const float* kbuf
                            deg, src, x_in, m->fk + (size_t)layer * 16 * 16 * C, m->conv_bias + (size_t)layer * C, n0, Ng, m->k, x_conv);
     }
     ARREAU_CHECK_HIP(hipGetLastError());
-    if (r.after_conv) ARREAU_CHECK_HIP(hipEventRecord((hipEvent_t)r.after_conv, s));
     // variant switch: 3 (default) = fp16x3 on 16x16x32 MFMAs (node_f16m.hip); 2 = fp16x3 on 32x32x16 MFMAs (node_f16.hip) -- both
     // need weights that fit fp16; 1 = bf16x6 split-precision MLP kernel (node_bf16.hip); 0 = fp32-MFMA kernel below
     const int mlp_variant = m->mlp_variant;
