@@ -131,7 +131,8 @@ class DiffusionLoss(nn.Module):
     def sample(self, *, model, z_table: AtomicNumberTable, t_emb_weights=None, num_atoms_per_sample,
                num_samples_in_batch: int, vis_name: str = "", visualization_setting=VisualizationSetting.NONE,
                show_bonds: bool = False, constant_atoms: Optional[torch.Tensor] = None, noise: str = "philox",
-               max_steps: Optional[int] = None, use_graph: Optional[bool] = None, seed: Optional[int] = None) -> SampleResult:
+               max_steps: Optional[int] = None, use_graph: Optional[bool] = None, seed: Optional[int] = None,
+               fixed_cell: bool = False) -> SampleResult:
         """diffusion_loss.py:276-377.  The initial state is drawn on the host exactly like the reference (numpy
         uniforms for the angles, then randn lengths, randn fractional coordinates from torch's global CPU generator).
         Per-step noise:
@@ -144,7 +145,9 @@ class DiffusionLoss(nn.Module):
               least 200 steps, which amortise the capture).
           noise="reference": randn[B,3], randn[N,3], rand[N,S] from the global CPU generator in the reference's order
               (diffusion_helpers.py:193-197, :79; d3pm.py:206), uploaded every step -- the parity mode.
-          noise="device": the same loop with torch's device generator (three RNG launches per step)."""
+          noise="device": the same loop with torch's device generator (three RNG launches per step).
+        `fixed_cell=True` (extension, noise="philox" only): fixed-cell sampling -- the initial cell lengths are re-imposed
+        after every step (arreau_sample_loop's d_fixed_lengths); coordinates and species are sampled as usual."""
         if visualization_setting != VisualizationSetting.NONE:
             raise NotImplementedError("per-step visualisation is outside this build; use VisualizationSetting.NONE")
         if noise not in ("philox", "device", "reference"):
@@ -182,8 +185,8 @@ class DiffusionLoss(nn.Module):
         off_d = crystal_offsets(num_atoms, dev)
         lattice_d = torch.zeros((B, 3, 3), **f32)
         n_steps = self.T - 1 if max_steps is None else min(self.T - 1, int(max_steps))
-        if use_graph and noise != "philox":
-            raise ValueError("graph replay needs noise='philox' (the in-kernel generator)")
+        if (use_graph or fixed_cell) and noise != "philox":
+            raise ValueError("graph replay and fixed-cell sampling need noise='philox' (the in-kernel generator)")
 
         # Two pipelined slices of the batch (own stream and step graph each, staggered by one edge kernel; bit-identical
         # results) pay for batches that fill the chip several times over: 1.57-1.59 vs 1.61-1.62 ms per step at 256 x 20 on
@@ -195,7 +198,7 @@ class DiffusionLoss(nn.Module):
             if use_graph is None:
                 use_graph = n_steps >= 200  # capture + instantiation (about 2 ms) against ~4 us saved per kernel boundary
             eng.sample_loop(frac_d, types_d, len_d, ang_d, off_d, self.T - 1, n_steps, seed, const_d, lattice_d,
-                            use_graph=bool(use_graph))
+                            use_graph=bool(use_graph), fixed_lengths=len_d.clone() if fixed_cell else None)
         else:
             t_d = torch.empty(B, device=dev, dtype=torch.int32)
             done = 0

@@ -218,7 +218,7 @@ class PONITA_DIFFUSION(nn.Module):
                visualization_setting: VisualizationSetting = VisualizationSetting.NONE, show_bonds: bool = False,
                use_constant_atomic_symbols: Optional[list] = None, noise: str = "philox",
                max_steps: Optional[int] = None, use_graph: Optional[bool] = None,
-               seed: Optional[int] = None) -> SampleResult:
+               seed: Optional[int] = None, fixed_cell: bool = False) -> SampleResult:
         """lightning_wrappers/diffusion.py:220-253.  `num_atoms_per_sample` may also be a sequence with one atom count
         per crystal of the batch (extension; the reference supports a single int)."""
         z_table = AtomicNumberTable(self.z_table_zs.tolist())
@@ -235,4 +235,4 @@ class PONITA_DIFFUSION(nn.Module):
             model=self, z_table=z_table, t_emb_weights=self.t_emb, num_atoms_per_sample=num_atoms_per_sample,
             num_samples_in_batch=num_samples_in_batch, vis_name=f"{DIFFUSION_DIR}/step",
             visualization_setting=visualization_setting, show_bonds=show_bonds, constant_atoms=constant_atoms,
-            noise=noise, max_steps=max_steps, use_graph=use_graph, seed=seed)
+            noise=noise, max_steps=max_steps, use_graph=use_graph, seed=seed, fixed_cell=fixed_cell)

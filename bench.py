@@ -104,6 +104,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fp32-variant", action="store_true", help="skip the second timed loop on the fp32-MFMA kernels")
     ap.add_argument("--cpu-steps", type=int, default=2)
+    ap.add_argument("--no-full-sampler", action="store_true", help="skip the measured run of the whole T-1 step sampler")
     ap.add_argument("--groups", type=int, default=0, help="slices of the batch run on separate streams (0: library default)")
     args = ap.parse_args(argv)
     B, n, T = CONFIGS[args.config or "c2"]
@@ -330,6 +331,24 @@ def run_rank(args, rank, local_rank, world):
                               "`value` is the eager whole-batch loop, which is also what the edge-kernel events time"}
         eng.check_status()
 
+    # The headline metric measured rather than extrapolated: ONE call of PONITA_DIFFUSION.sample for the whole sampler
+    # (T - 1 network evaluations of this batch; host-side initial draws, the library loop in its default mode, the
+    # SampleResult copied back to the host), wall clock.  fixed_cell keeps the synthetic checkpoint's cells at the
+    # sampler-start density, as in the timed loop above.
+    full_sampler = None
+    if world == 1 and not args.no_full_sampler and B * n <= 256 * 20:
+        from arreau_amd.diffusion.inference.visualize_crystal import VisualizationSetting
+        torch.manual_seed(5)
+        np.random.seed(5)
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        res = model.sample(n, B, VisualizationSetting.NONE, False, fixed_cell=True)
+        wall = time.perf_counter() - t0
+        assert res.frac_x.shape == (N, 3) and np.isfinite(res.frac_x).all()
+        full_sampler = {"wall_s": wall, "steps": T - 1, "crystals": B, "crystals_per_min": 60.0 * B / wall,
+                        "ms_per_step_incl_everything": 1e3 * wall / (T - 1)}
+        eng.set_batch_layout(torch.full((B,), n), groups=groups)
+
     # second, short timed loop on the exact fp32-MFMA kernels (v_mfma_f32_32x32x2_f32): what the same step costs
     # without the split-precision scheme, priced against the 157.3 TFLOP/s fp32 matrix peak
     fp32_variant = None
@@ -406,6 +425,7 @@ def run_rank(args, rank, local_rank, world):
                 "slices_per_gpu": launches_per_step,
             },
             "graph_loop": graph_loop,
+            "full_sampler_measured": full_sampler,
             "batch_steps_per_sec": world * args.steps / elapsed,
             "crystals_per_min": 60.0 * crystal_steps_per_s / (T - 1),
             "step_tflops_algorithmic": world * step_flops / (ms_per_step * 1e-3) / 1e12,
