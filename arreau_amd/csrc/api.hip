@@ -209,6 +209,17 @@ int run_network(const arreau_model* m, const Workspace& w, bool given, int32_t* 
                 const float* d_frac, const int32_t* d_types, const int32_t* d_off, int B, int N, float* d_eps,
                 float* d_logits, float* d_len0, hipStream_t s) {
     int rc;
+    if (arreau_general_path(m)) {
+        // shape-general fp32 kernels (train_net.hip): any hidden_dim / basis_dim / widening, plain weights (never stale)
+        arreau_model* mm = const_cast<arreau_model*>(m);  // the activation buffers are a cache owned by the model
+        if (!given && (rc = arreau_launch_neighbor(w.cart, w.lattice, d_off, w.batch, B, N, m->cfg.radius, m->k, deg, src, w.cell, dir, dist, s)))
+            return rc;
+        float* x0 = arreau_general_x0(mm, N, B, s);
+        if (!x0) return ARREAU_EHIP;
+        if ((rc = arreau_launch_embed(m, d_frac, d_types, w.lattice, w.batch, w.cvec, N, x0, s))) return rc;
+        return arreau_general_network(mm, arreau_graph_view{w.batch, deg, src, w.lattice, dir, dist}, d_off, B, N, d_eps, d_logits,
+                                      d_len0, s);
+    }
     arreau_partition* p = m->part;
     // Fork-join slicing of a single evaluation keeps the slices in lockstep (they start together and have the same work),
     // so it overlaps nothing and costs 4 G extra host calls per step: measured 1.70 / 2.59 ms per step at G = 2 / 4 against
@@ -258,8 +269,9 @@ extern "C" int arreau_predict_scores(const arreau_model* m, const float* d_frac,
     ARREAU_REQUIRE(m && d_frac && d_types && d_lengths && d_angles && d_t && d_off && d_eps && d_logits && d_len0,
                    "arreau_predict_scores: null pointer");
     ARREAU_REQUIRE(B >= 1 && N >= 0, "arreau_predict_scores: bad size");
-    ARREAU_REQUIRE(!m->packed_stale, "arreau_predict_scores: weights were updated for training only "
-                                     "(arreau_model_update_train_weights); re-create the model before sampling");
+    ARREAU_REQUIRE(!m->packed_stale || arreau_general_path(m),
+                   "arreau_predict_scores: weights were updated for training only (arreau_model_update_train_weights); "
+                   "re-create the model before sampling, or select the general path (arreau_model_set_variant(model, 5, -1))");
     ARREAU_REQUIRE(d_workspace != nullptr, "arreau_predict_scores: null workspace");
     Workspace w = carve(&m->cfg, N, B, d_workspace, workspace_bytes);
     if (w.bytes > workspace_bytes) {
@@ -289,7 +301,8 @@ extern "C" int arreau_ponita_forward(const arreau_model* m, const float* d_x, co
     ARREAU_REQUIRE(m && d_x && d_vec && d_lattice && d_off && d_deg && d_src && d_dir && d_dist && d_logits && d_vec_out &&
                        d_global_scalar, "arreau_ponita_forward: null pointer");
     ARREAU_REQUIRE(B >= 1 && N >= 0, "arreau_ponita_forward: bad size");
-    ARREAU_REQUIRE(!m->packed_stale, "arreau_ponita_forward: weights were updated for training only; re-create the model");
+    ARREAU_REQUIRE(!m->packed_stale || arreau_general_path(m),
+                   "arreau_ponita_forward: weights were updated for training only; re-create the model or select the general path");
     ARREAU_REQUIRE(d_workspace != nullptr, "arreau_ponita_forward: null workspace");
     Workspace w = carve(&m->cfg, N, B, d_workspace, workspace_bytes);
     if (w.bytes > workspace_bytes) {
@@ -300,6 +313,14 @@ extern "C" int arreau_ponita_forward(const arreau_model* m, const float* d_x, co
     int rc;
     if ((rc = arreau_launch_batch_index(d_off, B, N, w.batch, s))) return rc;
     w.lattice = const_cast<float*>(d_lattice);  // the edge kernel reads the caller's cells (cos features, invariants.py:82-85)
+    if (arreau_general_path(m)) {
+        arreau_model* mm = const_cast<arreau_model*>(m);
+        float* x0 = arreau_general_x0(mm, N, B, s);
+        if (!x0) return ARREAU_EHIP;
+        if ((rc = arreau_launch_embed_general(m, d_x, d_vec, N, x0, s))) return rc;
+        return arreau_general_network(mm, arreau_graph_view{w.batch, d_deg, d_src, d_lattice, d_dir, d_dist}, d_off, B, N,
+                                      d_vec_out, d_logits, d_global_scalar, s);
+    }
     if ((rc = run_edge_kernel(m, d_dir, d_dist, d_deg, w, N, s))) return rc;
     if ((rc = arreau_launch_embed_general(m, d_x, d_vec, N, w.xa, s))) return rc;
     return run_layers_and_readout(m, w, d_deg, d_src, d_off, B, N, d_vec_out, d_logits, d_global_scalar, s);
@@ -355,7 +376,8 @@ extern "C" int arreau_sample_loop(arreau_model* m, float* d_frac, int32_t* d_typ
                                   const float* d_fixed_lengths, float* d_lattice, void* d_workspace, size_t workspace_bytes, int32_t use_graph, void* stream) {
     ARREAU_REQUIRE(m && d_frac && d_types && d_lengths && d_angles && d_off && d_lattice, "arreau_sample_loop: null pointer");
     ARREAU_REQUIRE(B >= 1 && N >= 0 && n_steps >= 0, "arreau_sample_loop: bad size");
-    ARREAU_REQUIRE(!m->packed_stale, "arreau_sample_loop: weights were updated for training only; re-create the model");
+    ARREAU_REQUIRE(!m->packed_stale || arreau_general_path(m),
+                   "arreau_sample_loop: weights were updated for training only; re-create the model or select the general path");
     ARREAU_REQUIRE(t_start <= m->T && t_start - n_steps >= 0, "arreau_sample_loop: timesteps t_start .. t_start-n_steps+1 must lie in 1..T");
     ARREAU_REQUIRE(d_workspace != nullptr, "arreau_sample_loop: null workspace");
     Workspace w = carve(&m->cfg, N, B, d_workspace, workspace_bytes);

@@ -64,6 +64,7 @@ struct arreau_model {
     // crystal-aligned slices of the batch the score network may be run in, on separate streams (api.hip: set by
     // arreau_model_set_batch_layout; used when (B, N) of a call match and the default kernel set is selected)
     struct arreau_partition* part;
+    int fused;               // 1: shape (C, D, W) = (128, 256, 4), the fused kernels' packed weights exist
     int packed_stale;        // 1 after arreau_model_update_train_weights: the sampling kernels' packed planes are out of date
     void* loop_stream;       // hipStream_t / hipEvent_t of arreau_sample_loop's graph mode (capture is not allowed on the
     void* loop_event;        //   legacy default stream callers usually pass); created on first use
@@ -206,6 +207,19 @@ struct StepNoiseSrc {
 };
 
 void arreau_train_ctx_destroy(struct arreau_train_ctx* t);
+// edge_variant value that selects the shape-general fp32 network (train_net.hip) for the whole evaluation
+#define ARREAU_VARIANT_GENERAL 5
+inline bool arreau_general_path(const arreau_model* m) { return !m->fused || m->edge_variant == ARREAU_VARIANT_GENERAL; }
+// The score network on the shape-general fp32 kernels (the training forward without its own graph construction): graph
+// arrays and the embedded features x0 [N*16][C] (null: t.x already holds them) are the caller's; outputs as
+// arreau_predict_scores.  Keeps every activation (a following arreau_train_backward is valid when keep_graph copies).
+struct arreau_graph_view {
+    const int32_t *batch, *deg, *src;
+    const float *lattice, *dir, *dist;
+};
+int arreau_general_network(arreau_model* m, const arreau_graph_view& g, const int32_t* d_off, int B, int N, float* d_eps,
+                           float* d_logits, float* d_len0, hipStream_t s);
+float* arreau_general_x0(arreau_model* m, int N, int B, hipStream_t s);  // (re)sizes the context; returns its layer-0 feature buffer
 void arreau_model_retire_graph(arreau_model* m, void* exec, void* stream);  // takes ownership; frees the previous one
 
 // A launch over part of the batch: receivers / atoms n0 .. n1-1 (n1 < 0: all), crystals b0 .. b1-1, and for the persistent

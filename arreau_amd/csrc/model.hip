@@ -252,8 +252,13 @@ extern "C" int arreau_model_create(const arreau_config* cfg, const arreau_state_
     const int H = W * C;
     ARREAU_REQUIRE(O == ARREAU_ORI, "unsupported num_ori (this build handles num_ori = 16)");
     ARREAU_REQUIRE(cfg->degree == 3, "unsupported polynomial degree (this build handles degree = 3)");
-    ARREAU_REQUIRE(C == 128 && D == 256, "unsupported hidden_dim/basis_dim (this build instantiates C=128, D=256)");
-    ARREAU_REQUIRE(W == 4, "unsupported widening_factor (this build handles 4)");
+    // The fused kernels (edge_f16.hip, node*.hip) are instantiated for hidden_dim 128, basis_dim 256, widening 4 -- the
+    // shipped checkpoint's shape.  Any other shape (the reference's `make train` preset is hidden_dim = 200) runs on the
+    // shape-general fp32 kernels of train_net.hip (exact fp32 MFMA GEMMs + element-wise kernels): same results, no fusion.
+    ARREAU_REQUIRE(C >= 4 && C % 4 == 0 && C <= 1024, "hidden_dim must be a multiple of 4 in 4..1024");
+    ARREAU_REQUIRE(D >= 4 && D % 4 == 0 && D <= 1024, "basis_dim must be a multiple of 4 in 4..1024");
+    ARREAU_REQUIRE(W >= 1 && H <= 1024, "widening_factor * hidden_dim must be at most 1024");
+    const bool fused = C == 128 && D == 256 && W == 4;
     ARREAU_REQUIRE(k >= 1 && k <= ARREAU_MAX_K, "max_neighbors must be in 1..8");
     ARREAU_REQUIRE(S >= 2 && S <= 124, "num_atomic_states must be in 2..124");
     ARREAU_REQUIRE(L >= 1 && L <= 8 && T >= 2, "bad num_layers (1..8) / num_timesteps");
@@ -276,21 +281,23 @@ extern "C" int arreau_model_create(const arreau_config* cfg, const arreau_state_
     const size_t n_w2 = (size_t)(D / 32) * (C / 32) * ARREAU_PACK_TILE_FLOATS;
     const size_t wk_tile = (size_t)(C / 32) * (D / 32) * ARREAU_PACK_TILE_FLOATS;
     const size_t stream_pad = 16 * 256;
-    const size_t off_w1p = bb.reserve(n_w1 + n_w2 + wk_tile * L + stream_pad);
+    const size_t off_w1p = bb.reserve(fused ? n_w1 + n_w2 + wk_tile * L + stream_pad : 0);
     const size_t off_w2p = off_w1p + n_w1;
     const size_t off_wkp = off_w2p + n_w2;
-    pack_linear(w1f.data(), C, ARREAU_MONO_PAD, ARREAU_MONO_PAD, C, ARREAU_MONO_PAD, bb.data.data() + off_w1p);
-    pack_linear(sd->basis_w2, D, C, C, D, C, bb.data.data() + off_w2p);
-    for (int l = 0; l < L; ++l)
-        pack_linear(sd->conv_kernel_w + (size_t)l * C * D, C, D, D, C, D, bb.data.data() + off_wkp + l * wk_tile);
+    if (fused) {
+        pack_linear(w1f.data(), C, ARREAU_MONO_PAD, ARREAU_MONO_PAD, C, ARREAU_MONO_PAD, bb.data.data() + off_w1p);
+        pack_linear(sd->basis_w2, D, C, C, D, C, bb.data.data() + off_w2p);
+        for (int l = 0; l < L; ++l)
+            pack_linear(sd->conv_kernel_w + (size_t)l * C * D, C, D, D, C, D, bb.data.data() + off_wkp + l * wk_tile);
+    }
     const size_t off_b1 = bb.put(sd->basis_b1, C);
     const size_t off_b2 = bb.put(sd->basis_b2, D);
     // the same three matrices as bf16x3 chunks (one chunk per output tile): w1 | w2 | wk_0..L-1
     const size_t h_w1 = (size_t)(C / 32) * (ARREAU_MONO_PAD / 32) * 6 * 512;   // uint16 count
     const size_t h_w2 = (size_t)(D / 32) * (C / 32) * 6 * 512;
     const size_t h_wk = (size_t)(C / 32) * (D / 32) * 6 * 512;
-    const size_t off_es16 = bb.reserve((h_w1 + h_w2 + h_wk * L) / 2 + 64);
-    {
+    const size_t off_es16 = bb.reserve(fused ? (h_w1 + h_w2 + h_wk * L) / 2 + 64 : 0);
+    if (fused) {
         uint16_t* q = reinterpret_cast<uint16_t*>(bb.data.data() + off_es16);
         pack_linear_bf16x3(w1f.data(), C, ARREAU_MONO_PAD, ARREAU_MONO_PAD, C, ARREAU_MONO_PAD, q);
         pack_linear_bf16x3(sd->basis_w2, D, C, C, D, C, q + h_w1);
@@ -302,9 +309,9 @@ extern "C" int arreau_model_create(const arreau_config* cfg, const arreau_state_
     const size_t f_w1 = (size_t)(C / 32) * (ARREAU_MONO_PAD / 32) * 4 * 512;   // uint16 count
     const size_t f_w2 = (size_t)(D / 32) * (C / 32) * 4 * 512;
     const size_t f_wk = (size_t)(C / 32) * (D / 32) * 4 * 512;
-    const size_t off_ef16 = bb.reserve((f_w1 + f_w2 + f_wk * L) / 2 + 64);
+    const size_t off_ef16 = bb.reserve(fused ? (f_w1 + f_w2 + f_wk * L) / 2 + 64 : 0);
     float wmax16 = 0.f;
-    {
+    if (fused) {
         uint16_t* q = reinterpret_cast<uint16_t*>(bb.data.data() + off_ef16);
         wmax16 = fmaxf(wmax16, pack_linear_f16x3(w1f.data(), C, ARREAU_MONO_PAD, ARREAU_MONO_PAD, C, ARREAU_MONO_PAD, q));
         wmax16 = fmaxf(wmax16, pack_linear_f16x3_m16(sd->basis_w2, D, C, C, q + f_w1));  // K = re-laid layer-1 tiles
@@ -322,8 +329,8 @@ extern "C" int arreau_model_create(const arreau_config* cfg, const arreau_state_
     const int HQ = H / 4;
     const size_t q1 = (size_t)(HQ / 32) * (C / 32) * ARREAU_PACK_TILE_FLOATS;
     const size_t q2 = (size_t)(C / 32) * (HQ / 32) * ARREAU_PACK_TILE_FLOATS;
-    const size_t off_mlp = bb.reserve((q1 + q2) * 4 * L + stream_pad);
-    for (int l = 0; l < L; ++l)
+    const size_t off_mlp = bb.reserve(fused ? (q1 + q2) * 4 * L + stream_pad : 0);
+    for (int l = 0; l < L && fused; ++l)
         for (int w = 0; w < 4; ++w) {
             float* dst = bb.data.data() + off_mlp + ((size_t)l * 4 + w) * (q1 + q2);
             pack_linear(sd->linear1_w + ((size_t)l * H + (size_t)w * HQ) * C, HQ, C, C, HQ, C, dst);
@@ -332,8 +339,8 @@ extern "C" int arreau_model_create(const arreau_config* cfg, const arreau_state_
     // the same per-quarter layout as bf16x3 chunks (one 24 KiB block per output tile; the kernel takes two per chunk)
     const size_t hq1 = (size_t)(HQ / 32) * (C / 32) * 6 * 512;   // uint16 count of W1 quarter
     const size_t hq2 = (size_t)(C / 32) * (HQ / 32) * 6 * 512;   // uint16 count of W2 quarter
-    const size_t off_mlp16 = bb.reserve((hq1 + hq2) * 4 * L / 2 + 64);
-    for (int l = 0; l < L; ++l)
+    const size_t off_mlp16 = bb.reserve(fused ? (hq1 + hq2) * 4 * L / 2 + 64 : 0);
+    for (int l = 0; l < L && fused; ++l)
         for (int w = 0; w < 4; ++w) {
             uint16_t* dst = reinterpret_cast<uint16_t*>(bb.data.data() + off_mlp16) + ((size_t)l * 4 + w) * (hq1 + hq2);
             pack_linear_bf16x3(sd->linear1_w + ((size_t)l * H + (size_t)w * HQ) * C, HQ, C, C, HQ, C, dst);
@@ -342,16 +349,16 @@ extern "C" int arreau_model_create(const arreau_config* cfg, const arreau_state_
     // ... and as fp16x3 chunks (16 KiB per output tile)
     const size_t fq1 = (size_t)(HQ / 32) * (C / 32) * 4 * 512;   // uint16 count of W1 quarter
     const size_t fq2 = (size_t)(C / 32) * (HQ / 32) * 4 * 512;   // uint16 count of W2 quarter
-    const size_t off_mlpf16 = bb.reserve((fq1 + fq2) * 4 * L / 2 + 64);
-    for (int l = 0; l < L; ++l)
+    const size_t off_mlpf16 = bb.reserve(fused ? (fq1 + fq2) * 4 * L / 2 + 64 : 0);
+    for (int l = 0; l < L && fused; ++l)
         for (int w = 0; w < 4; ++w) {
             uint16_t* dst = reinterpret_cast<uint16_t*>(bb.data.data() + off_mlpf16) + ((size_t)l * 4 + w) * (fq1 + fq2);
             wmax16 = fmaxf(wmax16, pack_linear_f16x3(sd->linear1_w + ((size_t)l * H + (size_t)w * HQ) * C, HQ, C, C, HQ, C, dst));
             wmax16 = fmaxf(wmax16, pack_linear_f16x3(sd->linear2_w + (size_t)l * C * H + (size_t)w * HQ, C, HQ, H, C, HQ, dst + fq1));
         }
     // ... and as fp16x3 chunks for the 16x16x32 kernel (native k order), same sizes
-    const size_t off_mlpf16m = bb.reserve((fq1 + fq2) * 4 * L / 2 + 64);
-    for (int l = 0; l < L; ++l)
+    const size_t off_mlpf16m = bb.reserve(fused ? (fq1 + fq2) * 4 * L / 2 + 64 : 0);
+    for (int l = 0; l < L && fused; ++l)
         for (int w = 0; w < 4; ++w) {
             uint16_t* dst = reinterpret_cast<uint16_t*>(bb.data.data() + off_mlpf16m) + ((size_t)l * 4 + w) * (fq1 + fq2);
             pack_linear_f16x3_m16(sd->linear1_w + ((size_t)l * H + (size_t)w * HQ) * C, HQ, C, C, dst, true);
@@ -382,8 +389,8 @@ extern "C" int arreau_model_create(const arreau_config* cfg, const arreau_state_
     // tiles of 1024 floats, + ARREAU_PF groups of slack behind the last layer for the prefetch ring
     const int RO_PAD = RO <= 96 ? 96 : ((RO + 31) / 32) * 32;  // the kernel is instantiated for three output tiles
     const size_t ro_layer = (size_t)(RO_PAD / 32) * (C / 32) * ARREAU_PACK_TILE_FLOATS;
-    tmp.assign((size_t)L * ro_layer + (size_t)ARREAU_PF * 256, 0.f);
-    for (int l = 0; l < L; ++l) pack_linear(sd->readout_w + (size_t)l * RO * C, RO, C, C, RO_PAD, C, tmp.data() + (size_t)l * ro_layer);
+    tmp.assign(fused ? (size_t)L * ro_layer + (size_t)ARREAU_PF * 256 : 0, 0.f);
+    for (int l = 0; l < L && fused; ++l) pack_linear(sd->readout_w + (size_t)l * RO * C, RO, C, C, RO_PAD, C, tmp.data() + (size_t)l * ro_layer);
     const size_t off_ro_pack = bb.put(tmp.data(), tmp.size());
     tmp.assign((size_t)L * C, 0.f);
     for (int l = 0; l < L; ++l)
@@ -433,7 +440,7 @@ extern "C" int arreau_model_create(const arreau_config* cfg, const arreau_state_
     }
     float* b = m->blob;
     m->ori = b + off_ori; m->w1p = b + off_w1p; m->b1 = b + off_b1; m->w2p = b + off_w2p; m->b2 = b + off_b2;
-    m->wkp = b + off_wkp; m->edge_bf16 = b + off_es16; m->edge_f16 = b + off_ef16; m->f16_ok = wmax16 < 60000.0f ? 1 : 0; m->fk = b + off_fk; m->conv_bias = b + off_conv_bias; m->ln_w = b + off_ln_w;
+    m->wkp = b + off_wkp; m->edge_bf16 = b + off_es16; m->edge_f16 = b + off_ef16; m->f16_ok = fused && wmax16 < 60000.0f ? 1 : 0; m->fk = b + off_fk; m->conv_bias = b + off_conv_bias; m->ln_w = b + off_ln_w;
     m->ln_b = b + off_ln_b; m->mlp = b + off_mlp; m->mlp_bf16 = b + off_mlp16; m->mlp_f16 = b + off_mlpf16; m->mlp_f16m = b + off_mlpf16m; m->mb1 = b + off_mb1; m->mb2 = b + off_mb2;
     m->ls = b + off_ls; m->embT = b + off_embT; m->ro_wT = b + off_ro_wT; m->ro_b = b + off_ro_b; m->ro_pack = b + off_ro_pack; m->ro_wv = b + off_ro_wv;
     for (int l = 0; l < L; ++l) m->ro_bv_host[l] = sd->readout_b[(size_t)l * RO + S];
@@ -461,6 +468,9 @@ extern "C" int arreau_model_create(const arreau_config* cfg, const arreau_state_
     m->conv_variant = env_int("ARREAU_CONV_VARIANT", 1);
     m->readout_variant = env_int("ARREAU_READOUT_VARIANT", 1);
     m->ran_edge = m->ran_mlp = m->ran_conv = -1;
+    m->fused = fused ? 1 : 0;
+    // ARREAU_GENERAL_PATH=1 (or edge variant 5): run the shape-general fp32 kernels also for the fused shape (cross-check)
+    if (!fused || getenv("ARREAU_GENERAL_PATH")) m->edge_variant = ARREAU_VARIANT_GENERAL;
 
     int rc = arreau_launch_fiber_precompute(m, s);
     if (rc == ARREAU_OK) {
@@ -513,8 +523,11 @@ extern "C" int arreau_model_config(const arreau_model* model, arreau_config* out
 
 extern "C" int arreau_model_set_variant(arreau_model* model, int32_t edge_variant, int32_t mlp_variant) {
     ARREAU_REQUIRE(model, "arreau_model_set_variant: null model");
-    ARREAU_REQUIRE(edge_variant >= -1 && edge_variant <= 4 && mlp_variant >= -1 && mlp_variant <= 3,
-                   "arreau_model_set_variant: edge variant must be in 0..4, mlp variant in 0..3 (-1 keeps)");
+    ARREAU_REQUIRE(edge_variant >= -1 && edge_variant <= ARREAU_VARIANT_GENERAL && mlp_variant >= -1 && mlp_variant <= 3,
+                   "arreau_model_set_variant: edge variant must be in 0..5, mlp variant in 0..3 (-1 keeps)");
+    ARREAU_REQUIRE(model->fused || edge_variant < 0 || edge_variant == ARREAU_VARIANT_GENERAL,
+                   "arreau_model_set_variant: this model's shape (hidden_dim, basis_dim, widening_factor) has no fused kernels; "
+                   "only the general path (edge variant 5) is available");
     if (edge_variant >= 0) model->edge_variant = edge_variant;
     if (mlp_variant >= 0) model->mlp_variant = mlp_variant;
     return ARREAU_OK;

@@ -688,23 +688,16 @@ static int ensure_ctx(arreau_model* m, int N, int B, hipStream_t s) {
     return ARREAU_OK;
 }
 
-extern "C" int arreau_train_forward(arreau_model* m, const float* d_frac, const int32_t* d_types, const float* d_lengths,
-                                    const float* d_angles, const int32_t* d_t, const int32_t* d_off, int32_t B, int32_t N,
-                                    float* d_eps, float* d_logits, float* d_len0, void* stream) {
-    ARREAU_REQUIRE(m && d_frac && d_types && d_lengths && d_angles && d_t && d_off && d_eps && d_logits && d_len0,
-                   "arreau_train_forward: null pointer");
-    ARREAU_REQUIRE(B >= 1 && N >= 1, "arreau_train_forward: bad size");
-    hipStream_t s = (hipStream_t)stream;
-    TRY(ensure_ctx(m, N, B, s));
+// The network from the edge basis to the read-outs, on graph arrays and layer-0 features supplied by the caller (t.x).
+int arreau_general_network(arreau_model* m, const arreau_graph_view& g, const int32_t* d_off, int B, int N, float* d_eps,
+                           float* d_logits, float* d_len0, hipStream_t s) {
+    ARREAU_REQUIRE(m->train && m->train->capN >= N && m->train->capB >= B, "arreau_general_network: context not prepared");
     arreau_train_ctx& t = *m->train;
     const int C = m->C, D = m->D, L = m->L, H = m->H, k = m->k, S = m->S, RO = S + 4;
     const long R = (long)N * k * 16, M = (long)N * 16;
-    t.tstep = d_t; t.offsets = d_off; t.types = d_types; t.frac = d_frac; t.lengths = d_lengths; t.angles = d_angles;
-    // geometry and graph: the sampling path's own kernels (prep, neighbour list)
-    TRY(arreau_launch_prep(m, d_frac, d_lengths, d_angles, d_t, d_off, B, N, t.lattice, t.cart, t.batch, t.cvec, s));
-    TRY(arreau_launch_neighbor(t.cart, t.lattice, d_off, t.batch, B, N, m->cfg.radius, k, t.deg, t.src, t.cell, t.dir, t.dist, s));
+    if (N == 0) return ARREAU_OK;
     // edge basis: kb = gelu(W2 gelu(W1 poly + b1) + b2) * window   (ponita.py:65,94)
-    LAUNCH(edge_rows_kernel, dim3(blocks(R)), dim3(256), t.dir, t.dist, t.deg, t.batch, t.lattice, m->ori, m->cfg.radius, N, k,
+    LAUNCH(edge_rows_kernel, dim3(blocks(R)), dim3(256), g.dir, g.dist, g.deg, g.batch, g.lattice, m->ori, m->cfg.radius, N, k,
            t.mono, t.window);
     TRY(linear(s, t, R, ARREAU_MONO_PAD, C, t.mono, t.w1f, t.h1pre));
     LAUNCH(bias_gelu_kernel, dim3(blocks(R * C)), dim3(256), t.h1pre, m->b1, (const float*)nullptr, R, C, t.h1);
@@ -716,10 +709,6 @@ extern "C" int arreau_train_forward(arreau_model* m, const float* d_frac, const 
     LAUNCH(bias_gelu_kernel, dim3(blocks(256L * C)), dim3(256), t.fh1pre, m->fiber_b1, (const float*)nullptr, 256L, C, t.fh1);
     TRY(linear(s, t, 256, C, D, t.fh1, m->fiber_w2, t.fh2pre));
     LAUNCH(bias_gelu_kernel, dim3(blocks(256L * D)), dim3(256), t.fh2pre, m->fiber_b2, (const float*)nullptr, 256L, D, t.fkb);
-    // embedding (ponita.py:98): x_0 = F . W_emb^T, embT = W_emb^T [S+78][C]
-    LAUNCH(features_kernel, dim3((unsigned)M), dim3(64), d_frac, d_types, d_lengths, d_angles, d_t, d_off, t.batch, t.lattice,
-           m->vp_betas, m->t_emb_w, m->ori, S, m->T, N, t.F);
-    TRY(gemm(s, t, (int)M, C, S + 78, t.F, S + 78, 1, m->embT, C, 1, t.x, C));
     ARREAU_CHECK_HIP(hipMemsetAsync(t.rbar, 0, (size_t)M * RO * sizeof(float), s));
     // kernel_l = kb . Wk_l^T for all layers in one product (conv.py:110; conv.kernel.weight stacked [L*C][D])
     TRY(linear(s, t, R, D, L * C, t.kb, t.wk, t.kern));
@@ -728,7 +717,7 @@ extern "C" int arreau_train_forward(arreau_model* m, const float* d_frac, const 
         float* xnext = t.x + (size_t)(l + 1) * M * C;
         float* x1 = t.x1 + (size_t)l * M * C;
         float* fk = t.fk + (size_t)l * 256 * C;
-        LAUNCH(conv_forward_kernel, dim3(blocks(M * C)), dim3(256), t.kern + (size_t)l * C, L * C, xl, t.deg, t.src, N, k, C, x1);
+        LAUNCH(conv_forward_kernel, dim3(blocks(M * C)), dim3(256), t.kern + (size_t)l * C, L * C, xl, g.deg, g.src, N, k, C, x1);
         TRY(linear(s, t, 256, D, C, t.fkb, m->fiber_wk + (size_t)l * C * D, fk));
         LAUNCH(mix_forward_kernel, dim3(blocks(M * C)), dim3(256), x1, fk, m->conv_bias + (size_t)l * C, N, C, t.dtmp);
         LAUNCH(ln_forward_kernel, dim3(blocks(M, 4)), dim3(256), t.dtmp, m->ln_w + (size_t)l * C, m->ln_b + (size_t)l * C, M, C,
@@ -746,7 +735,37 @@ extern "C" int arreau_train_forward(arreau_model* m, const float* d_frac, const 
     }
     LAUNCH(train_outputs_kernel, dim3(N), dim3(128), t.rbar, m->ro_b, m->ori, S, L, N, d_eps, d_logits, t.gs);
     LAUNCH(pool_crystals_kernel, dim3(blocks(3 * B, 128)), dim3(128), t.gs, d_off, B, d_len0);
+    m->ran_edge = m->ran_mlp = ARREAU_VARIANT_GENERAL;
+    m->ran_conv = ARREAU_VARIANT_GENERAL;
     return ARREAU_OK;
+}
+
+float* arreau_general_x0(arreau_model* m, int N, int B, hipStream_t s) {
+    if (ensure_ctx(m, N, B, s) != ARREAU_OK) return nullptr;
+    return m->train->x;
+}
+
+extern "C" int arreau_train_forward(arreau_model* m, const float* d_frac, const int32_t* d_types, const float* d_lengths,
+                                    const float* d_angles, const int32_t* d_t, const int32_t* d_off, int32_t B, int32_t N,
+                                    float* d_eps, float* d_logits, float* d_len0, void* stream) {
+    ARREAU_REQUIRE(m && d_frac && d_types && d_lengths && d_angles && d_t && d_off && d_eps && d_logits && d_len0,
+                   "arreau_train_forward: null pointer");
+    ARREAU_REQUIRE(B >= 1 && N >= 1, "arreau_train_forward: bad size");
+    hipStream_t s = (hipStream_t)stream;
+    TRY(ensure_ctx(m, N, B, s));
+    arreau_train_ctx& t = *m->train;
+    const int C = m->C, k = m->k, S = m->S;
+    const long M = (long)N * 16;
+    t.tstep = d_t; t.offsets = d_off; t.types = d_types; t.frac = d_frac; t.lengths = d_lengths; t.angles = d_angles;
+    // geometry and graph: the sampling path's own kernels (prep, neighbour list)
+    TRY(arreau_launch_prep(m, d_frac, d_lengths, d_angles, d_t, d_off, B, N, t.lattice, t.cart, t.batch, t.cvec, s));
+    TRY(arreau_launch_neighbor(t.cart, t.lattice, d_off, t.batch, B, N, m->cfg.radius, k, t.deg, t.src, t.cell, t.dir, t.dist, s));
+    // embedding (ponita.py:98): x_0 = F . W_emb^T, embT = W_emb^T [S+78][C]  (F is kept for the embedder's gradient)
+    LAUNCH(features_kernel, dim3((unsigned)M), dim3(64), d_frac, d_types, d_lengths, d_angles, d_t, d_off, t.batch, t.lattice,
+           m->vp_betas, m->t_emb_w, m->ori, S, m->T, N, t.F);
+    TRY(gemm(s, t, (int)M, C, S + 78, t.F, S + 78, 1, m->embT, C, 1, t.x, C));
+    return arreau_general_network(m, arreau_graph_view{t.batch, t.deg, t.src, t.lattice, t.dir, t.dist}, d_off, B, N, d_eps,
+                                  d_logits, d_len0, s);
 }
 
 extern "C" int arreau_train_backward(arreau_model* m, const float* d_g_eps, const float* d_g_logits, const float* d_g_len0,

@@ -4,6 +4,7 @@ Host-side plumbing only: tensors are allocated with torch, every arithmetic step
 state runs in libarreau_hip.so.
 """
 import ctypes
+import os
 
 import torch
 
@@ -73,6 +74,10 @@ class HipEngine:
         self._ws_cap = (0, 0)
         self.S, self.k = S, cfg.max_neighbors
         self.stale_for_sampling = False
+        # shapes without fused kernels run on the shape-general fp32 kernels (csrc/train_net.hip), which read the plain
+        # weights update_train_weights refreshes: such an engine never goes stale for sampling
+        self.fused_shape = (cfg.hidden_dim, cfg.basis_dim, cfg.widening_factor) == (128, 256, 4)
+        self._general = not self.fused_shape or bool(os.environ.get("ARREAU_GENERAL_PATH"))
 
     def close(self):
         if getattr(self, "_handle", None) is not None and self._handle.value:
@@ -125,8 +130,11 @@ class HipEngine:
 
     def set_variant(self, edge=-1, mlp=-1):
         """Select the arithmetic of the dense kernels (edge: 0 fp32 MFMA, 3 bf16x6, 4 fp16x3; mlp: 0 fp32 MFMA,
-        1 bf16x6, 2/3 fp16x3); -1 keeps."""
+        1 bf16x6, 2/3 fp16x3); -1 keeps.  edge = 5 runs the whole network on the shape-general fp32 GEMM kernels (the only
+        choice for shapes other than hidden_dim 128 / basis_dim 256 / widening 4)."""
         _hip.check(_hip.lib().arreau_model_set_variant(self._handle, int(edge), int(mlp)), "arreau_model_set_variant")
+        if int(edge) >= 0:
+            self._general = int(edge) == _hip.VARIANT_GENERAL
 
     def ponita_forward(self, x, vec, lattice, offsets, edges):
         """The inner operator seam (PonitaFiberBundle.forward on the reference's batch attributes).
@@ -284,7 +292,7 @@ class HipEngine:
         _hip.check(_hip.lib().arreau_model_update_train_weights(self._handle, ctypes.byref(csd), _hip.stream_ptr(dev)),
                    "arreau_model_update_train_weights")
         self._keep = d  # alive until the copies have been enqueued and run (stream-ordered; freed at the next update)
-        self.stale_for_sampling = True
+        self.stale_for_sampling = not self._general
 
     def conv_stats(self):
         """[L,3] unbiased std of (x, x_1, x_2) per layer from the last train_forward (FiberBundleConv.callibrate)."""

@@ -77,6 +77,16 @@ def main():
     ap.add_argument("--batch_size", type=int, default=64, help="crystals per rank")
     ap.add_argument("--lr", type=float, default=3e-4)
     ap.add_argument("--seed", type=int, default=0)
+    # network / diffusion flags of the reference's training CLI (main_diffusion.py:63-148; `make train`: --hidden_dim=200)
+    ap.add_argument("--hidden_dim", type=int, default=128)
+    ap.add_argument("--basis_dim", type=int, default=256)
+    ap.add_argument("--layers", type=int, default=5)
+    ap.add_argument("--widening_factor", type=int, default=4)
+    ap.add_argument("--num_timesteps", type=int, default=1000)
+    ap.add_argument("--radius", type=float, default=5)
+    ap.add_argument("--max_neighbors", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--weight_decay", type=float, default=1e-10)
     ap.add_argument("--out", type=str, default=None, help="write a Lightning-format checkpoint here (rank 0)")
     args = ap.parse_args()
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
@@ -97,7 +107,11 @@ def main():
     from .lightning_wrappers.diffusion import PONITA_DIFFUSION
     ds = CrystalDataset(args.data) if args.data else CrystalDataset(configs=synthetic_alexandria_like(args.num_synthetic, args.seed))
     torch.manual_seed(args.seed)  # same initial weights on every rank
-    model = PONITA_DIFFUSION(default_args(lr=args.lr, epochs=args.epochs), ds.z_table).to(f"cuda:{local_rank}")
+    net_args = default_args(lr=args.lr, epochs=args.epochs, hidden_dim=args.hidden_dim, basis_dim=args.basis_dim,
+                            layers=args.layers, widening_factor=args.widening_factor, num_timesteps=args.num_timesteps,
+                            radius=args.radius, max_neighbors=args.max_neighbors, warmup=args.warmup,
+                            weight_decay=args.weight_decay)
+    model = PONITA_DIFFUSION(net_args, ds.z_table).to(f"cuda:{local_rank}")
     torch.manual_seed(args.seed + 1000 + rank)  # different noise per rank
     train_epochs(model, ds, args.epochs, args.batch_size, rank, world, args.seed)
     if rank == 0 and args.out:

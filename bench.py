@@ -104,6 +104,8 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-fp32-variant", action="store_true", help="skip the second timed loop on the fp32-MFMA kernels")
     ap.add_argument("--cpu-steps", type=int, default=2)
+    ap.add_argument("--hidden-dim", type=int, default=128, help="c5 only: hidden_dim of the trained network (the reference's "
+                    "`make train` preset is 200; shapes other than 128 run on the shape-general kernels)")
     ap.add_argument("--no-full-sampler", action="store_true", help="skip the measured run of the whole T-1 step sampler")
     ap.add_argument("--groups", type=int, default=0, help="slices of the batch run on separate streams (0: library default)")
     args = ap.parse_args(argv)
@@ -479,8 +481,9 @@ def run_rank_c5(args, rank, local_rank, world):
     B = args.batch_per_gpu
     ds = CrystalDataset(configs=synthetic_alexandria_like(4096, seed=0))  # same table (S = 90) on every rank
     torch.manual_seed(1234)
-    model = PONITA_DIFFUSION(default_args(lr=3e-4, epochs=10), ds.z_table).to(dev)
+    model = PONITA_DIFFUSION(default_args(lr=3e-4, epochs=10, hidden_dim=args.hidden_dim), ds.z_table).to(dev)
     optimizer = model.configure_optimizers(max_epochs=10)["optimizer"]
+    n_params = sum(p.numel() for p in model.parameters() if p.requires_grad)
     rng = np.random.RandomState(100 + rank)
     batches = [collate([ds[int(i)] for i in rng.choice(len(ds), B, replace=False)]) for _ in range(8)]
     torch.manual_seed(2000 + rank)
@@ -524,23 +527,24 @@ def run_rank_c5(args, rank, local_rank, world):
     fb_ms = 1e3 * (time.perf_counter() - t1) / args.steps
     if rank == 0:
         ms = 1e3 * elapsed / args.steps
-        flops = 3.0 * step_flops_per_atom() * n_atoms  # forward + backward ~ 3 x forward
+        flops = 3.0 * step_flops_per_atom(C=args.hidden_dim) * n_atoms  # forward + backward ~ 3 x forward
         out = {
             "metric": "training steps/sec (crystal-steps, whole node) -- BASELINE configs[4]",
             "value": world * B * args.steps / elapsed, "unit": "crystal-steps/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": ms, "per_rank_ms": [1e3 * e / args.steps for e in per_rank],
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"BASELINE configs[4]: score-matching training step, global batch {B * world} = {B} crystals x "
-                                   f"{world} GPUs, Alexandria-like synthetic crystals (mean {n_atoms / B:.1f} atoms), T=1000, fp32",
-                       "crystals_per_gpu": B, "mean_atoms_per_batch": n_atoms,
-                       "parallelism": f"data parallel x{world}: one all-reduce of the 1.17M-parameter fp32 gradient per step"},
+                                   f"{world} GPUs, Alexandria-like synthetic crystals (mean {n_atoms / B:.1f} atoms), T=1000, fp32, "
+                                   f"hidden_dim {args.hidden_dim}" + (" (the reference's `make train` preset)" if args.hidden_dim == 200 else ""),
+                       "crystals_per_gpu": B, "mean_atoms_per_batch": n_atoms, "hidden_dim": args.hidden_dim,
+                       "parallelism": f"data parallel x{world}: one all-reduce of the {n_params / 1e6:.2f}M-parameter fp32 gradient per step"},
             "last_loss": float(loss),
             "forward_backward_ms": fb_ms,
             "roofline": {"kernel": "training step, forward + backward (sgemm_kernel + elementwise kernels of train_net.hip)",
                          "bound": "mfma", "achieved": flops / (fb_ms * 1e-3) / 1e12, "peak": MFMA_F32_PEAK_TFLOPS,
                          "unit": "TFLOP/s", "frac": flops / (fb_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, "traffic": None,
-                         "peak_note": "fp32 vector / fp32-MFMA peak; the training kernels are plain fp32 FMA code (first "
-                                      "correct version, not tuned)"},
+                         "peak_note": "dense fp32-MFMA peak; the training kernels are one exact-fp32 MFMA GEMM per Linear "
+                                      "(v_mfma_f32_32x32x2_f32) + element-wise kernels, every intermediate in HBM"},
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline_training(model, batches[0], args.cpu_steps)

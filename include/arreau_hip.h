@@ -100,7 +100,12 @@ const char* arreau_version(void);
  * polynomial columns onto their 83 distinct monomials, repacks every Linear for the MFMA
  * fragment order, uploads, and evaluates the input-independent fiber kernels
  * fiber_kernel(fiber_basis_fn(o_a . o_b)) (ponita.py:95, conv.py:113) once on the GPU.
- * Allocates device memory (the only entry point besides arreau_model_destroy that does). */
+ * Allocates device memory (the only entry point besides arreau_model_destroy that does).
+ * Shapes: the fused sampling kernels exist for hidden_dim 128, basis_dim 256, widening_factor 4 (the shipped
+ * checkpoint).  Any other shape with hidden_dim, basis_dim multiples of 4 and widening_factor * hidden_dim <= 1024
+ * (e.g. the reference's `make train` preset hidden_dim = 200, Makefile:7) is accepted and runs every entry point --
+ * scores, inner seam, sampling loop, training -- on the shape-general fp32 kernels (exact fp32 MFMA GEMMs +
+ * element-wise kernels): same results, no fusion.  num_ori = 16, degree = 3, max_neighbors <= 8 are fixed. */
 int arreau_model_create(const arreau_config* cfg, const arreau_state_dict* h_sd, void* stream,
                         arreau_model** out_model);
 void arreau_model_destroy(arreau_model* model);
@@ -130,7 +135,10 @@ typedef struct arreau_status {
 int arreau_model_status(const arreau_model* model, arreau_status* out, int32_t reset, void* stream);
 /* Selects the arithmetic of the dense kernels for this model (-1 keeps the current choice); the defaults come from
  * the environment (ARREAU_EDGE_VARIANT, ARREAU_MLP_VARIANT) at arreau_model_create.  Used by the parity report and
- * bench.py to time/compare the exact fp32-MFMA kernels against the default fp16x3 ones in one process. */
+ * bench.py to time/compare the exact fp32-MFMA kernels against the default fp16x3 ones in one process.
+ * edge_variant 5 runs the whole score network on the shape-general fp32 GEMM kernels (what shapes without fused kernels
+ * always use; such models accept no other value).  Those kernels read the plain weights
+ * arreau_model_update_train_weights refreshes, so with variant 5 a model keeps sampling between optimiser steps. */
 int arreau_model_set_variant(arreau_model* model, int32_t edge_variant, int32_t mlp_variant);
 
 /* Optional: tell the library how the batch is laid out (HOST copy of d_crystal_offsets[B+1]) so that the score network
