@@ -1,0 +1,205 @@
+// Exact-fp32 GEMM on the matrix pipe (v_mfma_f32_32x32x2_f32) for the shape-general / training network (train_net.hip).
+#pragma once
+#include "internal.h"
+
+constexpr size_t ARREAU_SGEMM_PARTIAL_FLOATS = (size_t)64 * 512 * 512;  // split-K partial sums (64 slices of the largest weight)
+
+namespace arreau_sgemm_detail {
+
+// C[m,n] = alpha * sum_k A(m,k) B(k,n) + beta * C[m,n];  A(m,k) = A[m*as0 + k*as1], B(k,n) = B[k*bs0 + n*bs1].
+// Exact fp32 on the matrix pipe (v_mfma_f32_32x32x2_f32): a (64 WM) x (64 WN) output tile per workgroup, four waves in a
+// 2 x 2 arrangement, each holding WM x WN MFMA tiles of 32 x 32 (16 accumulator registers per tile); operands staged
+// k-major in LDS (a lane reads A(m0 + lane % 32, k + lane / 32) and B(k + lane / 32, n0 + lane % 32): conflict-free
+// rows).  Accumulator register r of lane (h, j) is C[m0 + (r & 3) + 8 (r >> 2) + 4 h][n0 + j] (internal.h), so stores
+// are coalesced along n.
+//   WM = WN = 2: 128 x 128 tiles, 32 MFMAs per wave and k-step of 16 -- the large products (edge rows x basis).
+//   WM = WN = 1: 64 x 64 tiles, k-step of 32 -- products whose 128 x 128 tiling would leave most of the
+//                chip idle (the node-level linears at 64 crystals: 8512 x 128 outputs = 67 tiles of 128 x 128, 266 of
+//                64 x 64).
+// gridDim.z > 1: split-K, partial sums to `partial[z][M][N]` (reduced in z order by splitk_reduce_kernel: deterministic).
+// Operand staging: each thread fetches its 16-byte pieces of the next A and B tiles into registers -- along whichever
+// dimension is contiguous in memory -- BEFORE the matrix work of the current tile, and writes them to LDS after it
+// (register double buffering: the global latency hides behind the tile's MFMAs).  A second LDS buffer with one barrier
+// per k-step was measured and is no faster (tools/exp/sgemm_bench.hip: 330 vs 304 us at 8512 x 512 x 2048): the kernel
+// is bound by the matrix pipe of the busiest CU, i.e. by how evenly the tiles divide over the 256 CUs.
+// VEC = 0: element-wise path for shapes that are not multiples of four (K = 3, M = 94 ...).
+template <int VEC, int WM, int WN, int BK>
+__global__ __launch_bounds__(256) void sgemm_kernel(int M, int N, int K, const float* __restrict__ A, long as0, long as1,
+                                                    const float* __restrict__ B, long bs0, long bs1, float* __restrict__ C,
+                                                    int ldc, float alpha, float beta, int kchunk,
+                                                    float* __restrict__ partial) {
+    constexpr int TM = 64 * WM, TN = 64 * WN;
+    constexpr int KP = BK / 4;                              // 16-byte pieces per k-row of a tile
+    constexpr int PA = WM * BK / 16, PB = WN * BK / 16;     // pieces per thread (VEC); elements per thread = 4 x that
+    __shared__ __attribute__((aligned(16))) float As[BK][TM + 4], Bs[BK][TN + 4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int h = lane >> 5, j = lane & 31, wm = (wave >> 1) * (32 * WM), wn = (wave & 1) * (32 * WN);
+    const int m0 = blockIdx.y * TM, n0 = blockIdx.x * TN;
+    const int kbeg = blockIdx.z * kchunk, kend = min(K, kbeg + kchunk);
+    f32x16 acc[WM][WN];
+#pragma unroll
+    for (int a = 0; a < WM; ++a)
+#pragma unroll
+        for (int b = 0; b < WN; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+    const bool a_kmajor = as1 == 1, b_nmajor = bs1 == 1;  // which dimension is contiguous
+    f32x4 ra[PA], rb[PB];
+    float sa[4 * PA], sb[4 * PB];
+    auto fetch = [&](int k0) {
+        if (VEC) {
+#pragma unroll
+            for (int i = 0; i < PA; ++i) {  // TM x BK / 4 pieces of the A tile
+                const int idx = tid + 256 * i;
+                const int mm = a_kmajor ? idx / KP : (idx % (TM / 4)) * 4, kk = a_kmajor ? (idx % KP) * 4 : idx / (TM / 4);
+                const int m = m0 + mm, k = k0 + kk;
+                ra[i] = (m < M && k < kend) ? *reinterpret_cast<const f32x4*>(A + (long)m * as0 + (long)k * as1) : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+#pragma unroll
+            for (int i = 0; i < PB; ++i) {
+                const int idx = tid + 256 * i;
+                const int nn = b_nmajor ? (idx % (TN / 4)) * 4 : idx / KP, kk = b_nmajor ? idx / (TN / 4) : (idx % KP) * 4;
+                const int n = n0 + nn, k = k0 + kk;
+                rb[i] = (n < N && k < kend) ? *reinterpret_cast<const f32x4*>(B + (long)k * bs0 + (long)n * bs1) : f32x4{0.f, 0.f, 0.f, 0.f};
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4 * PA; ++i) {  // TM x BK elements of the A tile
+                const int idx = tid + 256 * i;
+                const int mm = a_kmajor ? idx / BK : idx % TM, kk = a_kmajor ? idx % BK : idx / TM;
+                const int m = m0 + mm, k = k0 + kk;
+                sa[i] = (m < M && k < kend) ? A[(long)m * as0 + (long)k * as1] : 0.f;
+            }
+#pragma unroll
+            for (int i = 0; i < 4 * PB; ++i) {
+                const int idx = tid + 256 * i;
+                const int nn = b_nmajor ? idx % TN : idx / BK, kk = b_nmajor ? idx / TN : idx % BK;
+                const int n = n0 + nn, k = k0 + kk;
+                sb[i] = (n < N && k < kend) ? B[(long)k * bs0 + (long)n * bs1] : 0.f;
+            }
+        }
+    };
+    auto stage = [&]() {
+        if (VEC) {
+#pragma unroll
+            for (int i = 0; i < PA; ++i) {
+                const int idx = tid + 256 * i;
+                if (a_kmajor) {
+                    const int mm = idx / KP, kk = (idx % KP) * 4;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) As[kk + q][mm] = ra[i][q];
+                } else {
+                    *reinterpret_cast<f32x4*>(&As[idx / (TM / 4)][(idx % (TM / 4)) * 4]) = ra[i];
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < PB; ++i) {
+                const int idx = tid + 256 * i;
+                if (b_nmajor) {
+                    *reinterpret_cast<f32x4*>(&Bs[idx / (TN / 4)][(idx % (TN / 4)) * 4]) = rb[i];
+                } else {
+                    const int nn = idx / KP, kk = (idx % KP) * 4;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) Bs[kk + q][nn] = rb[i][q];
+                }
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 4 * PA; ++i) {
+                const int idx = tid + 256 * i;
+                if (a_kmajor) As[idx % BK][idx / BK] = sa[i]; else As[idx / TM][idx % TM] = sa[i];
+            }
+#pragma unroll
+            for (int i = 0; i < 4 * PB; ++i) {
+                const int idx = tid + 256 * i;
+                if (b_nmajor) Bs[idx / TN][idx % TN] = sb[i]; else Bs[idx % BK][idx / BK] = sb[i];
+            }
+        }
+    };
+    fetch(kbeg);
+    for (int k0 = kbeg; k0 < kend; k0 += BK) {
+        stage();
+        __syncthreads();
+        if (k0 + BK < kend) fetch(k0 + BK);
+#pragma unroll
+        for (int kk = 0; kk < BK; kk += 2) {
+            float av[WM], bv[WN];
+#pragma unroll
+            for (int a = 0; a < WM; ++a) av[a] = As[kk + h][wm + 32 * a + j];
+#pragma unroll
+            for (int b = 0; b < WN; ++b) bv[b] = Bs[kk + h][wn + 32 * b + j];
+#pragma unroll
+            for (int a = 0; a < WM; ++a)
+#pragma unroll
+                for (int b = 0; b < WN; ++b) acc[a][b] = arreau_mfma(av[a], bv[b], acc[a][b]);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int a = 0; a < WM; ++a)
+#pragma unroll
+        for (int b = 0; b < WN; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * h, n = n0 + wn + 32 * b + j;
+                if (m < M && n < N) {
+                    if (gridDim.z > 1) partial[((size_t)blockIdx.z * M + m) * N + n] = acc[a][b][r];
+                    else C[(size_t)m * ldc + n] = alpha * acc[a][b][r] + (beta != 0.f ? beta * C[(size_t)m * ldc + n] : 0.f);
+                }
+            }
+}
+__global__ void splitk_reduce_kernel(const float* __restrict__ partial, int Z, int M, int N, float* __restrict__ C, int ldc,
+                                     float alpha, float beta) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)M * N) return;
+    float s = 0.f;
+    for (int z = 0; z < Z; ++z) s += partial[(size_t)z * M * N + i];
+    const int m = (int)(i / N), n = (int)(i % N);
+    C[(size_t)m * ldc + n] = alpha * s + (beta != 0.f ? beta * C[(size_t)m * ldc + n] : 0.f);
+}
+}  // namespace arreau_sgemm_detail
+
+inline int arreau_sgemm(hipStream_t s, float* partial, int M, int N, int K, const float* A, long as0, long as1, const float* B,
+                        long bs0, long bs1, float* C, int ldc, float alpha = 1.f, float beta = 0.f) {
+    using namespace arreau_sgemm_detail;
+    if (M == 0 || N == 0) return ARREAU_OK;
+    // Tile size.  The kernel is bound by the matrix pipe of the busiest CU, so what matters is how evenly the tiles divide
+    // over the 256 CUs: 268 tiles of 128 x 128 (8512 x 512 outputs) leave 12 CUs with two workgroups and everybody waits for
+    // them (measured 304 us at K = 2048: half the rate of four times the rows); as 64 x 64 tiles the same product is 1064
+    // workgroups, 4.2 per CU.  So 128 x 128 only when there are at least two of them per CU.  If even those are too few (weight gradients: a handful of
+    // tiles under a reduction over all rows), split K as well: enough slices for about one workgroup per CU, at least two k-steps
+    // each, more slices for very long reductions.
+    const int tiles128 = ((M + 127) / 128) * ((N + 127) / 128);
+    const bool small = tiles128 < 512;
+    const int T = small ? 64 : 128;
+    const int gm = (M + T - 1) / T, gn = (N + T - 1) / T;
+    int Z = 1;
+    const int tiles = gm * gn;
+    if (tiles < 128 && K >= 256) {
+        const int fill = (256 + tiles - 1) / tiles;
+        Z = min(64, min(max(fill, K / 1024), K / 128));
+        while (Z > 1 && (size_t)Z * M * N > ARREAU_SGEMM_PARTIAL_FLOATS) --Z;
+    }
+    const int BK = small ? 32 : 16;
+    const int kchunk = ((K + Z - 1) / Z + BK - 1) / BK * BK;
+    Z = (K + kchunk - 1) / kchunk;
+    // 16-byte operand fetches need the contiguous dimension and the leading dimension to be multiples of four floats
+    const bool a_ok = (as1 == 1 && as0 % 4 == 0 && K % 4 == 0) || (as0 == 1 && as1 % 4 == 0 && M % 4 == 0);
+    const bool b_ok = (bs1 == 1 && bs0 % 4 == 0 && N % 4 == 0) || (bs0 == 1 && bs1 % 4 == 0 && K % 4 == 0);
+    const bool vec = a_ok && b_ok && ((size_t)A % 16 == 0) && ((size_t)B % 16 == 0);
+    auto launch = [&](auto kernel) {
+        hipLaunchKernelGGL(kernel, dim3(gn, gm, Z), dim3(256), 0, s, M, N, K, A, as0, as1, B, bs0, bs1, C, ldc, alpha, beta, kchunk,
+                           partial);
+    };
+    if (small) {
+        if (vec) launch(sgemm_kernel<1, 1, 1, 32>); else launch(sgemm_kernel<0, 1, 1, 32>);
+    } else {
+        if (vec) launch(sgemm_kernel<1, 2, 2, 16>); else launch(sgemm_kernel<0, 2, 2, 16>);
+    }
+    ARREAU_CHECK_HIP(hipGetLastError());
+    if (Z > 1) {
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)(((long)M * N + 255) / 256)), dim3(256), 0, s, partial, Z, M, N, C, ldc, alpha, beta);
+        ARREAU_CHECK_HIP(hipGetLastError());
+    }
+    return ARREAU_OK;
+}

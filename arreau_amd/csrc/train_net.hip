@@ -17,162 +17,70 @@
 #include <vector>
 
 #include "internal.h"
+#include "sgemm.h"
 
 namespace {
-constexpr int TILE = 128, BK = 16;
-
-// C[m,n] = alpha * sum_k A(m,k) B(k,n) + beta * C[m,n];  A(m,k) = A[m*as0 + k*as1], B(k,n) = B[k*bs0 + n*bs1].
-// Exact fp32 on the matrix pipe (v_mfma_f32_32x32x2_f32): a 128 x 128 output tile per workgroup, four waves of 64 x 64
-// (2 x 2 MFMA tiles, 64 accumulator registers), operands staged k-major in LDS (a lane reads A(m0 + lane % 32,
-// k + lane / 32) and B(k + lane / 32, n0 + lane % 32): conflict-free rows).  Accumulator register r of lane (h, j) is
-// C[m0 + (r & 3) + 8 (r >> 2) + 4 h][n0 + j] (internal.h), so stores are coalesced along n.
-// gridDim.z > 1: split-K, partial sums to `partial[z][M][N]` (reduced in z order by splitk_reduce_kernel: deterministic).
-// Operand staging: each thread fetches two 16-byte pieces of the A tile (128 x 16) and two of the B tile (16 x 128)
-// into registers -- along whichever dimension is contiguous in memory -- BEFORE the matrix work of the current tile, and
-// writes them to LDS after it (register double buffering: the global latency hides behind 32 MFMAs per wave).
-// VEC = 0: element-wise path for shapes that are not multiples of four (K = 3, M = 94 ...).
-template <int VEC>
-__global__ __launch_bounds__(256) void sgemm_kernel(int M, int N, int K, const float* __restrict__ A, long as0, long as1,
-                                                    const float* __restrict__ B, long bs0, long bs1, float* __restrict__ C,
-                                                    int ldc, float alpha, float beta, int kchunk,
-                                                    float* __restrict__ partial) {
-    __shared__ __attribute__((aligned(16))) float As[BK][TILE + 4], Bs[BK][TILE + 4];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int h = lane >> 5, j = lane & 31, wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
-    const int m0 = blockIdx.y * TILE, n0 = blockIdx.x * TILE;
-    const int kbeg = blockIdx.z * kchunk, kend = min(K, kbeg + kchunk);
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = 0; b < 2; ++b)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
-    const bool a_kmajor = as1 == 1, b_nmajor = bs1 == 1;  // which dimension is contiguous
-    f32x4 ra[2], rb[2];
-    float sa[8], sb[8];
-    auto fetch = [&](int k0) {
-        if (VEC) {
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int idx = tid + 256 * i;  // 512 pieces per operand
-                {
-                    const int mm = a_kmajor ? idx >> 2 : (idx & 31) * 4, kk = a_kmajor ? (idx & 3) * 4 : idx >> 5;
-                    const int m = m0 + mm, k = k0 + kk;
-                    ra[i] = (m < M && k < kend) ? *reinterpret_cast<const f32x4*>(A + (long)m * as0 + (long)k * as1) : f32x4{0.f, 0.f, 0.f, 0.f};
-                }
-                {
-                    const int nn = b_nmajor ? (idx & 31) * 4 : idx >> 2, kk = b_nmajor ? idx >> 5 : (idx & 3) * 4;
-                    const int n = n0 + nn, k = k0 + kk;
-                    rb[i] = (n < N && k < kend) ? *reinterpret_cast<const f32x4*>(B + (long)k * bs0 + (long)n * bs1) : f32x4{0.f, 0.f, 0.f, 0.f};
-                }
-            }
-        } else {
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int idx = tid + 256 * i;  // 2048 elements per operand
-                int mm, kk;
-                if (a_kmajor) { kk = idx & 15; mm = idx >> 4; } else { mm = idx & 127; kk = idx >> 7; }
-                const int m = m0 + mm, k = k0 + kk;
-                sa[i] = (m < M && k < kend) ? A[(long)m * as0 + (long)k * as1] : 0.f;
-                int nn;
-                if (b_nmajor) { nn = idx & 127; kk = idx >> 7; } else { kk = idx & 15; nn = idx >> 4; }
-                const int n = n0 + nn, kb = k0 + kk;
-                sb[i] = (n < N && kb < kend) ? B[(long)kb * bs0 + (long)n * bs1] : 0.f;
-            }
-        }
-    };
-    auto stage = [&]() {
-        if (VEC) {
-#pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int idx = tid + 256 * i;
-                if (a_kmajor) {
-                    const int mm = idx >> 2, kk = (idx & 3) * 4;
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) As[kk + q][mm] = ra[i][q];
-                } else {
-                    *reinterpret_cast<f32x4*>(&As[idx >> 5][(idx & 31) * 4]) = ra[i];
-                }
-                if (b_nmajor) {
-                    *reinterpret_cast<f32x4*>(&Bs[idx >> 5][(idx & 31) * 4]) = rb[i];
-                } else {
-                    const int nn = idx >> 2, kk = (idx & 3) * 4;
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) Bs[kk + q][nn] = rb[i][q];
-                }
-            }
-        } else {
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int idx = tid + 256 * i;
-                if (a_kmajor) As[idx & 15][idx >> 4] = sa[i]; else As[idx >> 7][idx & 127] = sa[i];
-                if (b_nmajor) Bs[idx >> 7][idx & 127] = sb[i]; else Bs[idx & 15][idx >> 4] = sb[i];
-            }
-        }
-    };
-    fetch(kbeg);
-    for (int k0 = kbeg; k0 < kend; k0 += BK) {
-        stage();
-        __syncthreads();
-        if (k0 + BK < kend) fetch(k0 + BK);
-#pragma unroll
-        for (int kk = 0; kk < BK; kk += 2) {
-            const float a0 = As[kk + h][wm + j], a1 = As[kk + h][wm + 32 + j];
-            const float b0 = Bs[kk + h][wn + j], b1 = Bs[kk + h][wn + 32 + j];
-            acc[0][0] = arreau_mfma(a0, b0, acc[0][0]);
-            acc[0][1] = arreau_mfma(a0, b1, acc[0][1]);
-            acc[1][0] = arreau_mfma(a1, b0, acc[1][0]);
-            acc[1][1] = arreau_mfma(a1, b1, acc[1][1]);
-        }
-        __syncthreads();
-    }
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = 0; b < 2; ++b)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wm + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * h, n = n0 + wn + 32 * b + j;
-                if (m < M && n < N) {
-                    if (gridDim.z > 1) partial[((size_t)blockIdx.z * M + m) * N + n] = acc[a][b][r];
-                    else C[(size_t)m * ldc + n] = alpha * acc[a][b][r] + (beta != 0.f ? beta * C[(size_t)m * ldc + n] : 0.f);
-                }
-            }
-}
-__global__ void splitk_reduce_kernel(const float* __restrict__ partial, int Z, int M, int N, float* __restrict__ C, int ldc,
-                                     float alpha, float beta) {
-    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (long)M * N) return;
-    float s = 0.f;
-    for (int z = 0; z < Z; ++z) s += partial[(size_t)z * M * N + i];
-    const int m = (int)(i / N), n = (int)(i % N);
-    C[(size_t)m * ldc + n] = alpha * s + (beta != 0.f ? beta * C[(size_t)m * ldc + n] : 0.f);
-}
-
-// out[c] = scale * sum_r a[r][c] * (b ? b[r][c] : 1)  (+ out[c] if accumulate), in two deterministic stages: each
-// workgroup of stage 1 sums one chunk of rows (four row phases added in a fixed order), stage 2 adds the chunks in order.
+// out[c] = scale * sum_r a[r][c] * (b ? b[r][c] : 1)  (+ out[c] if accumulate), deterministic, in ONE launch: each
+// workgroup sums one chunk of rows for 64 columns (four row phases added in a fixed order) into part[chunk][c]; the
+// workgroup that finishes last for its column group (device-scope counter) adds the chunks in a fixed order (four
+// interleaved phases, combined in order) and resets the counter, so the result does not depend on which workgroup that was.
 constexpr int COLSUM_MAX_CHUNKS = 256;
-__global__ __launch_bounds__(256) void colsum_partial_kernel(const float* __restrict__ a, const float* __restrict__ b, long rows,
-                                                             int cols, long rows_per_chunk, float* __restrict__ part) {
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ a, const float* __restrict__ b, long rows,
+                                                     int cols, long rows_per_chunk, float* __restrict__ part,
+                                                     int* __restrict__ counters, float scale, int accumulate,
+                                                     float* __restrict__ out) {
     __shared__ float sh[4][64];
+    __shared__ int is_last;
     const int c = blockIdx.x * 64 + (threadIdx.x & 63), ph = threadIdx.x >> 6;
     const long r0 = (long)blockIdx.y * rows_per_chunk, r1 = min(rows, r0 + rows_per_chunk);
     float s = 0.f;
-    if (c < cols)
-        for (long r = r0 + ph; r < r1; r += 4) s += a[(size_t)r * cols + c] * (b ? b[(size_t)r * cols + c] : 1.0f);
+    if (c < cols) {
+        long r = r0 + ph;
+        float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};  // eight loads in flight per thread; combined in a fixed order
+        const size_t st = (size_t)4 * cols;
+        for (; r + 28 < r1; r += 32) {
+            const size_t i0 = (size_t)r * cols + c;
+#pragma unroll
+            for (int u = 0; u < 8; ++u) acc[u] += a[i0 + u * st] * (b ? b[i0 + u * st] : 1.0f);
+        }
+        for (; r < r1; r += 4) acc[0] += a[(size_t)r * cols + c] * (b ? b[(size_t)r * cols + c] : 1.0f);
+        s = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+    }
     sh[ph][threadIdx.x & 63] = s;
     __syncthreads();
     if (ph == 0 && c < cols)
         part[(size_t)blockIdx.y * cols + c] = ((sh[0][threadIdx.x] + sh[1][threadIdx.x]) + sh[2][threadIdx.x]) + sh[3][threadIdx.x];
-}
-__global__ void colsum_final_kernel(const float* __restrict__ part, int chunks, int cols, float scale, int accumulate,
-                                    float* __restrict__ out) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= cols) return;
-    float s = 0.f;
-    for (int i = 0; i < chunks; ++i) s += part[(size_t)i * cols + c];
-    out[c] = scale * s + (accumulate ? out[c] : 0.f);
+    __threadfence();  // this workgroup's partial sums are visible device-wide before it is counted
+    __syncthreads();
+    if (threadIdx.x == 0) is_last = atomicAdd(&counters[blockIdx.x], 1) == (int)gridDim.y - 1;
+    __syncthreads();
+    if (!is_last) return;
+    __threadfence();
+    // (relaxed device-scope atomic loads: written by other workgroups during this launch, so they must not be served from
+    // this CU's cache -- and unlike volatile accesses the compiler may keep many of them in flight)
+    float tot = 0.f;
+    if (c < cols) {
+        int i = ph;
+        const int n = (int)gridDim.y;
+        for (; i + 28 < n; i += 32) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+                v[u] = __hip_atomic_load(part + (size_t)(i + 4 * u) * cols + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+            for (int u = 0; u < 8; ++u) tot += v[u];
+        }
+        for (; i < n; i += 4)
+            tot += __hip_atomic_load(part + (size_t)i * cols + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    __syncthreads();  // (sh was last read before the counter)
+    sh[ph][threadIdx.x & 63] = tot;
+    __syncthreads();
+    if (ph == 0 && c < cols) {
+        tot = ((sh[0][threadIdx.x] + sh[1][threadIdx.x]) + sh[2][threadIdx.x]) + sh[3][threadIdx.x];
+        out[c] = scale * tot + (accumulate ? out[c] : 0.f);
+    }
+    if (threadIdx.x == 0) counters[blockIdx.x] = 0;  // ready for the next launch (stream-ordered)
 }
 
 __device__ __forceinline__ float gelu_exact(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
@@ -546,6 +454,7 @@ struct arreau_train_ctx {
     float *x, *x1, *xhat, *rstd, *xn, *hpre, *h, *out, *fk, *rbar, *gs, *kern;
     // backward temporaries
     float *dx, *dtmp, *dh, *drbar, *dx1, *dkern, *dkb, *dh1, *dfk, *dfkb, *dfh1, *dw1f, *partial, *scratch_cols, *colpart;
+    int32_t* colcount;  // colsum_kernel's arrival counters (one per 64-column group; zero between launches)
     const int32_t *tstep, *offsets, *types;
     const float *frac, *lengths, *angles;
 };
@@ -562,7 +471,7 @@ struct Carve {
         return r;
     }
 };
-constexpr size_t PARTIAL_FLOATS = (size_t)64 * 512 * 512;  // split-K partial sums (64 slices of the largest weight)
+constexpr size_t PARTIAL_FLOATS = ARREAU_SGEMM_PARTIAL_FLOATS;
 
 size_t layout(arreau_train_ctx& t, const arreau_model* m, int N, int B, float* base) {
     Carve c{base};
@@ -585,36 +494,13 @@ size_t layout(arreau_train_ctx& t, const arreau_model* m, int N, int B, float* b
     t.dfk = c.take<float>(256 * C); t.dfkb = c.take<float>(256 * D); t.dfh1 = c.take<float>(256 * C);
     t.dw1f = c.take<float>(C * ARREAU_MONO_PAD); t.partial = c.take<float>(PARTIAL_FLOATS); t.scratch_cols = c.take<float>(1024);
     t.colpart = c.take<float>((size_t)COLSUM_MAX_CHUNKS * 1024);
+    t.colcount = c.take<int32_t>(64);
     return c.off;
 }
 
 int gemm(hipStream_t s, arreau_train_ctx& t, int M, int N, int K, const float* A, long as0, long as1, const float* B, long bs0,
          long bs1, float* C, int ldc, float alpha = 1.f, float beta = 0.f) {
-    if (M == 0 || N == 0) return ARREAU_OK;
-    const int gm = (M + TILE - 1) / TILE, gn = (N + TILE - 1) / TILE;
-    int Z = 1;
-    if (K >= 4096 && gm * gn < 256) {  // weight gradients: few output tiles, long reduction -> split K
-        Z = min(64, (K + 1023) / 1024);
-        while (Z > 1 && (size_t)Z * M * N > PARTIAL_FLOATS) --Z;
-    }
-    const int kchunk = ((K + Z - 1) / Z + BK - 1) / BK * BK;
-    Z = (K + kchunk - 1) / kchunk;
-    // 16-byte operand fetches need the contiguous dimension and the leading dimension to be multiples of four floats
-    const bool a_ok = (as1 == 1 && as0 % 4 == 0 && K % 4 == 0) || (as0 == 1 && as1 % 4 == 0 && M % 4 == 0);
-    const bool b_ok = (bs1 == 1 && bs0 % 4 == 0 && N % 4 == 0) || (bs0 == 1 && bs1 % 4 == 0 && K % 4 == 0);
-    const bool vec = a_ok && b_ok && ((size_t)A % 16 == 0) && ((size_t)B % 16 == 0);
-    if (vec)
-        hipLaunchKernelGGL(sgemm_kernel<1>, dim3(gn, gm, Z), dim3(256), 0, s, M, N, K, A, as0, as1, B, bs0, bs1, C, ldc, alpha,
-                           beta, kchunk, t.partial);
-    else
-        hipLaunchKernelGGL(sgemm_kernel<0>, dim3(gn, gm, Z), dim3(256), 0, s, M, N, K, A, as0, as1, B, bs0, bs1, C, ldc, alpha,
-                           beta, kchunk, t.partial);
-    ARREAU_CHECK_HIP(hipGetLastError());
-    if (Z > 1) {
-        hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks((long)M * N)), dim3(256), 0, s, t.partial, Z, M, N, C, ldc, alpha, beta);
-        ARREAU_CHECK_HIP(hipGetLastError());
-    }
-    return ARREAU_OK;
+    return arreau_sgemm(s, t.partial, M, N, K, A, as0, as1, B, bs0, bs1, C, ldc, alpha, beta);
 }
 // Y[rows][out] = X[rows][in] . W[out][in]^T
 int linear(hipStream_t s, arreau_train_ctx& t, long rows, int in, int out, const float* X, const float* W, float* Y,
@@ -637,11 +523,10 @@ int colsum(hipStream_t s, arreau_train_ctx& t, const float* a, const float* b, l
         arreau_set_error("colsum: more than 1024 columns");
         return ARREAU_EINVAL;
     }
-    const int chunks = (int)std::min<long>(COLSUM_MAX_CHUNKS, std::max<long>(1, rows / 256));
+    const int chunks = (int)std::min<long>(COLSUM_MAX_CHUNKS, std::max<long>(1, rows / 128));
     const long rpc = (rows + chunks - 1) / chunks;
-    hipLaunchKernelGGL(colsum_partial_kernel, dim3((cols + 63) / 64, chunks), dim3(256), 0, s, a, b, rows, cols, rpc, t.colpart);
-    ARREAU_CHECK_HIP(hipGetLastError());
-    hipLaunchKernelGGL(colsum_final_kernel, dim3((cols + 127) / 128), dim3(128), 0, s, t.colpart, chunks, cols, scale, accumulate, out);
+    hipLaunchKernelGGL(colsum_kernel, dim3((cols + 63) / 64, chunks), dim3(256), 0, s, a, b, rows, cols, rpc, t.colpart,
+                       t.colcount, scale, accumulate, out);
     ARREAU_CHECK_HIP(hipGetLastError());
     return ARREAU_OK;
 }
@@ -685,6 +570,7 @@ static int ensure_ctx(arreau_model* m, int N, int B, hipStream_t s) {
     t->N = N; t->B = B;
     m->train = t;
     ARREAU_CHECK_HIP(hipMemsetAsync(t->scratch_cols, 0, 1024 * sizeof(float), s));
+    ARREAU_CHECK_HIP(hipMemsetAsync(t->colcount, 0, 64 * sizeof(int32_t), s));
     return ARREAU_OK;
 }
 

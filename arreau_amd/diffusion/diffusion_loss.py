@@ -94,7 +94,10 @@ class DiffusionLoss(nn.Module):
         eps, logits, len0 = evaluate(nz["noisy_frac"], nz["noisy_types"], nz["noisy_lengths"], nz["angles"], t_d, off)
         losses, grads = eng.diffusion_losses(eps, nz["target_eps"], logits, types0, nz["noisy_types"], t_d, len0,
                                              nz["lengths"], off, with_grads=True)
-        eng.check_status()
+        if not training:
+            # sticky device flags -> raise.  Reading them synchronises the stream, so the training step (whose host work
+            # overlaps the device's) leaves that to PONITA_DIFFUSION.training_step, every STATUS_CHECK_EVERY steps.
+            eng.check_status()
         if return_parts:
             return losses[0], dict(error_frac_x=losses[1], error_atomic_type=losses[2], error_lattice=losses[3],
                                    vb=losses[4], ce=losses[5], pred_eps=eps, logits=logits, pred_lengths=len0,

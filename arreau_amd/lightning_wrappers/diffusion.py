@@ -82,6 +82,7 @@ class PONITA_DIFFUSION(nn.Module):
             self.model.ori_grid = torch.as_tensor(grid).detach().cpu().clone()
         out = super().load_state_dict(state_dict, strict=strict, **kw)
         self._engine = None
+        self._all_callibrated = False  # re-read the `callibrated` buffers at the next training step
         return out
 
     def engine(self, for_training: bool = False):
@@ -125,6 +126,11 @@ class PONITA_DIFFUSION(nn.Module):
             if p is not None and p.requires_grad:
                 p.grad = g.to(device=p.device, dtype=p.dtype).reshape(p.shape)
         self._callibrate_if_needed(eng)
+        # the device status word is sticky: checking it every few steps loses nothing and keeps the step free of host
+        # synchronisation (a check is a device-to-host read)
+        self._train_steps = getattr(self, "_train_steps", 0) + 1
+        if self._train_steps % self.STATUS_CHECK_EVERY == 1:
+            eng.check_status()
         return loss
 
     @torch.no_grad()
@@ -134,9 +140,14 @@ class PONITA_DIFFUSION(nn.Module):
 
     test_step = validation_step  # :139-150
 
+    STATUS_CHECK_EVERY = 32
+
     def _callibrate_if_needed(self, eng):
         layers = self.model.interaction_layers
+        if getattr(self, "_all_callibrated", False):  # (the buffers live on the device: read them once, not every step)
+            return
         if all(bool(layer.conv.callibrated) for layer in layers):
+            self._all_callibrated = True
             return
         st = eng.conv_stats().cpu().double()
         with torch.no_grad():
@@ -147,6 +158,7 @@ class PONITA_DIFFUSION(nn.Module):
                 layer.conv.kernel.weight.mul_(std_in / std_1)
                 layer.conv.fiber_kernel.weight.mul_(std_1 / std_2)
                 layer.conv.callibrated.fill_(True)
+        self._all_callibrated = True
         self.notify_parameters_changed()
 
     def notify_parameters_changed(self):
