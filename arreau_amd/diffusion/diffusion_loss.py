@@ -11,7 +11,7 @@ import torch.nn as nn
 
 from .d3pm import D3PM
 from .diffusion_helpers import VE_pbc, VP_lattice, crystal_offsets, sample_bravais_angles
-from .inference.visualize_crystal import VisualizationSetting
+from .inference.visualize_crystal import VisualizationSetting, vis_crystal_during_sampling
 from .tools.atomic_number_table import AtomicNumberTable, atomic_number_indexes_to_atomic_numbers
 
 pos_sigma_min = 0.001
@@ -149,10 +149,14 @@ class DiffusionLoss(nn.Module):
           noise="reference": randn[B,3], randn[N,3], rand[N,S] from the global CPU generator in the reference's order
               (diffusion_helpers.py:193-197, :79; d3pm.py:206), uploaded every step -- the parity mode.
           noise="device": the same loop with torch's device generator (three RNG launches per step).
+        visualization_setting: LAST writes the final state, ALL every 10th timestep + final, ALL_DETAILED every timestep + final
+        (the reference's schedule, diffusion_loss.py:351-370), as `<vis_name>_<timestep>.cif` / `<vis_name>_final.cif`
+        structure files (inference/visualize_crystal.py; the reference renders PNGs through plotly + pymatgen).
         `fixed_cell=True` (extension, noise="philox" only): fixed-cell sampling -- the initial cell lengths are re-imposed
         after every step (arreau_sample_loop's d_fixed_lengths); coordinates and species are sampled as usual."""
-        if visualization_setting != VisualizationSetting.NONE:
-            raise NotImplementedError("per-step visualisation is outside this build; use VisualizationSetting.NONE")
+        frames = visualization_setting != VisualizationSetting.NONE
+        if frames and not vis_name:
+            raise ValueError("visualization_setting other than NONE needs vis_name (prefix of the frame files)")
         if noise not in ("philox", "device", "reference"):
             raise ValueError("noise must be 'philox', 'device' or 'reference'")
         eng = model.engine()
@@ -200,8 +204,24 @@ class DiffusionLoss(nn.Module):
                 seed = int(torch.randint(0, 2 ** 62, (1,)).item())
             if use_graph is None:
                 use_graph = n_steps >= 200  # capture + instantiation (about 2 ms) against ~4 us saved per kernel boundary
-            eng.sample_loop(frac_d, types_d, len_d, ang_d, off_d, self.T - 1, n_steps, seed, const_d, lattice_d,
-                            use_graph=bool(use_graph), fixed_lengths=len_d.clone() if fixed_cell else None)
+            fixed = len_d.clone() if fixed_cell else None
+            # Frames (diffusion_loss.py:351-370): the loop is cut at the timesteps the reference visualises -- every 10th
+            # for ALL, every one for ALL_DETAILED, never the first (T - 1).  The noise is a function of (seed, timestep),
+            # so a run in segments is the same trajectory as a run in one call.
+            t_first, t_last = self.T - 1, self.T - n_steps
+            stops = [t for t in range(t_first - 1, t_last - 1, -1)
+                     if (visualization_setting == VisualizationSetting.ALL and t % 10 == 0)
+                     or visualization_setting == VisualizationSetting.ALL_DETAILED]
+            t_cur = t_first
+            for t_stop in stops + [None]:
+                n_seg = (t_cur - t_stop + 1) if t_stop is not None else (t_cur - t_last + 1)
+                if n_seg > 0:
+                    eng.sample_loop(frac_d, types_d, len_d, ang_d, off_d, t_cur, n_seg, seed, const_d, lattice_d,
+                                    use_graph=bool(use_graph), fixed_lengths=fixed)
+                    t_cur -= n_seg
+                if t_stop is not None:
+                    vis_crystal_during_sampling(z_table, types_d.cpu().numpy(), lattice_d.cpu().numpy(),
+                                                frac_d.cpu().numpy(), vis_name + f"_{t_stop}", show_bonds, num_atoms.numpy())
         else:
             t_d = torch.empty(B, device=dev, dtype=torch.int32)
             done = 0
@@ -222,7 +242,14 @@ class DiffusionLoss(nn.Module):
                 if const_d is not None:
                     types_d.copy_(const_d)
                 done += 1
+                if timestep != self.T - 1 and ((visualization_setting == VisualizationSetting.ALL and timestep % 10 == 0)
+                                               or visualization_setting == VisualizationSetting.ALL_DETAILED):
+                    vis_crystal_during_sampling(z_table, types_d.cpu().numpy(), lattice_d.cpu().numpy(),
+                                                frac_d.cpu().numpy(), vis_name + f"_{timestep}", show_bonds, num_atoms.numpy())
         eng.check_status()  # sticky device flags (non-finite outputs, clamped indices): raise instead of returning them
+        if frames:
+            vis_crystal_during_sampling(z_table, types_d.cpu().numpy(), lattice_d.cpu().numpy(), frac_d.cpu().numpy(),
+                                        vis_name + "_final", show_bonds, num_atoms.numpy())
         atomic_numbers = atomic_number_indexes_to_atomic_numbers(z_table, types_d.cpu().numpy())
         return SampleResult(num_atoms=num_atoms.numpy(), frac_x=frac_d.cpu().numpy().astype(np.float64),
                             atomic_numbers=atomic_numbers, lattice=lattice_d.cpu().numpy().astype(np.float64))

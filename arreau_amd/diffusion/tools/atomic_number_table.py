@@ -54,5 +54,10 @@ _SYMBOLS = (
 SYMBOL_TO_Z = {s: i + 1 for i, s in enumerate(_SYMBOLS)}
 
 
+def symbol_of(atomic_number: int) -> str:
+    """Element symbol; "X" (the CIF dummy species) for the mask state / anything beyond the table."""
+    return _SYMBOLS[atomic_number - 1] if 1 <= atomic_number <= len(_SYMBOLS) else "X"
+
+
 def atomic_symbols_to_indices(z_table: AtomicNumberTable, atomic_symbols) -> np.ndarray:
     return atomic_numbers_to_indices(z_table, [SYMBOL_TO_Z[s] for s in atomic_symbols])

@@ -161,6 +161,19 @@ class PONITA_DIFFUSION(nn.Module):
         self._all_callibrated = True
         self.notify_parameters_changed()
 
+    @staticmethod
+    def _frame_prefix(vis_name, visualization_setting):
+        if visualization_setting == VisualizationSetting.NONE:
+            return vis_name or ""
+        import os
+        if vis_name is None:
+            os.makedirs(DIFFUSION_DIR, exist_ok=True)  # (:239-240)
+            return f"{DIFFUSION_DIR}/step"
+        if not vis_name:
+            return ""  # DiffusionLoss.sample rejects it
+        os.makedirs(os.path.dirname(os.path.abspath(vis_name)), exist_ok=True)
+        return vis_name
+
     def notify_parameters_changed(self):
         """Call after an optimizer step: the HIP engine holds copies of the weights.  An engine that exists is refreshed
         for training in place (device-to-device copies, no host repack); sampling re-creates it on next use."""
@@ -230,9 +243,11 @@ class PONITA_DIFFUSION(nn.Module):
                visualization_setting: VisualizationSetting = VisualizationSetting.NONE, show_bonds: bool = False,
                use_constant_atomic_symbols: Optional[list] = None, noise: str = "philox",
                max_steps: Optional[int] = None, use_graph: Optional[bool] = None,
-               seed: Optional[int] = None, fixed_cell: bool = False) -> SampleResult:
+               seed: Optional[int] = None, fixed_cell: bool = False, vis_name: Optional[str] = None) -> SampleResult:
         """lightning_wrappers/diffusion.py:220-253.  `num_atoms_per_sample` may also be a sequence with one atom count
-        per crystal of the batch (extension; the reference supports a single int)."""
+        per crystal of the batch (extension; the reference supports a single int).  Frames of a visualization_setting
+        other than NONE go to `<DIFFUSION_DIR>/step_<timestep>.cif` like the reference's PNGs (`vis_name` overrides the
+        prefix)."""
         z_table = AtomicNumberTable(self.z_table_zs.tolist())
         if use_constant_atomic_symbols is not None:
             if not isinstance(num_atoms_per_sample, (int, np.integer)):
@@ -245,6 +260,6 @@ class PONITA_DIFFUSION(nn.Module):
             constant_atoms = None
         return self.diffusion_loss.sample(
             model=self, z_table=z_table, t_emb_weights=self.t_emb, num_atoms_per_sample=num_atoms_per_sample,
-            num_samples_in_batch=num_samples_in_batch, vis_name=f"{DIFFUSION_DIR}/step",
+            num_samples_in_batch=num_samples_in_batch, vis_name=self._frame_prefix(vis_name, visualization_setting),
             visualization_setting=visualization_setting, show_bonds=show_bonds, constant_atoms=constant_atoms,
             noise=noise, max_steps=max_steps, use_graph=use_graph, seed=seed, fixed_cell=fixed_cell)

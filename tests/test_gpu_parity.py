@@ -929,3 +929,34 @@ def test_graph_replay_matches_eager_loop(dev, small_model):
     assert np.isfinite(b.frac_x).all() and (b.frac_x >= 0).all() and (b.frac_x <= 1).all()
     assert np.array_equal(a.frac_x, b.frac_x) and np.array_equal(a.lattice, b.lattice)
     assert np.array_equal(a.atomic_numbers, b.atomic_numbers)
+
+
+def test_visualization_frames_follow_the_reference_schedule(dev, small_model, tmp_path):
+    """DiffusionLoss.sample with VisualizationSetting.ALL / ALL_DETAILED / LAST (diffusion_loss.py:351-370): frames at
+    every 10th timestep (never the first, T - 1) resp. every timestep, plus `_final`; cutting the library loop at the
+    frame timesteps does not change the trajectory (Philox noise is a function of seed and timestep)."""
+    import glob
+    from arreau_amd.diffusion.inference.visualize_crystal import VisualizationSetting
+    m, _, _ = small_model  # T = 100
+
+    def run(setting, name, **kw):
+        torch.manual_seed(3); np.random.seed(3)
+        return m.sample(5, 2, setting, False, seed=77, vis_name=str(tmp_path / name) if name else None, **kw)
+
+    ref = run(VisualizationSetting.NONE, "")
+    res = run(VisualizationSetting.ALL, "all")
+    names = sorted(f.split("/")[-1] for f in glob.glob(str(tmp_path / "all_*_0.cif")))
+    assert names == sorted([f"all_{t}_0.cif" for t in range(90, 0, -10)] + ["all_final_0.cif"])
+    assert np.array_equal(res.frac_x, ref.frac_x) and np.array_equal(res.lattice, ref.lattice)
+    assert np.array_equal(res.atomic_numbers, ref.atomic_numbers)
+    last = open(tmp_path / "all_final_1.cif").read()
+    assert f"{np.mod(ref.frac_x[5, 0], 1.0):.6f}" in last  # the final frame is the returned state (crystal 1, atom 0)
+    res = run(VisualizationSetting.ALL_DETAILED, "det", max_steps=12)
+    names = sorted(f.split("/")[-1] for f in glob.glob(str(tmp_path / "det_*_0.cif")))
+    assert names == sorted([f"det_{t}_0.cif" for t in range(98, 87, -1)] + ["det_final_0.cif"])
+    run(VisualizationSetting.LAST, "last", max_steps=5)
+    assert sorted(f.split("/")[-1] for f in glob.glob(str(tmp_path / "last_*.cif"))) == ["last_final_0.cif", "last_final_1.cif"]
+    res_ref = run(VisualizationSetting.ALL, "refnoise", noise="reference", max_steps=15)  # the host-noise loop, same schedule
+    assert sorted(f.split("/")[-1] for f in glob.glob(str(tmp_path / "refnoise_*_0.cif"))) == ["refnoise_90_0.cif", "refnoise_final_0.cif"]
+    with pytest.raises(ValueError):
+        m.sample(5, 2, VisualizationSetting.ALL, False, vis_name="")  # no prefix for the frame files

@@ -124,3 +124,26 @@ def test_synthetic_alexandria_statistics():
     dens = np.array([len(c.atomic_numbers) / abs(np.linalg.det(c.L0)) for c in cs])
     assert 7.0 < n.mean() < 9.5 and n.max() <= 64 and n.min() >= 1
     np.testing.assert_allclose(dens, 0.05539856, rtol=1e-9)  # exploration/find_avg_density_of_dataset.py:40
+
+
+def test_frame_files_are_valid_cif(tmp_path):
+    """vis_crystal_during_sampling (visualize_crystal.py:57-67): one P1 CIF per crystal, cell parameters from the
+    row-vector lattice, wrapped fractional coordinates, the mask state as the dummy species X."""
+    from arreau_amd.diffusion.inference.visualize_crystal import vis_crystal_during_sampling
+    from arreau_amd.diffusion.tools.atomic_number_table import AtomicNumberTable
+    zt = AtomicNumberTable([1, 8, 26, AtomicNumberTable.MASK_ATOMIC_NUMBER])
+    lattice = np.array([[[4.0, 0, 0], [0, 5.0, 0], [0, 0, 6.0]], [[3.0, 0, 0], [1.5, 2.598076, 0], [0, 0, 7.0]]])
+    frac = np.array([[0.1, 0.2, 0.3], [1.25, -0.5, 0.0], [0.5, 0.5, 0.5], [0.9, 0.1, 0.2], [0.3, 0.3, 0.3]])
+    files = vis_crystal_during_sampling(zt, np.array([0, 1, 2, 3, 1]), lattice, frac, str(tmp_path / "run_40"), False,
+                                        num_atoms=np.array([3, 2]))
+    assert [f.split("/")[-1] for f in files] == ["run_40_0.cif", "run_40_1.cif"]
+    a = open(files[0]).read().split("\n")
+    assert "_cell_length_b 5.000000" in a and "_cell_angle_gamma 90.000000" in a
+    sites = [ln.split() for ln in a if ln[:1].isalpha() and len(ln.split()) == 5]
+    assert [s[1] for s in sites] == ["H", "O", "Fe"]
+    assert sites[1][2:] == ["0.250000", "0.500000", "0.000000"]  # wrapped into [0, 1)
+    b = open(files[1]).read()
+    gamma = float([ln.split()[1] for ln in b.split("\n") if ln.startswith("_cell_angle_gamma")][0])
+    assert abs(gamma - 60.0) < 1e-4 and "X1 X " in b and b.startswith("data_run_40\n")  # hexagonal cell; mask state -> dummy species
+    single = vis_crystal_during_sampling(zt, np.array([0, 1]), lattice[:1], frac[:2], str(tmp_path / "one_final"))
+    assert single == [str(tmp_path / "one_final.cif")]
