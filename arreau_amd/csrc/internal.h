@@ -260,6 +260,8 @@ int arreau_launch_mlp_bf16x6(const arreau_model* m, int layer, const float* x_co
                              float* xbar, float* vsum, int N, hipStream_t s);
 int arreau_launch_mlp_f16x3_m16(const arreau_model* m, int layer, const float* x_conv, const float* x_in, float* x_out,
                                 float* xbar, float* vsum, int N, hipStream_t s, NodeRange r = NodeRange());
+int arreau_launch_mlp_f16x3_m16_split(const arreau_model* m, int layer, const float* x_conv, const float* x_in, float* x_out,
+                                      float* xbar, float* vsum, int N, hipStream_t s, NodeRange r = NodeRange());
 int arreau_launch_mlp_f16x3(const arreau_model* m, int layer, const float* x_conv, const float* x_in, float* x_out,
                             float* xbar, float* vsum, int N, hipStream_t s);
 int arreau_launch_readout(const arreau_model* m, const float* xbar, const float* vsum, const int32_t* offsets,

@@ -523,8 +523,8 @@ extern "C" int arreau_model_config(const arreau_model* model, arreau_config* out
 
 extern "C" int arreau_model_set_variant(arreau_model* model, int32_t edge_variant, int32_t mlp_variant) {
     ARREAU_REQUIRE(model, "arreau_model_set_variant: null model");
-    ARREAU_REQUIRE(edge_variant >= -1 && edge_variant <= ARREAU_VARIANT_GENERAL && mlp_variant >= -1 && mlp_variant <= 3,
-                   "arreau_model_set_variant: edge variant must be in 0..5, mlp variant in 0..3 (-1 keeps)");
+    ARREAU_REQUIRE(edge_variant >= -1 && edge_variant <= ARREAU_VARIANT_GENERAL && mlp_variant >= -1 && mlp_variant <= 4,
+                   "arreau_model_set_variant: edge variant must be in 0..5, mlp variant in 0..4 (-1 keeps)");
     ARREAU_REQUIRE(model->fused || edge_variant < 0 || edge_variant == ARREAU_VARIANT_GENERAL,
                    "arreau_model_set_variant: this model's shape (hidden_dim, basis_dim, widening_factor) has no fused kernels; "
                    "only the general path (edge variant 5) is available");

@@ -277,6 +277,227 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_kernel_f16x3_m16(
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Small-batch form ("hidden split", mlp variant 4): ONE NODE PER WORKGROUP, the 512 hidden units split over eight waves.
+//
+// With a handful of nodes (1 x 8 atoms: 8 tiles of 16 rows) the kernel above is one wave walking through all 32 weight
+// chunks of a layer: 22 us of pure latency while 250 CUs idle.  Here wave w = (quarter q, half e) owns 64 hidden units:
+// two chunks of linear_1 (32 hidden units each) and, of each of the quarter's four linear_2 chunks, the four steps that
+// contract over its own 64 units -- 32 steps instead of 256.  Its 64 weight fragments come straight from the packed
+// stream in L2 into registers in two batches (no LDS ring, no barriers): the second batch is requested while the first
+// is being consumed.  The eight partial outputs meet in LDS and are added in wave order (fixed); the epilogue is shared
+// too, one 16-channel output tile per wave, its operands requested at the top of the kernel.  Same arithmetic as the kernel above (fp16x3 planes, fp32 accumulate, the same GELU), but the sum over the
+// hidden dimension is grouped differently, so results agree to rounding, not bit for bit: the variant is chosen per
+// model (arreau_model_set_variant), never by batch size.
+// ---------------------------------------------------------------------------------------------------------------------
+namespace {
+template <int NST>
+__device__ __forceinline__ void load_steps(u32x4 (&w)[2 * NST], const u32x4* __restrict__ chunk, int st0, int lane) {
+#pragma unroll
+    for (int i = 0; i < NST; ++i) {
+        w[2 * i] = chunk[(size_t)(st0 + i) * 128 + lane];
+        w[2 * i + 1] = chunk[(size_t)(st0 + i) * 128 + 64 + lane];
+    }
+}
+// steps i = 0 .. NST-1 of a chunk from registers: k-block KB0 + (i >> 1) of the B operand, 16-row output tile i & 1
+template <int NST, int KB0, int NKB, int NW>
+__device__ __forceinline__ void mma16_regs(f32x4v (&am)[2], f32x4v (&ax)[2], const u32x4 (&w)[NW], int w0,
+                                           const u32x4 (&b)[NKB][2]) {
+#pragma unroll
+    for (int i = 0; i < NST; ++i) {
+        const int kb = KB0 + (i >> 1), mt = i & 1;
+        am[mt] = mfma16_f16(w[w0 + 2 * i], b[kb][0], am[mt]);
+        ax[mt] = mfma16_f16(w[w0 + 2 * i], b[kb][1], ax[mt]);
+        ax[mt] = mfma16_f16(w[w0 + 2 * i + 1], b[kb][0], ax[mt]);
+    }
+}
+}  // namespace
+
+template <int C, int H>
+__global__ __launch_bounds__(512) void mlp_kernel_f16x3_m16_split(
+    const float* __restrict__ x_conv, const float* __restrict__ x_in, float* __restrict__ x_out,
+    const float* __restrict__ ln_w, const float* __restrict__ ln_b, const u32x4* __restrict__ stream,
+    const float* __restrict__ mb1, const float* __restrict__ mb2, const float* __restrict__ ls,
+    const float* __restrict__ wv, float bv, int n0, int first_layer, float* __restrict__ xbar, float* __restrict__ vsum) {
+    static_assert(C == 128 && H == 512, "chunking below assumes C = 128, H = 512");
+    constexpr int KC = C / 32, HQ = H / 4;
+    __shared__ f32x4v part[8][KC * 2][64];  // [wave][output chunk u, tile mt][lane]: 64 KiB
+    __shared__ float vpart[8][64];
+
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int q = wave >> 1, e = wave & 1;     // hidden quarter, half of the quarter
+    const int cp = lane & 15, gp = lane >> 4;
+    const int n = n0 + blockIdx.x;
+    const u32x4* qs = stream + (size_t)q * 8 * 1024;  // this quarter: 4 linear_1 chunks, then 4 linear_2 chunks
+
+    // batch 1 of the weights: this wave's two linear_1 chunks (u = 2 e, 2 e + 1), 16 fragments each
+    u32x4 wa[16], wb[16];
+    load_steps<8>(wa, qs + (size_t)(2 * e) * 1024, 0, lane);
+    load_steps<8>(wb, qs + (size_t)(2 * e + 1) * 1024, 0, lane);
+    // operands of this wave's share of the epilogue (output tile u = wave >> 1, mt = wave & 1), requested now
+    const int ep_c0 = 32 * (wave >> 1) + 16 * (wave & 1) + 4 * gp;  // this lane's four channels
+    const size_t ep_off = ((size_t)n * 16 + cp) * C + ep_c0;
+    const f32x4 ep_b2 = *reinterpret_cast<const f32x4*>(mb2 + ep_c0);
+    const f32x4 ep_ls = *reinterpret_cast<const f32x4*>(ls + ep_c0);
+    const f32x4 ep_wv = *reinterpret_cast<const f32x4*>(wv + ep_c0);
+    const f32x4 ep_xi = *reinterpret_cast<const f32x4*>(x_in + ep_off);
+
+    // ---- the node's 16 rows in B-operand layout, LayerNorm (eps 1e-5, biased variance), split (as in the kernel above) ----
+    u32x4 xn[KC][2];
+    {
+        const float* rowp = x_conv + ((size_t)n * 16 + cp) * C + 4 * gp;
+        float x[KC][8];
+        float sum = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < KC; ++kb)
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {
+                const f32x4 v = *reinterpret_cast<const f32x4*>(rowp + 32 * kb + 16 * hf);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) x[kb][4 * hf + r] = v[r];
+                sum += (v[0] + v[1]) + (v[2] + v[3]);
+            }
+        const float mean = group4_sum(sum) * (1.0f / C);
+        float sq = 0.f;
+#pragma unroll
+        for (int kb = 0; kb < KC; ++kb)
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const float dlt = x[kb][i] - mean;
+                x[kb][i] = dlt;
+                sq += dlt * dlt;
+            }
+        const float rstd = 1.0f / sqrtf(group4_sum(sq) * (1.0f / C) + 1e-5f);
+#pragma unroll
+        for (int kb = 0; kb < KC; ++kb) {
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {
+                const f32x4 gw = *reinterpret_cast<const f32x4*>(ln_w + 32 * kb + 16 * hf + 4 * gp);
+                const f32x4 gb = *reinterpret_cast<const f32x4*>(ln_b + 32 * kb + 16 * hf + 4 * gp);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) x[kb][4 * hf + r] = x[kb][4 * hf + r] * rstd * gw[r] + gb[r];
+            }
+            split8<true>(x[kb], xn[kb][0], xn[kb][1]);
+        }
+    }
+
+    // ---- hidden units: two chunks of 32, GELU, split -> B operand of linear_2 (k-blocks 0, 1 of this wave) ----------
+    u32x4 hid[2][2];
+    auto hidden_chunk = [&](const u32x4 (&w)[16], int j) {
+        f32x4v am[2], ax[2];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            const f32x4 b = *reinterpret_cast<const f32x4*>(mb1 + q * HQ + 32 * (2 * e + j) + 16 * mt + 4 * gp);
+            am[mt] = f32x4v{b[0], b[1], b[2], b[3]};
+            ax[mt] = f32x4v{0.f, 0.f, 0.f, 0.f};
+        }
+        mma16_regs<8, 0, KC>(am, ax, w, 0, xn);
+        float v[8];
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int pr = 0; pr < 2; ++pr) {
+                const f32x2 pre = fma2(f32x2{ax[mt][2 * pr], ax[mt][2 * pr + 1]}, splat2(F16X3_INV_SCALE),
+                                       f32x2{am[mt][2 * pr], am[mt][2 * pr + 1]});
+                const f32x2 act = gelu_fast2(pre);
+                v[4 * mt + 2 * pr] = act.x;
+                v[4 * mt + 2 * pr + 1] = act.y;
+            }
+        split8<false>(v, hid[j][0], hid[j][1]);
+    };
+    hidden_chunk(wa, 0);
+    // batch 2a: of linear_2 chunks u = 0, 1 the steps 4 e .. 4 e + 3 (this wave's 64 hidden units), 8 fragments each
+    {
+        u32x4 t0[8], t1[8];
+        load_steps<4>(t0, qs + (size_t)4 * 1024, 4 * e, lane);
+        load_steps<4>(t1, qs + (size_t)5 * 1024, 4 * e, lane);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { wa[i] = t0[i]; wa[8 + i] = t1[i]; }
+    }
+    hidden_chunk(wb, 1);
+    {   // batch 2b: linear_2 chunks u = 2, 3
+        u32x4 t0[8], t1[8];
+        load_steps<4>(t0, qs + (size_t)6 * 1024, 4 * e, lane);
+        load_steps<4>(t1, qs + (size_t)7 * 1024, 4 * e, lane);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { wb[i] = t0[i]; wb[8 + i] = t1[i]; }
+    }
+
+    // ---- partial outputs: chunk u = 32 outputs, contracted over this wave's 64 hidden units -------------------------
+    auto output_chunk = [&](const u32x4 (&w)[16], auto w0c, int u) {
+        constexpr int w0 = decltype(w0c)::value;
+        f32x4v am[2] = {f32x4v{0.f, 0.f, 0.f, 0.f}, f32x4v{0.f, 0.f, 0.f, 0.f}};
+        f32x4v ax[2] = {f32x4v{0.f, 0.f, 0.f, 0.f}, f32x4v{0.f, 0.f, 0.f, 0.f}};
+        mma16_regs<4, 0, 2>(am, ax, w, w0, hid);
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            f32x4v o;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[r] = fmaf(ax[mt][r], F16X3_INV_SCALE, am[mt][r]);
+            part[wave][2 * u + mt][lane] = o;
+        }
+    };
+    output_chunk(wa, std::integral_constant<int, 0>{}, 0);
+    output_chunk(wa, std::integral_constant<int, 8>{}, 1);
+    output_chunk(wb, std::integral_constant<int, 0>{}, 2);
+    output_chunk(wb, std::integral_constant<int, 8>{}, 3);
+    __syncthreads();
+
+    // ---- epilogue, one 16-channel output tile (u, mt) per wave: sum of the eight partial outputs in wave order, bias,
+    // layer scale, residual, x_out, per-channel orientation means; the vector read-out partials meet in LDS -------------
+    {
+        const int u = wave >> 1, mt = wave & 1;
+        f32x4v acc = part[0][2 * u + mt][lane];
+#pragma unroll
+        for (int w2 = 1; w2 < 8; ++w2) acc += part[w2][2 * u + mt][lane];
+        f32x4 xo;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) xo[r] = (acc[r] + ep_b2[r]) * ep_ls[r] + ep_xi[r];
+        *reinterpret_cast<f32x4*>(x_out + ep_off) = xo;
+        float vdot = 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) vdot += xo[r] * ep_wv[r];
+        f32x4 sum;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sum[r] = row16_sum_m(xo[r]);
+        if (cp == 0) {
+            const float inv16 = 1.0f / 16.0f;
+            const f32x4 mean = {sum[0] * inv16, sum[1] * inv16, sum[2] * inv16, sum[3] * inv16};
+            *reinterpret_cast<f32x4*>(xbar + (size_t)n * C + ep_c0) = mean;
+        }
+        vpart[wave][lane] = vdot;
+    }
+    __syncthreads();
+    if (wave != 0) return;
+    float vdot = vpart[0][lane];
+#pragma unroll
+    for (int w2 = 1; w2 < 8; ++w2) vdot += vpart[w2][lane];
+    const float tot = group4_sum(vdot);
+    if (gp == 0) {
+        const size_t o = (size_t)n * 16 + cp;
+        vsum[o] = (first_layer ? 0.0f : vsum[o]) + (tot + bv);
+    }
+}
+
+int arreau_launch_mlp_f16x3_m16_split(const arreau_model* m, int layer, const float* x_conv, const float* x_in, float* x_out,
+                                      float* xbar, float* vsum, int Ntot, hipStream_t s, NodeRange r) {
+    const int n0 = r.n0, n1 = r.n1 < 0 ? Ntot : r.n1;
+    if (n1 <= n0) return ARREAU_OK;
+    const int C = m->C, H = m->H;
+    if (!(C == 128 && H == 512)) {
+        arreau_set_error("mlp kernel (fp16x3, hidden split): unsupported (hidden_dim, widening_factor)");
+        return ARREAU_EINVAL;
+    }
+    const size_t layer_u32x4 = (size_t)2 * H * C * 2 * 2 / 16;
+    const u32x4* stream = reinterpret_cast<const u32x4*>(m->mlp_f16m) + (size_t)layer * layer_u32x4;
+    hipLaunchKernelGGL((mlp_kernel_f16x3_m16_split<128, 512>), dim3((unsigned)(n1 - n0)), dim3(512), 0, s, x_conv, x_in, x_out,
+                       m->ln_w + (size_t)layer * C, m->ln_b + (size_t)layer * C, stream, m->mb1 + (size_t)layer * H,
+                       m->mb2 + (size_t)layer * C, m->ls + (size_t)layer * C, m->ro_wv + (size_t)layer * C, m->ro_bv_host[layer],
+                       n0, layer == 0 ? 1 : 0, xbar + (size_t)layer * Ntot * C, vsum);
+    ARREAU_CHECK_HIP(hipGetLastError());
+    return ARREAU_OK;
+}
+
 int arreau_launch_mlp_f16x3_m16(const arreau_model* m, int layer, const float* x_conv, const float* x_in, float* x_out,
                                 float* xbar, float* vsum, int Ntot, hipStream_t s, NodeRange r) {
     const int n0 = r.n0, n1 = r.n1 < 0 ? Ntot : r.n1;
