@@ -80,6 +80,27 @@ def log(msg):
     sys.stderr.flush()
 
 
+_RESULT_OUT = None
+
+
+def claim_stdout():
+    """The contract is ONE JSON line on stdout.  Libraries print there too (gloo announces its connections, ROCm warns
+    about missing files), so a rank process keeps the real stdout for the result line and points file descriptor 1 at
+    stderr for everything else, C++ writers included."""
+    global _RESULT_OUT
+    if _RESULT_OUT is None:
+        sys.stdout.flush()
+        _RESULT_OUT = os.fdopen(os.dup(1), "w")
+        os.dup2(2, 1)
+    return _RESULT_OUT
+
+
+def emit(result):
+    out = claim_stdout()
+    out.write(json.dumps(result) + "\n")
+    out.flush()
+
+
 def host_cores():
     """CPU threads this process may really use: affinity mask, capped by the cgroup CPU quota."""
     n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
@@ -168,6 +189,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if args.gpus != world:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    claim_stdout()
     if stub:
         return run_stub(args, rank, world)
     if args.config == "c5":
@@ -202,9 +224,9 @@ def run_stub(args, rank, world):
         per_rank = [float(g[0]) for g in gathered]
         elapsed = max(float(g[1]) for g in gathered)
     if rank == 0:
-        print(json.dumps({"metric": "stub", "value": world * args.batch_per_gpu * args.steps / elapsed, "n_gpus": world,
-                          "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
-                          "per_rank_ms": [1e3 * e / args.steps for e in per_rank]}), flush=True)
+        emit({"metric": "stub", "value": world * args.batch_per_gpu * args.steps / elapsed, "n_gpus": world,
+              "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+              "per_rank_ms": [1e3 * e / args.steps for e in per_rank]})
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -449,7 +471,7 @@ def run_rank(args, rank, local_rank, world):
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(model, B, n, T, args.cpu_steps)
-        print(json.dumps(out), flush=True)
+        emit(out)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
@@ -554,7 +576,7 @@ def run_rank_c5(args, rank, local_rank, world):
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline_training(model, batches[0], args.cpu_steps)
-        print(json.dumps(out), flush=True)
+        emit(out)
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
