@@ -682,22 +682,27 @@ static int ensure_ctx(arreau_model* m, int N, int B, hipStream_t s) {
         t->N = N; t->B = B;
         return ARREAU_OK;
     }
+    // Growing means a device synchronisation, a free and an allocation of gigabytes (milliseconds): a training loop whose
+    // batches creep upwards in size must not pay that every few steps, so a regrown context gets 25 % headroom.
+    int capN = N, capB = B;
     if (t) {
+        capN = std::max(N, t->capN) + std::max(N, t->capN) / 4;
+        capB = std::max(B, t->capB) + std::max(B, t->capB) / 4;
         ARREAU_CHECK_HIP(hipStreamSynchronize(s));
         arreau_train_ctx_destroy(t);
         m->train = nullptr;
     }
     t = new arreau_train_ctx();
-    t->capN = N; t->capB = B;
+    t->capN = capN; t->capB = capB;
     arreau_train_ctx probe;
-    t->buf_floats = layout(probe, m, N, B, nullptr);
+    t->buf_floats = layout(probe, m, capN, capB, nullptr);
     hipError_t e = hipMalloc((void**)&t->buf, t->buf_floats * sizeof(float));
     if (e != hipSuccess) {
         delete t;
         arreau_set_error(std::string("hipMalloc(training buffers): ") + hipGetErrorString(e));
         return ARREAU_EHIP;
     }
-    layout(*t, m, N, B, t->buf);
+    layout(*t, m, capN, capB, t->buf);
     t->N = N; t->B = B;
     m->train = t;
     ARREAU_CHECK_HIP(hipMemsetAsync(t->scratch_cols, 0, 1024 * sizeof(float), s));

