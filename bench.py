@@ -15,6 +15,13 @@ selects the other BASELINE configurations (c1: 1 crystal x 8 atoms, T = 100; c3:
 Crystals are independent, so ranks hold disjoint sub-batches and there is no data-path collective (weak scaling); the
 process group is used only for the timing barrier / max-over-ranks.
 
+The K steps are ONE arreau_sample_loop call per stretch of timesteps (Philox noise inside the update kernels, timestep on
+the device, nothing on the host between steps), timed twice: as eager launches -- hipEvents bracket every edge-kernel
+launch there: the roofline figure -- and as hipGraph replay of the captured step with the batch as pipelined
+crystal-aligned slices (bit-identical results).  `value` is the loop PONITA_DIFFUSION.sample runs by default for the
+configuration (graph replay for samplers of at least 200 steps, i.e. every 1000-step config; eager for the 100-step
+single-crystal config): `loop_mode` names it, `eager_loop` / `graph_loop` hold both.
+
 Prints ONE JSON line on rank 0 (see the keys at the bottom).
 """
 import argparse
@@ -130,6 +137,8 @@ def parse_args(argv=None):
     ap.add_argument("--no-full-sampler", action="store_true", help="skip the measured run of the whole T-1 step sampler")
     ap.add_argument("--mlp-variant", type=int, default=None, help="ConvNext kernel of the model (3: default; 4: small-batch "
                     "hidden-split form; default: 4 for the single-crystal config c1, 3 otherwise)")
+    ap.add_argument("--eager-value", action="store_true", help="report the eager loop as `value` even where the product "
+                    "defaults to graph replay")
     ap.add_argument("--groups", type=int, default=0, help="slices of the batch run on separate streams (0: library default)")
     args = ap.parse_args(argv)
     B, n, T = CONFIGS[args.config or "c2"]
@@ -331,35 +340,45 @@ def run_rank(args, rank, local_rank, world):
     run_steps(args.warmup)
     torch.cuda.synchronize(dev)
     log("warm-up done; timing")
+    def gather(local, total):
+        """per-rank own times and the barrier-to-barrier time, MAX over ranks"""
+        if dist is None:
+            return [local], total
+        tt = torch.tensor([local, total], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
+        gathered = [torch.zeros_like(tt) for _ in range(world)]
+        dist.all_gather(gathered, tt)
+        return [float(g[0]) for g in gathered], max(float(g[1]) for g in gathered)
+
+    # Loop 1, eager: one launch per kernel and step, hipEvents around every edge-kernel launch (the roofline figure).
     e_start = degree_sum()
     _hip.check(_hip.lib().arreau_profile_edge_kernel(1), "profile on")
-    elapsed = timed_loop(args.steps)
+    el_eager = timed_loop(args.steps)
     mean_ms, launches = ctypes.c_double(), ctypes.c_int64()
     _hip.check(_hip.lib().arreau_edge_kernel_time_ms(ctypes.byref(mean_ms), ctypes.byref(launches)), "edge time")
     _hip.check(_hip.lib().arreau_profile_edge_kernel(0), "profile off")
     e_end = degree_sum()
     status = eng.check_status()  # raises on non-finite outputs / clamped indices; names the kernels that really ran
+    per_rank_eager, el_eager = gather(local_elapsed[0], el_eager)
 
-    per_rank = [local_elapsed[0]]
-    if dist is not None:
-        tt = torch.tensor([local_elapsed[0], elapsed], device=dev if backend == "nccl" else "cpu", dtype=torch.float64)
-        gathered = [torch.zeros_like(tt) for _ in range(world)]
-        dist.all_gather(gathered, tt)
-        per_rank = [float(g[0]) for g in gathered]
-        elapsed = max(float(g[1]) for g in gathered)  # barrier-to-barrier time, MAX over ranks
+    # Loop 2, hipGraph replay of the captured step (arreau_sample_loop use_graph = 1), the batch as pipelined
+    # crystal-aligned slices when the layout has them: bit-identical results, what PONITA_DIFFUSION.sample runs by
+    # default for samplers of at least 200 steps (DiffusionLoss.sample).
+    run_steps(3, use_graph=True)  # warm-up of the graph path (capture, instantiation, stream / event creation)
+    el_graph = timed_loop(args.steps, use_graph=True)
+    per_rank_graph, el_graph = gather(local_elapsed[0], el_graph)
+    eng.check_status()
 
-    # The same K steps as a hipGraph replay of one captured step (arreau_sample_loop use_graph = 1): what small,
-    # launch-bound batches gain from it; `value` stays the eager loop above.
-    graph_loop = None
-    if world == 1:
-        run_steps(3, use_graph=True)  # warm-up of the graph path (stream / event creation)
-        el_g = timed_loop(args.steps, use_graph=True)
-        graph_loop = {"steps": args.steps, "ms_per_step": 1e3 * el_g / args.steps,
-                      "slices": groups,
-                      "note": "what PONITA_DIFFUSION.sample runs for a 1000-step sampler: hipGraph replay of the captured step, "
-                              "the batch as pipelined crystal-aligned slices on separate streams (bit-identical results); "
-                              "`value` is the eager whole-batch loop, which is also what the edge-kernel events time"}
-        eng.check_status()
+    # `value` is the loop the product runs for THIS configuration: the same policy as DiffusionLoss.sample's default
+    # (graph replay from 200 sampler steps on; the 100-step single-crystal config runs eagerly).
+    production_graph = (T - 1) >= 200 and not args.eager_value
+    elapsed, per_rank = (el_graph, per_rank_graph) if production_graph else (el_eager, per_rank_eager)
+    loop_mode = (f"hipGraph replay of the captured step, {groups} pipelined slice(s) per GPU" if production_graph
+                 else "eager launches")
+    eager_loop = {"steps": args.steps, "ms_per_step": 1e3 * el_eager / args.steps,
+                  "note": "one launch per kernel and step; the edge-kernel hipEvents (roofline) are taken here"}
+    graph_loop = {"steps": args.steps, "ms_per_step": 1e3 * el_graph / args.steps, "slices": groups,
+                  "note": "hipGraph replay of the captured step, the batch as pipelined crystal-aligned slices on separate "
+                          "streams (bit-identical results): PONITA_DIFFUSION.sample's default for >= 200 sampler steps"}
 
     # The headline metric measured rather than extrapolated: ONE call of PONITA_DIFFUSION.sample for the whole sampler
     # (T - 1 network evaluations of this batch; host-side initial draws, the library loop in its default mode, the
@@ -454,6 +473,8 @@ def run_rank(args, rank, local_rank, world):
                 "parallelism": f"replicas x{world}, disjoint sub-batches, no data-path collective",
                 "slices_per_gpu": launches_per_step,
             },
+            "loop_mode": loop_mode,
+            "eager_loop": eager_loop,
             "graph_loop": graph_loop,
             "full_sampler_measured": full_sampler,
             "batch_steps_per_sec": world * args.steps / elapsed,
