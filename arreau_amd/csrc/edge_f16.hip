@@ -392,6 +392,243 @@ __global__ __launch_bounds__(64 * EH_WAVES, 2) void edge_kernel_f16x3(
 #endif
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Small-batch form of the same kernel: ONE 32-ROW TILE PER WORKGROUP, its output chunks split over eight waves.
+//
+// Above, a wave carries its 32 rows (two edge slots x 16 orientations) through all 32 weight chunks: 39 k matrix-pipe
+// cycles per tile, fine when 20 k tiles keep every SIMD busy, 62 us of one wave's latency when a single crystal of 8
+// atoms brings 32 tiles to a 256-CU chip.  Here a workgroup owns one tile and the OUTPUT chunks of each layer are dealt
+// to its waves: layer 1 (4 chunks) to waves 0-3, layer 2 (8 chunks) one per wave, the 20 projection chunks round-robin.
+// A wave's weight fragments come straight from the packed stream in L2 into registers (no LDS ring, no counted waits);
+// the layer outputs meet in LDS (the re-layout pad of the kernel above, now shared by the workgroup).  Every output
+// chunk is computed by exactly the instruction sequence of the kernel above -- same operand planes, same k order, same
+// epilogues -- so the K tiles are BIT-IDENTICAL: the launcher may pick either form by batch size.
+// ---------------------------------------------------------------------------------------------------------------------
+#define ARREAU_EDGE_SPLIT_MAX_NODES 64
+template <int C, int D>
+__global__ __launch_bounds__(512) void edge_kernel_f16x3_split(
+    const float* __restrict__ nbr_dir, const float* __restrict__ nbr_dist, const int32_t* __restrict__ deg,
+    const int32_t* __restrict__ batch, const float* __restrict__ lattice, const float* __restrict__ ori,
+    const u32x4* __restrict__ stream, const float* __restrict__ b1, const float* __restrict__ b2, float r_max, int N, int k,
+    int L, float* __restrict__ kbuf, int n0) {
+    constexpr int TC = C / 32, TD = D / 32, TM = ARREAU_MONO_PAD / 32;
+    constexpr int NF1 = TM * 4, NF2 = TC * 4, NF3 = TD * 4;  // 1 KiB fragments per chunk: 12, 16, 32
+    static_assert(TM == 3 && TC == 4 && TD == 8, "wave roles below assume C = 128, D = 256");
+    __shared__ u32x4 hpad[TC][256];        // layer-1 tiles in the re-layout format of the kernel above (4 KiB each)
+    __shared__ u32x4 bpad[TD][2][2][64];   // layer-2 output as B operand: [k-block u][column block nb][plane][lane]
+
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int node = n0 + (int)(blockIdx.x >> 2), wn = blockIdx.x & 3;  // receiver, its tile: slots 2 wn, 2 wn + 1
+    const int nd = min(deg[node], k);
+    if (2 * wn >= nd) return;  // no edge in this tile (the kernel above stores nothing for it either)
+    const int h = lane >> 5, j = lane & 31;
+    const int c16 = lane & 15, g16 = lane >> 4;
+
+    const u32x4* s1 = stream;                                   // layer-1 chunks
+    const u32x4* s2 = stream + (size_t)TC * NF1 * 64;           // layer-2 chunks
+    const u32x4* s3 = s2 + (size_t)TD * NF2 * 64;               // projection chunks, L * TC of them
+    const int nchunks = L * TC;
+
+    // ---- weight requests first: layer 1 (waves 0-3), layer 2 (chunk = wave), first half of the first projection chunk ----
+    u32x4 w1[NF1], w2[NF2], wx[16], wy[16];
+    if (wave < TC) {
+#pragma unroll
+        for (int i = 0; i < NF1; ++i) w1[i] = s1[(size_t)wave * NF1 * 64 + i * 64 + lane];
+    }
+#pragma unroll
+    for (int i = 0; i < NF2; ++i) w2[i] = s2[(size_t)wave * NF2 * 64 + i * 64 + lane];
+    auto load_half = [&](u32x4 (&w)[16], int cidx, int half) {
+        const u32x4* src = s3 + (size_t)cidx * NF3 * 64 + (size_t)half * 16 * 64 + lane;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) w[i] = src[i * 64];
+    };
+
+    // ---- per-row attributes (transforms/invariants.py:82-88), as in the kernel above ------------------------------
+    const int slot = 2 * wn + (j >> 4);
+    const int o = j & 15;
+    const int slot_c = min(slot, k - 1);
+    float a[6], window;
+    {
+        const size_t e = (size_t)node * k + slot_c;
+        const float dx = nbr_dir[3 * e + 0], dy = nbr_dir[3 * e + 1], dz = nbr_dir[3 * e + 2];
+        const float dist = nbr_dist[e];
+        const float ox = ori[3 * o + 0], oy = ori[3 * o + 1], oz = ori[3 * o + 2];
+        a[0] = (dx * ox + dy * oy) + dz * oz;
+        const float rx = dx - a[0] * ox, ry = dy - a[0] * oy, rz = dz - a[0] * oz;
+        a[1] = sqrtf((rx * rx + ry * ry) + rz * rz);
+        a[2] = dist;
+        const float* Lm = lattice + 9 * (size_t)batch[node];
+        const float inv_dn = __builtin_amdgcn_rcpf(fmaxf(sqrtf((dx * dx + dy * dy) + dz * dz), 1e-8f));
+        const float ux = dx * inv_dn, uy = dy * inv_dn, uz = dz * inv_dn;
+#pragma unroll
+        for (int i = 0; i < 3; ++i) {
+            const float lx = Lm[3 * i], ly = Lm[3 * i + 1], lz = Lm[3 * i + 2];
+            const float inv_ln = __builtin_amdgcn_rcpf(fmaxf(sqrtf((lx * lx + ly * ly) + lz * lz), 1e-8f));
+            a[3 + i] = (ux * (lx * inv_ln) + uy * (ly * inv_ln)) + uz * (lz * inv_ln);
+        }
+        const float u = dist * __builtin_amdgcn_rcpf(r_max);
+        const float u2 = u * u, u6 = u2 * u2 * u2;
+        const float w = 1.0f - 28.0f * u6 + 48.0f * u6 * u - 21.0f * u6 * u2;
+        window = (slot < nd && dist < r_max) ? w : 0.0f;
+    }
+    float win16[2];
+    win16[0] = __shfl(window, c16, 64);
+    win16[1] = __shfl(window, 16 + c16, 64);
+
+    // ---- layer 1, chunk u = wave (waves 0-3): h = GELU(W1f . mono + b1), into the shared re-layout pad -------------
+    if (wave < TC) {
+        Planes2 bm[TM];
+        bm[0] = split_tile2(mono_tile_h<0>(a, h, std::make_integer_sequence<int, 16>{}));
+        bm[1] = split_tile2(mono_tile_h<1>(a, h, std::make_integer_sequence<int, 16>{}));
+        bm[2] = split_tile2(mono_tile_h<2>(a, h, std::make_integer_sequence<int, 16>{}));
+        f32x16 acc = arreau_bias_tile(b1, wave, h), cross;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) cross[r] = 0.f;
+#pragma unroll
+        for (int ks = 0; ks < 2 * TM; ++ks) {
+            const int t = ks >> 1, s = ks & 1;
+            acc = mfma_f16(w1[2 * ks], bm[t].p[0][s], acc);
+            cross = mfma_f16(w1[2 * ks], bm[t].p[1][s], cross);
+            cross = mfma_f16(w1[2 * ks + 1], bm[t].p[0][s], cross);
+        }
+        const Planes2 pl = gelu_split_tile2(acc, cross, 1.0f);
+#pragma unroll
+        for (int plane = 0; plane < 2; ++plane) {
+            hpad[wave][128 * plane + (j * 2 + h) * 2 + 0] = pl.p[plane][0];
+            hpad[wave][128 * plane + (j * 2 + h) * 2 + 1] = pl.p[plane][1];
+        }
+    }
+    __syncthreads();
+    asm volatile("" ::: "memory");  // (keeps the later phases' weight requests from being hoisted over this phase)
+    load_half(wx, wave, 0);  // first half of this wave's first projection chunk (wave < nchunks: checked by the launcher)
+
+    // ---- layer 2, chunk u = wave: basis = GELU(W2 . h + b2) * window, into the shared B-operand pad ----------------
+    {
+        Acc16 acc;
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            const f32x4 bv4 = *reinterpret_cast<const f32x4*>(b2 + 32 * wave + 16 * mt + 4 * g16);
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb) {
+                acc.m[mt][nb] = f32x4v{bv4[0], bv4[1], bv4[2], bv4[3]};
+                acc.x[mt][nb] = f32x4v{0.f, 0.f, 0.f, 0.f};
+            }
+        }
+#pragma unroll
+        for (int kb = 0; kb < TC; ++kb) {
+            // the layer-1 tile kb in the (c = orientation, g) layout of column block nb (re-layout read of the kernel above)
+            u32x4 hq[2][2];
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                for (int plane = 0; plane < 2; ++plane)
+                    hq[nb][plane] = hpad[kb][128 * plane + ((16 * nb + c16) * 2 + (g16 >> 1)) * 2 + (g16 & 1)];
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb) {
+                    const int st = 2 * kb + mt;
+                    acc.m[mt][nb] = mfma16_f16(w2[2 * st], hq[nb][0], acc.m[mt][nb]);
+                    acc.x[mt][nb] = mfma16_f16(w2[2 * st], hq[nb][1], acc.x[mt][nb]);
+                    acc.x[mt][nb] = mfma16_f16(w2[2 * st + 1], hq[nb][0], acc.x[mt][nb]);
+                }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb) {
+            u32x4 hi4, lo4;
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int pr = 0; pr < 2; ++pr) {
+                    const f32x2 pre = fma2(f32x2{acc.x[mt][nb][2 * pr], acc.x[mt][nb][2 * pr + 1]}, splat2(F16X3_INV_SCALE),
+                                           f32x2{acc.m[mt][nb][2 * pr], acc.m[mt][nb][2 * pr + 1]});
+                    unsigned hi, lo;
+                    split_pair2<false>(gelu_fast2(pre) * splat2(win16[nb]), hi, lo);  // |window| <= 1
+                    hi4[2 * mt + pr] = hi;
+                    lo4[2 * mt + pr] = lo;
+                }
+            bpad[wave][nb][0][lane] = hi4;
+            bpad[wave][nb][1][lane] = lo4;
+        }
+    }
+    asm volatile("" ::: "memory");
+    load_half(wy, wave, 1);
+    __syncthreads();
+    asm volatile("" ::: "memory");
+
+    // ---- projections: chunks wave, wave + 8, wave + 16: kernel_l = Wk_l . basis (conv.py:110), one K tile each --------
+    const size_t layer_stride = (size_t)N * k * 16 * C;
+    const size_t row0 = ((size_t)node * k + 2 * wn) * 16;  // first K row of this tile
+    const bool full = 2 * wn + 1 < k;                      // the tile's second slot (column block 1) exists
+    Acc16 acc;
+    auto zero_acc = [&]() {
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+            for (int nb = 0; nb < 2; ++nb) { acc.m[mt][nb] = f32x4v{0.f, 0.f, 0.f, 0.f}; acc.x[mt][nb] = f32x4v{0.f, 0.f, 0.f, 0.f}; }
+    };
+    auto half_steps = [&](const u32x4 (&w)[16], int half) {  // steps 8 half .. 8 half + 7 of the chunk, from registers
+        // B operands (k-block kb of the basis, both column blocks, both planes) from the shared pad; the scheduling fences
+        // keep the compiler from hoisting all of a chunk's LDS reads (128 registers beside the 192 of the weight buffers)
+        u32x4 bq[2][4];  // one k-block ahead of its MFMAs
+#pragma unroll
+        for (int i = 0; i < 4; ++i) bq[0][i] = bpad[4 * half][i >> 1][i & 1][lane];
+#pragma unroll
+        for (int kbi = 0; kbi < 4; ++kbi) {
+            if (kbi + 1 < 4) {
+#pragma unroll
+                for (int i = 0; i < 4; ++i) bq[(kbi + 1) & 1][i] = bpad[4 * half + kbi + 1][i >> 1][i & 1][lane];
+            }
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+                for (int nb = 0; nb < 2; ++nb) {
+                    const int i = 2 * kbi + mt;
+                    acc.m[mt][nb] = mfma16_f16(w[2 * i], bq[kbi & 1][2 * nb], acc.m[mt][nb]);
+                    acc.x[mt][nb] = mfma16_f16(w[2 * i], bq[kbi & 1][2 * nb + 1], acc.x[mt][nb]);
+                    acc.x[mt][nb] = mfma16_f16(w[2 * i + 1], bq[kbi & 1][2 * nb], acc.x[mt][nb]);
+                }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+    auto store_tile = [&](int cidx) {
+        const int l = cidx / TC, u = cidx % TC;
+        float* tile = kbuf + (size_t)l * layer_stride + row0 * C + 32 * u;
+#pragma unroll
+        for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+            for (int mt = 0; mt < 2; ++mt) {
+                f32x4 v;
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = fmaf(acc.x[mt][nb][r], F16X3_INV_SCALE, acc.m[mt][nb][r]);
+                if (nb == 0 || full) *reinterpret_cast<f32x4*>(tile + (size_t)(16 * nb + c16) * C + 16 * mt + 4 * g16) = v;
+            }
+    };
+    // two register buffers of half a chunk each: while one is consumed the other is in flight (a third would hide more of
+    // the L2 latency but does not fit beside them: 3 x 64 + accumulators + operands spills)
+    zero_acc();
+    half_steps(wx, 0);
+    if (wave + 8 < nchunks) load_half(wx, wave + 8, 0);
+    half_steps(wy, 1);
+    store_tile(wave);
+    if (wave + 8 < nchunks) {
+        load_half(wy, wave + 8, 1);
+        zero_acc();
+        half_steps(wx, 0);
+        if (wave + 16 < nchunks) load_half(wx, wave + 16, 0);
+        half_steps(wy, 1);
+        store_tile(wave + 8);
+        if (wave + 16 < nchunks) {
+            load_half(wy, wave + 16, 1);
+            zero_acc();
+            half_steps(wx, 0);
+            half_steps(wy, 1);
+            store_tile(wave + 16);
+        }
+    }
+}
+
 int arreau_launch_edge_f16x3(const arreau_model* m, const float* dir, const float* dist, const int32_t* deg,
                              const int32_t* batch, const float* lattice, int N, float* kbuf, hipStream_t s, NodeRange r) {
     const int n0 = r.n0, n1 = r.n1 < 0 ? N : r.n1;
@@ -412,6 +649,18 @@ int arreau_launch_edge_f16x3(const arreau_model* m, const float* dir, const floa
             return (int)prop.multiProcessorCount;
         return 256;
     }();
+    // Small launches: one tile per workgroup, output chunks split over its waves (bit-identical K tiles): while the tiles
+    // are fewer than the chip's wave slots the persistent form above is one wave's latency (62 us at 1 x 8 atoms).
+    static const int split_env = [] { const char* e = getenv("ARREAU_EDGE_SPLIT"); return e ? atoi(e) : -1; }();
+    const bool split_ok = m->L * 4 >= 8 && m->L * 4 <= 24;
+    const bool use_split = split_ok && (split_env >= 0 ? split_env != 0 : (n1 - n0) <= ARREAU_EDGE_SPLIT_MAX_NODES);
+    if (use_split) {
+        hipLaunchKernelGGL((edge_kernel_f16x3_split<128, 256>), dim3((unsigned)(n1 - n0) * 4), dim3(512), 0, s, dir, dist, deg,
+                           batch, lattice, m->ori, reinterpret_cast<const u32x4*>(m->edge_f16), m->b1, m->b2, m->cfg.radius, N,
+                           m->k, m->L, kbuf, n0);
+        ARREAU_CHECK_HIP(hipGetLastError());
+        return ARREAU_OK;
+    }
     const int npairs = (n1 - n0 + 1) / 2;
     int wgs = wgs_env > 0 ? (wgs_env < npairs ? wgs_env : npairs) : (npairs < n_cu ? npairs : n_cu);
     if (r.wg_cap > 0 && wgs > r.wg_cap) wgs = r.wg_cap;

@@ -772,13 +772,15 @@ def test_launch_geometry_switches_and_counted_waits_are_bitwise_neutral(dev):
     with tempfile.TemporaryDirectory() as d:
         for tag, env in (("default", {}), ("conv0", {"ARREAU_CONV_VARIANT": "0"}), ("wgs", {"ARREAU_EDGE_WGS": "100000"}),
                          ("dbgwait", {"ARREAU_HIP_LIB": LIB_DEBUG_WAIT}), ("nb1", {"ARREAU_MLP_NB": "1"}),
-                         ("nb2", {"ARREAU_MLP_NB": "2"}), ("slots4", {"ARREAU_MLP_SLOTS": "4"})):
+                         ("nb2", {"ARREAU_MLP_NB": "2"}), ("slots4", {"ARREAU_MLP_SLOTS": "4"}),
+                         ("edgesplit", {"ARREAU_EDGE_SPLIT": "1"})):
             path = os.path.join(d, tag + ".pt")
             subprocess.run([sys.executable, "-c", code, path], check=True, env={**os.environ, **env}, timeout=300)
             outs[tag] = torch.load(path)
     # nb1 / nb2: the MLP kernel on 16-row (one node) and 32-row (two nodes) wave tiles -- the small-batch geometry
     # slots4: the MLP kernel's weight ring with four slots instead of three (another set of counted waits)
-    for tag in ("conv0", "wgs", "dbgwait", "nb1", "nb2", "slots4"):
+    # edgesplit: the small-batch form of the edge kernel (one tile per workgroup, output chunks split over eight waves)
+    for tag in ("conv0", "wgs", "dbgwait", "nb1", "nb2", "slots4", "edgesplit"):
         for x, y in zip(outs["default"], outs[tag]):
             assert torch.equal(x, y), tag
 
@@ -999,3 +1001,39 @@ def test_hidden_split_mlp_variant_for_small_batches(dev, small_model, full_model
     finally:
         eng.set_variant(mlp=3)
     assert np.isfinite(r1.frac_x).all() and np.array_equal(r1.frac_x, r2.frac_x) and np.array_equal(r1.lattice, r2.lattice)
+
+
+def test_small_batch_edge_kernel_is_bit_identical_to_the_persistent_one(dev):
+    """The launcher picks the tile-per-workgroup form of the edge kernel for launches of at most 64 receivers (it computes
+    every K tile with the instruction sequence of the persistent kernel): forcing either form (ARREAU_EDGE_SPLIT = 0 / 1)
+    on ragged small crystals -- tiles with one slot, atoms with fewer than k neighbours, an isolated atom -- gives the
+    same bits, and so does the default choice."""
+    import subprocess
+    import sys
+    import tempfile
+    code = (
+        "import torch, sys; sys.path.insert(0, %r)\n"
+        "from arreau_amd.checkpoint import make_synthetic_model\n"
+        "from arreau_amd.diffusion.diffusion_helpers import crystal_offsets\n"
+        "from tests.helpers import random_state\n"
+        "dev = torch.device('cuda', 0)\n"
+        "outs = []\n"
+        "for S, T, k in ((12, 100, 8), (12, 100, 5)):\n"
+        "    m = make_synthetic_model(S=S, seed=1234, num_timesteps=T, max_neighbors=k).to(dev)\n"
+        "    for num_atoms, cell, seed in (([8], (4.0, 8.0), 1), ([3, 1, 6, 2], (3.0, 5.0), 2), ([1, 2], (9.0, 12.0), 3), ([20, 20, 9], (4.0, 7.0), 4)):\n"
+        "        frac, types, lengths, angles, na = random_state(S, num_atoms, seed, cell=cell)\n"
+        "        d = lambda v: v.to(dev).contiguous()\n"
+        "        t_c = torch.full((len(num_atoms),), 40, device=dev, dtype=torch.int32)\n"
+        "        out = m.engine().predict_scores(d(frac), d(types.to(torch.int32)), d(lengths), d(angles), t_c, crystal_offsets(na, dev))\n"
+        "        outs += [x.cpu() for x in out]\n"
+        "torch.save(outs, sys.argv[1])\n" % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    outs = {}
+    with tempfile.TemporaryDirectory() as d:
+        for tag, env in (("default", {}), ("persistent", {"ARREAU_EDGE_SPLIT": "0"}), ("split", {"ARREAU_EDGE_SPLIT": "1"})):
+            path = os.path.join(d, tag + ".pt")
+            subprocess.run([sys.executable, "-c", code, path], check=True, env={**os.environ, **env}, timeout=300)
+            outs[tag] = torch.load(path)
+    assert len(outs["default"]) == 24 and all(torch.isfinite(x).all() for x in outs["default"])
+    for tag in ("persistent", "split"):
+        for x, y in zip(outs["default"], outs[tag]):
+            assert torch.equal(x, y), tag
