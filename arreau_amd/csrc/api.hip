@@ -351,9 +351,10 @@ int enqueue_slice_step(const arreau_model* m, float* d_frac, int32_t* d_types, f
     if ((rc = run_edge_kernel(m, w.dir, w.dist, w.deg, w, N, s, r))) return rc;
     if (after_edge) ARREAU_CHECK_HIP(hipEventRecord(after_edge, s));
     if ((rc = arreau_launch_embed(m, d_frac, d_types, w.lattice, w.batch, w.cvec, N, w.xa, s, r))) return rc;
-    if ((rc = run_layers_and_readout(m, w, w.deg, w.src, d_off, B, N, w.eps, w.logits, w.len0, s, r))) return rc;
+    // (the per-crystal pooling of the lattice read-out happens inside the lattice update: no launch of its own)
+    if ((rc = run_layers_and_readout(m, w, w.deg, w.src, d_off, B, N, w.eps, w.logits, nullptr, s, r))) return rc;
     return arreau_launch_reverse(m, d_frac, d_types, d_lengths, d_angles, w.t_cur, d_off, B, N, w.eps, w.logits, w.len0,
-                                 StepNoiseSrc{nullptr, nullptr, nullptr, seed}, d_const_types, d_lattice, s, d_fixed_lengths, r);
+                                 StepNoiseSrc{nullptr, nullptr, nullptr, seed}, d_const_types, d_lattice, s, d_fixed_lengths, r, w.gs, w.batch);
 }
 
 int enqueue_sample_step(const arreau_model* m, float* d_frac, int32_t* d_types, float* d_lengths, const float* d_angles,
@@ -363,10 +364,14 @@ int enqueue_sample_step(const arreau_model* m, float* d_frac, int32_t* d_types, 
     if ((rc = arreau_launch_prep(m, d_frac, d_lengths, d_angles, nullptr, d_off, B, N, w.lattice, w.cart, w.batch, w.cvec, s,
                                  w.t_next, w.t_cur)))
         return rc;
-    if ((rc = run_network(m, w, false, w.deg, w.src, w.dir, w.dist, d_frac, d_types, d_off, B, N, w.eps, w.logits, w.len0, s)))
+    // fused kernels: the per-crystal pooling of the lattice read-out happens inside the lattice update (no launch of its own)
+    const bool pool_in_update = !arreau_general_path(m);
+    if ((rc = run_network(m, w, false, w.deg, w.src, w.dir, w.dist, d_frac, d_types, d_off, B, N, w.eps, w.logits,
+                          pool_in_update ? nullptr : w.len0, s)))
         return rc;
     return arreau_launch_reverse(m, d_frac, d_types, d_lengths, d_angles, w.t_cur, d_off, B, N, w.eps, w.logits, w.len0,
-                                 StepNoiseSrc{nullptr, nullptr, nullptr, seed}, d_const_types, d_lattice, s, d_fixed_lengths);
+                                 StepNoiseSrc{nullptr, nullptr, nullptr, seed}, d_const_types, d_lattice, s, d_fixed_lengths,
+                                 NodeRange(), pool_in_update ? w.gs : nullptr, w.batch);
 }
 }  // namespace
 

@@ -242,7 +242,9 @@ int arreau_launch_prep(const arreau_model* m, const float* frac, const float* le
 int arreau_launch_reverse(const arreau_model* m, float* d_frac, int32_t* d_types, float* d_lengths, const float* d_angles,
                           const int32_t* d_t, const int32_t* d_off, int B, int N, const float* d_eps,
                           const float* d_logits, const float* d_len0, StepNoiseSrc noise, const int32_t* d_const_types,
-                          float* d_lattice, hipStream_t s, const float* d_fixed_lengths = nullptr, NodeRange r = NodeRange());
+                          float* d_lattice, hipStream_t s, const float* d_fixed_lengths = nullptr, NodeRange r = NodeRange(),
+                          const float* d_gs_atoms = nullptr /* pool these per-atom read-outs into d_len0 first */,
+                          const int32_t* d_batch = nullptr /* crystal index of each atom, if the caller has it */);
 int arreau_launch_edge(const arreau_model* m, const float* dir, const float* dist, const int32_t* deg,
                        const int32_t* batch, const float* lattice, int N, float* kbuf, hipStream_t s, NodeRange r = NodeRange());
 int arreau_launch_edge_bf16x6(const arreau_model* m, const float* dir, const float* dist, const int32_t* deg,

@@ -819,7 +819,9 @@ __global__ __launch_bounds__(1024) void readout_nodes_kernel(
 // (weights streamed from their packed form, xbar rows loaded straight into the B-operand layout); the L partial
 // tiles meet in LDS and are added in layer order (deterministic), biases included, then scaled by 1/L.
 // The vector channel (column S) is not read from here (its per-orientation form comes from the MLP kernel).
-template <int C, int ROT /* output tiles */>
+// USPLIT = 1 (small launches): gridDim.y = ROT and a workgroup computes only output tile blockIdx.y -- a third of the serial
+// matrix work per wave; every tile is computed and summed over the layers exactly as in the unsplit form (bit-identical).
+template <int C, int ROT /* output tiles */, int USPLIT = 0>
 __global__ __launch_bounds__(512) void readout_mfma_kernel(
     const float* __restrict__ xbar,     // [L][N][C]
     const float* __restrict__ vsum,     // [N][16]
@@ -846,20 +848,22 @@ __global__ __launch_bounds__(512) void readout_mfma_kernel(
                 const f32x4 v = *reinterpret_cast<const f32x4*>(rowp + 32 * t + 8 * q);
                 bx[t][0][4 * q] = v[0]; bx[t][0][4 * q + 1] = v[1]; bx[t][0][4 * q + 2] = v[2]; bx[t][0][4 * q + 3] = v[3];
             }
-        const float* region = ro_pack + (size_t)l * ROT * TC * ARREAU_PACK_TILE_FLOATS + lane * 4;
+        constexpr int G = 4 * TC;
+        const float* region = ro_pack + (size_t)l * ROT * TC * ARREAU_PACK_TILE_FLOATS + lane * 4 +
+                              (USPLIT ? (size_t)blockIdx.y * G * 256 : 0);
         f32x4 ring[ARREAU_PF];
 #pragma unroll
         for (int i = 0; i < ARREAU_PF; ++i) ring[i] = *reinterpret_cast<const f32x4*>(region + (size_t)i * 256);
-        constexpr int G = 4 * TC;
 #pragma unroll
-        for (int u = 0; u < ROT; ++u) {
+        for (int ui = 0; ui < (USPLIT ? 1 : ROT); ++ui) {
+            const int u = USPLIT ? (int)blockIdx.y : ui;
             f32x16 acc[1];
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int col = 32 * u + (r & 3) + 8 * (r >> 2) + 4 * h;
                 acc[0][r] = col < RO ? ro_b[l * RO + col] : 0.0f;
             }
-            arreau_stream_tile<G, TC, 1>(acc, ring, region, u * G, bx);
+            arreau_stream_tile<G, TC, 1>(acc, ring, region, ui * G, bx);
             float* dst = part + (((size_t)l * ROT + u) * 64 + lane) * 16;
 #pragma unroll
             for (int q = 0; q < 4; ++q)
@@ -869,7 +873,8 @@ __global__ __launch_bounds__(512) void readout_mfma_kernel(
     __syncthreads();
     // ordered sum over the layers; thread -> (tile u, lane ln, register group q)
     bool bad = false;  // a non-finite output (an overflowed fp16 plane upstream, or non-finite inputs) sets the sticky flag
-    for (int i = threadIdx.x; i < ROT * 64 * 4; i += blockDim.x) {
+    const int i_beg = USPLIT ? (int)blockIdx.y * 256 : 0, i_end = USPLIT ? i_beg + 256 : ROT * 64 * 4;
+    for (int i = i_beg + threadIdx.x; i < i_end; i += blockDim.x) {
         const int q = i & 3, ln = (i >> 2) & 63, u = i >> 8;
         f32x4 tot = {0.f, 0.f, 0.f, 0.f};
         for (int ll = 0; ll < L; ++ll) {
@@ -889,7 +894,7 @@ __global__ __launch_bounds__(512) void readout_mfma_kernel(
         }
     }
     // vector channel: eps component d of atom a (sphere_to_vec of the per-orientation dot products)
-    if (threadIdx.x < 96) {
+    if (threadIdx.x < 96 && (!USPLIT || blockIdx.y == 0)) {
         const int a = threadIdx.x / 3, dd = threadIdx.x - 3 * a;
         const size_t n = (size_t)n0 + a;
         if (n < (size_t)N) {
@@ -935,8 +940,17 @@ int arreau_launch_readout(const arreau_model* m, const float* xbar, const float*
             static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&readout_mfma_kernel<128, 3>),
                                                                hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 3 * 64 * 16 * 4);
             ARREAU_CHECK_HIP(attr);
-            hipLaunchKernelGGL((readout_mfma_kernel<128, 3>), dim3((n1 - n0 + 31) / 32), dim3(64 * m->L), smem_m, s, xbar, vsum,
-                               m->ro_pack, m->ro_b, m->ori, m->S, m->L, N, n0, n1, eps, logits, gs, m->status);
+            static const hipError_t attr_s = hipFuncSetAttribute(reinterpret_cast<const void*>(&readout_mfma_kernel<128, 3, 1>),
+                                                                 hipFuncAttributeMaxDynamicSharedMemorySize, 8 * 3 * 64 * 16 * 4);
+            ARREAU_CHECK_HIP(attr_s);
+            const unsigned blocks32 = (unsigned)((n1 - n0 + 31) / 32);
+            static const int split_env = [] { const char* e = getenv("ARREAU_READOUT_SPLIT"); return e ? atoi(e) : -1; }();
+            if (split_env >= 0 ? split_env != 0 : blocks32 < 64)  // small launch: one workgroup per output tile
+                hipLaunchKernelGGL((readout_mfma_kernel<128, 3, 1>), dim3(blocks32, 3), dim3(64 * m->L), smem_m, s, xbar, vsum,
+                                   m->ro_pack, m->ro_b, m->ori, m->S, m->L, N, n0, n1, eps, logits, gs, m->status);
+            else
+                hipLaunchKernelGGL((readout_mfma_kernel<128, 3>), dim3(blocks32), dim3(64 * m->L), smem_m, s, xbar, vsum,
+                                   m->ro_pack, m->ro_b, m->ori, m->S, m->L, N, n0, n1, eps, logits, gs, m->status);
         } else {
             if (!whole) {
                 arreau_set_error("read-out: range launches are implemented for the MFMA kernel only");
@@ -947,7 +961,7 @@ int arreau_launch_readout(const arreau_model* m, const float* xbar, const float*
         }
         ARREAU_CHECK_HIP(hipGetLastError());
     }
-    if (b1 > b0)
+    if (b1 > b0 && len0 != nullptr)  // (len0 == nullptr: the caller pools the crystals itself -- the sampling loop's lattice update)
         hipLaunchKernelGGL(readout_crystals_kernel, dim3((3 * (b1 - b0) + 127) / 128), dim3(128), 0, s, gs, offsets, b0, b1, len0);
     ARREAU_CHECK_HIP(hipGetLastError());
     return ARREAU_OK;

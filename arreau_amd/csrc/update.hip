@@ -12,7 +12,10 @@ __global__ void reverse_lattice_kernel(float* __restrict__ lengths, const float*
                                        const float* __restrict__ len0, StepNoiseSrc noise,
                                        const float* __restrict__ alpha_bars, const float* __restrict__ betas, int B,
                                        int T, float* __restrict__ lattice, const float* __restrict__ fixed_lengths,
-                                       int32_t* __restrict__ status, int b0) {
+                                       int32_t* __restrict__ status, int b0,
+                                       // sampling loop: pool the per-atom read-out here (same ordered sum as
+                                       // readout_crystals_kernel) instead of a launch of its own; len0_out receives it
+                                       const float* __restrict__ gs_atoms, float* __restrict__ len0_out) {
     const int b = b0 + blockIdx.x * blockDim.x + threadIdx.x;  // crystals b0 .. B-1
     if (b >= B) return;
     const float* __restrict__ z = noise.z_lattice;
@@ -29,7 +32,15 @@ __global__ void reverse_lattice_kernel(float* __restrict__ lengths, const float*
     float newlen[3];
 #pragma unroll
     for (int i = 0; i < 3; ++i) {
-        const float x0 = len0[3 * b + i] * n;  // pred_lengths_0 * num_atoms (diffusion_loss.py:338)
+        float pooled;
+        if (gs_atoms != nullptr) {
+            pooled = 0.f;
+            for (int a = offsets[b]; a < offsets[b + 1]; ++a) pooled += gs_atoms[(size_t)a * 3 + i];
+            len0_out[3 * b + i] = pooled;
+        } else {
+            pooled = len0[3 * b + i];
+        }
+        const float x0 = pooled * n;  // pred_lengths_0 * num_atoms (diffusion_loss.py:338)
         const float xt = lengths[3 * b + i];
         const float mean = (c0 * x0 + c1 * xt) / denom;
         const float zdraw = z ? z[3 * b + i] : philox_normal(noise.seed, (uint32_t)t, ARREAU_DRAW_Z_LATTICE, 3u * b + i);
@@ -66,7 +77,8 @@ __global__ __launch_bounds__(256) void reverse_atoms_kernel(
     const int32_t* __restrict__ offsets, int B, int N, const float* __restrict__ eps,
     const float* __restrict__ logits, StepNoiseSrc noise,
     const float* __restrict__ ve_sigmas, const float* __restrict__ q1t, const float* __restrict__ qmats, int S,
-    int T, const int32_t* __restrict__ const_types, int absorbing, int32_t* __restrict__ status, int n0) {
+    int T, const int32_t* __restrict__ const_types, int absorbing, int32_t* __restrict__ status, int n0,
+    const int32_t* __restrict__ batch /* crystal of each atom, or null: searched in `offsets` */) {
     const float* __restrict__ z_frac = noise.z_frac;
     const float* __restrict__ u_types = noise.u_types;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
@@ -75,6 +87,9 @@ __global__ __launch_bounds__(256) void reverse_atoms_kernel(
     // crystal of this atom = largest b with offsets[b] <= i: a 64-ary search by the whole wave (each level one
     // load per lane + a ballot) instead of log2(B) dependent loads
     int lo = 0, hi = B;
+    if (batch != nullptr) {
+        lo = batch[i];  // (the sampling loop has the index from prep_kernel: two dependent loads fewer)
+    } else
     while (hi - lo > 1) {
         const int span = hi - lo, step = (span + 63) >> 6;
         const int probe = lo + lane * step;
@@ -192,17 +207,19 @@ __global__ __launch_bounds__(256) void reverse_atoms_kernel(
 int arreau_launch_reverse(const arreau_model* m, float* d_frac, int32_t* d_types, float* d_lengths, const float* d_angles,
                           const int32_t* d_t, const int32_t* d_off, int B, int N, const float* d_eps,
                           const float* d_logits, const float* d_len0, StepNoiseSrc noise, const int32_t* d_const_types,
-                          float* d_lattice, hipStream_t s, const float* d_fixed_lengths, NodeRange r) {
+                          float* d_lattice, hipStream_t s, const float* d_fixed_lengths, NodeRange r, const float* d_gs_atoms,
+                          const int32_t* d_batch) {
     const int n0 = r.n0, n1 = r.n1 < 0 ? N : r.n1, b0 = r.b0, b1 = r.b1 < 0 ? B : r.b1;
     if (b1 > b0) {
         hipLaunchKernelGGL(reverse_lattice_kernel, dim3((b1 - b0 + 127) / 128), dim3(128), 0, s, d_lengths, d_angles, d_t, d_off,
-                           d_len0, noise, m->vp_alpha_bars, m->vp_betas, b1, m->T, d_lattice, d_fixed_lengths, m->status, b0);
+                           d_len0, noise, m->vp_alpha_bars, m->vp_betas, b1, m->T, d_lattice, d_fixed_lengths, m->status, b0,
+                           d_gs_atoms, d_gs_atoms ? const_cast<float*>(d_len0) : nullptr);
         ARREAU_CHECK_HIP(hipGetLastError());
     }
     if (n1 > n0) {
         hipLaunchKernelGGL(reverse_atoms_kernel, dim3((n1 - n0 + 3) / 4), dim3(256), 0, s, d_frac, d_types, d_t, d_off, B, n1,
                            d_eps, d_logits, noise, m->ve_sigmas, m->q1t, m->qmats, m->S, m->T, d_const_types, m->qmats_absorbing,
-                           m->status, n0);
+                           m->status, n0, d_batch);
         ARREAU_CHECK_HIP(hipGetLastError());
     }
     return ARREAU_OK;

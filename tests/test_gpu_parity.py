@@ -773,7 +773,7 @@ def test_launch_geometry_switches_and_counted_waits_are_bitwise_neutral(dev):
         for tag, env in (("default", {}), ("conv0", {"ARREAU_CONV_VARIANT": "0"}), ("wgs", {"ARREAU_EDGE_WGS": "100000"}),
                          ("dbgwait", {"ARREAU_HIP_LIB": LIB_DEBUG_WAIT}), ("nb1", {"ARREAU_MLP_NB": "1"}),
                          ("nb2", {"ARREAU_MLP_NB": "2"}), ("slots4", {"ARREAU_MLP_SLOTS": "4"}),
-                         ("edgesplit", {"ARREAU_EDGE_SPLIT": "1"})):
+                         ("edgesplit", {"ARREAU_EDGE_SPLIT": "1", "ARREAU_READOUT_SPLIT": "1"})):
             path = os.path.join(d, tag + ".pt")
             subprocess.run([sys.executable, "-c", code, path], check=True, env={**os.environ, **env}, timeout=300)
             outs[tag] = torch.load(path)
@@ -1029,7 +1029,9 @@ def test_small_batch_edge_kernel_is_bit_identical_to_the_persistent_one(dev):
         "torch.save(outs, sys.argv[1])\n" % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     outs = {}
     with tempfile.TemporaryDirectory() as d:
-        for tag, env in (("default", {}), ("persistent", {"ARREAU_EDGE_SPLIT": "0"}), ("split", {"ARREAU_EDGE_SPLIT": "1"})):
+        # (the read-out kernel has the same kind of small-launch form -- one workgroup per output tile -- switched along)
+        for tag, env in (("default", {}), ("persistent", {"ARREAU_EDGE_SPLIT": "0", "ARREAU_READOUT_SPLIT": "0"}),
+                         ("split", {"ARREAU_EDGE_SPLIT": "1", "ARREAU_READOUT_SPLIT": "1"})):
             path = os.path.join(d, tag + ".pt")
             subprocess.run([sys.executable, "-c", code, path], check=True, env={**os.environ, **env}, timeout=300)
             outs[tag] = torch.load(path)
