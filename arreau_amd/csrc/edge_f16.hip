@@ -402,9 +402,11 @@ __global__ __launch_bounds__(64 * EH_WAVES, 2) void edge_kernel_f16x3(
 // A wave's weight fragments come straight from the packed stream in L2 into registers (no LDS ring, no counted waits);
 // the layer outputs meet in LDS (the re-layout pad of the kernel above, now shared by the workgroup).  Every output
 // chunk is computed by exactly the instruction sequence of the kernel above -- same operand planes, same k order, same
-// epilogues -- so the K tiles are BIT-IDENTICAL: the launcher may pick either form by batch size.
+// epilogues -- so the K tiles are BIT-IDENTICAL: the launcher picks the form by batch size.
 // ---------------------------------------------------------------------------------------------------------------------
-#define ARREAU_EDGE_SPLIT_MAX_NODES 64
+// measured on MI355X (tools/gpu_edge_split_sweep.sh): 60 / 120 / 200 / 260 / 380 receivers: 19.8 / 31.8 / 56.9 / 71.0 / 88.1 us
+// against 65.9 / 67.0 / 69.0 / 71.8 / 74.0 us of the persistent form
+#define ARREAU_EDGE_SPLIT_MAX_NODES 240
 template <int C, int D>
 __global__ __launch_bounds__(512) void edge_kernel_f16x3_split(
     const float* __restrict__ nbr_dir, const float* __restrict__ nbr_dist, const int32_t* __restrict__ deg,
