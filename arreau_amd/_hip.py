@@ -26,7 +26,7 @@ EXPORTS = [
 
 STATUS_NONFINITE, STATUS_BAD_TIMESTEP, STATUS_BAD_TYPE = 1, 2, 4
 EDGE_KERNELS = {0: "fp32-mfma", 1: "fp32-mfma", 2: "fp32-mfma", 3: "bf16x6", 4: "fp16x3", 5: "general-fp32-gemm"}
-MLP_KERNELS = {0: "fp32-mfma", 1: "bf16x6", 2: "fp16x3-32x32x16", 3: "fp16x3-16x16x32", 4: "fp16x3-16x16x32-hidden-split",
+MLP_KERNELS = {0: "fp32-mfma", 1: "bf16x6", 2: "fp16x3-32x32x16", 3: "fp16x3-16x16x32",
                5: "general-fp32-gemm"}
 VARIANT_GENERAL = 5  # edge variant selecting the shape-general fp32 network (any hidden_dim / basis_dim / widening)
 

@@ -686,10 +686,10 @@ int arreau_launch_node_layer(const arreau_model* m, int layer, const float* kbuf
     ARREAU_CHECK_HIP(hipGetLastError());
     // variant switch: 3 (default) = fp16x3 on 16x16x32 MFMAs (node_f16m.hip); 2 = fp16x3 on 32x32x16 MFMAs (node_f16.hip) -- both
     // need weights that fit fp16; 1 = bf16x6 split-precision MLP kernel (node_bf16.hip); 0 = fp32-MFMA kernel below
-    // 4 = the small-batch "hidden split" form of 3 (one node per workgroup, node_f16m.hip; chosen per model, never by size)
+    // 4 = always the small-launch form of 3 (one node per workgroup, node_f16m.hip: bit-identical; 3 picks it by size)
     const int mlp_variant = m->mlp_variant;
     if (mlp_variant == 4 && m->f16_ok) {
-        m->ran_mlp = 4;
+        m->ran_mlp = 3;
         return arreau_launch_mlp_f16x3_m16_split(m, layer, x_conv, x_in, x_out, xbar, vsum, N, s, r);
     }
     if (mlp_variant == 3 && m->f16_ok) {

@@ -278,17 +278,21 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_kernel_f16x3_m16(
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// Small-batch form ("hidden split", mlp variant 4): ONE NODE PER WORKGROUP, the 512 hidden units split over eight waves.
+// Small-launch form: ONE NODE PER WORKGROUP, the layer's work dealt to eight waves -- bit-identical to the kernel above.
 //
-// With a handful of nodes (1 x 8 atoms: 8 tiles of 16 rows) the kernel above is one wave walking through all 32 weight
-// chunks of a layer: 22 us of pure latency while 250 CUs idle.  Here wave w = (quarter q, half e) owns 64 hidden units:
-// two chunks of linear_1 (32 hidden units each) and, of each of the quarter's four linear_2 chunks, the four steps that
-// contract over its own 64 units -- 32 steps instead of 256.  Its 64 weight fragments come straight from the packed
-// stream in L2 into registers in two batches (no LDS ring, no barriers): the second batch is requested while the first
-// is being consumed.  The eight partial outputs meet in LDS and are added in wave order (fixed); the epilogue is shared
-// too, one 16-channel output tile per wave, its operands requested at the top of the kernel.  Same arithmetic as the kernel above (fp16x3 planes, fp32 accumulate, the same GELU), but the sum over the
-// hidden dimension is grouped differently, so results agree to rounding, not bit for bit: the variant is chosen per
-// model (arreau_model_set_variant), never by batch size.
+// With few nodes (1 x 8 atoms: 8 tiles of 16 rows) the kernel above is one wave walking through all 32 weight chunks of
+// a layer: 22 us of pure latency while 250 CUs idle.  Here
+//   phase 1: wave w computes hidden chunks (quarter w >> 1, chunks 2 (w & 1), 2 (w & 1) + 1): 64 of the 512 hidden units
+//            (the same instruction sequence per chunk: bias, 8 steps over the LayerNorm'ed input, GELU, plane split); the
+//            sixteen chunks meet in LDS as the B operand of linear_2;
+//   phase 2: wave w owns ONE 16-channel output tile (chunk u = w >> 1, tile mt = w & 1) and contracts it over all 512
+//            hidden units in the order of the kernel above -- quarter by quarter, the cross terms folded into the
+//            accumulator after each quarter -- then runs that tile's epilogue (operands requested at the top);
+//   the vector read-out needs the tiles' outputs in ONE chain of fused multiply-adds, so they meet in LDS and wave 0 walks
+//   the chain in the original order.
+// A wave's 64 + 32 weight fragments come straight from the packed stream in L2 into registers (no LDS ring, no counted
+// waits).  Every number is produced by the instruction sequence of the kernel above, so the launcher picks the form by
+// size (tests: test_small_launch_kernels_are_bit_identical...).
 // ---------------------------------------------------------------------------------------------------------------------
 namespace {
 template <int NST>
@@ -297,18 +301,6 @@ __device__ __forceinline__ void load_steps(u32x4 (&w)[2 * NST], const u32x4* __r
     for (int i = 0; i < NST; ++i) {
         w[2 * i] = chunk[(size_t)(st0 + i) * 128 + lane];
         w[2 * i + 1] = chunk[(size_t)(st0 + i) * 128 + 64 + lane];
-    }
-}
-// steps i = 0 .. NST-1 of a chunk from registers: k-block KB0 + (i >> 1) of the B operand, 16-row output tile i & 1
-template <int NST, int KB0, int NKB, int NW>
-__device__ __forceinline__ void mma16_regs(f32x4v (&am)[2], f32x4v (&ax)[2], const u32x4 (&w)[NW], int w0,
-                                           const u32x4 (&b)[NKB][2]) {
-#pragma unroll
-    for (int i = 0; i < NST; ++i) {
-        const int kb = KB0 + (i >> 1), mt = i & 1;
-        am[mt] = mfma16_f16(w[w0 + 2 * i], b[kb][0], am[mt]);
-        ax[mt] = mfma16_f16(w[w0 + 2 * i], b[kb][1], ax[mt]);
-        ax[mt] = mfma16_f16(w[w0 + 2 * i + 1], b[kb][0], ax[mt]);
     }
 }
 }  // namespace
@@ -321,11 +313,11 @@ __global__ __launch_bounds__(512) void mlp_kernel_f16x3_m16_split(
     const float* __restrict__ wv, float bv, int n0, int first_layer, float* __restrict__ xbar, float* __restrict__ vsum) {
     static_assert(C == 128 && H == 512, "chunking below assumes C = 128, H = 512");
     constexpr int KC = C / 32, HQ = H / 4;
-    __shared__ f32x4v part[8][KC * 2][64];  // [wave][output chunk u, tile mt][lane]: 64 KiB
-    __shared__ float vpart[8][64];
+    __shared__ u32x4 hidx[16][2][64];   // hidden chunk (quarter * 4 + u) as B operand: [chunk][plane][lane], 32 KiB
+    __shared__ f32x4 xo_s[8][64];       // the eight output tiles' x_out values, for the vector read-out chain
 
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    const int q = wave >> 1, e = wave & 1;     // hidden quarter, half of the quarter
+    const int q = wave >> 1, e = wave & 1;     // phase 1: hidden quarter, half of the quarter
     const int cp = lane & 15, gp = lane >> 4;
     const int n = n0 + blockIdx.x;
     const u32x4* qs = stream + (size_t)q * 8 * 1024;  // this quarter: 4 linear_1 chunks, then 4 linear_2 chunks
@@ -334,12 +326,12 @@ __global__ __launch_bounds__(512) void mlp_kernel_f16x3_m16_split(
     u32x4 wa[16], wb[16];
     load_steps<8>(wa, qs + (size_t)(2 * e) * 1024, 0, lane);
     load_steps<8>(wb, qs + (size_t)(2 * e + 1) * 1024, 0, lane);
-    // operands of this wave's share of the epilogue (output tile u = wave >> 1, mt = wave & 1), requested now
-    const int ep_c0 = 32 * (wave >> 1) + 16 * (wave & 1) + 4 * gp;  // this lane's four channels
+    // operands of this wave's output tile (chunk u = wave >> 1, tile mt = wave & 1), requested now
+    const int ou = wave >> 1, omt = wave & 1;
+    const int ep_c0 = 32 * ou + 16 * omt + 4 * gp;  // this lane's four channels
     const size_t ep_off = ((size_t)n * 16 + cp) * C + ep_c0;
     const f32x4 ep_b2 = *reinterpret_cast<const f32x4*>(mb2 + ep_c0);
     const f32x4 ep_ls = *reinterpret_cast<const f32x4*>(ls + ep_c0);
-    const f32x4 ep_wv = *reinterpret_cast<const f32x4*>(wv + ep_c0);
     const f32x4 ep_xi = *reinterpret_cast<const f32x4*>(x_in + ep_off);
 
     // ---- the node's 16 rows in B-operand layout, LayerNorm (eps 1e-5, biased variance), split (as in the kernel above) ----
@@ -381,17 +373,23 @@ __global__ __launch_bounds__(512) void mlp_kernel_f16x3_m16_split(
         }
     }
 
-    // ---- hidden units: two chunks of 32, GELU, split -> B operand of linear_2 (k-blocks 0, 1 of this wave) ----------
-    u32x4 hid[2][2];
+    // ---- phase 1: two hidden chunks of 32, GELU, split -> the shared B operand of linear_2 ----------------------------
     auto hidden_chunk = [&](const u32x4 (&w)[16], int j) {
+        const int u = 2 * e + j;
         f32x4v am[2], ax[2];
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) {
-            const f32x4 b = *reinterpret_cast<const f32x4*>(mb1 + q * HQ + 32 * (2 * e + j) + 16 * mt + 4 * gp);
+            const f32x4 b = *reinterpret_cast<const f32x4*>(mb1 + q * HQ + 32 * u + 16 * mt + 4 * gp);
             am[mt] = f32x4v{b[0], b[1], b[2], b[3]};
             ax[mt] = f32x4v{0.f, 0.f, 0.f, 0.f};
         }
-        mma16_regs<8, 0, KC>(am, ax, w, 0, xn);
+#pragma unroll
+        for (int st = 0; st < 2 * KC; ++st) {
+            const int kb = st >> 1, mt = st & 1;
+            am[mt] = mfma16_f16(w[2 * st], xn[kb][0], am[mt]);
+            ax[mt] = mfma16_f16(w[2 * st], xn[kb][1], ax[mt]);
+            ax[mt] = mfma16_f16(w[2 * st + 1], xn[kb][0], ax[mt]);
+        }
         float v[8];
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt)
@@ -403,60 +401,54 @@ __global__ __launch_bounds__(512) void mlp_kernel_f16x3_m16_split(
                 v[4 * mt + 2 * pr] = act.x;
                 v[4 * mt + 2 * pr + 1] = act.y;
             }
-        split8<false>(v, hid[j][0], hid[j][1]);
+        u32x4 hi, lo;
+        split8<false>(v, hi, lo);
+        hidx[4 * q + u][0][lane] = hi;
+        hidx[4 * q + u][1][lane] = lo;
     };
-    hidden_chunk(wa, 0);
-    // batch 2a: of linear_2 chunks u = 0, 1 the steps 4 e .. 4 e + 3 (this wave's 64 hidden units), 8 fragments each
-    {
-        u32x4 t0[8], t1[8];
-        load_steps<4>(t0, qs + (size_t)4 * 1024, 4 * e, lane);
-        load_steps<4>(t1, qs + (size_t)5 * 1024, 4 * e, lane);
+    // batch 2 of the weights: of linear_2 chunk (quarter w2, u = ou) the steps of this wave's tile: st = 2 kb + omt
+    auto load_out = [&](u32x4 (&w)[16], int w0, int w2) {
+        const u32x4* chunk = stream + ((size_t)w2 * 8 + 4 + ou) * 1024 + lane;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) { wa[i] = t0[i]; wa[8 + i] = t1[i]; }
-    }
-    hidden_chunk(wb, 1);
-    {   // batch 2b: linear_2 chunks u = 2, 3
-        u32x4 t0[8], t1[8];
-        load_steps<4>(t0, qs + (size_t)6 * 1024, 4 * e, lane);
-        load_steps<4>(t1, qs + (size_t)7 * 1024, 4 * e, lane);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) { wb[i] = t0[i]; wb[8 + i] = t1[i]; }
-    }
-
-    // ---- partial outputs: chunk u = 32 outputs, contracted over this wave's 64 hidden units -------------------------
-    auto output_chunk = [&](const u32x4 (&w)[16], auto w0c, int u) {
-        constexpr int w0 = decltype(w0c)::value;
-        f32x4v am[2] = {f32x4v{0.f, 0.f, 0.f, 0.f}, f32x4v{0.f, 0.f, 0.f, 0.f}};
-        f32x4v ax[2] = {f32x4v{0.f, 0.f, 0.f, 0.f}, f32x4v{0.f, 0.f, 0.f, 0.f}};
-        mma16_regs<4, 0, 2>(am, ax, w, w0, hid);
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt) {
-            f32x4v o;
-#pragma unroll
-            for (int r = 0; r < 4; ++r) o[r] = fmaf(ax[mt][r], F16X3_INV_SCALE, am[mt][r]);
-            part[wave][2 * u + mt][lane] = o;
+        for (int kb = 0; kb < 4; ++kb) {
+            w[w0 + 2 * kb] = chunk[(size_t)(2 * kb + omt) * 128];
+            w[w0 + 2 * kb + 1] = chunk[(size_t)(2 * kb + omt) * 128 + 64];
         }
     };
-    output_chunk(wa, std::integral_constant<int, 0>{}, 0);
-    output_chunk(wa, std::integral_constant<int, 8>{}, 1);
-    output_chunk(wb, std::integral_constant<int, 0>{}, 2);
-    output_chunk(wb, std::integral_constant<int, 8>{}, 3);
+    hidden_chunk(wa, 0);
+    load_out(wa, 0, 0);
+    load_out(wa, 8, 1);
+    hidden_chunk(wb, 1);
+    load_out(wb, 0, 2);
+    load_out(wb, 8, 3);
     __syncthreads();
 
-    // ---- epilogue, one 16-channel output tile (u, mt) per wave: sum of the eight partial outputs in wave order, bias,
-    // layer scale, residual, x_out, per-channel orientation means; the vector read-out partials meet in LDS -------------
-    {
-        const int u = wave >> 1, mt = wave & 1;
-        f32x4v acc = part[0][2 * u + mt][lane];
+    // ---- phase 2: this wave's output tile over all 512 hidden units, quarter by quarter (order of the kernel above) -----
+    f32x4v acc = f32x4v{0.f, 0.f, 0.f, 0.f};
+    auto quarter = [&](const u32x4 (&w)[16], auto w0c, int w2) {
+        constexpr int w0 = decltype(w0c)::value;
+        f32x4v cross = f32x4v{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-        for (int w2 = 1; w2 < 8; ++w2) acc += part[w2][2 * u + mt][lane];
+        for (int kb = 0; kb < 4; ++kb) {
+            const u32x4 bh = hidx[4 * w2 + kb][0][lane], bl = hidx[4 * w2 + kb][1][lane];
+            acc = mfma16_f16(w[w0 + 2 * kb], bh, acc);
+            cross = mfma16_f16(w[w0 + 2 * kb], bl, cross);
+            cross = mfma16_f16(w[w0 + 2 * kb + 1], bh, cross);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[r] = fmaf(cross[r], F16X3_INV_SCALE, acc[r]);
+    };
+    quarter(wa, std::integral_constant<int, 0>{}, 0);
+    quarter(wa, std::integral_constant<int, 8>{}, 1);
+    quarter(wb, std::integral_constant<int, 0>{}, 2);
+    quarter(wb, std::integral_constant<int, 8>{}, 3);
+
+    // ---- epilogue of the tile: bias, layer scale, residual, x_out, per-channel orientation means ------------------------
+    {
         f32x4 xo;
 #pragma unroll
         for (int r = 0; r < 4; ++r) xo[r] = (acc[r] + ep_b2[r]) * ep_ls[r] + ep_xi[r];
         *reinterpret_cast<f32x4*>(x_out + ep_off) = xo;
-        float vdot = 0.f;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) vdot += xo[r] * ep_wv[r];
         f32x4 sum;
 #pragma unroll
         for (int r = 0; r < 4; ++r) sum[r] = row16_sum_m(xo[r]);
@@ -465,13 +457,21 @@ __global__ __launch_bounds__(512) void mlp_kernel_f16x3_m16_split(
             const f32x4 mean = {sum[0] * inv16, sum[1] * inv16, sum[2] * inv16, sum[3] * inv16};
             *reinterpret_cast<f32x4*>(xbar + (size_t)n * C + ep_c0) = mean;
         }
-        vpart[wave][lane] = vdot;
+        xo_s[wave][lane] = xo;
     }
     __syncthreads();
     if (wave != 0) return;
-    float vdot = vpart[0][lane];
+    // vector read-out partial: the chain of the kernel above over (u, mt, r), then the four lane groups
+    float vdot = 0.f;
 #pragma unroll
-    for (int w2 = 1; w2 < 8; ++w2) vdot += vpart[w2][lane];
+    for (int u = 0; u < KC; ++u)
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt) {
+            const f32x4 xo = xo_s[2 * u + mt][lane];
+            const f32x4 wvv = *reinterpret_cast<const f32x4*>(wv + 32 * u + 16 * mt + 4 * gp);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) vdot += xo[r] * wvv[r];
+        }
     const float tot = group4_sum(vdot);
     if (gp == 0) {
         const size_t o = (size_t)n * 16 + cp;
@@ -498,6 +498,7 @@ int arreau_launch_mlp_f16x3_m16_split(const arreau_model* m, int layer, const fl
     return ARREAU_OK;
 }
 
+#define ARREAU_MLP_SPLIT_MAX_NODES 512
 int arreau_launch_mlp_f16x3_m16(const arreau_model* m, int layer, const float* x_conv, const float* x_in, float* x_out,
                                 float* xbar, float* vsum, int Ntot, hipStream_t s, NodeRange r) {
     const int n0 = r.n0, n1 = r.n1 < 0 ? Ntot : r.n1;
@@ -516,6 +517,12 @@ int arreau_launch_mlp_f16x3_m16(const arreau_model* m, int layer, const float* x
     // rounds cost less: 16-row tiles while a batch leaves slots idle (1 x 8: -20 % step time) or has an expensive tail
     // (256 x 20: 2.5 rounds of 0.6 against 1.25 rounds -> 2 of 1.0: 1.70 vs 1.73 ms per step), 32-row tiles for large
     // batches (1024 x 20: 5 full rounds).  ARREAU_MLP_NB = 1 / 2 forces a geometry (tests).
+    // Small launches: one node per workgroup, the layer's work dealt to eight waves (bit-identical; see below).  Measured on
+    // MI355X: 10.7 us per layer at 8 nodes against 22.5 us; the forms cross where the node-per-workgroup form needs more
+    // than about two rounds of the chip.  ARREAU_MLP_SPLIT = 0 / 1 forces a form (tests).
+    static const int split_env = [] { const char* e = getenv("ARREAU_MLP_SPLIT"); return e ? atoi(e) : -1; }();
+    if (split_env >= 0 ? split_env != 0 : N <= ARREAU_MLP_SPLIT_MAX_NODES)
+        return arreau_launch_mlp_f16x3_m16_split(m, layer, x_conv, x_in, x_out, xbar, vsum, Ntot, s, r);
     static const int nb_env = [] { const char* e = getenv("ARREAU_MLP_NB"); return e ? atoi(e) : 0; }();
     static const int wave_slots = [] {
         int dev = 0;

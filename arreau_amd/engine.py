@@ -130,7 +130,7 @@ class HipEngine:
 
     def set_variant(self, edge=-1, mlp=-1):
         """Select the arithmetic of the dense kernels (edge: 0 fp32 MFMA, 3 bf16x6, 4 fp16x3; mlp: 0 fp32 MFMA,
-        1 bf16x6, 2/3 fp16x3, 4 = the small-batch hidden-split form of 3); -1 keeps.  edge = 5 runs the whole network on the shape-general fp32 GEMM kernels (the only
+        1 bf16x6, 2/3 fp16x3, 4 = always the (bit-identical) small-launch form of 3); -1 keeps.  edge = 5 runs the whole network on the shape-general fp32 GEMM kernels (the only
         choice for shapes other than hidden_dim 128 / basis_dim 256 / widening 4)."""
         _hip.check(_hip.lib().arreau_model_set_variant(self._handle, int(edge), int(mlp)), "arreau_model_set_variant")
         if int(edge) >= 0:

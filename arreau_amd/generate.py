@@ -75,9 +75,6 @@ def main():
     ap.add_argument("--batch", type=int, default=256)
     ap.add_argument("--out", type=str, default="out/crystals.npz")
     ap.add_argument("--seed", type=int, default=None, help="seed of the host/device generators (rank is added)")
-    ap.add_argument("--small_batch_kernels", action="store_true",
-                    help="ConvNext kernel for a handful of atoms per launch (one node per workgroup; results agree with the "
-                         "default kernel to rounding)")
     args = ap.parse_args()
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -97,7 +94,6 @@ def main():
     from .diffusion.inference.visualize_crystal import VisualizationSetting
     from .lightning_wrappers.diffusion import PONITA_DIFFUSION
     model = PONITA_DIFFUSION.load_from_checkpoint(args.model_path, map_location=f"cuda:{local_rank}", strict=False)
-    model.small_batch_kernels = bool(args.small_batch_kernels)
     if args.seed is not None:
         import numpy as np
         torch.manual_seed(args.seed + rank)

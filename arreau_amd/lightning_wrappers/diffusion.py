@@ -95,10 +95,6 @@ class PONITA_DIFFUSION(nn.Module):
             from ..engine import HipEngine
             dev = self._device if self._device.type == "cuda" else torch.device("cuda", 0)
             self._engine = HipEngine(self, dev)
-            # per-MODEL kernel choice (never made by batch size): `small_batch_kernels = True` on a module that samples
-            # single small crystals selects the hidden-split ConvNext kernel (mlp variant 4, csrc/node_f16m.hip)
-            if getattr(self, "small_batch_kernels", False) and self._engine.fused_shape:
-                self._engine.set_variant(mlp=4)
         return self._engine
 
     # ---- checkpoint I/O (Lightning dict format) --------------------------------------------------

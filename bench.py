@@ -135,8 +135,8 @@ def parse_args(argv=None):
     ap.add_argument("--hidden-dim", type=int, default=128, help="c5 only: hidden_dim of the trained network (the reference's "
                     "`make train` preset is 200; shapes other than 128 run on the shape-general kernels)")
     ap.add_argument("--no-full-sampler", action="store_true", help="skip the measured run of the whole T-1 step sampler")
-    ap.add_argument("--mlp-variant", type=int, default=None, help="ConvNext kernel of the model (3: default; 4: small-batch "
-                    "hidden-split form; default: 4 for the single-crystal config c1, 3 otherwise)")
+    ap.add_argument("--mlp-variant", type=int, default=3, help="ConvNext kernel set (3: default, picks its small-launch form by "
+                    "size; 4: always the small-launch form; 0-2: cross-check arithmetic)")
     ap.add_argument("--eager-value", action="store_true", help="report the eager loop as `value` even where the product "
                     "defaults to graph replay")
     ap.add_argument("--groups", type=int, default=0, help="slices of the batch run on separate streams (0: library default)")
@@ -145,8 +145,6 @@ def parse_args(argv=None):
     args.batch_per_gpu = args.batch_per_gpu or B
     args.atoms = args.atoms or n
     args.T = T
-    if args.mlp_variant is None:
-        args.mlp_variant = 4 if args.batch_per_gpu * args.atoms <= 64 else 3
     return args
 
 
@@ -275,7 +273,6 @@ def run_rank(args, rank, local_rank, world):
     N = B * n
     model = make_synthetic_model(S=S, seed=1234, num_timesteps=T).to(dev)  # same weights on every rank
     eng = model.engine()
-    # a property of the MODEL (a sampler of single crystals picks the small-batch ConvNext kernel), reported by the library
     eng.set_variant(mlp=args.mlp_variant)
 
     # sampler-start state (diffusion_loss.py:294-316), different crystals per rank

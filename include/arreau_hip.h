@@ -136,9 +136,8 @@ int arreau_model_status(const arreau_model* model, arreau_status* out, int32_t r
 /* Selects the arithmetic of the dense kernels for this model (-1 keeps the current choice); the defaults come from
  * the environment (ARREAU_EDGE_VARIANT, ARREAU_MLP_VARIANT) at arreau_model_create.  Used by the parity report and
  * bench.py to time/compare the exact fp32-MFMA kernels against the default fp16x3 ones in one process.
- * mlp_variant 4 is the small-batch form of the default ConvNext kernel (one node per workgroup, the hidden dimension split
- * over eight waves): the same arithmetic with the hidden sum grouped differently -- results agree with variant 3 to
- * rounding, not bit for bit, so it is a per-model choice (a sampler of single crystals), never made by batch size.
+ * mlp_variant 4 forces the small-launch form of the default ConvNext kernel (one node per workgroup, the layer's work dealt
+ * to eight waves; bit-identical to variant 3, which picks it by itself for small launches) at every size (tests).
  * edge_variant 5 runs the whole score network on the shape-general fp32 GEMM kernels (what shapes without fused kernels
  * always use; such models accept no other value).  Those kernels read the plain weights
  * arreau_model_update_train_weights refreshes, so with variant 5 a model keeps sampling between optimiser steps. */

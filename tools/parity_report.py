@@ -50,7 +50,7 @@ def main():
                   ("ragged_420", [int(v) for v in rng.randint(1, 7, size=420)], dict(cell=(3.5, 9.0)), 91)]
     # (edge variant, mlp variant): the default kernels, the exact fp32-MFMA kernels, the small-batch ConvNext kernel
     # (hidden dimension split over eight waves) and the shape-general fp32 GEMM network
-    variants = [("default_fp16x3", 4, 3), ("fp32_mfma", 0, 0), ("hidden_split_mlp", 4, 4), ("general_fp32_gemm", 5, 3)]
+    variants = [("default_fp16x3", 4, 3), ("fp32_mfma", 0, 0), ("small_launch_mlp_form", 4, 4), ("general_fp32_gemm", 5, 3)]
     report = {"model": "synthetic S=90 T=1000 C=128 D=256 L=5 (make_synthetic_model seed 1234, trained_like)",
               "edges": "oracle's radius_graph_pbc, teacher-forced", "device": torch.cuda.get_device_name(0),
               "cases": {}}
