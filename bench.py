@@ -137,6 +137,8 @@ def parse_args(argv=None):
     ap.add_argument("--no-full-sampler", action="store_true", help="skip the measured run of the whole T-1 step sampler")
     ap.add_argument("--mlp-variant", type=int, default=3, help="ConvNext kernel set (3: default, picks its small-launch form by "
                     "size; 4: always the small-launch form; 0-2: cross-check arithmetic)")
+    ap.add_argument("--no-graph-loop", action="store_true", help="time only the eager loop (profiling runs: per-kernel "
+                    "statistics and PMC counters of whole-batch launches only); implies --eager-value")
     ap.add_argument("--eager-value", action="store_true", help="report the eager loop as `value` even where the product "
                     "defaults to graph replay")
     ap.add_argument("--groups", type=int, default=0, help="slices of the batch run on separate streams (0: library default)")
@@ -360,20 +362,23 @@ def run_rank(args, rank, local_rank, world):
     # Loop 2, hipGraph replay of the captured step (arreau_sample_loop use_graph = 1), the batch as pipelined
     # crystal-aligned slices when the layout has them: bit-identical results, what PONITA_DIFFUSION.sample runs by
     # default for samplers of at least 200 steps (DiffusionLoss.sample).
-    run_steps(3, use_graph=True)  # warm-up of the graph path (capture, instantiation, stream / event creation)
-    el_graph = timed_loop(args.steps, use_graph=True)
-    per_rank_graph, el_graph = gather(local_elapsed[0], el_graph)
-    eng.check_status()
+    if args.no_graph_loop:
+        el_graph, per_rank_graph = el_eager, per_rank_eager
+    else:
+        run_steps(3, use_graph=True)  # warm-up of the graph path (capture, instantiation, stream / event creation)
+        el_graph = timed_loop(args.steps, use_graph=True)
+        per_rank_graph, el_graph = gather(local_elapsed[0], el_graph)
+        eng.check_status()
 
     # `value` is the loop the product runs for THIS configuration: the same policy as DiffusionLoss.sample's default
     # (graph replay from 200 sampler steps on; the 100-step single-crystal config runs eagerly).
-    production_graph = (T - 1) >= 200 and not args.eager_value
+    production_graph = (T - 1) >= 200 and not args.eager_value and not args.no_graph_loop
     elapsed, per_rank = (el_graph, per_rank_graph) if production_graph else (el_eager, per_rank_eager)
     loop_mode = (f"hipGraph replay of the captured step, {groups} pipelined slice(s) per GPU" if production_graph
                  else "eager launches")
     eager_loop = {"steps": args.steps, "ms_per_step": 1e3 * el_eager / args.steps,
                   "note": "one launch per kernel and step; the edge-kernel hipEvents (roofline) are taken here"}
-    graph_loop = {"steps": args.steps, "ms_per_step": 1e3 * el_graph / args.steps, "slices": groups,
+    graph_loop = None if args.no_graph_loop else {"steps": args.steps, "ms_per_step": 1e3 * el_graph / args.steps, "slices": groups,
                   "note": "hipGraph replay of the captured step, the batch as pipelined crystal-aligned slices on separate "
                           "streams (bit-identical results): PONITA_DIFFUSION.sample's default for >= 200 sampler steps"}
 

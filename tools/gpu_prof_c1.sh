@@ -2,7 +2,7 @@
 # usage (GPU box): tools/gpu_prof_c1.sh <tag>  -- kernel stats of the 1 x 8 sampler bench (c1)
 tag=$1
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_${tag}_c1 -- python3 bench.py --config c1 --steps 99 --no-cpu-baseline --no-fp32-variant --no-full-sampler > gpurun_out/${tag}_prof_c1.json 2> gpurun_out/${tag}_prof_c1.err || { tail -n 20 gpurun_out/${tag}_prof_c1.err; exit 1; }
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_${tag}_c1 -- python3 bench.py --config c1 --steps 99 --no-cpu-baseline --no-graph-loop --no-full-sampler --no-fp32-variant > gpurun_out/${tag}_prof_c1.json 2> gpurun_out/${tag}_prof_c1.err || { tail -n 20 gpurun_out/${tag}_prof_c1.err; exit 1; }
 python3 - <<PY
 import csv,glob,json
 f=sorted(glob.glob("gpurun_out/prof_${tag}_c1/*/*kernel_stats.csv"))[-1]

@@ -5,7 +5,7 @@ tag=$1; shift
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 i=0
 for grp in "$@"; do
-  timeout -k 10 300 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d gpurun_out/pmc_${tag}_$i -- python bench.py --steps 6 --warmup 2 --no-cpu-baseline $PMC_BENCH_ARGS > gpurun_out/pmc_bench_$i.json 2> gpurun_out/pmc_bench_$i.err || exit 1
+  timeout -k 10 300 rocprofv3 --kernel-trace --pmc $grp --output-format csv -d gpurun_out/pmc_${tag}_$i -- python bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-graph-loop --no-full-sampler $PMC_BENCH_ARGS > gpurun_out/pmc_bench_$i.json 2> gpurun_out/pmc_bench_$i.err || exit 1
   i=$((i+1))
 done
 python - <<PY

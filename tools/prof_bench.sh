@@ -2,7 +2,7 @@
 # usage: tools/prof_bench.sh <tag> [bench args...]   (GPU box): kernel stats of one bench run, no tests
 tag=$1; shift
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_$tag -- python bench.py --steps 30 --warmup 5 --no-cpu-baseline "$@" > gpurun_out/bench_prof_$tag.json 2> gpurun_out/bench_prof_$tag.err || exit 1
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/prof_$tag -- python bench.py --steps 30 --warmup 5 --no-cpu-baseline --no-graph-loop --no-full-sampler "$@" > gpurun_out/bench_prof_$tag.json 2> gpurun_out/bench_prof_$tag.err || exit 1
 python - <<PY
 import csv,glob,json
 f=glob.glob("gpurun_out/prof_$tag/*/*kernel_stats.csv")[0]
