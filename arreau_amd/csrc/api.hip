@@ -242,6 +242,29 @@ int run_network(const arreau_model* m, const Workspace& w, bool given, int32_t* 
     }();
     static const int cap_env = [] { const char* e = getenv("ARREAU_GROUP_WGS"); return e ? atoi(e) : 0; }();
     const int cap = cap_env > 0 ? cap_env : (n_cu + p->G - 1) / p->G;
+    static const int dbg_mode = [] { const char* e = getenv("ARREAU_DEBUG_SLICE_MODE"); return e ? atoi(e) : 0; }();
+    if (dbg_mode) {
+        // debugging aid: 1 = only the edge kernels run sliced (neighbour lists before, everything else after, on `s`);
+        //                2 = neighbour list + edge kernel sliced, the rest whole-batch on `s`
+        if (dbg_mode == 1 && !given &&
+            (rc = arreau_launch_neighbor(w.cart, w.lattice, d_off, w.batch, B, N, m->cfg.radius, m->k, deg, src, w.cell, dir, dist, s)))
+            return rc;
+        ARREAU_CHECK_HIP(hipEventRecord(p->fork, s));
+        for (int g = 0; g < p->G; ++g) {
+            hipStream_t sg = p->stream[g];
+            ARREAU_CHECK_HIP(hipStreamWaitEvent(sg, p->fork, 0));
+            NodeRange r;
+            r.n0 = p->nb[g]; r.n1 = p->nb[g + 1]; r.b0 = p->bb[g]; r.b1 = p->bb[g + 1]; r.wg_cap = cap;
+            if (dbg_mode == 2 && !given &&
+                (rc = arreau_launch_neighbor(w.cart, w.lattice, d_off, w.batch, B, N, m->cfg.radius, m->k, deg, src, w.cell, dir, dist, sg, r)))
+                return rc;
+            if ((rc = run_edge_kernel(m, dir, dist, deg, w, N, sg, r))) return rc;
+            ARREAU_CHECK_HIP(hipEventRecord(p->join[g], sg));
+            ARREAU_CHECK_HIP(hipStreamWaitEvent(s, p->join[g], 0));
+        }
+        if ((rc = arreau_launch_embed(m, d_frac, d_types, w.lattice, w.batch, w.cvec, N, w.xa, s))) return rc;
+        return run_layers_and_readout(m, w, deg, src, d_off, B, N, d_eps, d_logits, d_len0, s);
+    }
     ARREAU_CHECK_HIP(hipEventRecord(p->fork, s));
     for (int g = 0; g < p->G; ++g) {
         hipStream_t sg = p->stream[g];
@@ -352,9 +375,11 @@ int enqueue_slice_step(const arreau_model* m, float* d_frac, int32_t* d_types, f
     if (after_edge) ARREAU_CHECK_HIP(hipEventRecord(after_edge, s));
     if ((rc = arreau_launch_embed(m, d_frac, d_types, w.lattice, w.batch, w.cvec, N, w.xa, s, r))) return rc;
     // (the per-crystal pooling of the lattice read-out happens inside the lattice update: no launch of its own)
-    if ((rc = run_layers_and_readout(m, w, w.deg, w.src, d_off, B, N, w.eps, w.logits, nullptr, s, r))) return rc;
+    static const bool no_fuse = getenv("ARREAU_NO_POOL_FUSION") != nullptr;
+    if ((rc = run_layers_and_readout(m, w, w.deg, w.src, d_off, B, N, w.eps, w.logits, no_fuse ? w.len0 : nullptr, s, r))) return rc;
     return arreau_launch_reverse(m, d_frac, d_types, d_lengths, d_angles, w.t_cur, d_off, B, N, w.eps, w.logits, w.len0,
-                                 StepNoiseSrc{nullptr, nullptr, nullptr, seed}, d_const_types, d_lattice, s, d_fixed_lengths, r, w.gs, w.batch);
+                                 StepNoiseSrc{nullptr, nullptr, nullptr, seed}, d_const_types, d_lattice, s, d_fixed_lengths, r,
+                                 no_fuse ? nullptr : w.gs, getenv("ARREAU_NO_BATCH_ARG") ? nullptr : w.batch);
 }
 
 int enqueue_sample_step(const arreau_model* m, float* d_frac, int32_t* d_types, float* d_lengths, const float* d_angles,

@@ -163,7 +163,8 @@ __global__ __launch_bounds__(256) void noise_atoms_kernel(
 struct Post { float a, b; };
 // q_posterior_logits for float x0 logits held as (l0, l1) per lane; returns the posterior logits (d3pm.py:74-110)
 __device__ __forceinline__ Post posterior(float l0, float l1, bool v0, bool v1, int s0, int s1, const float* q1row,
-                                          const float* qm, int S, int t, float& p0, float& p1, float& f0, float& f1) {
+                                          const float* qm, int S, int t, float& p0, float& p1, float& f0, float& f1,
+                                          int absorbing) {
     const float mx = wave_max(fmaxf(v0 ? l0 : -INFINITY, v1 ? l1 : -INFINITY));
     const float e0 = v0 ? expf(l0 - mx) : 0.f, e1 = v1 ? expf(l1 - mx) : 0.f;
     const float sum = wave_sum(e0 + e1);
@@ -172,6 +173,24 @@ __device__ __forceinline__ Post posterior(float l0, float l1, bool v0, bool v1, 
     f0 = 0.f;
     f1 = 0.f;
     if (t == 1) return {l0, l1};
+    if (absorbing) {
+        // Absorbing ("mask") chain: Qbar is diagonal plus the mask column (checked on the host for every t at model
+        // creation).  The dense loop below adds exact zeros everywhere else, so these are bit for bit its sums: for an
+        // ordinary class s only the term c = s, for the mask class the whole column in class order (update.hip does the same).
+        const int mask = S - 1;
+        const float d0 = v0 ? qm[(size_t)s0 * S + s0] : 0.f, d1 = v1 ? qm[(size_t)s1 * S + s1] : 0.f;
+        const float c0 = v0 ? qm[(size_t)s0 * S + mask] : 0.f, c1 = v1 ? qm[(size_t)s1 * S + mask] : 0.f;
+        if (v0) f0 += p0 * d0;
+        if (v1) f1 += p1 * d1;
+        float fm = 0.f;
+        for (int c = 0; c < S; ++c) {  // wave-uniform
+            const float pc = c < 64 ? __shfl(p0, c, 64) : __shfl(p1, c - 64, 64);
+            const float qc = c < 64 ? __shfl(c0, c, 64) : __shfl(c1, c - 64, 64);
+            fm += pc * qc;
+        }
+        if (s0 == mask) f0 = fm;
+        if (s1 == mask) f1 = fm;
+    } else
     for (int c = 0; c < S; ++c) {  // fact2 = softmax . Qbar_{t-1}
         const float sc = c < 64 ? __shfl(p0, c, 64) : __shfl(p1, c - 64, 64);
         if (v0) f0 += sc * qm[(size_t)c * S + s0];
@@ -188,7 +207,7 @@ __global__ __launch_bounds__(256) void loss_atoms_kernel(
     const int32_t* __restrict__ types0, const int32_t* __restrict__ noisy_types, const int32_t* __restrict__ tstep,
     const int32_t* __restrict__ offsets, int B, int N, const float* __restrict__ q1t, const float* __restrict__ qmats,
     int S, int T, float* __restrict__ terms /*[N][3]*/, float* __restrict__ g_eps /*[N][3] or null*/,
-    float* __restrict__ g_logits /*[N][S] or null*/) {
+    float* __restrict__ g_logits /*[N][S] or null*/, int absorbing) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int i = blockIdx.x * 4 + wave;
     if (i >= N) return;
@@ -229,8 +248,8 @@ __global__ __launch_bounds__(256) void loss_atoms_kernel(
     // x0 given as class index: logits log(onehot + eps) (d3pm.py:80-84)
     const float on = logf(1.0f + D3PM_EPS), offv = logf(D3PM_EPS);
     float tp0, tp1, tf0, tf1, pp0, pp1, pf0, pf1;
-    const Post tpost = posterior(s0 == x0 ? on : offv, s1 == x0 ? on : offv, v0, v1, s0, s1, q1row, qm, S, t, tp0, tp1, tf0, tf1);
-    const Post ppost = posterior(l0, l1, v0, v1, s0, s1, q1row, qm, S, t, pp0, pp1, pf0, pf1);
+    const Post tpost = posterior(s0 == x0 ? on : offv, s1 == x0 ? on : offv, v0, v1, s0, s1, q1row, qm, S, t, tp0, tp1, tf0, tf1, absorbing);
+    const Post ppost = posterior(l0, l1, v0, v1, s0, s1, q1row, qm, S, t, pp0, pp1, pf0, pf1, absorbing);
     // vb = sum_s softmax(true + eps) (log_softmax(true + eps) - log_softmax(pred + eps))   (d3pm.py:112-117)
     auto log_softmax2 = [&](float a, float b, float& la, float& lb) {
         const float mx = wave_max(fmaxf(v0 ? a : -INFINITY, v1 ? b : -INFINITY));
@@ -261,6 +280,14 @@ __global__ __launch_bounds__(256) void loss_atoms_kernel(
             const float g0 = v0 ? gv0 / (pf0 + D3PM_EPS) : 0.f, g1 = v1 ? gv1 / (pf1 + D3PM_EPS) : 0.f;
             // h_c = sum_s Qbar[c, s] g_s for this lane's classes c = s0, s1 (row c of Qbar against the wave's g)
             float h0 = 0.f, h1 = 0.f;
+            if (absorbing) {
+                // row c of Qbar holds its diagonal entry and the mask column: the dense chain below in its order (s = c, then
+                // s = mask; for the mask row only the diagonal)
+                const int mask = S - 1;
+                const float gm = mask < 64 ? __shfl(g0, mask, 64) : __shfl(g1, mask - 64, 64);
+                if (v0) { h0 += qm[(size_t)s0 * S + s0] * g0; if (s0 != mask) h0 += qm[(size_t)s0 * S + mask] * gm; }
+                if (v1) { h1 += qm[(size_t)s1 * S + s1] * g1; if (s1 != mask) h1 += qm[(size_t)s1 * S + mask] * gm; }
+            } else
             for (int s = 0; s < S; ++s) {
                 const float gs = s < 64 ? __shfl(g0, s, 64) : __shfl(g1, s - 64, 64);
                 if (v0) h0 += qm[(size_t)s0 * S + s] * gs;
@@ -353,7 +380,8 @@ extern "C" int arreau_diffusion_losses(const arreau_model* m, const float* d_pre
     ARREAU_REQUIRE(m->S <= 128, "arreau_diffusion_losses: num_atomic_states must be <= 128");
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(loss_atoms_kernel, dim3((N + 3) / 4), dim3(256), 0, s, d_pred_eps, d_target_eps, d_logits, d_types0,
-                       d_noisy_types, d_t, d_off, B, N, m->q1t, m->qmats, m->S, m->T, d_terms, d_grad_eps, d_grad_logits);
+                       d_noisy_types, d_t, d_off, B, N, m->q1t, m->qmats, m->S, m->T, d_terms, d_grad_eps, d_grad_logits,
+                       m->qmats_absorbing);
     ARREAU_CHECK_HIP(hipGetLastError());
     hipLaunchKernelGGL(loss_reduce_kernel, dim3(1), dim3(256), 0, s, d_terms, N, d_pred_lengths, d_lengths, d_off, B,
                        d_losses, d_grad_lengths);

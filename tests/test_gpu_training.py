@@ -78,6 +78,25 @@ def test_training_loss_and_output_gradients_match_oracle(setup):
         assert (got.cpu() - want).abs().max() <= 1e-4 * scale, name
 
 
+def test_absorbing_chain_shortcut_in_the_loss_is_bitwise_the_dense_product(setup):
+    """The D3PM loss terms and gradients with the mask-chain structure of Qbar exploited (diagonal + mask column: the
+    default for the reference's forward_type = "mask" buffers) against the dense S x S products (ARREAU_D3PM_DENSE at model
+    creation): the shortcut adds the same numbers in the same order, so every output is bit-identical."""
+    import copy
+    import os
+    m, om, batch, lattice0, timestep, noise = setup
+    _, a = m.diffusion_loss(m, batch, None, timestep=timestep, noise=noise, return_parts=True)
+    os.environ["ARREAU_D3PM_DENSE"] = "1"
+    try:
+        m2 = copy.deepcopy(m)
+        _, b = m2.diffusion_loss(m2, batch, None, timestep=timestep, noise=noise, return_parts=True)
+    finally:
+        del os.environ["ARREAU_D3PM_DENSE"]
+    for k in ("error_frac_x", "error_atomic_type", "error_lattice", "vb", "ce", "grad_eps", "grad_logits", "grad_lengths"):
+        assert torch.equal(a[k], b[k]), k
+    assert float(a["grad_logits"].abs().max()) > 0
+
+
 def test_training_loss_draws_its_own_noise_in_reference_order(setup):
     """Without injected noise the draws come from the global CPU generator in the reference's order
     (randint [B,1], randn [N,3], rand [N,S], randn [B,3]): reproducing them by hand gives the same loss."""
