@@ -4,37 +4,7 @@
 
 constexpr size_t ARREAU_SGEMM_PARTIAL_FLOATS = (size_t)64 * 512 * 512;  // split-K partial sums (64 slices of the largest weight)
 
-// Optional epilogue of a product, applied where the final value of C[m][n] is formed (in the GEMM kernel, or in the split-K
-// reduction when K was split):
-//   mode 1 (hidden layer, forward):  v += bias[n];  C = v (the pre-activation, kept for the backward pass);
-//                                    act[m][n] = GELU(v) * (rowscale ? rowscale[m] : 1)
-//   mode 2 (hidden layer, backward): C = v * GELU'(pre[m][n]) * (rowscale ? rowscale[m] : 1)
-// act / pre share C's leading dimension.  The arithmetic is that of the separate element-wise kernels it replaces.
-struct arreau_sgemm_epilogue {
-    int mode = 0;
-    const float* bias = nullptr;
-    const float* rowscale = nullptr;
-    float* act = nullptr;
-    const float* pre = nullptr;
-};
-
 namespace arreau_sgemm_detail {
-__device__ __forceinline__ float gelu_exact(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
-__device__ __forceinline__ float gelu_grad(float x) {
-    return 0.5f * (1.0f + erff(x * 0.70710678118654752440f)) + x * 0.39894228040143267794f * expf(-0.5f * x * x);
-}
-__device__ __forceinline__ void store_with_epilogue(float* __restrict__ C, size_t idx, int m, int n, float v,
-                                                    const arreau_sgemm_epilogue& e) {
-    if (e.mode == 1) {
-        v += e.bias[n];
-        C[idx] = v;
-        e.act[idx] = gelu_exact(v) * (e.rowscale ? e.rowscale[m] : 1.0f);
-    } else if (e.mode == 2) {
-        C[idx] = v * gelu_grad(e.pre[idx]) * (e.rowscale ? e.rowscale[m] : 1.0f);
-    } else {
-        C[idx] = v;
-    }
-}
 
 // C[m,n] = alpha * sum_k A(m,k) B(k,n) + beta * C[m,n];  A(m,k) = A[m*as0 + k*as1], B(k,n) = B[k*bs0 + n*bs1].
 // Exact fp32 on the matrix pipe (v_mfma_f32_32x32x2_f32): a (64 WM) x (64 WN) output tile per workgroup, four waves in a
@@ -57,7 +27,7 @@ template <int VEC, int WM, int WN, int BK>
 __global__ __launch_bounds__(256) void sgemm_kernel(int M, int N, int K, const float* __restrict__ A, long as0, long as1,
                                                     const float* __restrict__ B, long bs0, long bs1, float* __restrict__ C,
                                                     int ldc, float alpha, float beta, int kchunk,
-                                                    float* __restrict__ partial, arreau_sgemm_epilogue epi) {
+                                                    float* __restrict__ partial) {
     constexpr int TM = 64 * WM, TN = 64 * WN;
     constexpr int KP = BK / 4;                              // 16-byte pieces per k-row of a tile
     constexpr int PA = WM * BK / 16, PB = WN * BK / 16;     // pieces per thread (VEC); elements per thread = 4 x that
@@ -174,25 +144,23 @@ __global__ __launch_bounds__(256) void sgemm_kernel(int M, int N, int K, const f
                 const int m = m0 + wm + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * h, n = n0 + wn + 32 * b + j;
                 if (m < M && n < N) {
                     if (gridDim.z > 1) partial[((size_t)blockIdx.z * M + m) * N + n] = acc[a][b][r];
-                    else store_with_epilogue(C, (size_t)m * ldc + n, m, n,
-                                             alpha * acc[a][b][r] + (beta != 0.f ? beta * C[(size_t)m * ldc + n] : 0.f), epi);
+                    else C[(size_t)m * ldc + n] = alpha * acc[a][b][r] + (beta != 0.f ? beta * C[(size_t)m * ldc + n] : 0.f);
                 }
             }
 }
 __global__ void splitk_reduce_kernel(const float* __restrict__ partial, int Z, int M, int N, float* __restrict__ C, int ldc,
-                                     float alpha, float beta, arreau_sgemm_epilogue epi) {
+                                     float alpha, float beta) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (long)M * N) return;
     float s = 0.f;
     for (int z = 0; z < Z; ++z) s += partial[(size_t)z * M * N + i];
     const int m = (int)(i / N), n = (int)(i % N);
-    store_with_epilogue(C, (size_t)m * ldc + n, m, n, alpha * s + (beta != 0.f ? beta * C[(size_t)m * ldc + n] : 0.f), epi);
+    C[(size_t)m * ldc + n] = alpha * s + (beta != 0.f ? beta * C[(size_t)m * ldc + n] : 0.f);
 }
 }  // namespace arreau_sgemm_detail
 
 inline int arreau_sgemm(hipStream_t s, float* partial, int M, int N, int K, const float* A, long as0, long as1, const float* B,
-                        long bs0, long bs1, float* C, int ldc, float alpha = 1.f, float beta = 0.f,
-                        arreau_sgemm_epilogue epi = arreau_sgemm_epilogue()) {
+                        long bs0, long bs1, float* C, int ldc, float alpha = 1.f, float beta = 0.f) {
     using namespace arreau_sgemm_detail;
     if (M == 0 || N == 0) return ARREAU_OK;
     // Tile size.  The kernel is bound by the matrix pipe of the busiest CU, so what matters is how evenly the tiles divide
@@ -221,7 +189,7 @@ inline int arreau_sgemm(hipStream_t s, float* partial, int M, int N, int K, cons
     const bool vec = a_ok && b_ok && ((size_t)A % 16 == 0) && ((size_t)B % 16 == 0);
     auto launch = [&](auto kernel) {
         hipLaunchKernelGGL(kernel, dim3(gn, gm, Z), dim3(256), 0, s, M, N, K, A, as0, as1, B, bs0, bs1, C, ldc, alpha, beta, kchunk,
-                           partial, epi);
+                           partial);
     };
     if (small) {
         if (vec) launch(sgemm_kernel<1, 1, 1, 32>); else launch(sgemm_kernel<0, 1, 1, 32>);
@@ -230,7 +198,7 @@ inline int arreau_sgemm(hipStream_t s, float* partial, int M, int N, int K, cons
     }
     ARREAU_CHECK_HIP(hipGetLastError());
     if (Z > 1) {
-        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)(((long)M * N + 255) / 256)), dim3(256), 0, s, partial, Z, M, N, C, ldc, alpha, beta, epi);
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)(((long)M * N + 255) / 256)), dim3(256), 0, s, partial, Z, M, N, C, ldc, alpha, beta);
         ARREAU_CHECK_HIP(hipGetLastError());
     }
     return ARREAU_OK;

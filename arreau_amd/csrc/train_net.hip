@@ -178,9 +178,22 @@ __global__ __launch_bounds__(256) void colsum4_kernel(const f32x4* __restrict__ 
     if (threadIdx.x == 0) *counter = 0;
 }
 
-using arreau_sgemm_detail::gelu_exact;
-using arreau_sgemm_detail::gelu_grad;
+__device__ __forceinline__ float gelu_exact(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float gelu_grad(float x) {
+    return 0.5f * (1.0f + erff(x * 0.70710678118654752440f)) + x * 0.39894228040143267794f * expf(-0.5f * x * x);
+}
 
+// pre[r][c] += bias[c]; act[r][c] = gelu(pre) * (rowscale ? rowscale[r] : 1)
+__global__ void bias_gelu_kernel(float* __restrict__ pre, const float* __restrict__ bias, const float* __restrict__ rowscale,
+                                 long rows, int cols, float* __restrict__ act) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * cols) return;
+    const long r = i / cols;
+    const int c = (int)(i % cols);
+    const float v = pre[i] + bias[c];
+    pre[i] = v;
+    act[i] = gelu_exact(v) * (rowscale ? rowscale[r] : 1.0f);
+}
 // g[r][c] = g[r][c] * gelu'(pre[r][c]) * (rowscale ? rowscale[r] : 1)
 __global__ void gelu_backward_kernel(float* __restrict__ g, const float* __restrict__ pre, const float* __restrict__ rowscale,
                                      long rows, int cols) {
@@ -595,27 +608,13 @@ size_t layout(arreau_train_ctx& t, const arreau_model* m, int N, int B, float* b
 }
 
 int gemm(hipStream_t s, arreau_train_ctx& t, int M, int N, int K, const float* A, long as0, long as1, const float* B, long bs0,
-         long bs1, float* C, int ldc, float alpha = 1.f, float beta = 0.f, arreau_sgemm_epilogue epi = arreau_sgemm_epilogue()) {
-    return arreau_sgemm(s, t.partial, M, N, K, A, as0, as1, B, bs0, bs1, C, ldc, alpha, beta, epi);
+         long bs1, float* C, int ldc, float alpha = 1.f, float beta = 0.f) {
+    return arreau_sgemm(s, t.partial, M, N, K, A, as0, as1, B, bs0, bs1, C, ldc, alpha, beta);
 }
 // Y[rows][out] = X[rows][in] . W[out][in]^T
 int linear(hipStream_t s, arreau_train_ctx& t, long rows, int in, int out, const float* X, const float* W, float* Y,
            float alpha = 1.f, float beta = 0.f) {
     return gemm(s, t, (int)rows, out, in, X, in, 1, W, 1, in, Y, out, alpha, beta);
-}
-// pre[rows][out] = X . W^T + bias;  act = GELU(pre) * (rowscale ? rowscale[row] : 1)   (bias + activation in the GEMM's epilogue)
-int linear_bias_gelu(hipStream_t s, arreau_train_ctx& t, long rows, int in, int out, const float* X, const float* W, const float* bias,
-                     const float* rowscale, float* pre, float* act) {
-    arreau_sgemm_epilogue e;
-    e.mode = 1; e.bias = bias; e.rowscale = rowscale; e.act = act;
-    return gemm(s, t, (int)rows, out, in, X, in, 1, W, 1, in, pre, out, 1.f, 0.f, e);
-}
-// dX[rows][in] = (dY[rows][out] . W[out][in]) * GELU'(pre[rows][in]) * (rowscale ? rowscale[row] : 1)
-int linear_dx_gelu(hipStream_t s, arreau_train_ctx& t, long rows, int in, int out, const float* dY, const float* W, const float* pre,
-                   const float* rowscale, float* dX) {
-    arreau_sgemm_epilogue e;
-    e.mode = 2; e.pre = pre; e.rowscale = rowscale;
-    return gemm(s, t, (int)rows, in, out, dY, out, 1, W, in, 1, dX, in, 1.f, 0.f, e);
 }
 // dX[rows][in] (+)= dY[rows][out] . W[out][in]
 int linear_dx(hipStream_t s, arreau_train_ctx& t, long rows, int in, int out, const float* dY, const float* W, float* dX,
@@ -722,12 +721,16 @@ int arreau_general_network(arreau_model* m, const arreau_graph_view& g, const in
     // edge basis: kb = gelu(W2 gelu(W1 poly + b1) + b2) * window   (ponita.py:65,94)
     LAUNCH(edge_rows_kernel, dim3(blocks(R)), dim3(256), g.dir, g.dist, g.deg, g.batch, g.lattice, m->ori, m->cfg.radius, N, k,
            t.mono, t.window);
-    TRY(linear_bias_gelu(s, t, R, ARREAU_MONO_PAD, C, t.mono, t.w1f, m->b1, nullptr, t.h1pre, t.h1));
-    TRY(linear_bias_gelu(s, t, R, C, D, t.h1, t.w2, m->b2, t.window, t.h2pre, t.kb));
+    TRY(linear(s, t, R, ARREAU_MONO_PAD, C, t.mono, t.w1f, t.h1pre));
+    LAUNCH(bias_gelu_kernel, dim3(blocks(R * C)), dim3(256), t.h1pre, m->b1, (const float*)nullptr, R, C, t.h1);
+    TRY(linear(s, t, R, C, D, t.h1, t.w2, t.h2pre));
+    LAUNCH(bias_gelu_kernel, dim3(blocks(R * D)), dim3(256), t.h2pre, m->b2, (const float*)t.window, R, D, t.kb);
     // fiber basis (ponita.py:66,95)
     LAUNCH(fiber_poly_kernel, dim3(1), dim3(256), m->ori, t.fpoly);
-    TRY(linear_bias_gelu(s, t, 256, 3, C, t.fpoly, m->fiber_w1, m->fiber_b1, nullptr, t.fh1pre, t.fh1));
-    TRY(linear_bias_gelu(s, t, 256, C, D, t.fh1, m->fiber_w2, m->fiber_b2, nullptr, t.fh2pre, t.fkb));
+    TRY(linear(s, t, 256, 3, C, t.fpoly, m->fiber_w1, t.fh1pre));
+    LAUNCH(bias_gelu_kernel, dim3(blocks(256L * C)), dim3(256), t.fh1pre, m->fiber_b1, (const float*)nullptr, 256L, C, t.fh1);
+    TRY(linear(s, t, 256, C, D, t.fh1, m->fiber_w2, t.fh2pre));
+    LAUNCH(bias_gelu_kernel, dim3(blocks(256L * D)), dim3(256), t.fh2pre, m->fiber_b2, (const float*)nullptr, 256L, D, t.fkb);
     ARREAU_CHECK_HIP(hipMemsetAsync(t.rbar, 0, (size_t)M * RO * sizeof(float), s));
     // kernel_l = kb . Wk_l^T for all layers in one product (conv.py:110; conv.kernel.weight stacked [L*C][D])
     TRY(linear(s, t, R, D, L * C, t.kb, t.wk, t.kern));
@@ -744,7 +747,8 @@ int arreau_general_network(arreau_model* m, const arreau_graph_view& g, const in
         float* hpre = t.hpre + (size_t)l * M * H;
         float* h = t.h + (size_t)l * M * H;
         float* out = t.out + (size_t)l * M * C;
-        TRY(linear_bias_gelu(s, t, M, C, H, t.xn, t.lin1 + (size_t)l * H * C, m->mb1 + (size_t)l * H, nullptr, hpre, h));
+        TRY(linear(s, t, M, C, H, t.xn, t.lin1 + (size_t)l * H * C, hpre));
+        LAUNCH(bias_gelu_kernel, dim3(blocks(M * H)), dim3(256), hpre, m->mb1 + (size_t)l * H, (const float*)nullptr, M, H, h);
         TRY(linear(s, t, M, H, C, h, t.lin2 + (size_t)l * C * H, out));
         LAUNCH(bias_scale_residual_kernel, dim3(blocks(M * C)), dim3(256), out, m->mb2 + (size_t)l * C, m->ls + (size_t)l * C, xl, M, C, xnext);
         // read-out of this layer, averaged over layers (ponita.py:105,108); biases are added in train_outputs_kernel
@@ -826,7 +830,8 @@ extern "C" int arreau_train_backward(arreau_model* m, const float* d_g_eps, cons
         LAUNCH(scale_cols_kernel, dim3(blocks(M * C)), dim3(256), t.dx, m->ls + (size_t)l * C, M, C, t.dtmp);   // dout
         TRY(linear_dw(s, t, M, H, C, t.dtmp, h, W(g->linear2_w) + (size_t)l * C * H));
         if (!m->cfg.has_layer_scale) TRY(colsum(s, t, t.dtmp, nullptr, M, C, 1.0f, W(g->linear2_b) + (size_t)l * C));
-        TRY(linear_dx_gelu(s, t, M, H, C, t.dtmp, t.lin2 + (size_t)l * C * H, hpre, nullptr, t.dh));                  // dhpre
+        TRY(linear_dx(s, t, M, H, C, t.dtmp, t.lin2 + (size_t)l * C * H, t.dh));
+        LAUNCH(gelu_backward_kernel, dim3(blocks(M * H)), dim3(256), t.dh, hpre, (const float*)nullptr, M, H);      // dhpre
         // xn = xhat * g + b (recomputed)
         LAUNCH(affine_cols_kernel, dim3(blocks(M * C)), dim3(256), xhat, m->ln_w + (size_t)l * C, m->ln_b + (size_t)l * C, M, C, t.xn);
         TRY(linear_dw(s, t, M, C, H, t.dh, t.xn, W(g->linear1_w) + (size_t)l * H * C));
@@ -856,13 +861,15 @@ extern "C" int arreau_train_backward(arreau_model* m, const float* d_g_eps, cons
     }
     // kernel projections of all layers at once: dWk [L*C][D] = dkern^T . kb,  dkb = dkern . Wk
     TRY(linear_dw(s, t, R, D, L * C, t.dkern, t.kb, W(g->conv_kernel_w)));
-    TRY(linear_dx_gelu(s, t, R, D, L * C, t.dkern, t.wk, t.h2pre, t.window, t.dkb));                                 // dh2pre
+    TRY(linear_dx(s, t, R, D, L * C, t.dkern, t.wk, t.dkb));
     // embedding: x_0 = F . W_emb^T  -> dW_emb[c][i] = sum_rows dx[row][c] F[row][i]
     TRY(linear_dw(s, t, M, S + 78, C, t.dx, t.F, W(g->x_embedder_w)));
     // edge basis MLP
+    LAUNCH(gelu_backward_kernel, dim3(blocks(R * D)), dim3(256), t.dkb, t.h2pre, (const float*)t.window, R, D);      // dh2pre
     TRY(linear_dw(s, t, R, C, D, t.dkb, t.h1, W(g->basis_w2)));
     TRY(colsum(s, t, t.dkb, nullptr, R, D, 1.0f, W(g->basis_b2)));
-    TRY(linear_dx_gelu(s, t, R, C, D, t.dkb, t.w2, t.h1pre, nullptr, t.dh1));                                        // dh1pre
+    TRY(linear_dx(s, t, R, C, D, t.dkb, t.w2, t.dh1));
+    LAUNCH(gelu_backward_kernel, dim3(blocks(R * C)), dim3(256), t.dh1, t.h1pre, (const float*)nullptr, R, C);       // dh1pre
     TRY(linear_dw(s, t, R, ARREAU_MONO_PAD, C, t.dh1, t.mono, t.dw1f));
     LAUNCH(unfold_poly_grad_kernel, dim3(blocks((long)C * ARREAU_POLY_COLS)), dim3(256), t.dw1f, C, W(g->basis_w1));
     TRY(colsum(s, t, t.dh1, nullptr, R, C, 1.0f, W(g->basis_b1)));
