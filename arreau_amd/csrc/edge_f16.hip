@@ -658,9 +658,9 @@ int arreau_launch_edge_f16x3(const arreau_model* m, const float* dir, const floa
     // Whole-batch launches only: in every single-stream test the K tiles are bit-identical to the persistent form's, but when
     // two slices of a batch run on separate streams (arreau_model_set_batch_layout) and one slice's neighbour-list kernel
     // overlaps the other's tile-per-workgroup edge kernel, about one evaluation in ten came out different at the 1e-5
-    // level (tools/exp/debug_sliced4.py; never with the persistent form, never when the neighbour lists were built before
-    // the fork).  Inputs and every buffer those kernels touch are identical from evaluation to evaluation, so this is not
-    // a stale read or a lost write; the cause is not found.  Slices exist for batches of thousands of
+    // level (tools/exp/debug_sliced4.py / debug_sliced5.py; never with the persistent form, never when the neighbour lists
+    // were built before the fork): one receiver of the later slice gets a neighbour list without its nearest candidate.
+    // Inputs are identical from evaluation to evaluation; the cause is not found.  Slices exist for batches of thousands of
     // atoms, far above the switch-over, so nothing is lost by keeping the small-launch form to unsliced launches.
     const bool whole_batch = n0 == 0 && n1 == N && r.wg_cap == 0;
     const bool use_split = split_ok && (split_env >= 0 ? split_env != 0 : (whole_batch && (n1 - n0) <= ARREAU_EDGE_SPLIT_MAX_NODES));
