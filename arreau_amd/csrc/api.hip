@@ -375,11 +375,10 @@ int enqueue_slice_step(const arreau_model* m, float* d_frac, int32_t* d_types, f
     if (after_edge) ARREAU_CHECK_HIP(hipEventRecord(after_edge, s));
     if ((rc = arreau_launch_embed(m, d_frac, d_types, w.lattice, w.batch, w.cvec, N, w.xa, s, r))) return rc;
     // (the per-crystal pooling of the lattice read-out happens inside the lattice update: no launch of its own)
-    static const bool no_fuse = getenv("ARREAU_NO_POOL_FUSION") != nullptr;
-    if ((rc = run_layers_and_readout(m, w, w.deg, w.src, d_off, B, N, w.eps, w.logits, no_fuse ? w.len0 : nullptr, s, r))) return rc;
+    if ((rc = run_layers_and_readout(m, w, w.deg, w.src, d_off, B, N, w.eps, w.logits, nullptr, s, r))) return rc;
     return arreau_launch_reverse(m, d_frac, d_types, d_lengths, d_angles, w.t_cur, d_off, B, N, w.eps, w.logits, w.len0,
                                  StepNoiseSrc{nullptr, nullptr, nullptr, seed}, d_const_types, d_lattice, s, d_fixed_lengths, r,
-                                 no_fuse ? nullptr : w.gs, getenv("ARREAU_NO_BATCH_ARG") ? nullptr : w.batch);
+                                 w.gs, w.batch);
 }
 
 int enqueue_sample_step(const arreau_model* m, float* d_frac, int32_t* d_types, float* d_lengths, const float* d_angles,
