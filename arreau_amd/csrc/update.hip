@@ -16,26 +16,35 @@ __global__ void reverse_lattice_kernel(float* __restrict__ lengths, const float*
                                        // sampling loop: pool the per-atom read-out here (same ordered sum as
                                        // readout_crystals_kernel) instead of a launch of its own; len0_out receives it
                                        const float* __restrict__ gs_atoms, float* __restrict__ len0_out) {
-    const int b = b0 + blockIdx.x * blockDim.x + threadIdx.x;  // crystals b0 .. B-1
-    if (b >= B) return;
+    // four lanes per crystal: lane i < 3 owns length component i (pooling, update), lane 0 then writes the cell
+    const int gt = blockIdx.x * blockDim.x + threadIdx.x;
+    const int b = b0 + (gt >> 2), i = gt & 3;
+    const bool live = b < B;  // (whole groups of four are live or not; the shuffles below need every lane)
+    const int bc = live ? b : B - 1;
     const float* __restrict__ z = noise.z_lattice;
-    int t = tstep[b];
-    if (t < 1 || t > T) atomicOr(status, ARREAU_STATUS_BAD_TIMESTEP);  // clamped, but flagged
+    int t = tstep[bc];
+    if (live && i == 0 && (t < 1 || t > T)) atomicOr(status, ARREAU_STATUS_BAD_TIMESTEP);  // clamped, but flagged
     t = t < 1 ? 1 : (t > T ? T : t);
-    const float n = (float)(offsets[b + 1] - offsets[b]);
+    const int first = offsets[bc], last = offsets[bc + 1];
+    const float n = (float)(last - first);
     const float ab_t = alpha_bars[t], ab_p = alpha_bars[t - 1], beta = betas[t];
     const float denom = 1.0f - ab_t;
     const float alpha_t = 1.0f - beta;
     const float c0 = sqrtf(ab_p) * beta;
     const float c1 = sqrtf(alpha_t) * (1.0f - ab_p);
     const float variance = (1.0f - ab_p) * beta / denom;
-    float newlen[3];
-#pragma unroll
-    for (int i = 0; i < 3; ++i) {
+    float mylen = 0.f;
+    if (live && i < 3) {
         float pooled;
         if (gs_atoms != nullptr) {
-            pooled = 0.f;
-            for (int a = offsets[b]; a < offsets[b + 1]; ++a) pooled += gs_atoms[(size_t)a * 3 + i];
+            pooled = 0.f;  // the ordered sum of readout_crystals_kernel, four loads in flight at a time
+            int a = first;
+            for (; a + 3 < last; a += 4) {
+                const float v0 = gs_atoms[(size_t)a * 3 + i], v1 = gs_atoms[(size_t)(a + 1) * 3 + i];
+                const float v2 = gs_atoms[(size_t)(a + 2) * 3 + i], v3 = gs_atoms[(size_t)(a + 3) * 3 + i];
+                pooled = (((pooled + v0) + v1) + v2) + v3;
+            }
+            for (; a < last; ++a) pooled += gs_atoms[(size_t)a * 3 + i];
             len0_out[3 * b + i] = pooled;
         } else {
             pooled = len0[3 * b + i];
@@ -46,9 +55,14 @@ __global__ void reverse_lattice_kernel(float* __restrict__ lengths, const float*
         const float zdraw = z ? z[3 * b + i] : philox_normal(noise.seed, (uint32_t)t, ARREAU_DRAW_Z_LATTICE, 3u * b + i);
         const float zz = t > 1 ? zdraw : 0.0f;
         // fixed-cell sampling (arreau_sample_loop, d_fixed_lengths): the given lengths are re-imposed after the update
-        newlen[i] = fixed_lengths ? fixed_lengths[3 * b + i] : mean + variance * zz;
-        lengths[3 * b + i] = newlen[i];
+        mylen = fixed_lengths ? fixed_lengths[3 * b + i] : mean + variance * zz;
+        lengths[3 * b + i] = mylen;
     }
+    const int base = (threadIdx.x & 63) & ~3;
+    float newlen[3];
+#pragma unroll
+    for (int q = 0; q < 3; ++q) newlen[q] = __shfl(mylen, base + q, 64);
+    if (!live || i != 0) return;
     // lattice_from_params (lattice_helpers.py:55-105)
     const float* ang = angles + 3 * b;
     const float ca = cosf(ang[0]), cb = cosf(ang[1]), cg = cosf(ang[2]);
@@ -211,7 +225,7 @@ int arreau_launch_reverse(const arreau_model* m, float* d_frac, int32_t* d_types
                           const int32_t* d_batch) {
     const int n0 = r.n0, n1 = r.n1 < 0 ? N : r.n1, b0 = r.b0, b1 = r.b1 < 0 ? B : r.b1;
     if (b1 > b0) {
-        hipLaunchKernelGGL(reverse_lattice_kernel, dim3((b1 - b0 + 127) / 128), dim3(128), 0, s, d_lengths, d_angles, d_t, d_off,
+        hipLaunchKernelGGL(reverse_lattice_kernel, dim3((4 * (b1 - b0) + 127) / 128), dim3(128), 0, s, d_lengths, d_angles, d_t, d_off,
                            d_len0, noise, m->vp_alpha_bars, m->vp_betas, b1, m->T, d_lattice, d_fixed_lengths, m->status, b0,
                            d_gs_atoms, d_gs_atoms ? const_cast<float*>(d_len0) : nullptr);
         ARREAU_CHECK_HIP(hipGetLastError());
