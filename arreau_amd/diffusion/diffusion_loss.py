@@ -32,6 +32,52 @@ class SampleResult:
     num_atoms: Optional[np.ndarray] = None
 
 
+class DiffusionLossMetric:
+    """diffusion_loss.py:52-65 (a torchmetrics.Metric there): running sum of the step losses and of the crystals seen,
+    `compute()` = their ratio.  The two states are what a data-parallel run reduces over the ranks (`dist_reduce_fx="sum"`
+    in the reference): `sync()` does those two scalar all-reduces.  States stay on the device of the losses they are fed,
+    so updating the metric does not synchronise the training loop."""
+
+    def __init__(self):
+        self.reset()
+
+    def reset(self):
+        self.total_loss = None
+        self.total_samples = 0
+
+    def update(self, loss, batch=None, num_crystals=None):
+        loss = torch.as_tensor(loss).detach().sum()
+        self.total_loss = loss.clone() if self.total_loss is None else self.total_loss + loss
+        if num_crystals is None:
+            if hasattr(batch, "num_atoms"):
+                num_crystals = int(torch.as_tensor(batch.num_atoms).numel())
+            else:  # the reference counts torch.unique(batch.batch)
+                num_crystals = int(torch.unique(torch.as_tensor(batch.batch)).numel())
+        self.total_samples += int(num_crystals)
+
+    def sync(self, group=None):
+        """Sum both states over the ranks of the default (or given) process group; a no-op without one."""
+        import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+            return self
+        backend = dist.get_backend(group)
+        dev = self.total_loss.device if (self.total_loss is not None and backend == "nccl") else torch.device("cpu")
+        if backend == "nccl" and dev.type != "cuda":
+            dev = torch.device("cuda", torch.cuda.current_device())
+        tl = (self.total_loss if self.total_loss is not None else torch.zeros(())).to(dev, torch.float64).reshape(1)
+        ts = torch.tensor([float(self.total_samples)], device=dev, dtype=torch.float64)
+        dist.all_reduce(tl, op=dist.ReduceOp.SUM, group=group)
+        dist.all_reduce(ts, op=dist.ReduceOp.SUM, group=group)
+        self.total_loss = tl.reshape(()).to(torch.float32)
+        self.total_samples = int(round(float(ts)))
+        return self
+
+    def compute(self):
+        if self.total_loss is None or self.total_samples == 0:
+            return torch.tensor(float("nan"))
+        return self.total_loss / self.total_samples
+
+
 class DiffusionLoss(nn.Module):
     def __init__(self, args, num_atomic_states: int):
         super().__init__()

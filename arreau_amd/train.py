@@ -53,19 +53,28 @@ def train_epochs(model, dataset, epochs: int, batch_size: int, rank: int = 0, wo
                  log=print):
     """`batch_size` is per rank (global batch = batch_size * world_size).  Returns the list of per-step losses."""
     from .diffusion.lattice_dataset import iterate_batches
+    from .diffusion.diffusion_loss import DiffusionLossMetric
     opt = model.configure_optimizers(max_epochs=epochs)
     optimizer, scheduler = opt["optimizer"], opt["lr_scheduler"]
     losses = []
     for epoch in range(epochs):
+        metric = DiffusionLossMetric()  # (diffusion_loss.py:52-65; the reference logs it per epoch with sync_dist)
+        step_losses = []                # device scalars: read back once per epoch, not per step (no host sync in the loop)
         for step, batch in enumerate(iterate_batches(dataset, batch_size, shuffle=True, seed=seed + epoch, rank=rank,
                                                      world_size=world_size, drop_last=True)):
             loss = model.training_step(batch)
             optimizer_step(model, optimizer, world_size)
-            losses.append(float(loss))
+            step_losses.append(loss.detach())
+            metric.update(loss, batch)
         scheduler.step()
+        if step_losses:
+            losses += [float(v) for v in torch.stack(step_losses).cpu()]
+        mean = float(metric.sync().compute())  # two scalar all-reduces: loss sum and crystal count over the ranks
+        if getattr(model, "_engine", None) is not None:
+            model._engine.check_status()  # sticky device flags of the whole epoch
         if rank == 0:
-            log(f"epoch {epoch}: {len(losses)} steps, last loss {losses[-1] if losses else float('nan'):.5f}, "
-                f"lr {scheduler.get_last_lr()[0]:.3e}")
+            log(f"epoch {epoch}: {len(step_losses)} steps, loss per crystal {mean:.5f} (all ranks), last loss "
+                f"{losses[-1] if losses else float('nan'):.5f}, lr {scheduler.get_last_lr()[0]:.3e}")
     return losses
 
 

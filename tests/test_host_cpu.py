@@ -147,3 +147,16 @@ def test_frame_files_are_valid_cif(tmp_path):
     assert abs(gamma - 60.0) < 1e-4 and "X1 X " in b and b.startswith("data_run_40\n")  # hexagonal cell; mask state -> dummy species
     single = vis_crystal_during_sampling(zt, np.array([0, 1]), lattice[:1], frac[:2], str(tmp_path / "one_final"))
     assert single == [str(tmp_path / "one_final.cif")]
+
+
+def test_diffusion_loss_metric_sums_and_counts():
+    """DiffusionLossMetric (diffusion_loss.py:52-65): total loss / crystals seen; batches given either with num_atoms or
+    with the reference's per-atom `batch` index."""
+    from types import SimpleNamespace
+    from arreau_amd.diffusion.diffusion_loss import DiffusionLossMetric
+    m = DiffusionLossMetric()
+    assert torch.isnan(m.compute())
+    m.update(torch.tensor(3.0), SimpleNamespace(num_atoms=torch.tensor([4, 2, 7])))
+    m.update(torch.tensor([1.0, 2.0]), SimpleNamespace(batch=torch.tensor([0, 0, 1, 1, 1])))
+    assert m.total_samples == 5 and abs(float(m.compute()) - 6.0 / 5.0) < 1e-7
+    assert m.sync() is m and m.total_samples == 5  # no process group: nothing to reduce

@@ -108,6 +108,36 @@ def test_gradient_all_reduce_averages_one_flat_bucket():
         assert torch.equal(g1, torch.arange(5.0) * 0.5)            # (1 * arange + 0) / 2
 
 
+def _metric_worker(rank, world, port, outfile):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from types import SimpleNamespace
+    from arreau_amd.diffusion.diffusion_loss import DiffusionLossMetric
+    m = DiffusionLossMetric()
+    for step in range(3):  # rank r sees batches of r + 2 crystals with loss (r + 1) * (step + 1)
+        m.update(torch.tensor(float((rank + 1) * (step + 1))), SimpleNamespace(num_atoms=torch.ones(rank + 2)))
+    m.sync()
+    if rank == 0:
+        torch.save([m.total_loss, m.total_samples, m.compute()], outfile)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_loss_metric_reduces_its_two_scalars_over_the_ranks():
+    """besides the gradient bucket, the loss metric's two states (loss sum, crystals seen) are
+    summed over the ranks (diffusion_loss.py:52-65, dist_reduce_fx="sum"); world_size 2 over gloo."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    with tempfile.TemporaryDirectory() as d:
+        out = os.path.join(d, "m.pt")
+        mp.spawn(_metric_worker, args=(2, port, out), nprocs=2, join=True)
+        total_loss, total_samples, mean = torch.load(out)
+        assert float(total_loss) == 6.0 + 12.0 and total_samples == 3 * 2 + 3 * 3
+        assert abs(float(mean) - 18.0 / 15.0) < 1e-6
+
+
 def test_optimizer_groups_and_cosine_warmup_schedule():
     """configure_optimizers (lightning_wrappers/diffusion.py:152-218): Linear weights decay, everything else does not;
     CosineWarmupScheduler (scheduler.py:5-19) factors."""
