@@ -945,7 +945,8 @@ int arreau_launch_readout(const arreau_model* m, const float* xbar, const float*
             ARREAU_CHECK_HIP(attr_s);
             const unsigned blocks32 = (unsigned)((n1 - n0 + 31) / 32);
             static const int split_env = [] { const char* e = getenv("ARREAU_READOUT_SPLIT"); return e ? atoi(e) : -1; }();
-            if (split_env >= 0 ? split_env != 0 : blocks32 < 64)  // small launch: one workgroup per output tile
+            // small unsliced launch: one workgroup per output tile
+            if (split_env >= 0 ? split_env != 0 : (whole && r.wg_cap == 0 && blocks32 < 64))
                 hipLaunchKernelGGL((readout_mfma_kernel<128, 3, 1>), dim3(blocks32, 3), dim3(64 * m->L), smem_m, s, xbar, vsum,
                                    m->ro_pack, m->ro_b, m->ori, m->S, m->L, N, n0, n1, eps, logits, gs, m->status);
             else

@@ -521,7 +521,9 @@ int arreau_launch_mlp_f16x3_m16(const arreau_model* m, int layer, const float* x
     // MI355X: 10.7 us per layer at 8 nodes against 22.5 us; the forms cross where the node-per-workgroup form needs more
     // than about two rounds of the chip.  ARREAU_MLP_SPLIT = 0 / 1 forces a form (tests).
     static const int split_env = [] { const char* e = getenv("ARREAU_MLP_SPLIT"); return e ? atoi(e) : -1; }();
-    if (split_env >= 0 ? split_env != 0 : N <= ARREAU_MLP_SPLIT_MAX_NODES)
+    // (unsliced launches only, like the edge kernel's small-launch form: edge_f16.hip)
+    const bool whole_batch = n0 == 0 && n1 == Ntot && r.wg_cap == 0;
+    if (split_env >= 0 ? split_env != 0 : (whole_batch && N <= ARREAU_MLP_SPLIT_MAX_NODES))
         return arreau_launch_mlp_f16x3_m16_split(m, layer, x_conv, x_in, x_out, xbar, vsum, Ntot, s, r);
     static const int nb_env = [] { const char* e = getenv("ARREAU_MLP_NB"); return e ? atoi(e) : 0; }();
     static const int wave_slots = [] {
