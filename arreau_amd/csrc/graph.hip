@@ -123,52 +123,54 @@ __global__ __launch_bounds__(256) void neighbor_kernel(
     // Crystals of up to 64 * NBR_KEYS / 27 = 28 atoms (wave-uniform test): every lane evaluates its candidates once
     // and keeps their keys in registers; each of the k selection rounds is then a scan of those keys.  Larger
     // crystals re-evaluate the candidates in every round (same keys, same selection).
+    // Selection keys: (bits of d^2, enumeration index c) ordered lexicographically, held as the DOUBLE d2bits * 2^21 + c
+    // (exact: d2bits < 2^32, c < 2^21), so that "smallest key above the last one" is a compare + select + v_min_f64 per
+    // key and the wave minimum a v_min_f64 butterfly -- no 64-bit integer compares with their chains of scalar lane masks.
     constexpr int NBR_KEYS = 12;
+    constexpr double KEY_NONE = 1.0e300;
+    auto make_key = [](float d2, int c) { return (double)__float_as_uint(d2) * 2097152.0 + (double)c; };
     const bool cached = ncand <= 64 * NBR_KEYS;
-    unsigned long long keys[NBR_KEYS];
+    double keys[NBR_KEYS];
     if (cached) {
 #pragma unroll
         for (int q = 0; q < NBR_KEYS; ++q) {
             const int c = lane + 64 * q;
-            keys[q] = ~0ull;
+            keys[q] = KEY_NONE;
             if (c < ncand) {
                 const Cand cd = arreau_candidate(cart, first, c, Lm, pix, piy, piz);
-                if (cd.d2 <= r2 && cd.d2 > 0.0001f) keys[q] = ((unsigned long long)__float_as_uint(cd.d2) << 32) | (unsigned)c;
+                if (cd.d2 <= r2 && cd.d2 > 0.0001f) keys[q] = make_key(cd.d2, c);
             }
         }
     }
-    unsigned long long last = 0ull, mine = ~0ull;
+    double last = -1.0, mine = KEY_NONE;
     int count = 0;
     for (int s = 0; s < k; ++s) {
-        unsigned long long best = ~0ull;
+        double best = KEY_NONE;
         if (cached) {
 #pragma unroll
-            for (int q = 0; q < NBR_KEYS; ++q)
-                if (keys[q] > last && keys[q] < best) best = keys[q];
+            for (int q = 0; q < NBR_KEYS; ++q) best = fmin(best, keys[q] > last ? keys[q] : KEY_NONE);
         } else {
             for (int c = lane; c < ncand; c += 64) {
                 const Cand cd = arreau_candidate(cart, first, c, Lm, pix, piy, piz);
                 if (cd.d2 <= r2 && cd.d2 > 0.0001f) {
-                    const unsigned long long key = ((unsigned long long)__float_as_uint(cd.d2) << 32) | (unsigned)c;
-                    if (key > last && key < best) best = key;
+                    const double key = make_key(cd.d2, c);
+                    best = fmin(best, key > last ? key : KEY_NONE);
                 }
             }
         }
 #pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) {
-            const unsigned long long other = __shfl_xor(best, off, 64);
-            best = other < best ? other : best;
-        }
-        if (best == ~0ull) break;  // wave-uniform: fewer than k candidates
+        for (int off = 32; off >= 1; off >>= 1) best = fmin(best, __shfl_xor(best, off, 64));
+        if (best == KEY_NONE) break;  // wave-uniform: fewer than k candidates
         last = best;
         if (lane == s) mine = best;
         ++count;
     }
     // rank of my selection by enumeration index (output order of the reference)
-    const unsigned myc = (unsigned)(mine & 0xffffffffull);
+    auto index_of = [](double key) { return (unsigned)((unsigned long long)key & 0x1fffffull); };
+    const unsigned myc = index_of(mine);
     int rank = 0;
     for (int s = 0; s < count; ++s) {
-        const unsigned oc = (unsigned)(__shfl(mine, s, 64) & 0xffffffffull);
+        const unsigned oc = index_of(__shfl(mine, s, 64));
         rank += (oc < myc) ? 1 : 0;
     }
     if (lane == 0) deg[i] = count;

@@ -181,7 +181,7 @@ class DiffusionLoss(nn.Module):
                num_samples_in_batch: int, vis_name: str = "", visualization_setting=VisualizationSetting.NONE,
                show_bonds: bool = False, constant_atoms: Optional[torch.Tensor] = None, noise: str = "philox",
                max_steps: Optional[int] = None, use_graph: Optional[bool] = None, seed: Optional[int] = None,
-               fixed_cell: bool = False) -> SampleResult:
+               fixed_cell: bool = False, pipelined_slices: int = 1) -> SampleResult:
         """diffusion_loss.py:276-377.  The initial state is drawn on the host exactly like the reference (numpy
         uniforms for the angles, then randn lengths, randn fractional coordinates from torch's global CPU generator).
         Per-step noise:
@@ -241,10 +241,11 @@ class DiffusionLoss(nn.Module):
         if (use_graph or fixed_cell) and noise != "philox":
             raise ValueError("graph replay and fixed-cell sampling need noise='philox' (the in-kernel generator)")
 
-        # Two pipelined slices of the batch (own stream and step graph each, staggered by one edge kernel; bit-identical
-        # results) pay for batches that fill the chip several times over: 1.57-1.59 vs 1.61-1.62 ms per step at 256 x 20 on
-        # MI355X; three or four slices are slower (the persistent kernels are capped to a share of the CUs).
-        eng.set_batch_layout(num_atoms, groups=2 if N >= 4096 else 1)
+        # One stream.  Running the batch as two pipelined slices on separate streams (arreau_model_set_batch_layout, kept as
+        # an opt-in: `pipelined_slices=2`) was 3 % faster at 256 x 20 on MI355X, but its results are not reproducible:
+        # in about one run in four one crystal differs at the 1e-5 level from the one-stream loop (DESIGN.md section 8:
+        # kernels of different slices sharing a CU), and parity comes first.
+        eng.set_batch_layout(num_atoms, groups=max(1, int(pipelined_slices)))
         if noise == "philox":
             if seed is None:
                 seed = int(torch.randint(0, 2 ** 62, (1,)).item())

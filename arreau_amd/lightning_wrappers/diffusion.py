@@ -243,7 +243,8 @@ class PONITA_DIFFUSION(nn.Module):
                visualization_setting: VisualizationSetting = VisualizationSetting.NONE, show_bonds: bool = False,
                use_constant_atomic_symbols: Optional[list] = None, noise: str = "philox",
                max_steps: Optional[int] = None, use_graph: Optional[bool] = None,
-               seed: Optional[int] = None, fixed_cell: bool = False, vis_name: Optional[str] = None) -> SampleResult:
+               seed: Optional[int] = None, fixed_cell: bool = False, vis_name: Optional[str] = None,
+               pipelined_slices: int = 1) -> SampleResult:
         """lightning_wrappers/diffusion.py:220-253.  `num_atoms_per_sample` may also be a sequence with one atom count
         per crystal of the batch (extension; the reference supports a single int).  Frames of a visualization_setting
         other than NONE go to `<DIFFUSION_DIR>/step_<timestep>.cif` like the reference's PNGs (`vis_name` overrides the
@@ -262,4 +263,5 @@ class PONITA_DIFFUSION(nn.Module):
             model=self, z_table=z_table, t_emb_weights=self.t_emb, num_atoms_per_sample=num_atoms_per_sample,
             num_samples_in_batch=num_samples_in_batch, vis_name=self._frame_prefix(vis_name, visualization_setting),
             visualization_setting=visualization_setting, show_bonds=show_bonds, constant_atoms=constant_atoms,
-            noise=noise, max_steps=max_steps, use_graph=use_graph, seed=seed, fixed_cell=fixed_cell)
+            noise=noise, max_steps=max_steps, use_graph=use_graph, seed=seed, fixed_cell=fixed_cell,
+            pipelined_slices=pipelined_slices)

@@ -17,8 +17,7 @@ process group is used only for the timing barrier / max-over-ranks.
 
 The K steps are ONE arreau_sample_loop call per stretch of timesteps (Philox noise inside the update kernels, timestep on
 the device, nothing on the host between steps), timed twice: as eager launches -- hipEvents bracket every edge-kernel
-launch there: the roofline figure -- and as hipGraph replay of the captured step with the batch as pipelined
-crystal-aligned slices (bit-identical results).  `value` is the loop PONITA_DIFFUSION.sample runs by default for the
+launch there: the roofline figure -- and as hipGraph replay of the captured step (bit-identical results).  `value` is the loop PONITA_DIFFUSION.sample runs by default for the
 configuration (graph replay for samplers of at least 200 steps, i.e. every 1000-step config; eager for the 100-step
 single-crystal config): `loop_mode` names it, `eager_loop` / `graph_loop` hold both.
 
@@ -141,7 +140,8 @@ def parse_args(argv=None):
                     "statistics and PMC counters of whole-batch launches only); implies --eager-value")
     ap.add_argument("--eager-value", action="store_true", help="report the eager loop as `value` even where the product "
                     "defaults to graph replay")
-    ap.add_argument("--groups", type=int, default=0, help="slices of the batch run on separate streams (0: library default)")
+    ap.add_argument("--groups", type=int, default=0, help="opt-in: slices of the batch run on separate streams (0 = the product's "
+                    "default, one stream; 2 was 3 %% faster at 256 x 20 but is not run-to-run reproducible)")
     args = ap.parse_args(argv)
     B, n, T = CONFIGS[args.config or "c2"]
     args.batch_per_gpu = args.batch_per_gpu or B
@@ -299,7 +299,7 @@ def run_rank(args, rank, local_rank, world):
     seed = 77 + rank
     timestep = [T - 1]
     # crystal-aligned slices on separate streams for the graph loop (0: what PONITA_DIFFUSION.sample chooses: 2 from 4096 atoms)
-    groups = args.groups if args.groups > 0 else (2 if N >= 4096 else 1)
+    groups = args.groups if args.groups > 0 else 1  # (the product's default: one stream; see DiffusionLoss.sample)
     eng.set_batch_layout(torch.full((B,), n), groups=groups)
 
     def run_steps(k, use_graph=False):
@@ -359,9 +359,9 @@ def run_rank(args, rank, local_rank, world):
     status = eng.check_status()  # raises on non-finite outputs / clamped indices; names the kernels that really ran
     per_rank_eager, el_eager = gather(local_elapsed[0], el_eager)
 
-    # Loop 2, hipGraph replay of the captured step (arreau_sample_loop use_graph = 1), the batch as pipelined
-    # crystal-aligned slices when the layout has them: bit-identical results, what PONITA_DIFFUSION.sample runs by
-    # default for samplers of at least 200 steps (DiffusionLoss.sample).
+    # Loop 2, hipGraph replay of the captured step (arreau_sample_loop use_graph = 1) on one stream: bit-identical results,
+    # what PONITA_DIFFUSION.sample runs by default for samplers of at least 200 steps (DiffusionLoss.sample).
+    # (--groups 2: the opt-in pipelined slices on two streams.)
     if args.no_graph_loop:
         el_graph, per_rank_graph = el_eager, per_rank_eager
     else:
@@ -374,13 +374,14 @@ def run_rank(args, rank, local_rank, world):
     # (graph replay from 200 sampler steps on; the 100-step single-crystal config runs eagerly).
     production_graph = (T - 1) >= 200 and not args.eager_value and not args.no_graph_loop
     elapsed, per_rank = (el_graph, per_rank_graph) if production_graph else (el_eager, per_rank_eager)
-    loop_mode = (f"hipGraph replay of the captured step, {groups} pipelined slice(s) per GPU" if production_graph
+    loop_mode = ("hipGraph replay of the captured step" + (f", {groups} pipelined slices per GPU" if groups > 1 else "")
+                 if production_graph
                  else "eager launches")
     eager_loop = {"steps": args.steps, "ms_per_step": 1e3 * el_eager / args.steps,
                   "note": "one launch per kernel and step; the edge-kernel hipEvents (roofline) are taken here"}
     graph_loop = None if args.no_graph_loop else {"steps": args.steps, "ms_per_step": 1e3 * el_graph / args.steps, "slices": groups,
-                  "note": "hipGraph replay of the captured step, the batch as pipelined crystal-aligned slices on separate "
-                          "streams (bit-identical results): PONITA_DIFFUSION.sample's default for >= 200 sampler steps"}
+                  "note": "hipGraph replay of the captured step on one stream (bit-identical to the eager loop): "
+                          "PONITA_DIFFUSION.sample's default for >= 200 sampler steps"}
 
     # The headline metric measured rather than extrapolated: ONE call of PONITA_DIFFUSION.sample for the whole sampler
     # (T - 1 network evaluations of this batch; host-side initial draws, the library loop in its default mode, the

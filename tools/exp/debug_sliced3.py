@@ -8,6 +8,8 @@ m = make_synthetic_model(S=90, seed=1234).to(dev)
 eng = m.engine()
 rng = np.random.RandomState(3)
 counts = [int(v) for v in rng.randint(3, 21, size=37)]
+if os.environ.get("CRYSTALS"):  # uniform batch of a BASELINE configuration instead of the ragged test batch
+    counts = [int(os.environ.get("ATOMS", "20"))] * int(os.environ["CRYSTALS"])
 frac, types, lengths, angles, na = random_state(90, counts, 12, sampler_like=True)
 B, N = len(counts), sum(counts)
 d = lambda v: v.to(dev).contiguous()
