@@ -112,11 +112,13 @@ __global__ __launch_bounds__(256) void embed_kernel(
     int32_t* __restrict__ status) {
     // thread = (atom n, float4 column c4): the atom's scalar part and the four vector-channel weight rows are
     // loaded once and serve all 16 orientations (16 coalesced 512-byte row stores per 32 lanes)
+    // (32-bit index arithmetic: the launcher checks (N - n0) * C / 4 < 2^31.  Per-lane 64-bit compares are avoided in the
+    // kernels that may share a CU with another stream's kernels: DESIGN.md section 8)
     const int C4 = C / 4;
-    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= (long long)(N - n0) * C4) return;
-    const int c4 = (int)(idx % C4);
-    const int n = n0 + (int)(idx / C4);
+    const unsigned idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= (unsigned)(N - n0) * (unsigned)C4) return;
+    const int c4 = (int)(idx % (unsigned)C4);
+    const int n = n0 + (int)(idx / (unsigned)C4);
     const int b = batch[n];
     int ty = types[n];
     if ((ty < 0 || ty >= S) && c4 == 0) atomicOr(status, ARREAU_STATUS_BAD_TYPE);  // clamped, but flagged
@@ -150,6 +152,10 @@ int arreau_launch_embed(const arreau_model* m, const float* frac, const int32_t*
     const int n0 = r.n0, n1 = r.n1 < 0 ? N : r.n1;
     if (n1 <= n0) return ARREAU_OK;
     const long long total = (long long)(n1 - n0) * (m->C / 4);
+    if (total >= (1ll << 31)) {
+        arreau_set_error("embed kernel: more than 2^31 (atom, channel group) pairs in one launch");
+        return ARREAU_EINVAL;
+    }
     hipLaunchKernelGGL(embed_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, frac, types, lattice, batch,
                        cvec, m->ori, m->embT, m->S, m->C, n0, n1, x0, m->status);
     ARREAU_CHECK_HIP(hipGetLastError());
