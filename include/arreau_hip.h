@@ -147,9 +147,12 @@ int arreau_model_set_variant(arreau_model* model, int32_t edge_variant, int32_t 
  * of subsequent arreau_predict_scores / arreau_sample_loop calls with the same (B, N) may run as `groups`
  * crystal-aligned slices on separate internal streams (forked from and joined to the caller's stream by events; no host
  * synchronisation).  Crystals are independent and every kernel takes a node range over whole-batch arrays, so
- * the results are bit for bit those of the unsliced run; the slices drift into different phases and the HBM-bound
- * message-passing kernel of one overlaps the matrix-bound edge / MLP kernels of another.  groups <= 0: the library's
- * default (environment ARREAU_GROUPS, else 1 = off).  Used only with the default kernel set; ignored otherwise. */
+ * every slice computes what the unsliced run computes for its atoms; the slices drift into different phases and the
+ * HBM-bound message-passing kernel of one overlaps the matrix-bound edge / MLP kernels of another (3-5 % at 256 x 20).
+ * OPT-IN, off by default: on MI355X kernels of different streams sharing a CU were seen to change a result at the 1e-5
+ * level in rare evaluations, so a sliced run is not guaranteed bit-identical to the unsliced one.
+ * groups <= 0: the library's default (environment ARREAU_GROUPS, else 1 = off).  Used only with the default kernel set;
+ * ignored otherwise. */
 int arreau_model_set_batch_layout(arreau_model* model, const int32_t* h_crystal_offsets, int32_t B, int32_t groups);
 
 /* Scratch for one step over at most max_atoms atoms / max_crystals crystals. */
