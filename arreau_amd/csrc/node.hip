@@ -902,8 +902,9 @@ __global__ __launch_bounds__(512) void readout_mfma_kernel(
     // vector channel: eps component d of atom a (sphere_to_vec of the per-orientation dot products)
     if (threadIdx.x < 96 && (!USPLIT || blockIdx.y == 0)) {
         const int a = threadIdx.x / 3, dd = threadIdx.x - 3 * a;
-        const size_t n = (size_t)n0 + a;
-        if (n < (size_t)N) {
+        const int ni = n0 + a;  // (32-bit bounds check: no per-lane 64-bit integer compares on this path)
+        if (ni < N) {
+            const size_t n = (size_t)ni;
             float acc = 0.f;
             for (int o = 0; o < 16; ++o) acc += (vsum[n * 16 + o] * invL) * ori[3 * o + dd];
             eps[n * 3 + dd] = acc * (1.0f / 16.0f);

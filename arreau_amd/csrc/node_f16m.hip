@@ -78,15 +78,16 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_kernel_f16x3_m16(
 
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int cp = lane & 15, gp = lane >> 4;  // prologue / matrix-phase copies
-    const long long tile = (long long)blockIdx.x * NW + wave;
+    // (32-bit: the launcher's grid is ceil((N - n0) / NB / NW) workgroups, so n0 + NB * tile + nb < N + NB * NW fits an int)
+    const int tile = (int)blockIdx.x * NW + wave;
     const bool active = n0 + NB * tile < N;  // wave-uniform; idle waves still copy weights and meet the barriers
     int nrow[NB];                      // node of column block nb (padding: a valid node, nothing written)
     bool valid[NB];
 #pragma unroll
     for (int nb = 0; nb < NB; ++nb) {
-        const long long n_ll = n0 + NB * tile + nb;
-        valid[nb] = n_ll < N;
-        nrow[nb] = valid[nb] ? (int)n_ll : N - 1;
+        const int n_i = n0 + NB * tile + nb;
+        valid[nb] = n_i < N;
+        nrow[nb] = valid[nb] ? n_i : N - 1;
     }
 
     const u32x4* dma_src = stream;  // next chunk to copy

@@ -192,9 +192,12 @@ __global__ __launch_bounds__(256) void reverse_atoms_kernel(
     }
     // ---- Gumbel arg-max (d3pm.py:206-214) ----------------------------------------------------------
     const float scale = (t != 1) ? 1.0f : 0.2f;
-    const float* un = u_types ? u_types + (size_t)i * S : nullptr;
+    // (the array-or-generator choice is made on the kernel argument itself -- a scalar compare -- not on a per-lane pointer:
+    // no per-lane 64-bit integer compares on this path)
+    const bool have_u = u_types != nullptr;
+    const float* un = u_types + (have_u ? (size_t)i * S : 0);
     auto draw_u = [&](int s_) {
-        return un ? un[s_] : philox_uniform(noise.seed, (uint32_t)t, ARREAU_DRAW_U_TYPES, (uint32_t)((size_t)i * S + s_));
+        return have_u ? un[s_] : philox_uniform(noise.seed, (uint32_t)t, ARREAU_DRAW_U_TYPES, (uint32_t)((size_t)i * S + s_));
     };
     float best = -INFINITY;
     int besti = 0x7fffffff;
