@@ -100,7 +100,11 @@ extern "C" int arreau_model_set_batch_layout(arreau_model* m, const int32_t* h_o
     m->part = p;
     const int N = h_off[B];
     p->B = B; p->N = N; p->G = G;
-    p->eager = getenv("ARREAU_SLICE_EAGER") != nullptr;
+    // ARREAU_SLICE_EAGER: also slice single evaluations (tests).  "serial" = the slices' range launches one after another on
+    // the caller's stream (what the range launches compute, without any concurrency); anything else = fork-join on the
+    // slice streams.
+    const char* se = getenv("ARREAU_SLICE_EAGER");
+    p->eager = se == nullptr ? 0 : (strcmp(se, "serial") == 0 ? 2 : 1);
     p->bb[0] = 0; p->nb[0] = 0;
     int b = 0;
     for (int g = 1; g < G; ++g) {  // cut at the crystal boundary nearest to g N / G (at least one crystal per slice)
@@ -265,10 +269,11 @@ int run_network(const arreau_model* m, const Workspace& w, bool given, int32_t* 
         if ((rc = arreau_launch_embed(m, d_frac, d_types, w.lattice, w.batch, w.cvec, N, w.xa, s))) return rc;
         return run_layers_and_readout(m, w, deg, src, d_off, B, N, d_eps, d_logits, d_len0, s);
     }
-    ARREAU_CHECK_HIP(hipEventRecord(p->fork, s));
+    const bool serial = p->eager == 2;
+    if (!serial) ARREAU_CHECK_HIP(hipEventRecord(p->fork, s));
     for (int g = 0; g < p->G; ++g) {
-        hipStream_t sg = p->stream[g];
-        ARREAU_CHECK_HIP(hipStreamWaitEvent(sg, p->fork, 0));
+        hipStream_t sg = serial ? s : p->stream[g];
+        if (!serial) ARREAU_CHECK_HIP(hipStreamWaitEvent(sg, p->fork, 0));
         NodeRange r;
         r.n0 = p->nb[g]; r.n1 = p->nb[g + 1]; r.b0 = p->bb[g]; r.b1 = p->bb[g + 1]; r.wg_cap = cap;
         if (!given && (rc = arreau_launch_neighbor(w.cart, w.lattice, d_off, w.batch, B, N, m->cfg.radius, m->k, deg, src, w.cell, dir, dist, sg, r)))
@@ -276,8 +281,10 @@ int run_network(const arreau_model* m, const Workspace& w, bool given, int32_t* 
         if ((rc = run_edge_kernel(m, dir, dist, deg, w, N, sg, r))) return rc;
         if ((rc = arreau_launch_embed(m, d_frac, d_types, w.lattice, w.batch, w.cvec, N, w.xa, sg, r))) return rc;
         if ((rc = run_layers_and_readout(m, w, deg, src, d_off, B, N, d_eps, d_logits, d_len0, sg, r))) return rc;
-        ARREAU_CHECK_HIP(hipEventRecord(p->join[g], sg));
-        ARREAU_CHECK_HIP(hipStreamWaitEvent(s, p->join[g], 0));
+        if (!serial) {
+            ARREAU_CHECK_HIP(hipEventRecord(p->join[g], sg));
+            ARREAU_CHECK_HIP(hipStreamWaitEvent(s, p->join[g], 0));
+        }
     }
     return ARREAU_OK;
 }

@@ -894,7 +894,8 @@ def test_sliced_multi_stream_execution_is_bitwise_the_whole_batch(dev, full_mode
     args = (d(frac), d(types.to(torch.int32)), d(lengths), d(angles), t_c, off)
     eng.set_batch_layout(na, groups=1)
     whole = eng.predict_scores(*args)
-    os.environ["ARREAU_SLICE_EAGER"] = "1"  # fork-join slicing of a single evaluation (read when the layout is set)
+    # the range launches of every kernel, slice after slice on ONE stream: bit for bit the whole-batch result
+    os.environ["ARREAU_SLICE_EAGER"] = "serial"  # (read when the layout is set)
     try:
         eng.set_batch_layout(na, groups=groups)
     finally:
@@ -902,6 +903,14 @@ def test_sliced_multi_stream_execution_is_bitwise_the_whole_batch(dev, full_mode
     sliced = eng.predict_scores(*args)
     for x, y in zip(whole, sliced):
         assert torch.equal(x, y)
+    # the same slices forked onto their own streams (kernels of different slices now share CUs: see below)
+    os.environ["ARREAU_SLICE_EAGER"] = "1"
+    try:
+        eng.set_batch_layout(na, groups=groups)
+    finally:
+        del os.environ["ARREAU_SLICE_EAGER"]
+    forked = eng.predict_scores(*args)
+    assert_scores_close(forked, tuple(x.cpu() for x in whole), tag="fork-join slices")
 
     def loop(use_graph):
         f, ty, le, lat = d(frac.clone()), d(types.to(torch.int32)), d(lengths.clone()), torch.zeros(B, 3, 3, device=dev)
