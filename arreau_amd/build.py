@@ -28,6 +28,9 @@ NO_SCRATCH = {"edge_f16.hip": None, "node.hip": ["conv_kernel_streamed"], "node_
 # -Wno-inline-asm: the lean LDS-DMA asm lists "m0" as clobbered (it overwrites M0 and does not restore it); clang warns
 # that reserved registers in a clobber list are not preserved for us -- which is what is declared, not asked for.  The
 # ISA check below verifies that the compiler itself never uses M0 in those kernels.
+# Extra flags per source.  The split-precision kernels keep their epilogue arithmetic as independent fp32 instructions
+# (f16x3.h): the SLP vectoriser would fuse adjacent ones back into v_pk_*_f32.
+PER_SOURCE_FLAGS = {src: ["-fno-slp-vectorize"] for src in ("edge_f16.hip", "node_f16.hip", "node_f16m.hip")}
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++20", "-fPIC", "-Wall", "-Wno-unused-function", "-Wno-inline-asm",
          "-Wno-unused-but-set-variable", "-ffp-contract=on"] + os.environ.get("ARREAU_EXTRA_HIPCC_FLAGS", "").split()
 
@@ -38,6 +41,7 @@ def _digest():
         with open(os.path.join(CSRC, f), "rb") as fh:
             h.update(fh.read())
     h.update(" ".join(FLAGS).encode())
+    h.update(repr(sorted(PER_SOURCE_FLAGS.items())).encode())
     return h.hexdigest()
 
 
@@ -119,7 +123,7 @@ def _compile_all(hipcc, sources, objdir, extra_flags, verbose):
     for src in sources:
         obj = os.path.join(objdir, src.replace(".hip", ".o"))
         objs.append(obj)
-        cmd = [hipcc] + FLAGS + extra_flags
+        cmd = [hipcc] + FLAGS + PER_SOURCE_FLAGS.get(src, []) + extra_flags
         tmp = None
         if src in NO_SCRATCH:  # + keep the device ISA for the M0 check (temporaries go to a scratch directory)
             tmp = tempfile.mkdtemp(prefix="arreau_isa_")

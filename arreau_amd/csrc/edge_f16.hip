@@ -14,6 +14,8 @@
 #include <utility>
 
 #include "f16x3.h"
+// (cache policy of the K-tile stores: default.  Measured at 256 x 20: " nt" +60 us per launch, " sc1" +25, " sc0 sc1" +10.)
+#define ARREAU_K_STORE_POLICY ""
 #include "internal.h"
 
 // ---- compile-time monomial table (same canonical order as fold_poly_weight in model.hip) -------------
@@ -334,7 +336,7 @@ __global__ __launch_bounds__(64 * EH_WAVES, 2) void edge_kernel_f16x3(
                     // asm store: the counted wait at SYNC assumes exactly 4 (or 2) store instructions per tile
                     // (scalar base + one per-lane 32-bit offset + immediate: no 64-bit vector address arithmetic)
                     if (nb == 0 || full)
-                        asm volatile("global_store_dwordx4 %0, %1, %2 offset:%3"
+                        asm volatile("global_store_dwordx4 %0, %1, %2 offset:%3" ARREAU_K_STORE_POLICY
                                      :
                                      : "v"(st_off), "v"(v), "s"(tile_base + 64 * nb * C), "n"(64 * mt)
                                      : "memory");

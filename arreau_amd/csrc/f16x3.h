@@ -24,10 +24,27 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 #define F16X3_SCALE 2048.0f
 #define F16X3_INV_SCALE (1.0f / 2048.0f)
 
+// Pair arithmetic of the epilogues.  Two forms of the same arithmetic (bit-identical results):
+//   packed (-DARREAU_F32_PACKED): ext-vector pairs -> v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32
+//   scalar (default): two independent fp32 instructions per pair.
+#ifdef ARREAU_F32_PACKED
 typedef float f32x2 __attribute__((ext_vector_type(2)));
-
-__device__ __forceinline__ f32x2 splat2(float v) { return f32x2{v, v}; }
 __device__ __forceinline__ f32x2 fma2(f32x2 a, f32x2 b, f32x2 c) { return __builtin_elementwise_fma(a, b, c); }
+__device__ __forceinline__ f16x2 cvt_f16x2(f32x2 v) { return __builtin_convertvector(v, f16x2); }
+__device__ __forceinline__ f32x2 cvt_f32x2(f16x2 h) { return __builtin_convertvector(h, f32x2); }
+#else
+struct f32x2 { float x, y; };
+__device__ __forceinline__ f32x2 operator*(f32x2 a, f32x2 b) { return f32x2{a.x * b.x, a.y * b.y}; }
+__device__ __forceinline__ f32x2 operator-(f32x2 a, f32x2 b) { return f32x2{a.x - b.x, a.y - b.y}; }
+__device__ __forceinline__ f32x2 operator+(f32x2 a, f32x2 b) { return f32x2{a.x + b.x, a.y + b.y}; }
+__device__ __forceinline__ f32x2 fma2(f32x2 a, f32x2 b, f32x2 c) { return f32x2{fmaf(a.x, b.x, c.x), fmaf(a.y, b.y, c.y)}; }
+__device__ __forceinline__ f16x2 cvt_f16x2(f32x2 v) {  // one v_cvt_pk_f16_f32 (round to nearest even)
+    typedef float vf2 __attribute__((ext_vector_type(2)));
+    return __builtin_convertvector(vf2{v.x, v.y}, f16x2);
+}
+__device__ __forceinline__ f32x2 cvt_f32x2(f16x2 h) { return f32x2{(float)h[0], (float)h[1]}; }
+#endif
+__device__ __forceinline__ f32x2 splat2(float v) { return f32x2{v, v}; }
 #define F16X3_PAIR(v, i) (f32x2{(v)[2 * (i)], (v)[2 * (i) + 1]})
 
 // GELU with the Abramowitz-Stegun 7.1.26 complementary error function (|error| <= 1.5e-7 on erf, i.e.
@@ -62,16 +79,19 @@ __device__ __forceinline__ float gelu_fast(float x) { return gelu_fast2(splat2(x
 // ---- fp16 planes of a 32x32 fp32 tile (B-operand form): registers 8s..8s+7 are the fragment of k-step s ------
 struct Planes2 { u32x4 p[2][2]; };  // [plane][k-step s]: 8 fp16 per lane each
 
-// Two planes of one register pair: v_cvt_pk_f16_f32 (round to nearest even) for both planes, the residual with
-// packed sub/mul.
+// Two planes of one register pair: v_cvt_pk_f16_f32 (round to nearest even) for the high plane; the residual plane
+// straight from the mixed-precision fma, which reads the fp16 half in place and rounds its fp32 result to fp16:
+//     lo = f16(v * 2^11 - 2^11 * f32(h1))     (v * 2^11 is exact, the fma's fp32 result is the exact scaled residual)
+// -- one multiply + one v_fma_mix{lo,hi}_f16 per element instead of v_cvt_f32_f16, subtract, multiply and a second
+// v_cvt_pk_f16_f32 per pair; the same bits.
 template <bool CLAMP = true>
 __device__ __forceinline__ void split_pair2(f32x2 v, unsigned& hi, unsigned& lo) {
     // (CLAMP is kept in the signature for the callers; no clamp is applied -- see gelu_fast2: overflow is loud)
-    const f16x2 h1 = __builtin_convertvector(v, f16x2);
-    const f32x2 res = (v - __builtin_convertvector(h1, f32x2)) * splat2(F16X3_SCALE);
-    const f16x2 h2 = __builtin_convertvector(res, f16x2);
-    hi = __builtin_bit_cast(unsigned, h1);
-    lo = __builtin_bit_cast(unsigned, h2);
+    hi = __builtin_bit_cast(unsigned, cvt_f16x2(v));
+    const f32x2 sc = v * splat2(F16X3_SCALE);
+    const float neg_scale = -F16X3_SCALE;
+    asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(lo) : "v"(hi), "s"(neg_scale), "v"(sc.x));
+    asm("v_fma_mixhi_f16 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(lo) : "v"(hi), "s"(neg_scale), "v"(sc.y));
 }
 __device__ __forceinline__ Planes2 split_tile2(const f32x16& x) {
     Planes2 r;

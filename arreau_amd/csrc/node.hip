@@ -326,8 +326,16 @@ __global__ __launch_bounds__(512, 4) void conv_kernel(
 // order): at the top of receiver i the queue ends with [x(i+1): 8] [K(i+1) copy: 8 per wave] [4 stores of receiver
 // i-1] -> vmcnt(20) retires what receiver i needs and leaves the rest in flight.
 // ---------------------------------------------------------------------------------------------
+// K is read exactly once, by one CU: the streaming hint keeps it from displacing the node features in L2 / Infinity Cache
+// (measured at 256 x 20, tools/exp/sweep_libs.sh: conv 81.7 -> 71.5 us, the ConvNext kernel behind it 82 -> 79.5 us, the edge
+// kernel of the next step 684 -> 700 us; sc0 / sc1 scopes change nothing).  -DARREAU_K_LOAD_POL=0: default policy.
+#if !defined(ARREAU_K_LOAD_POL) || ARREAU_K_LOAD_POL == 1
+#define ARREAU_K_LOAD_POLICY " nt"
+#else
+#define ARREAU_K_LOAD_POLICY ""
+#endif
 __device__ __forceinline__ void conv_glds16(const void* gsrc_lane, unsigned lds_dst) {
-    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" : : "v"(gsrc_lane), "s"(lds_dst) : "memory", "m0");
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ARREAU_K_LOAD_POLICY : : "v"(gsrc_lane), "s"(lds_dst) : "memory", "m0");
 }
 __device__ __forceinline__ f32x4 conv_load16(const void* p) {
     f32x4 v;
