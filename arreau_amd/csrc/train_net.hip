@@ -25,6 +25,7 @@ namespace {
 // workgroup that finishes last for its column group (device-scope counter) adds the chunks in a fixed order (four
 // interleaved phases, combined in order) and resets the counter, so the result does not depend on which workgroup that was.
 constexpr int COLSUM_MAX_CHUNKS = 256;
+constexpr int COLCOUNT_INTS = 64;
 __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ a, const float* __restrict__ b, long rows,
                                                      int cols, long rows_per_chunk, float* __restrict__ part,
                                                      int* __restrict__ counters, float scale, int accumulate,
@@ -85,17 +86,19 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ a
 
 // The same sum for cols % 4 == 0, cols <= 1024, on 16-byte columns: a workgroup covers whole rows (thread = float4 column
 // c4 and row phase ph of P = 256 / (cols / 4)), so every wave reads contiguous kilobytes instead of 256-byte pieces of
-// rows 2 KB apart (measured on the [8512, 512] hidden-layer gradients: 70 us with the scalar kernel).  Same protocol: chunk
-// partial sums in a fixed order, the last workgroup to arrive adds the chunks in a fixed order.
-__global__ __launch_bounds__(256) void colsum4_kernel(const f32x4* __restrict__ a, const f32x4* __restrict__ b, long rows,
-                                                      int cols4, long rows_per_chunk, float* __restrict__ part,
-                                                      int* __restrict__ counter, float scale, int accumulate,
-                                                      float* __restrict__ out,
-                                                      // optional second result from the same pass (needs b):
-                                                      // out2[c] = (colscale2 ? colscale2[c] : 1) * sum_r a[r][c]
-                                                      float* __restrict__ out2, const float* __restrict__ colscale2) {
+// rows 2 KB apart.  Two launches (round 2, third version), no atomics and no fences: the pass is latency-bound, not
+// bandwidth-bound (the one-launch form took 27 us for 17 MB: 133 workgroups of 64 rows, then ONE workgroup adding the 133
+// partial rows behind a device-scope fence; a one-launch two-level tree with 532 workgroups was slower still -- every
+// workgroup's release fence writes the L2 back), so a chunk is 16 rows (532 workgroups on the [8512, 512] hidden-layer
+// gradients: enough bytes in flight to cover the HBM latency) and a second small launch adds the chunk rows: 32 row
+// phases per column in a fixed order, then the phases in order.  Deterministic.
+constexpr int COLSUM4_MAX_CHUNKS = 1024;
+__global__ __launch_bounds__(256) void colsum4_partial_kernel(const f32x4* __restrict__ a, const f32x4* __restrict__ b, long rows,
+                                                              int cols4, long rows_per_chunk,
+                                                              f32x4* __restrict__ part,   // [chunks][cols4]
+                                                              f32x4* __restrict__ part2)  // plain sums of a (or null)
+{
     __shared__ f32x4 sh[256];
-    __shared__ int is_last;
     const int P = 256 / cols4;
     const int c4 = threadIdx.x % cols4, ph = threadIdx.x / cols4;
     const bool act = ph < P;
@@ -103,7 +106,7 @@ __global__ __launch_bounds__(256) void colsum4_kernel(const f32x4* __restrict__ 
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
     f32x4 acc[4] = {zero, zero, zero, zero};  // four 16-byte loads (per operand) in flight; combined in a fixed order
     f32x4 plain[4] = {zero, zero, zero, zero};
-    const bool dual = out2 != nullptr;
+    const bool dual = part2 != nullptr;
     if (act) {
         long r = r0 + ph;
         for (; r + 3 * P < r1; r += 4 * P) {
@@ -122,60 +125,61 @@ __global__ __launch_bounds__(256) void colsum4_kernel(const f32x4* __restrict__ 
             if (dual) plain[0] += av;
         }
     }
-    float* part2 = part + (size_t)COLSUM_MAX_CHUNKS * 1024;
-    auto block_sum = [&](f32x4 v, float* dst) {  // phases added in order by the phase-0 thread of each column
+    auto block_sum = [&](f32x4 v, f32x4* dst) {  // phases added in order by the phase-0 thread of each column
         __syncthreads();
         sh[threadIdx.x] = v;
         __syncthreads();
-        f32x4 tot = zero;
         if (ph == 0) {
-            tot = sh[c4];
+            f32x4 tot = sh[c4];
             for (int p = 1; p < P; ++p) tot += sh[p * cols4 + c4];
-            if (dst) reinterpret_cast<f32x4*>(dst)[(size_t)blockIdx.x * cols4 + c4] = tot;
+            dst[(size_t)blockIdx.x * cols4 + c4] = tot;
         }
-        return tot;
     };
     block_sum((acc[0] + acc[1]) + (acc[2] + acc[3]), part);
     if (dual) block_sum((plain[0] + plain[1]) + (plain[2] + plain[3]), part2);
-    __threadfence();
-    __syncthreads();
-    if (threadIdx.x == 0) is_last = atomicAdd(counter, 1) == (int)gridDim.x - 1;
-    __syncthreads();
-    if (!is_last) return;
-    __threadfence();
-    auto chunk_sum = [&](const float* src) {
+}
+// out[c] = scale * sum_chunks part[chunk][c] (+ out[c]); out2[c] = colscale2[c] * sum_chunks part2[chunk][c].
+// Workgroup = 8 float4 columns x 32 row phases.
+__global__ __launch_bounds__(256) void colsum4_final_kernel(const f32x4* __restrict__ part, const f32x4* __restrict__ part2,
+                                                            int chunks, int cols4, float scale, int accumulate,
+                                                            float* __restrict__ out, float* __restrict__ out2,
+                                                            const float* __restrict__ colscale2) {
+    __shared__ f32x4 sh[256];
+    const int cl = threadIdx.x & 7, ph = threadIdx.x >> 3;
+    const int c4 = blockIdx.x * 8 + cl;
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    auto column_sum = [&](const f32x4* src) {
         f32x4 tot = zero;
-        if (act) {
-            const int n = (int)gridDim.x;
-            auto load4 = [&](int i) {
-                const float* q = src + ((size_t)i * cols4 + c4) * 4;
-                return f32x4{__hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
-                             __hip_atomic_load(q + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
-                             __hip_atomic_load(q + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT),
-                             __hip_atomic_load(q + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)};
-            };
-            int i = ph;
-            for (; i + 3 * P < n; i += 4 * P) {
-                const f32x4 v0 = load4(i), v1 = load4(i + P), v2 = load4(i + 2 * P), v3 = load4(i + 3 * P);
-                tot = (((tot + v0) + v1) + v2) + v3;
+        if (c4 < cols4)
+            for (int i = ph; i < chunks; i += 32 * 8) {  // eight loads in flight, added in row order
+                f32x4 v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = i + 32 * u < chunks ? src[(size_t)(i + 32 * u) * cols4 + c4] : zero;
+#pragma unroll
+                for (int u = 0; u < 8; ++u) tot += v[u];
             }
-            for (; i < n; i += P) tot += load4(i);
+        __syncthreads();
+        sh[threadIdx.x] = tot;
+        __syncthreads();
+        f32x4 r = zero;
+        if (ph == 0) {
+            r = sh[cl];
+            for (int p = 1; p < 32; ++p) r += sh[p * 8 + cl];
         }
-        return block_sum(tot, nullptr);
+        return r;
     };
-    const f32x4 tot = chunk_sum(part);
-    if (ph == 0) {
+    const f32x4 tot = column_sum(part);
+    if (ph == 0 && c4 < cols4) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) out[4 * c4 + q] = scale * tot[q] + (accumulate ? out[4 * c4 + q] : 0.f);
     }
-    if (dual) {
-        const f32x4 tot2 = chunk_sum(part2);
-        if (ph == 0) {
+    if (part2 != nullptr) {
+        const f32x4 tot2 = column_sum(part2);
+        if (ph == 0 && c4 < cols4) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) out2[4 * c4 + q] = (colscale2 ? colscale2[4 * c4 + q] : 1.0f) * tot2[q];
         }
     }
-    if (threadIdx.x == 0) *counter = 0;
 }
 
 __device__ __forceinline__ float gelu_exact(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
@@ -200,6 +204,25 @@ __global__ void gelu_backward_kernel(float* __restrict__ g, const float* __restr
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= rows * cols) return;
     g[i] = g[i] * gelu_grad(pre[i]) * (rowscale ? rowscale[i / cols] : 1.0f);
+}
+// the same two maps on 16-byte columns (cols % 4 == 0): four elements per thread, the same arithmetic per element
+__global__ void bias_gelu_kernel4(f32x4* __restrict__ pre, const f32x4* __restrict__ bias, const float* __restrict__ rowscale,
+                                  long rows, int cols4, f32x4* __restrict__ act) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * cols4) return;
+    const float rs = rowscale ? rowscale[i / cols4] : 1.0f;
+    const f32x4 v = pre[i] + bias[i % cols4];
+    pre[i] = v;
+    act[i] = f32x4{gelu_exact(v[0]) * rs, gelu_exact(v[1]) * rs, gelu_exact(v[2]) * rs, gelu_exact(v[3]) * rs};
+}
+__global__ void gelu_backward_kernel4(f32x4* __restrict__ g, const f32x4* __restrict__ pre, const float* __restrict__ rowscale,
+                                      long rows, int cols4) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= rows * cols4) return;
+    const float rs = rowscale ? rowscale[i / cols4] : 1.0f;
+    const f32x4 gv = g[i], pv = pre[i];
+    g[i] = f32x4{gv[0] * gelu_grad(pv[0]) * rs, gv[1] * gelu_grad(pv[1]) * rs, gv[2] * gelu_grad(pv[2]) * rs,
+                 gv[3] * gelu_grad(pv[3]) * rs};
 }
 __global__ void add_bias_kernel(float* __restrict__ x, const float* __restrict__ bias, long rows, int cols) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -602,8 +625,8 @@ size_t layout(arreau_train_ctx& t, const arreau_model* m, int N, int B, float* b
     t.dx1 = c.take<float>(M * C); t.dkern = c.take<float>(R * L * C); t.dkb = c.take<float>(R * D); t.dh1 = c.take<float>(R * C);
     t.dfk = c.take<float>(256 * C); t.dfkb = c.take<float>(256 * D); t.dfh1 = c.take<float>(256 * C);
     t.dw1f = c.take<float>(C * ARREAU_MONO_PAD); t.partial = c.take<float>(PARTIAL_FLOATS); t.scratch_cols = c.take<float>(1024);
-    t.colpart = c.take<float>((size_t)2 * COLSUM_MAX_CHUNKS * 1024);  // (two results per pass)
-    t.colcount = c.take<int32_t>(64);
+    t.colpart = c.take<float>((size_t)2 * COLSUM4_MAX_CHUNKS * 1024);  // (two results per pass)
+    t.colcount = c.take<int32_t>(COLCOUNT_INTS);
     return c.off;
 }
 
@@ -633,11 +656,15 @@ int colsum(hipStream_t s, arreau_train_ctx& t, const float* a, const float* b, l
         return ARREAU_EINVAL;
     }
     if (cols % 4 == 0 && (size_t)a % 16 == 0 && (b == nullptr || (size_t)b % 16 == 0)) {
-        const int chunks = (int)std::min<long>(COLSUM_MAX_CHUNKS, std::max<long>(1, rows / 64));
+        const int chunks = (int)std::min<long>(COLSUM4_MAX_CHUNKS, std::max<long>(1, rows / 16));
         const long rpc = (rows + chunks - 1) / chunks;
-        hipLaunchKernelGGL(colsum4_kernel, dim3(chunks), dim3(256), 0, s, reinterpret_cast<const f32x4*>(a),
-                           reinterpret_cast<const f32x4*>(b), rows, cols / 4, rpc, t.colpart, t.colcount + 32, scale, accumulate, out,
-                           b ? out2 : nullptr, colscale2);
+        f32x4* part = reinterpret_cast<f32x4*>(t.colpart);
+        f32x4* part2 = b && out2 ? part + (size_t)COLSUM4_MAX_CHUNKS * 256 : nullptr;
+        hipLaunchKernelGGL(colsum4_partial_kernel, dim3(chunks), dim3(256), 0, s, reinterpret_cast<const f32x4*>(a),
+                           reinterpret_cast<const f32x4*>(b), rows, cols / 4, rpc, part, part2);
+        ARREAU_CHECK_HIP(hipGetLastError());
+        hipLaunchKernelGGL(colsum4_final_kernel, dim3((cols / 4 + 7) / 8), dim3(256), 0, s, part, part2, chunks, cols / 4, scale,
+                           accumulate, out, part2 ? out2 : nullptr, colscale2);
         ARREAU_CHECK_HIP(hipGetLastError());
         if (out2 && !b) {
             arreau_set_error("colsum: a second result needs a second operand");
@@ -659,6 +686,32 @@ int colsum(hipStream_t s, arreau_train_ctx& t, const float* a, const float* b, l
             ARREAU_CHECK_HIP(hipGetLastError());
         }
     }
+    return ARREAU_OK;
+}
+int launch_bias_gelu(hipStream_t s, float* pre, const float* bias, const float* rowscale, long rows, int cols, float* act) {
+    if (rows <= 0) return ARREAU_OK;
+    if (cols % 4 == 0 && ((size_t)pre | (size_t)bias | (size_t)act) % 16 == 0) {
+        const long n4 = rows * (cols / 4);
+        hipLaunchKernelGGL(bias_gelu_kernel4, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, reinterpret_cast<f32x4*>(pre),
+                           reinterpret_cast<const f32x4*>(bias), rowscale, rows, cols / 4, reinterpret_cast<f32x4*>(act));
+    } else {
+        hipLaunchKernelGGL(bias_gelu_kernel, dim3((unsigned)((rows * cols + 255) / 256)), dim3(256), 0, s, pre, bias, rowscale, rows,
+                           cols, act);
+    }
+    ARREAU_CHECK_HIP(hipGetLastError());
+    return ARREAU_OK;
+}
+int launch_gelu_backward(hipStream_t s, float* g, const float* pre, const float* rowscale, long rows, int cols) {
+    if (rows <= 0) return ARREAU_OK;
+    if (cols % 4 == 0 && ((size_t)g | (size_t)pre) % 16 == 0) {
+        const long n4 = rows * (cols / 4);
+        hipLaunchKernelGGL(gelu_backward_kernel4, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, reinterpret_cast<f32x4*>(g),
+                           reinterpret_cast<const f32x4*>(pre), rowscale, rows, cols / 4);
+    } else {
+        hipLaunchKernelGGL(gelu_backward_kernel, dim3((unsigned)((rows * cols + 255) / 256)), dim3(256), 0, s, g, pre, rowscale, rows,
+                           cols);
+    }
+    ARREAU_CHECK_HIP(hipGetLastError());
     return ARREAU_OK;
 }
 #define TRY(expr) do { int rc_ = (expr); if (rc_) return rc_; } while (0)
@@ -706,7 +759,7 @@ static int ensure_ctx(arreau_model* m, int N, int B, hipStream_t s) {
     t->N = N; t->B = B;
     m->train = t;
     ARREAU_CHECK_HIP(hipMemsetAsync(t->scratch_cols, 0, 1024 * sizeof(float), s));
-    ARREAU_CHECK_HIP(hipMemsetAsync(t->colcount, 0, 64 * sizeof(int32_t), s));
+    ARREAU_CHECK_HIP(hipMemsetAsync(t->colcount, 0, COLCOUNT_INTS * sizeof(int32_t), s));
     return ARREAU_OK;
 }
 
@@ -722,15 +775,15 @@ int arreau_general_network(arreau_model* m, const arreau_graph_view& g, const in
     LAUNCH(edge_rows_kernel, dim3(blocks(R)), dim3(256), g.dir, g.dist, g.deg, g.batch, g.lattice, m->ori, m->cfg.radius, N, k,
            t.mono, t.window);
     TRY(linear(s, t, R, ARREAU_MONO_PAD, C, t.mono, t.w1f, t.h1pre));
-    LAUNCH(bias_gelu_kernel, dim3(blocks(R * C)), dim3(256), t.h1pre, m->b1, (const float*)nullptr, R, C, t.h1);
+    TRY(launch_bias_gelu(s, t.h1pre, m->b1, (const float*)nullptr, R, C, t.h1));
     TRY(linear(s, t, R, C, D, t.h1, t.w2, t.h2pre));
-    LAUNCH(bias_gelu_kernel, dim3(blocks(R * D)), dim3(256), t.h2pre, m->b2, (const float*)t.window, R, D, t.kb);
+    TRY(launch_bias_gelu(s, t.h2pre, m->b2, (const float*)t.window, R, D, t.kb));
     // fiber basis (ponita.py:66,95)
     LAUNCH(fiber_poly_kernel, dim3(1), dim3(256), m->ori, t.fpoly);
     TRY(linear(s, t, 256, 3, C, t.fpoly, m->fiber_w1, t.fh1pre));
-    LAUNCH(bias_gelu_kernel, dim3(blocks(256L * C)), dim3(256), t.fh1pre, m->fiber_b1, (const float*)nullptr, 256L, C, t.fh1);
+    TRY(launch_bias_gelu(s, t.fh1pre, m->fiber_b1, (const float*)nullptr, 256L, C, t.fh1));
     TRY(linear(s, t, 256, C, D, t.fh1, m->fiber_w2, t.fh2pre));
-    LAUNCH(bias_gelu_kernel, dim3(blocks(256L * D)), dim3(256), t.fh2pre, m->fiber_b2, (const float*)nullptr, 256L, D, t.fkb);
+    TRY(launch_bias_gelu(s, t.fh2pre, m->fiber_b2, (const float*)nullptr, 256L, D, t.fkb));
     ARREAU_CHECK_HIP(hipMemsetAsync(t.rbar, 0, (size_t)M * RO * sizeof(float), s));
     // kernel_l = kb . Wk_l^T for all layers in one product (conv.py:110; conv.kernel.weight stacked [L*C][D])
     TRY(linear(s, t, R, D, L * C, t.kb, t.wk, t.kern));
@@ -748,7 +801,7 @@ int arreau_general_network(arreau_model* m, const arreau_graph_view& g, const in
         float* h = t.h + (size_t)l * M * H;
         float* out = t.out + (size_t)l * M * C;
         TRY(linear(s, t, M, C, H, t.xn, t.lin1 + (size_t)l * H * C, hpre));
-        LAUNCH(bias_gelu_kernel, dim3(blocks(M * H)), dim3(256), hpre, m->mb1 + (size_t)l * H, (const float*)nullptr, M, H, h);
+        TRY(launch_bias_gelu(s, hpre, m->mb1 + (size_t)l * H, (const float*)nullptr, M, H, h));
         TRY(linear(s, t, M, H, C, h, t.lin2 + (size_t)l * C * H, out));
         LAUNCH(bias_scale_residual_kernel, dim3(blocks(M * C)), dim3(256), out, m->mb2 + (size_t)l * C, m->ls + (size_t)l * C, xl, M, C, xnext);
         // read-out of this layer, averaged over layers (ponita.py:105,108); biases are added in train_outputs_kernel
@@ -831,7 +884,7 @@ extern "C" int arreau_train_backward(arreau_model* m, const float* d_g_eps, cons
         TRY(linear_dw(s, t, M, H, C, t.dtmp, h, W(g->linear2_w) + (size_t)l * C * H));
         if (!m->cfg.has_layer_scale) TRY(colsum(s, t, t.dtmp, nullptr, M, C, 1.0f, W(g->linear2_b) + (size_t)l * C));
         TRY(linear_dx(s, t, M, H, C, t.dtmp, t.lin2 + (size_t)l * C * H, t.dh));
-        LAUNCH(gelu_backward_kernel, dim3(blocks(M * H)), dim3(256), t.dh, hpre, (const float*)nullptr, M, H);      // dhpre
+        TRY(launch_gelu_backward(s, t.dh, hpre, (const float*)nullptr, M, H));      // dhpre
         // xn = xhat * g + b (recomputed)
         LAUNCH(affine_cols_kernel, dim3(blocks(M * C)), dim3(256), xhat, m->ln_w + (size_t)l * C, m->ln_b + (size_t)l * C, M, C, t.xn);
         TRY(linear_dw(s, t, M, C, H, t.dh, t.xn, W(g->linear1_w) + (size_t)l * H * C));
@@ -865,20 +918,20 @@ extern "C" int arreau_train_backward(arreau_model* m, const float* d_g_eps, cons
     // embedding: x_0 = F . W_emb^T  -> dW_emb[c][i] = sum_rows dx[row][c] F[row][i]
     TRY(linear_dw(s, t, M, S + 78, C, t.dx, t.F, W(g->x_embedder_w)));
     // edge basis MLP
-    LAUNCH(gelu_backward_kernel, dim3(blocks(R * D)), dim3(256), t.dkb, t.h2pre, (const float*)t.window, R, D);      // dh2pre
+    TRY(launch_gelu_backward(s, t.dkb, t.h2pre, (const float*)t.window, R, D));      // dh2pre
     TRY(linear_dw(s, t, R, C, D, t.dkb, t.h1, W(g->basis_w2)));
     TRY(colsum(s, t, t.dkb, nullptr, R, D, 1.0f, W(g->basis_b2)));
     TRY(linear_dx(s, t, R, C, D, t.dkb, t.w2, t.dh1));
-    LAUNCH(gelu_backward_kernel, dim3(blocks(R * C)), dim3(256), t.dh1, t.h1pre, (const float*)nullptr, R, C);       // dh1pre
+    TRY(launch_gelu_backward(s, t.dh1, t.h1pre, (const float*)nullptr, R, C));       // dh1pre
     TRY(linear_dw(s, t, R, ARREAU_MONO_PAD, C, t.dh1, t.mono, t.dw1f));
     LAUNCH(unfold_poly_grad_kernel, dim3(blocks((long)C * ARREAU_POLY_COLS)), dim3(256), t.dw1f, C, W(g->basis_w1));
     TRY(colsum(s, t, t.dh1, nullptr, R, C, 1.0f, W(g->basis_b1)));
     // fiber basis MLP
-    LAUNCH(gelu_backward_kernel, dim3(blocks(256L * D)), dim3(256), t.dfkb, t.fh2pre, (const float*)nullptr, 256L, D);
+    TRY(launch_gelu_backward(s, t.dfkb, t.fh2pre, (const float*)nullptr, 256L, D));
     TRY(linear_dw(s, t, 256, C, D, t.dfkb, t.fh1, W(g->fiber_w2)));
     TRY(colsum(s, t, t.dfkb, nullptr, 256, D, 1.0f, W(g->fiber_b2)));
     TRY(linear_dx(s, t, 256, C, D, t.dfkb, m->fiber_w2, t.dfh1));
-    LAUNCH(gelu_backward_kernel, dim3(blocks(256L * C)), dim3(256), t.dfh1, t.fh1pre, (const float*)nullptr, 256L, C);
+    TRY(launch_gelu_backward(s, t.dfh1, t.fh1pre, (const float*)nullptr, 256L, C));
     TRY(linear_dw(s, t, 256, 3, C, t.dfh1, t.fpoly, W(g->fiber_w1)));
     TRY(colsum(s, t, t.dfh1, nullptr, 256, C, 1.0f, W(g->fiber_b1)));
     return ARREAU_OK;
