@@ -129,7 +129,7 @@ __global__ __launch_bounds__(256) void neighbor_kernel(
     constexpr int NBR_KEYS = 12;
     constexpr double KEY_NONE = 1.0e300;
     auto make_key = [](float d2, int c) { return (double)__float_as_uint(d2) * 2097152.0 + (double)c; };
-    const bool cached = ncand <= 64 * NBR_KEYS;
+    bool cached = ncand <= 64 * NBR_KEYS;
     double keys[NBR_KEYS];
     if (cached) {
 #pragma unroll
@@ -140,6 +140,56 @@ __global__ __launch_bounds__(256) void neighbor_kernel(
                 const Cand cd = arreau_candidate(cart, first, c, Lm, pix, piy, piz);
                 if (cd.d2 <= r2 && cd.d2 > 0.0001f) keys[q] = make_key(cd.d2, c);
             }
+        }
+    } else {
+        // Larger crystals (round 2, last session: 1.29 ms per step at 1024 x 64 when each of the k selection rounds
+        // re-evaluated all 27 n candidates): TWO passes over the candidates instead of k.
+        //   pass 1: every lane keeps the smallest key among its candidates; the k-th smallest of these 64 lane minima is
+        //           an upper bound T of the k-th smallest key overall (they are k distinct candidates);
+        //   pass 2: the candidates with key <= T -- at least k, rarely many more -- are compacted into a per-wave LDS list
+        //           (wave ballot + lane prefix count; the order in the list does not matter, the keys are unique) and
+        //           become the register-resident key set of the rounds below.
+        // Should more than 64 * NBR_KEYS candidates pass (massive exact ties), the re-evaluating rounds remain.  Same keys,
+        // same selection, same output as before.
+        __shared__ double klist[4][64 * NBR_KEYS];
+        double* mylist = klist[(threadIdx.x >> 6) & 3];
+        double lmin = KEY_NONE;
+        for (int c = lane; c < ncand; c += 64) {
+            const Cand cd = arreau_candidate(cart, first, c, Lm, pix, piy, piz);
+            if (cd.d2 <= r2 && cd.d2 > 0.0001f) lmin = fmin(lmin, make_key(cd.d2, c));
+        }
+        double T = KEY_NONE, below = -1.0;
+        for (int s = 0; s < k; ++s) {
+            double best = lmin > below ? lmin : KEY_NONE;
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) best = fmin(best, __shfl_xor(best, off, 64));
+            T = best;
+            if (best == KEY_NONE) break;  // wave-uniform: fewer than k lanes hold a candidate -> everything in range passes
+            below = best;
+        }
+        int total = 0;  // wave-uniform
+        for (int c0 = 0; c0 < ncand; c0 += 64) {
+            const int c = c0 + lane;
+            bool in = false;
+            double key = KEY_NONE;
+            if (c < ncand) {
+                const Cand cd = arreau_candidate(cart, first, c, Lm, pix, piy, piz);
+                if (cd.d2 <= r2 && cd.d2 > 0.0001f) {
+                    key = make_key(cd.d2, c);
+                    in = key <= T;
+                }
+            }
+            const unsigned long long m = __ballot(in);
+            const int pos = total + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
+            if (in && pos < 64 * NBR_KEYS) mylist[pos] = key;
+            total += __builtin_popcountll(m);
+        }
+        if (total <= 64 * NBR_KEYS) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the wave's own list writes, before its reads
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int q = 0; q < NBR_KEYS; ++q) keys[q] = lane + 64 * q < total ? mylist[lane + 64 * q] : KEY_NONE;
+            cached = true;
         }
     }
     double last = -1.0, mine = KEY_NONE;

@@ -117,7 +117,10 @@ def test_radius_graph_matches_reference_fixture(dev, i):
 
 @pytest.mark.parametrize("num_atoms,cell,seed", [
     ([20] * 16, (4.0, 8.0), 0), ([1, 2, 3, 5, 8, 13, 20, 7], (3.0, 6.0), 1), ([64, 64], (6.0, 9.0), 2),
-    ([2] * 5, (9.0, 12.0), 3), ([33], (2.5, 4.0), 4)])
+    ([2] * 5, (9.0, 12.0), 3), ([33], (2.5, 4.0), 4),
+    # crystals beyond the register-resident candidate set: in-range keys compacted through LDS (relaxed cells) and the
+    # re-evaluating rounds (more than 768 candidates inside the cutoff)
+    ([48, 64, 29, 57], (7.0, 11.0), 5), ([64], (2.0, 3.0), 6), ([40, 40], (3.5, 5.0), 7)])
 def test_radius_graph_vs_oracle_random(dev, num_atoms, cell, seed):
     """Larger ragged / dense / sparse cases against the oracle's radius_graph_pbc (fp32).  Edges whose
     d^2 is within 1e-5 (relative) of the receiver's selection threshold may legitimately differ; none do
