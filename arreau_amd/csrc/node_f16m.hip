@@ -75,6 +75,8 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_kernel_f16x3_m16(
     constexpr int PER = NF / NW;                                      // DMA instructions per wave and chunk
     __shared__ u32x4 lds[NSLOT][NF * 64];
     __shared__ __attribute__((aligned(16))) float bias_s[H];      // mb1: no global loads while a DMA is in flight
+    __shared__ __attribute__((aligned(16))) float ep_s[3][C];     // mb2, layer scale, vector read-out weights: the epilogue
+                                                                  // takes them from LDS instead of three L2 round trips
 
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int cp = lane & 15, gp = lane >> 4;  // prologue / matrix-phase copies
@@ -100,6 +102,11 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_kernel_f16x3_m16(
         dma_src += (size_t)NF * 64;
     }
     for (int i = threadIdx.x; i < H; i += 64 * NW) bias_s[i] = mb1[i];
+    for (int i = threadIdx.x; i < C; i += 64 * NW) {
+        ep_s[0][i] = mb2[i];
+        ep_s[1][i] = ls[i];
+        ep_s[2][i] = wv[i];
+    }
 
     // ---- load the rows in B-operand layout, LayerNorm them (eps 1e-5, biased variance), split ---------------
     u32x4 xn[NB][KC][2];  // [column block][k-block][plane]
@@ -246,9 +253,9 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_kernel_f16x3_m16(
 #pragma unroll
         for (int mt = 0; mt < 2; ++mt) {
             const int c0 = 32 * u + 16 * mt + 4 * g;  // this lane's four channels
-            const f32x4 b2v = *reinterpret_cast<const f32x4*>(mb2 + c0);
-            const f32x4 lsv = *reinterpret_cast<const f32x4*>(ls + c0);
-            const f32x4 wvv = *reinterpret_cast<const f32x4*>(wv + c0);
+            const f32x4 b2v = *reinterpret_cast<const f32x4*>(&ep_s[0][c0]);
+            const f32x4 lsv = *reinterpret_cast<const f32x4*>(&ep_s[1][c0]);
+            const f32x4 wvv = *reinterpret_cast<const f32x4*>(&ep_s[2][c0]);
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb) {
                 const size_t off = ((size_t)nrow[nb] * 16 + c) * C + c0;
