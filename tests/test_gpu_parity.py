@@ -507,7 +507,6 @@ def test_ragged_batch_trajectory_parity(dev, small_model):
     f_h, ty_h, le_h = d(frac.clone()), d(types.to(torch.int32)), d(lengths.clone())  # free-running HIP state
     an = d(angles)
     lat = torch.zeros(B, 3, 3, device=dev)
-    worst = 0.0
     for t in (99, 98, 97, 3, 2, 1):
         scores = OS.predict_scores(om32, frac, F.one_hot(types, S), torch.full((N,), t), na, lengths, angles, batch)
         noise = OS.StepNoise(torch.randn(B, 3, generator=g), torch.randn(N, 3, generator=g), torch.rand(N, S, generator=g))
@@ -522,9 +521,15 @@ def test_ragged_batch_trajectory_parity(dev, small_model):
                          d(noise.u_types), lat)
         frac, types, lengths, lat_o = OS.reverse_step(om32, frac, types, lengths, angles, na, scores, t, noise)
         df = (f_h.cpu() - frac).abs()
-        worst = max(worst, float(torch.minimum(df, 1 - df).max()), float((le_h.cpu() - lengths).abs().max()))
+        d_frac, d_len = float(torch.minimum(df, 1 - df).max()), float((le_h.cpu() - lengths).abs().max())
+        print("[ragged trajectory] t", t, "frac", d_frac, "lengths", d_len, "|lengths|max", float(lengths.abs().max()))
+        # Each quantity against its own scale: fractional coordinates live in [0, 1): 1e-5 absolute; the cell lengths
+        # of this random-init model grow to 170-280 (fp32 spacing 1.5e-5 ... 3e-5), so six steps of accumulated rounding
+        # are bounded RELATIVE to the largest length: 1e-6 (about eight fp32 spacings; measured 5.5e-7 and 6.4e-7 with
+        # the two GELU forms this kernel set has had).
+        assert d_frac <= 1e-5, (t, d_frac)
+        assert d_len <= 1e-6 * max(1.0, float(lengths.abs().max())), (t, d_len)
         assert torch.equal(ty_h.cpu().long(), types), t
-    assert worst <= 1e-4, worst  # six steps of accumulated rounding, no divergence
     eng.check_status()
 
 
