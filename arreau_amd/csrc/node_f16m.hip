@@ -170,10 +170,14 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_kernel_f16x3_m16(
     constexpr int NCHUNK = 8 * 4;
     auto sync = [&]() {
         const int younger = min(max(NCHUNK - 2 - q, 0), P - 2);
+#if !(ARREAU_EXP & 16)
         if (P == 3 && younger == 1) dma_wait_but<PER>();
         else dma_wait();
+#endif
+#if !(ARREAU_EXP & 8)
         __syncthreads();
-        if (q + P < NCHUNK) dma_chunk_lean<NF, NW>(dma_src, lane16, wave, lds0 + (unsigned)(sl == 0 ? NSLOT - 1 : sl - 1) * (NF * 1024u));
+#endif
+        if (!(ARREAU_EXP & 32) && q + P < NCHUNK) dma_chunk_lean<NF, NW>(dma_src, lane16, wave, lds0 + (unsigned)(sl == 0 ? NSLOT - 1 : sl - 1) * (NF * 1024u));
         dma_src += (size_t)NF * 64;
         ++q;
     };
