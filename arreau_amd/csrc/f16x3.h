@@ -63,7 +63,7 @@ __device__ __forceinline__ f32x2 splat2(float v) { return f32x2{v, v}; }
 // kernel's time is made of is measured by removing parts of it (profiles/r02g_remove_parts_timing.txt).
 //   1 edge kernel: K tiles computed, not stored      2 GELU -> max(x, 0)            4 no plane split (low plane = high plane)
 //   8 ConvNext kernel: no ring barrier              16 ... no DMA waits            32 ... no DMA copies
-//  64 ConvNext kernel: no LDS fragment reads       128 ... no MFMAs
+//  64 ConvNext kernel: no LDS fragment reads       128 ... no MFMAs             256 ... no x_conv loads     512 ... no x_in loads / x_out stores
 #ifndef ARREAU_EXP
 #define ARREAU_EXP 0
 #endif
