@@ -16,6 +16,12 @@
 #include "f16x3.h"
 // (cache policy of the K-tile stores: default.  Measured at 256 x 20: " nt" +60 us per launch, " sc1" +25, " sc0 sc1" +10.)
 #define ARREAU_K_STORE_POLICY ""
+// Hazard of the hand-written K-tile stores: a VMEM store of more than 64 bits reads its data registers AFTER it has issued,
+// and a VALU write to those registers too soon afterwards corrupts the stored data.  hipcc inserts the wait states for its
+// own stores; it does not look inside inline asm.  Found with the 3-byte K format, whose packed data registers the
+// compiler re-uses for the next store at once (non-reproducible NaNs; a plain C++ store or four wait states cure it);
+// the 16-byte form carries the same wait states although its data registers were never re-used that fast.
+#define ARREAU_K_STORE_TAIL "\n\ts_nop 3"
 #include "internal.h"
 
 // ---- compile-time monomial table (same canonical order as fold_poly_weight in model.hip) -------------
@@ -72,7 +78,7 @@ extern "C" int arreau_debug_edge_ticks(unsigned long long* out8, int reset) {
 #define EDGE_TICK(i)
 #endif
 
-template <int C, int D, int EH_WAVES>
+template <int C, int D, int EH_WAVES, bool K3 /* K tiles as 3-byte floats (internal.h) */>
 __global__ __launch_bounds__(64 * EH_WAVES, 2) void edge_kernel_f16x3(
     const float* __restrict__ nbr_dir,   // [N][k][3]
     const float* __restrict__ nbr_dist,  // [N][k]
@@ -316,6 +322,7 @@ __global__ __launch_bounds__(64 * EH_WAVES, 2) void edge_kernel_f16x3(
         }
         EDGE_TICK(2);
         // ---- per layer: kernel_l = Wk_l . basis  (conv.py:110), one output tile per chunk ---------------------
+        constexpr int KB = K3 ? 3 : 4;  // bytes per K value
         const size_t layer_stride = (size_t)N * k * 16 * C;
         const size_t row0 = ((size_t)node * k + 2 * wn) * 16;  // first K row of this wave's 32-row tile
         const bool full = 2 * wn + 1 < k;  // wave-uniform: the wave's second slot (column block 1) exists
@@ -324,7 +331,7 @@ __global__ __launch_bounds__(64 * EH_WAVES, 2) void edge_kernel_f16x3(
         // row's 128-byte line).  Not predicated on the degree: a slot beyond it gets the zeros its window produced
         // (those rows of the K buffer are never read), so a wave issues a FIXED number of stores per tile (4, or 2 for
         // the wave whose second slot does not exist when k is odd) -- which the counted wait at SYNC relies on.
-        const unsigned st_off = 4u * (c16 * C + 4 * g16);
+        const unsigned st_off = (unsigned)KB * (c16 * C + 4 * g16);
         auto store_tile16 = [&](const Acc16& a, const char* tile_base /* wave-uniform */) {
 #pragma unroll
             for (int nb = 0; nb < 2; ++nb)
@@ -339,18 +346,27 @@ __global__ __launch_bounds__(64 * EH_WAVES, 2) void edge_kernel_f16x3(
                     asm volatile("" : : "v"(v), "v"(st_off));  // timing experiment: K tiles computed, not stored
                     if (false)
 #endif
-                    if (nb == 0 || full)
-                        asm volatile("global_store_dwordx4 %0, %1, %2 offset:%3" ARREAU_K_STORE_POLICY
-                                     :
-                                     : "v"(st_off), "v"(v), "s"(tile_base + 64 * nb * C), "n"(64 * mt)
-                                     : "memory");
+                    if (nb == 0 || full) {
+                        if constexpr (K3) {
+                            const u32x3_k d = arreau_pack_k3(v[0], v[1], v[2], v[3]);
+                            asm volatile("global_store_dwordx3 %0, %1, %2 offset:%3" ARREAU_K_STORE_POLICY ARREAU_K_STORE_TAIL
+                                         :
+                                         : "v"(st_off), "v"(d), "s"(tile_base + 16 * KB * nb * C), "n"(16 * 3 * mt)
+                                         : "memory");
+                        } else {
+                            asm volatile("global_store_dwordx4 %0, %1, %2 offset:%3" ARREAU_K_STORE_POLICY ARREAU_K_STORE_TAIL
+                                         :
+                                         : "v"(st_off), "v"(v), "s"(tile_base + 64 * nb * C), "n"(64 * mt)
+                                         : "memory");
+                        }
+                    }
                 }
         };
         // ST = step (of 2 TD) at which the chunk's barrier is taken (mid-chunk).  At SYNC the wave's queue holds, oldest
         // first, its DMA copies of the next chunk and -- from the second chunk on -- the stores of the previous tile
         // (issued two steps into this chunk): the counted wait retires the copies and leaves the stores in flight.
         constexpr int ST = TD;
-        const char* tile_base = reinterpret_cast<const char*>(kbuf + row0 * C);  // tile the next store_tile16 writes
+        const char* tile_base = reinterpret_cast<const char*>(kbuf) + row0 * C * KB;  // tile the next store_tile16 writes
         int u_cur = 0;
         Acc16 prev;  // accumulators of the previous tile (folded and stored two steps into the next one)
 #pragma unroll
@@ -369,7 +385,7 @@ __global__ __launch_bounds__(64 * EH_WAVES, 2) void edge_kernel_f16x3(
             if (cidx > 0) {  // the previous tile leaves while this tile's first MFMAs run
                 store_tile16(prv, tile_base);
                 // next tile: 32 columns on, or the first column tile of the next layer
-                tile_base += (++u_cur == TC) ? (u_cur = 0, (ptrdiff_t)layer_stride * 4 - (TC - 1) * 128) : 128;
+                tile_base += (++u_cur == TC) ? (u_cur = 0, (ptrdiff_t)layer_stride * KB - (TC - 1) * 32 * KB) : 32 * KB;
             }
             ms.template run<2, ST>(acc, b16);
             if (cidx == 0) dma_wait();
@@ -413,7 +429,7 @@ __global__ __launch_bounds__(64 * EH_WAVES, 2) void edge_kernel_f16x3(
 // measured on MI355X (tools/gpu_edge_split_sweep.sh): 60 / 120 / 200 / 260 / 380 receivers: 19.8 / 31.8 / 56.9 / 71.0 / 88.1 us
 // against 65.9 / 67.0 / 69.0 / 71.8 / 74.0 us of the persistent form
 #define ARREAU_EDGE_SPLIT_MAX_NODES 240
-template <int C, int D>
+template <int C, int D, bool K3>
 __global__ __launch_bounds__(512) void edge_kernel_f16x3_split(
     const float* __restrict__ nbr_dir, const float* __restrict__ nbr_dist, const int32_t* __restrict__ deg,
     const int32_t* __restrict__ batch, const float* __restrict__ lattice, const float* __restrict__ ori,
@@ -603,6 +619,7 @@ __global__ __launch_bounds__(512) void edge_kernel_f16x3_split(
     auto store_tile = [&](int cidx) {
         const int l = cidx / TC, u = cidx % TC;
         float* tile = kbuf + (size_t)l * layer_stride + row0 * C + 32 * u;
+        char* tile3 = reinterpret_cast<char*>(kbuf) + ((size_t)l * layer_stride + row0 * C + 32 * u) * 3;
 #pragma unroll
         for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
@@ -610,7 +627,13 @@ __global__ __launch_bounds__(512) void edge_kernel_f16x3_split(
                 f32x4 v;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] = fmaf(acc.x[mt][nb][r], F16X3_INV_SCALE, acc.m[mt][nb][r]);
-                if (nb == 0 || full) *reinterpret_cast<f32x4*>(tile + (size_t)(16 * nb + c16) * C + 16 * mt + 4 * g16) = v;
+                if (nb == 0 || full) {
+                    if constexpr (K3)
+                        *reinterpret_cast<u32x3_k*>(tile3 + ((size_t)(16 * nb + c16) * C + 16 * mt + 4 * g16) * 3) =
+                            arreau_pack_k3(v[0], v[1], v[2], v[3]);
+                    else
+                        *reinterpret_cast<f32x4*>(tile + (size_t)(16 * nb + c16) * C + 16 * mt + 4 * g16) = v;
+                }
             }
     };
     // two register buffers of half a chunk each: while one is consumed the other is in flight (a third would hide more of
@@ -670,19 +693,26 @@ int arreau_launch_edge_f16x3(const arreau_model* m, const float* dir, const floa
     // atoms, far above the switch-over, so nothing is lost by keeping the small-launch form to unsliced launches.
     const bool whole_batch = n0 == 0 && n1 == N && r.wg_cap == 0;
     const bool use_split = split_ok && (split_env >= 0 ? split_env != 0 : (whole_batch && (n1 - n0) <= ARREAU_EDGE_SPLIT_MAX_NODES));
+    const bool k3 = arreau_k3(m);  // K tiles as 3-byte floats (the node-layer launcher reads the same decision)
     if (use_split) {
-        hipLaunchKernelGGL((edge_kernel_f16x3_split<128, 256>), dim3((unsigned)(n1 - n0) * 4), dim3(512), 0, s, dir, dist, deg,
-                           batch, lattice, m->ori, reinterpret_cast<const u32x4*>(m->edge_f16), m->b1, m->b2, m->cfg.radius, N,
-                           m->k, m->L, kbuf, n0);
+        auto launch = [&](auto kernel) {
+            hipLaunchKernelGGL(kernel, dim3((unsigned)(n1 - n0) * 4), dim3(512), 0, s, dir, dist, deg, batch, lattice, m->ori,
+                               reinterpret_cast<const u32x4*>(m->edge_f16), m->b1, m->b2, m->cfg.radius, N, m->k, m->L, kbuf, n0);
+        };
+        if (k3) launch(edge_kernel_f16x3_split<128, 256, true>);
+        else launch(edge_kernel_f16x3_split<128, 256, false>);
         ARREAU_CHECK_HIP(hipGetLastError());
         return ARREAU_OK;
     }
     const int npairs = (n1 - n0 + 1) / 2;
     int wgs = wgs_env > 0 ? (wgs_env < npairs ? wgs_env : npairs) : (npairs < n_cu ? npairs : n_cu);
     if (r.wg_cap > 0 && wgs > r.wg_cap) wgs = r.wg_cap;
-    hipLaunchKernelGGL((edge_kernel_f16x3<128, 256, 8>), dim3(wgs), dim3(512), 0, s, dir, dist, deg, batch,
-                       lattice, m->ori, reinterpret_cast<const u32x4*>(m->edge_f16), m->b1, m->b2, m->cfg.radius, N,
-                       m->k, m->L, kbuf, n0, n1);
+    auto launch = [&](auto kernel) {
+        hipLaunchKernelGGL(kernel, dim3(wgs), dim3(512), 0, s, dir, dist, deg, batch, lattice, m->ori,
+                           reinterpret_cast<const u32x4*>(m->edge_f16), m->b1, m->b2, m->cfg.radius, N, m->k, m->L, kbuf, n0, n1);
+    };
+    if (k3) launch(edge_kernel_f16x3<128, 256, 8, true>);
+    else launch(edge_kernel_f16x3<128, 256, 8, false>);
     ARREAU_CHECK_HIP(hipGetLastError());
     return ARREAU_OK;
 }

@@ -258,6 +258,32 @@ int arreau_launch_batch_index(const int32_t* offsets, int B, int N, int32_t* bat
 int arreau_launch_node_layer(const arreau_model* m, int layer, const float* kbuf, const int32_t* deg,
                              const int32_t* src, const float* x_in, float* x_conv, float* x_out, float* xbar,
                              float* vsum, int N, hipStream_t s, NodeRange r = NodeRange());
+// ---- K stash format ------------------------------------------------------------------------------------------------
+// The per-layer edge kernels K [L][N*k*16][C] are the only large intermediate of a sampling step.  With the split-precision
+// edge kernel and the streamed conv kernel (the default pair) they are held as 3-BYTE floats: the top three bytes of the
+// fp32 value after rounding to nearest on the magnitude (1 sign + 8 exponent + 15 stored significand bits), four values in
+// three dwords, a row of C values in 3 C bytes.  Rounding K to 16 significand bits changes the network outputs by no more
+// than the fp32 oracle's own rounding floor (tools/exp/k_precision_study.py, profiles/r02g_k_precision_study.txt); it takes
+// a quarter off the stash's HBM traffic.  ARREAU_K3=0 keeps fp32.  Every other producer / consumer pair keeps fp32.
+typedef unsigned int u32x3_k __attribute__((ext_vector_type(3)));
+__device__ __forceinline__ u32x3_k arreau_pack_k3(float v0, float v1, float v2, float v3) {
+    const unsigned r0 = __float_as_uint(v0) + 0x80u, r1 = __float_as_uint(v1) + 0x80u;
+    const unsigned r2 = __float_as_uint(v2) + 0x80u, r3 = __float_as_uint(v3) + 0x80u;
+    u32x3_k d;
+    d[0] = __builtin_amdgcn_perm(r1, r0, 0x05030201u);  // r0.b1 r0.b2 r0.b3 r1.b1
+    d[1] = __builtin_amdgcn_perm(r2, r1, 0x06050302u);  // r1.b2 r1.b3 r2.b1 r2.b2
+    d[2] = __builtin_amdgcn_perm(r3, r2, 0x07060503u);  // r2.b3 r3.b1 r3.b2 r3.b3
+    return d;
+}
+__device__ __forceinline__ void arreau_unpack_k3(unsigned d0, unsigned d1, unsigned d2, float (&v)[4]) {
+    v[0] = __uint_as_float(d0 << 8);
+    v[1] = __uint_as_float(__builtin_amdgcn_perm(d1, d0, 0x0504030cu));  // 0 d0.b3 d1.b0 d1.b1
+    v[2] = __uint_as_float(__builtin_amdgcn_perm(d2, d1, 0x0403020cu));  // 0 d1.b2 d1.b3 d2.b0
+    v[3] = __uint_as_float(d2 & 0xffffff00u);
+}
+// the decision, shared by the edge and the node-layer launchers (both read the same model fields)
+bool arreau_k3(const arreau_model* m);
+
 int arreau_launch_mlp_bf16x6(const arreau_model* m, int layer, const float* x_conv, const float* x_in, float* x_out,
                              float* xbar, float* vsum, int N, hipStream_t s);
 int arreau_launch_mlp_f16x3_m16(const arreau_model* m, int layer, const float* x_conv, const float* x_in, float* x_out,

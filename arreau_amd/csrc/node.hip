@@ -347,9 +347,9 @@ template <int IMM>
 __device__ __forceinline__ void conv_store4(const float* base_uniform, unsigned lane_off, float v) {
     asm volatile("global_store_dword %0, %1, %2 offset:%3" : : "v"(lane_off), "v"(v), "s"(base_uniform), "n"(IMM) : "memory");
 }
-template <int C>
+template <int C, bool K3 /* K as 3-byte floats (internal.h: "K stash format") */>
 __global__ __launch_bounds__(512, 2) void conv_kernel_streamed(
-    const float* __restrict__ kl,        // this layer's kernels [N*8*16][C]
+    const float* __restrict__ kl,        // this layer's kernels [N*8*16][C] (fp32, or 3 bytes per value)
     const int32_t* __restrict__ deg, const int32_t* __restrict__ src,
     const float* __restrict__ x_in,      // [N][16][C]
     const float* __restrict__ fk,        // [16(o)][16(p)][C]
@@ -358,8 +358,9 @@ __global__ __launch_bounds__(512, 2) void conv_kernel_streamed(
 {
     static_assert(C == 128, "thread mapping assumes C = 128");
     constexpr int K = 8;
-    constexpr unsigned KBLOCK = K * 16 * C * 4;  // 64 KiB per receiver
-    __shared__ __attribute__((aligned(16))) float kbuf_s[2][K * 16 * C];
+    constexpr unsigned KBLOCK = K * 16 * C * (K3 ? 3 : 4);  // 64 KiB (48 KiB) per receiver
+    constexpr int NDMA = KBLOCK / 8 / 1024;                 // 1 KiB copies per wave and receiver: 8 (6)
+    __shared__ __attribute__((aligned(16))) float kbuf_s[2][KBLOCK / 4];
     __shared__ __attribute__((aligned(16))) float tile[2][16 * CONV_LDS_STRIDE];
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
@@ -391,10 +392,10 @@ __global__ __launch_bounds__(512, 2) void conv_kernel_streamed(
         return m;
     };
     const unsigned kb0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)&kbuf_s[0][0]);
-    auto copy_k = [&](int n, int b) {  // this wave's 8 KiB of receiver n's K block -> kbuf_s[b]
-        const char* g = reinterpret_cast<const char*>(kl) + (size_t)n * KBLOCK + 8192u * wave + 16u * lane;
+    auto copy_k = [&](int n, int b) {  // this wave's eighth of receiver n's K block -> kbuf_s[b]
+        const char* g = reinterpret_cast<const char*>(kl) + (size_t)n * KBLOCK + (1024u * NDMA) * wave + 16u * lane;
 #pragma unroll
-        for (int i = 0; i < 8; ++i) conv_glds16(g + 1024 * i, kb0 + b * KBLOCK + 8192u * wave + 1024u * i);
+        for (int i = 0; i < NDMA; ++i) conv_glds16(g + 1024 * i, kb0 + b * KBLOCK + (1024u * NDMA) * wave + 1024u * i);
     };
     f32x4 xv[2][K];  // x rows of the current and of the next receiver (static parity: the loop body is unrolled by two)
     auto load_x = [&](int n, auto par) {
@@ -431,9 +432,9 @@ __global__ __launch_bounds__(512, 2) void conv_kernel_streamed(
 #ifdef ARREAU_DEBUG_WAIT_ALL  // debug build: every counted wait becomes vmcnt(0); outputs must not change
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #else
-        if (mn < n_iter) {
-            if (first) asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(20)" ::: "memory");
+        if (mn < n_iter) {  // (8 x rows + NDMA K copies of the next receiver; + the 4 stores of the previous one)
+            if (first) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(8 + NDMA) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(8 + NDMA + 4) : "memory");
         } else {
             if (first) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
@@ -444,10 +445,17 @@ __global__ __launch_bounds__(512, 2) void conv_kernel_streamed(
         __syncthreads();  // every wave's share of K(n) has landed
         // ---- multiply . ordered sum over the in-edges -----------------------------------------------------
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        const float* kb = &kbuf_s[PAR][o_row * C + 4 * c4];
+        const float* kb = &kbuf_s[PAR][K3 ? o_row * (C * 3 / 4) + 3 * c4 : o_row * C + 4 * c4];
 #pragma unroll
         for (int s_ = 0; s_ < K; ++s_) {
-            const f32x4 kv = *reinterpret_cast<const f32x4*>(kb + s_ * 16 * C);
+            float kv[4];
+            if constexpr (K3) {
+                const unsigned* kq = reinterpret_cast<const unsigned*>(kb) + s_ * (16 * C * 3 / 4);
+                arreau_unpack_k3(kq[0], kq[1], kq[2], kv);
+            } else {
+                const f32x4 kf = *reinterpret_cast<const f32x4*>(kb + s_ * 16 * C);
+                kv[0] = kf[0]; kv[1] = kf[1]; kv[2] = kf[2]; kv[3] = kf[3];
+            }
             const bool on = s_ < nd;  // product rounded, then added in edge order (messages -> index_add_)
             acc[0] = on ? __fadd_rn(acc[0], __fmul_rn(kv[0], xv[PAR][s_][0])) : acc[0];
             acc[1] = on ? __fadd_rn(acc[1], __fmul_rn(kv[1], xv[PAR][s_][1])) : acc[1];
@@ -689,8 +697,13 @@ int arreau_launch_node_layer(const arreau_model* m, int layer, const float* kbuf
     if (conv_variant == 1 && m->k == 8) {
         int blocks = Ng < 256 ? Ng : 256;
         if (r.wg_cap > 0 && blocks > r.wg_cap) blocks = r.wg_cap;
-        hipLaunchKernelGGL((conv_kernel_streamed<128>), dim3(blocks), dim3(512), 0, s, kbuf + (size_t)layer * layer_stride, deg,
-                           src, x_in, m->fk + (size_t)layer * 16 * 16 * C, m->conv_bias + (size_t)layer * C, n0, Ng, x_conv);
+        if (arreau_k3(m))  // (the edge launcher took the same decision: a row of K is 3 C bytes)
+            hipLaunchKernelGGL((conv_kernel_streamed<128, true>), dim3(blocks), dim3(512), 0, s,
+                               reinterpret_cast<const float*>(reinterpret_cast<const char*>(kbuf) + (size_t)layer * layer_stride * 3), deg,
+                               src, x_in, m->fk + (size_t)layer * 16 * 16 * C, m->conv_bias + (size_t)layer * C, n0, Ng, x_conv);
+        else
+            hipLaunchKernelGGL((conv_kernel_streamed<128, false>), dim3(blocks), dim3(512), 0, s, kbuf + (size_t)layer * layer_stride, deg,
+                               src, x_in, m->fk + (size_t)layer * 16 * 16 * C, m->conv_bias + (size_t)layer * C, n0, Ng, x_conv);
     } else {
         int blocks = Ng < 512 ? Ng : 512;
         if (r.wg_cap > 0 && blocks > r.wg_cap) blocks = r.wg_cap;
@@ -930,6 +943,13 @@ __global__ void readout_crystals_kernel(const float* __restrict__ gs, const int3
     float acc = 0.f;
     for (int n = offsets[b]; n < offsets[b + 1]; ++n) acc += gs[(size_t)n * 3 + g];
     len0[idx] = acc;
+}
+
+// K tiles as 3-byte floats (internal.h, "K stash format"): only for the producer / consumer pair that implements it -- the
+// split-precision edge kernels (both forms) and the streamed conv kernel.  ARREAU_K3=0 keeps fp32 (A/B, tests).
+bool arreau_k3(const arreau_model* m) {
+    static const int env = [] { const char* e = getenv("ARREAU_K3"); return e ? atoi(e) : 1; }();
+    return env != 0 && m->edge_variant == 4 && m->f16_ok && m->conv_variant == 1 && m->k == 8 && m->C == 128 && m->D == 256;
 }
 
 bool arreau_range_launches_supported(const arreau_model* m) {

@@ -759,7 +759,8 @@ def test_alternative_arithmetic_variants_agree(dev, small_model, edge_variant, m
 
 
 def test_launch_geometry_switches_and_counted_waits_are_bitwise_neutral(dev):
-    """The register form of the conv kernel (ARREAU_CONV_VARIANT=0) and the streamed LDS-DMA form, and the persistent
+    """The register form of the conv kernel (ARREAU_CONV_VARIANT=0) and the streamed LDS-DMA form (both on an fp32 K
+    stash), and the persistent
     edge kernel at one receiver pair per workgroup (ARREAU_EDGE_WGS large) versus one workgroup per CU, evaluate the
     same sums in the same order: outputs must be bit-identical (full-size model, 96 crystals x 20 atoms, so that
     workgroups of the default geometry walk several receivers)."""
@@ -785,7 +786,8 @@ def test_launch_geometry_switches_and_counted_waits_are_bitwise_neutral(dev):
     assert os.path.exists(LIB_DEBUG_WAIT)
     outs = {}
     with tempfile.TemporaryDirectory() as d:
-        for tag, env in (("default", {}), ("conv0", {"ARREAU_CONV_VARIANT": "0"}), ("wgs", {"ARREAU_EDGE_WGS": "100000"}),
+        for tag, env in (("default", {}), ("k3off", {"ARREAU_K3": "0"}), ("conv0", {"ARREAU_CONV_VARIANT": "0"}),
+                         ("wgs", {"ARREAU_EDGE_WGS": "100000"}),
                          ("dbgwait", {"ARREAU_HIP_LIB": LIB_DEBUG_WAIT}), ("nb1", {"ARREAU_MLP_NB": "1"}),
                          ("nb2", {"ARREAU_MLP_NB": "2"}), ("slots4", {"ARREAU_MLP_SLOTS": "4"}),
                          ("edgesplit", {"ARREAU_EDGE_SPLIT": "1", "ARREAU_READOUT_SPLIT": "1", "ARREAU_MLP_SPLIT": "1"})):
@@ -795,9 +797,16 @@ def test_launch_geometry_switches_and_counted_waits_are_bitwise_neutral(dev):
     # nb1 / nb2: the MLP kernel on 16-row (one node) and 32-row (two nodes) wave tiles -- the small-batch geometry
     # slots4: the MLP kernel's weight ring with four slots instead of three (another set of counted waits)
     # edgesplit: the small-launch forms of the edge, ConvNext and read-out kernels, forced at this (large) size
-    for tag in ("conv0", "wgs", "dbgwait", "nb1", "nb2", "slots4", "edgesplit"):
+    for tag in ("wgs", "dbgwait", "nb1", "nb2", "slots4", "edgesplit"):
         for x, y in zip(outs["default"], outs[tag]):
             assert torch.equal(x, y), tag
+    # The K stash: 3-byte floats between the split-precision edge kernel and the streamed conv kernel (the default pair),
+    # fp32 for every other pair.  The register form of the conv kernel reads fp32 K, so it is compared bit for bit with the
+    # streamed form on fp32 K (ARREAU_K3=0); the two stash formats agree to the parity tolerance (K rounded to 16
+    # significand bits: tools/exp/k_precision_study.py).
+    for x, y in zip(outs["k3off"], outs["conv0"]):
+        assert torch.equal(x, y), "conv0"
+    assert_scores_close(outs["default"], outs["k3off"])
 
 
 def _philox_ref(ctr, key):
