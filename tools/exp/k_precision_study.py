@@ -31,8 +31,22 @@ def round_significand(k, bits):
     return a.view(torch.float32) * torch.sign(k)
 
 
+BLOCK = [None]  # (group size, signed mantissa bits) of a block-scaled format, or None
+
+
+def block_quant(k, group, mant_bits):
+    """`group` consecutive channels share one power-of-two scale; signed integer mantissas of `mant_bits` bits."""
+    g = k.reshape(-1, group)
+    m = g.abs().amax(dim=1, keepdim=True).clamp_min(1e-30)
+    step = torch.exp2(torch.floor(torch.log2(m)) + 1 - (mant_bits - 1))
+    lim = 2 ** (mant_bits - 1) - 1
+    return (torch.round(g / step).clamp(-lim, lim) * step).reshape(k.shape)
+
+
 def conv_with_rounded_k(sd, prefix, x, edge_index, kernel_basis, fiber_kernel_basis, stats=None):
     kernel = round_significand(F.linear(kernel_basis, sd[prefix + ".kernel.weight"]), BITS[0])
+    if BLOCK[0] is not None:
+        kernel = block_quant(kernel, *BLOCK[0])
     messages = kernel * x[edge_index[0]]
     x_1 = torch.zeros_like(x).index_add_(0, edge_index[1], messages)
     fiber_kernel = F.linear(fiber_kernel_basis, sd[prefix + ".fiber_kernel.weight"])
@@ -60,6 +74,13 @@ def main():
             q = OS.predict_scores(om32, *args)
             print("   K with %2d significand bits: max change of eps / logits / len0 = " % bits +
                   " / ".join("%.2e" % float((a - b).abs().max()) for a, b in zip(q[:3], base[:3])))
+        BITS[0] = 24
+        for cfg in ((16, 16), (4, 16), (8, 15), (4, 15), (4, 14)):  # 2.06 / 2.25 / 2.0 / 2.0 / 2.0 bytes per value with an 8-bit scale
+            BLOCK[0] = cfg
+            q = OS.predict_scores(om32, *args)
+            print("   K block-scaled, groups of %2d channels, %2d-bit signed mantissas: " % cfg +
+                  " / ".join("%.2e" % float((a - b).abs().max()) for a, b in zip(q[:3], base[:3])))
+        BLOCK[0] = None
 
 
 if __name__ == "__main__":
