@@ -464,6 +464,9 @@ def run_rank(args, rank, local_rank, world):
             "dtype_note": "fp32 inputs/outputs/accumulation; kernels that ran (reported by the library, "
                           f"arreau_model_status): edge={status['edge_kernel']}, mlp={status['mlp_kernel']}.  fp16x3 = each "
                           "fp32 product of the dense layers as 3 fp16 MFMA products (two 11-bit operand planes, f16x3.h); "
+                          "the per-layer edge-kernel stash K between the edge and conv kernels is held as 3-byte floats "
+                          "(16 significand bits; ARREAU_K3=0: fp32) unless the environment says otherwise: "
+                          f"ARREAU_K3={os.environ.get('ARREAU_K3', '1')}; "
                           "measured deviations from the fp32 / fp64 CPU oracle: profiles/parity_r02.json; "
                           "roofline.fp32_mfma_variant = the same step on the plain fp32-MFMA kernels",
             "data": "synthetic",
