@@ -13,7 +13,7 @@ import time
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 SOURCES = ["model.hip", "graph.hip", "edge.hip", "edge_bf16.hip", "edge_f16.hip", "node.hip", "node_bf16.hip", "node_f16.hip", "node_f16m.hip", "update.hip", "train.hip", "train_net.hip", "api.hip"]
-HEADERS = ["internal.h", "bf16x6.h", "f16x3.h", os.path.join("..", "..", "include", "arreau_hip.h"), "sgemm.h"]
+HEADERS = ["internal.h", "bf16x6.h", "f16x3.h", os.path.join("..", "..", "include", "arreau_hip.h"), "sgemm.h", "philox.h"]
 LIB = os.path.join(CSRC, "libarreau_hip.so")
 # Debug twin: the same sources with -DARREAU_DEBUG_WAIT_ALL (every hand-counted `s_waitcnt vmcnt(N)` becomes vmcnt(0)).
 # Its outputs must be bit-identical to the product library's (test_counted_waits_match_full_waits); only the sources
@@ -25,6 +25,11 @@ STAMP = os.path.join(CSRC, ".build_stamp")
 # would put scratch loads/stores into the same in-order queue and silently break the protocol, so the build fails if
 # the compiler reports scratch for them.  source -> substrings of the (mangled) kernel names to check (None = all).
 NO_SCRATCH = {"edge_f16.hip": None, "node.hip": ["conv_kernel_streamed"], "node_f16.hip": None, "node_f16m.hip": None}
+# Sources with inline asm: their device ISA is kept (-save-temps) and run through tools/isa_lint.py -- software wait
+# states around every asm instruction (store-data, VALU-written SGPR -> VMEM, M0 -> LDS-DMA, ...), asm loads' destination
+# registers untouched until their wait, no compiler use of M0, no unmodelled instruction kind inside asm.  hipcc pads and
+# counts none of that for inline asm; a violation fails the build.
+ASM_LINT = ("edge_f16.hip", "node.hip", "node_f16.hip", "node_f16m.hip", "graph.hip", "api.hip")
 # -Wno-inline-asm: the lean LDS-DMA asm lists "m0" as clobbered (it overwrites M0 and does not restore it); clang warns
 # that reserved registers in a clobber list are not preserved for us -- which is what is declared, not asked for.  The
 # ISA check below verifies that the compiler itself never uses M0 in those kernels.
@@ -32,12 +37,12 @@ NO_SCRATCH = {"edge_f16.hip": None, "node.hip": ["conv_kernel_streamed"], "node_
 # (f16x3.h): the SLP vectoriser would fuse adjacent ones back into v_pk_*_f32.
 PER_SOURCE_FLAGS = {src: ["-fno-slp-vectorize"] for src in ("edge_f16.hip", "node_f16.hip", "node_f16m.hip")}
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++20", "-fPIC", "-Wall", "-Wno-unused-function", "-Wno-inline-asm",
-         "-Wno-unused-but-set-variable", "-ffp-contract=on"] + os.environ.get("ARREAU_EXTRA_HIPCC_FLAGS", "").split()
+         "-Wno-unused-but-set-variable", "-Wno-misleading-indentation", "-ffp-contract=on"] + os.environ.get("ARREAU_EXTRA_HIPCC_FLAGS", "").split()
 
 
 def _digest():
     h = hashlib.sha256()
-    for f in SOURCES + HEADERS:
+    for f in SOURCES + HEADERS + [os.path.join("..", "..", "tools", "isa_lint.py")]:
         with open(os.path.join(CSRC, f), "rb") as fh:
             h.update(fh.read())
     h.update(" ".join(FLAGS).encode())
@@ -96,22 +101,14 @@ def _drop_remarks(diag):
     return "\n".join(keep)
 
 
-_M0_ALLOWED = (r"s_mov_b32 m0, s\d+$", r"s_add_u32 m0, s\d+, (0x[0-9a-f]+|\d+|s\d+)$", r"s_mov_b32 s\d+, m0$")
-
-
-def _m0_violations(asm_text):
-    """The LDS-DMA asm of these sources writes M0 itself (f16x3.h: glds16 saves/restores it, dma_chunk_lean and
-    conv_glds16 overwrite it).  That is only sound while the compiler has no use of M0 of its own in the same kernels:
-    every instruction of the device ISA that names m0 must be one of the asm's own forms."""
-    import re
-    bad = []
-    for line in asm_text.splitlines():
-        ins = line.split(";")[0].strip()
-        if "m0" not in ins or ins.startswith((".", "//")):
-            continue
-        if not any(re.search(pat, ins) for pat in _M0_ALLOWED):
-            bad.append(ins)
-    return bad
+def _isa_lint():
+    """tools/isa_lint.py as a module (the repository's tools/ directory is not a package)."""
+    import importlib.util
+    path = os.path.join(CSRC, "..", "..", "tools", "isa_lint.py")
+    spec = importlib.util.spec_from_file_location("arreau_isa_lint", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
 
 
 def _compile_all(hipcc, sources, objdir, extra_flags, verbose):
@@ -125,7 +122,7 @@ def _compile_all(hipcc, sources, objdir, extra_flags, verbose):
         objs.append(obj)
         cmd = [hipcc] + FLAGS + PER_SOURCE_FLAGS.get(src, []) + extra_flags
         tmp = None
-        if src in NO_SCRATCH:  # + keep the device ISA for the M0 check (temporaries go to a scratch directory)
+        if src in NO_SCRATCH or src in ASM_LINT:  # + keep the device ISA for the lint (temporaries go to a scratch directory)
             tmp = tempfile.mkdtemp(prefix="arreau_isa_")
             cmd += ["-Rpass-analysis=kernel-resource-usage", "-save-temps"]
         cmd += ["-c", os.path.join(CSRC, src), "-o", obj]
@@ -134,14 +131,22 @@ def _compile_all(hipcc, sources, objdir, extra_flags, verbose):
     for src, tmp, p in procs:
         out, _ = p.communicate()
         if tmp is not None:
-            if p.returncode == 0:
+            if p.returncode == 0 and src in ASM_LINT:
                 isa = glob.glob(os.path.join(tmp, "*-hip-amdgcn-amd-amdhsa-gfx950.s"))
-                bad = _m0_violations(open(isa[0]).read()) if isa else ["device ISA not found"]
-                if bad:
+                lint = _isa_lint()
+                bad = lint.lint_file(isa[0]) if isa else None
+                if bad is None or bad:
                     failed = True
-                    sys.stderr.write(f"[arreau_amd.build] {src}: M0 is used outside the LDS-DMA asm ({bad[:4]}); the asm "
-                                     "overwrites M0 without restoring it\n")
+                    sys.stderr.write(f"[arreau_amd.build] {src}: ISA hazard lint (tools/isa_lint.py): "
+                                     f"{'device ISA not found' if bad is None else str(len(bad)) + ' violation(s)'}\n")
+                    for v in (bad or [])[:8]:
+                        sys.stderr.write("  " + lint.format_violation(v) + "\n")
+                elif verbose:
+                    nf, ni, na = lint.summarize(isa[0])
+                    sys.stderr.write(f"[arreau_amd.build] {src}: ISA lint clean ({nf} kernels, {ni} instructions, {na} from inline asm)\n")
             shutil.rmtree(tmp, ignore_errors=True)
+        if p.returncode == 0 and src in ASM_LINT and src not in NO_SCRATCH:
+            out = _drop_remarks(out)
         if p.returncode == 0 and src in NO_SCRATCH:
             scratch = _scratch_by_kernel(out)
             want = NO_SCRATCH[src]

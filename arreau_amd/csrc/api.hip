@@ -423,7 +423,7 @@ extern "C" int arreau_sample_loop(arreau_model* m, float* d_frac, int32_t* d_typ
     }
     if (n_steps == 0) return ARREAU_OK;
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(fill_i32_kernel, dim3((B + 255) / 256), dim3(256), 0, s, w.t_next, t_start, B);
+    ARREAU_LAUNCH(fill_i32_kernel, dim3((B + 255) / 256), dim3(256), 0, s, w.t_next, t_start, B);
     ARREAU_CHECK_HIP(hipGetLastError());
     int rc;
     if (!use_graph || n_steps < 3) {
@@ -552,5 +552,59 @@ extern "C" int arreau_sample_loop(arreau_model* m, float* d_frac, int32_t* d_typ
     if (e == hipSuccess) e = hipEventRecord(ev, s);
     if (e == hipSuccess) e = hipStreamWaitEvent(user, ev, 0);  // the caller's stream continues after the loop
     ARREAU_CHECK_HIP(e);
+    return ARREAU_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Uninitialised-state probe (internal.h: ARREAU_LAUNCH).  One workgroup per CU takes the CU's whole LDS (160 KiB, so no
+// second one fits beside it) and 16 waves x ~112 registers per lane = most of the four SIMDs' register files, writes the
+// pattern everywhere and leaves.  The workgroups wait for each other (bounded: a clock limit, so the grid always drains)
+// to make sure none of them is placed on a CU another one has already left.
+// ---------------------------------------------------------------------------------------------
+unsigned arreau_debug_pollution = 0;
+namespace {
+__global__ __launch_bounds__(1024) void pollute_kernel(unsigned pattern, unsigned* __restrict__ arrived, unsigned target) {
+    extern __shared__ unsigned pl[];
+    for (int i = threadIdx.x; i < 40960; i += 1024) pl[i] = pattern;
+    float r[112];
+#pragma unroll
+    for (int i = 0; i < 112; ++i) asm volatile("v_mov_b32 %0, %1" : "=v"(r[i]) : "v"(pattern));
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        atomicAdd(arrived, 1u);
+        const long long t0 = wall_clock64();  // 100 MHz
+        while (__hip_atomic_load(arrived, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target && wall_clock64() - t0 < 20000) {}
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 112; ++i) asm volatile("" : : "v"(r[i]));
+    if (pl[(threadIdx.x * 37) % 40960] != pattern) arrived[1] = 1;  // (keeps the LDS writes alive; never true)
+}
+unsigned* g_pollute_counter = nullptr;
+unsigned g_pollute_launches = 0;
+}  // namespace
+
+int arreau_debug_pollute(hipStream_t s) {
+    static const int n_cu = [] {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0)
+            return (int)prop.multiProcessorCount;
+        return 256;
+    }();
+    if (!g_pollute_counter) {
+        ARREAU_CHECK_HIP(hipMalloc(&g_pollute_counter, 8));
+        ARREAU_CHECK_HIP(hipMemset(g_pollute_counter, 0, 8));
+        ARREAU_CHECK_HIP(hipFuncSetAttribute((const void*)pollute_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 163840));
+    }
+    ++g_pollute_launches;
+    hipLaunchKernelGGL(pollute_kernel, dim3(n_cu), dim3(1024), 163840, s, arreau_debug_pollution, g_pollute_counter,
+                       g_pollute_launches * (unsigned)n_cu);
+    ARREAU_CHECK_HIP(hipGetLastError());
+    return ARREAU_OK;
+}
+
+extern "C" int arreau_debug_set_pollution(uint32_t pattern) {
+    arreau_debug_pollution = pattern;
     return ARREAU_OK;
 }

@@ -210,7 +210,7 @@ static void launch_variant(const arreau_model* m, const float* dir, const float*
                            const int32_t* batch, const float* lattice, int N, float* kbuf, hipStream_t s) {
     constexpr int SLOTS = 2 * NCB;
     const long long wave_tiles = (long long)N * ((m->k + SLOTS - 1) / SLOTS);
-    hipLaunchKernelGGL((edge_kernel<128, 256, NCB, OCC>), dim3((unsigned)((wave_tiles + 3) / 4)), dim3(256), 0, s, dir,
+    ARREAU_LAUNCH((edge_kernel<128, 256, NCB, OCC>), dim3((unsigned)((wave_tiles + 3) / 4)), dim3(256), 0, s, dir,
                        dist, deg, batch, lattice, m->ori, m->w1p, m->b1, m->b2, m->cfg.radius, N, m->k, m->L, kbuf);
 }
 

@@ -228,7 +228,7 @@ int arreau_launch_edge_bf16x6(const arreau_model* m, const float* dir, const flo
         return ARREAU_EINVAL;
     }
     static const int dbg = [] { const char* e = getenv("ARREAU_EDGE_DBG"); return e ? atoi(e) : 0; }();
-    hipLaunchKernelGGL((edge_kernel_bf16x6<128, 256>), dim3(N), dim3(256), 0, s, dir, dist, deg, batch, lattice, m->ori,
+    ARREAU_LAUNCH((edge_kernel_bf16x6<128, 256>), dim3(N), dim3(256), 0, s, dir, dist, deg, batch, lattice, m->ori,
                        reinterpret_cast<const u32x4*>(m->edge_bf16), m->b1, m->b2, m->cfg.radius, N, m->k, m->L, kbuf, dbg);
     ARREAU_CHECK_HIP(hipGetLastError());
     return ARREAU_OK;

@@ -696,7 +696,7 @@ int arreau_launch_edge_f16x3(const arreau_model* m, const float* dir, const floa
     const bool k3 = arreau_k3(m);  // K tiles as 3-byte floats (the node-layer launcher reads the same decision)
     if (use_split) {
         auto launch = [&](auto kernel) {
-            hipLaunchKernelGGL(kernel, dim3((unsigned)(n1 - n0) * 4), dim3(512), 0, s, dir, dist, deg, batch, lattice, m->ori,
+            ARREAU_LAUNCH(kernel, dim3((unsigned)(n1 - n0) * 4), dim3(512), 0, s, dir, dist, deg, batch, lattice, m->ori,
                                reinterpret_cast<const u32x4*>(m->edge_f16), m->b1, m->b2, m->cfg.radius, N, m->k, m->L, kbuf, n0);
         };
         if (k3) launch(edge_kernel_f16x3_split<128, 256, true>);
@@ -708,7 +708,7 @@ int arreau_launch_edge_f16x3(const arreau_model* m, const float* dir, const floa
     int wgs = wgs_env > 0 ? (wgs_env < npairs ? wgs_env : npairs) : (npairs < n_cu ? npairs : n_cu);
     if (r.wg_cap > 0 && wgs > r.wg_cap) wgs = r.wg_cap;
     auto launch = [&](auto kernel) {
-        hipLaunchKernelGGL(kernel, dim3(wgs), dim3(512), 0, s, dir, dist, deg, batch, lattice, m->ori,
+        ARREAU_LAUNCH(kernel, dim3(wgs), dim3(512), 0, s, dir, dist, deg, batch, lattice, m->ori,
                            reinterpret_cast<const u32x4*>(m->edge_f16), m->b1, m->b2, m->cfg.radius, N, m->k, m->L, kbuf, n0, n1);
     };
     if (k3) launch(edge_kernel_f16x3<128, 256, 8, true>);

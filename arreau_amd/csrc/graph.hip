@@ -30,7 +30,7 @@ extern "C" int arreau_lattice_from_params(const float* d_lengths, const float* d
                                           float* d_lattice, void* stream) {
     ARREAU_REQUIRE(d_lengths && d_angles && d_lattice && B >= 0, "arreau_lattice_from_params: bad argument");
     if (B == 0) return ARREAU_OK;
-    hipLaunchKernelGGL(lattice_from_params_kernel, dim3((B + 127) / 128), dim3(128), 0, (hipStream_t)stream,
+    ARREAU_LAUNCH(lattice_from_params_kernel, dim3((B + 127) / 128), dim3(128), 0, (hipStream_t)stream,
                        d_lengths, d_angles, B, d_lattice);
     ARREAU_CHECK_HIP(hipGetLastError());
     return ARREAU_OK;
@@ -65,7 +65,7 @@ extern "C" int arreau_frac_to_cart(const float* d_frac, const float* d_lattice, 
                                    int32_t N, float* d_cart, void* stream) {
     ARREAU_REQUIRE(d_frac && d_lattice && d_off && d_cart && B >= 1 && N >= 0, "arreau_frac_to_cart: bad argument");
     if (N == 0) return ARREAU_OK;
-    hipLaunchKernelGGL(frac_to_cart_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, d_frac,
+    ARREAU_LAUNCH(frac_to_cart_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, d_frac,
                        d_lattice, d_off, B, N, d_cart);
     ARREAU_CHECK_HIP(hipGetLastError());
     return ARREAU_OK;
@@ -249,7 +249,7 @@ int arreau_launch_neighbor(const float* cart, const float* lattice, const int32_
     if (n1 <= n0) return ARREAU_OK;
     const float r2 = (float)((double)radius * (double)radius);
     const int waves_per_block = 4;
-    hipLaunchKernelGGL(neighbor_kernel, dim3((n1 - n0 + waves_per_block - 1) / waves_per_block), dim3(64 * waves_per_block),
+    ARREAU_LAUNCH(neighbor_kernel, dim3((n1 - n0 + waves_per_block - 1) / waves_per_block), dim3(64 * waves_per_block),
                        0, s, cart, lattice, offsets, batch, B, n0, n1, r2, k, deg, src, cell, dir, dist);
     ARREAU_CHECK_HIP(hipGetLastError());
     return ARREAU_OK;
@@ -326,10 +326,10 @@ extern "C" int arreau_compact_edges(const int32_t* d_deg, const int32_t* d_src, 
                        d_out_dist && d_out_dir, "arreau_compact_edges: null pointer");
     ARREAU_REQUIRE(N >= 0 && k >= 1, "arreau_compact_edges: bad size");
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(exclusive_scan_kernel, dim3(1), dim3(1024), 0, s, d_deg, N, d_edge_offsets);
+    ARREAU_LAUNCH(exclusive_scan_kernel, dim3(1), dim3(1024), 0, s, d_deg, N, d_edge_offsets);
     ARREAU_CHECK_HIP(hipGetLastError());
     if (N == 0) return ARREAU_OK;
-    hipLaunchKernelGGL(compact_edges_kernel, dim3((N * k + 255) / 256), dim3(256), 0, s, d_deg, d_src, d_cell, d_dir,
+    ARREAU_LAUNCH(compact_edges_kernel, dim3((N * k + 255) / 256), dim3(256), 0, s, d_deg, d_src, d_cell, d_dir,
                        d_dist, N, k, d_edge_offsets, d_edge_index, d_cell_offsets, d_out_dist, d_out_dir);
     ARREAU_CHECK_HIP(hipGetLastError());
     return ARREAU_OK;
@@ -382,7 +382,7 @@ extern "C" int arreau_edges_to_slots(const int64_t* d_edge_index, const float* d
     ARREAU_CHECK_HIP(hipMemsetAsync(d_slot_dist, 0, sizeof(float) * (size_t)N * k, s));
     if (E == 0) return ARREAU_OK;
     ARREAU_REQUIRE(d_edge_index && d_dist && d_dir, "arreau_edges_to_slots: null edge arrays");
-    hipLaunchKernelGGL(edges_to_slots_kernel, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, s, d_edge_index, d_dist,
+    ARREAU_LAUNCH(edges_to_slots_kernel, dim3((unsigned)((E + 255) / 256)), dim3(256), 0, s, d_edge_index, d_dist,
                        d_dir, (long long)E, N, k, d_deg, d_src, d_slot_dir, d_slot_dist, d_status);
     ARREAU_CHECK_HIP(hipGetLastError());
     return ARREAU_OK;

@@ -230,6 +230,21 @@ struct NodeRange {
     int n0 = 0, n1 = -1, b0 = 0, b1 = -1, wg_cap = 0;
 };
 
+// Debug aid (api.hip, "uninitialised-state probe"): when a pollution pattern is set (arreau_debug_set_pollution), every
+// kernel launch of the sampling path is preceded, on the same stream, by a kernel that fills every CU's LDS and vector
+// registers with the pattern.  A kernel that reads LDS / registers it never wrote sees whatever the previous wave on its
+// CU left there: alone on the GPU that is its own kernel's leftovers (the same every run), next to another stream's or
+// process's kernels it is not -- the signature of the non-reproducibility DESIGN.md section 8 records.  With the probe the
+// leftovers are under the test's control: outputs must be bit-identical for every pattern
+// (tests/test_gpu_parity.py::test_outputs_do_not_depend_on_leftover_lds_or_registers).
+extern unsigned arreau_debug_pollution;  // 0 = off (the product never sets it)
+int arreau_debug_pollute(hipStream_t s);
+#define ARREAU_LAUNCH(kernel, grid, block, smem, stream, ...)                      \
+    do {                                                                           \
+        if (arreau_debug_pollution) (void)arreau_debug_pollute(stream);            \
+        hipLaunchKernelGGL(kernel, grid, block, smem, stream, __VA_ARGS__);        \
+    } while (0)
+
 // launchers implemented in the other translation units ------------------------------------------
 int arreau_launch_fiber_precompute(arreau_model* m, hipStream_t s);
 int arreau_launch_neighbor(const float* cart, const float* lattice, const int32_t* offsets, const int32_t* batch, int B, int N,

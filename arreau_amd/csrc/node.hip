@@ -95,7 +95,7 @@ int arreau_launch_prep(const arreau_model* m, const float* frac, const float* le
                        int32_t* batch, float* cvec, hipStream_t s, int32_t* t_next, int32_t* t_cur, NodeRange r) {
     const int b0 = r.b0, b1 = r.b1 < 0 ? B : r.b1;
     if (b1 <= b0) return ARREAU_OK;
-    hipLaunchKernelGGL(prep_kernel, dim3(b1 - b0), dim3(128), 0, s, frac, lengths, angles, t, offsets, m->vp_betas,
+    ARREAU_LAUNCH(prep_kernel, dim3(b1 - b0), dim3(128), 0, s, frac, lengths, angles, t, offsets, m->vp_betas,
                        m->t_emb_w, m->embT, m->S, m->C, m->T, lattice, cart, batch, cvec, m->status, t_next, t_cur, b0);
     ARREAU_CHECK_HIP(hipGetLastError());
     return ARREAU_OK;
@@ -156,7 +156,7 @@ int arreau_launch_embed(const arreau_model* m, const float* frac, const int32_t*
         arreau_set_error("embed kernel: more than 2^31 (atom, channel group) pairs in one launch");
         return ARREAU_EINVAL;
     }
-    hipLaunchKernelGGL(embed_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, frac, types, lattice, batch,
+    ARREAU_LAUNCH(embed_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, frac, types, lattice, batch,
                        cvec, m->ori, m->embT, m->S, m->C, n0, n1, x0, m->status);
     ARREAU_CHECK_HIP(hipGetLastError());
     return ARREAU_OK;
@@ -207,7 +207,7 @@ __global__ __launch_bounds__(256) void embed_general_kernel(
 int arreau_launch_embed_general(const arreau_model* m, const float* x, const float* vec, int N, float* x0, hipStream_t s) {
     if (N == 0) return ARREAU_OK;
     const long long total = (long long)N * (m->C / 4);
-    hipLaunchKernelGGL(embed_general_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, vec, m->ori, m->embT,
+    ARREAU_LAUNCH(embed_general_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, x, vec, m->ori, m->embT,
                        m->S, m->C, N, x0);
     ARREAU_CHECK_HIP(hipGetLastError());
     return ARREAU_OK;
@@ -221,7 +221,7 @@ __global__ void batch_index_kernel(const int32_t* __restrict__ offsets, int B, i
 
 int arreau_launch_batch_index(const int32_t* offsets, int B, int N, int32_t* batch, hipStream_t s) {
     if (N == 0 || B == 0) return ARREAU_OK;
-    hipLaunchKernelGGL(batch_index_kernel, dim3(B), dim3(64), 0, s, offsets, B, batch);
+    ARREAU_LAUNCH(batch_index_kernel, dim3(B), dim3(64), 0, s, offsets, B, batch);
     ARREAU_CHECK_HIP(hipGetLastError());
     return ARREAU_OK;
 }
@@ -441,7 +441,9 @@ __global__ __launch_bounds__(512, 2) void conv_kernel_streamed(
         }
 #endif
 #pragma unroll
-        for (int s_ = 0; s_ < K; ++s_) asm volatile("" : "+v"(xv[PAR][s_]));  // the loaded values exist from here on
+        for (int s_ = 0; s_ < K; ++s_) asm volatile("; landed %0" : "+v"(xv[PAR][s_]));  // the loaded values exist from here on
+        // ("; landed" is the marker tools/isa_lint.py looks for: the build fails if the compiler touched a destination
+        // register of an asm load between the load and this point)
         __syncthreads();  // every wave's share of K(n) has landed
         // ---- multiply . ordered sum over the in-edges -----------------------------------------------------
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -698,16 +700,16 @@ int arreau_launch_node_layer(const arreau_model* m, int layer, const float* kbuf
         int blocks = Ng < 256 ? Ng : 256;
         if (r.wg_cap > 0 && blocks > r.wg_cap) blocks = r.wg_cap;
         if (arreau_k3(m))  // (the edge launcher took the same decision: a row of K is 3 C bytes)
-            hipLaunchKernelGGL((conv_kernel_streamed<128, true>), dim3(blocks), dim3(512), 0, s,
+            ARREAU_LAUNCH((conv_kernel_streamed<128, true>), dim3(blocks), dim3(512), 0, s,
                                reinterpret_cast<const float*>(reinterpret_cast<const char*>(kbuf) + (size_t)layer * layer_stride * 3), deg,
                                src, x_in, m->fk + (size_t)layer * 16 * 16 * C, m->conv_bias + (size_t)layer * C, n0, Ng, x_conv);
         else
-            hipLaunchKernelGGL((conv_kernel_streamed<128, false>), dim3(blocks), dim3(512), 0, s, kbuf + (size_t)layer * layer_stride, deg,
+            ARREAU_LAUNCH((conv_kernel_streamed<128, false>), dim3(blocks), dim3(512), 0, s, kbuf + (size_t)layer * layer_stride, deg,
                                src, x_in, m->fk + (size_t)layer * 16 * 16 * C, m->conv_bias + (size_t)layer * C, n0, Ng, x_conv);
     } else {
         int blocks = Ng < 512 ? Ng : 512;
         if (r.wg_cap > 0 && blocks > r.wg_cap) blocks = r.wg_cap;
-        hipLaunchKernelGGL((conv_kernel<128>), dim3(whole ? conv_blocks : blocks), dim3(512), 0, s, kbuf + (size_t)layer * layer_stride,
+        ARREAU_LAUNCH((conv_kernel<128>), dim3(whole ? conv_blocks : blocks), dim3(512), 0, s, kbuf + (size_t)layer * layer_stride,
                            deg, src, x_in, m->fk + (size_t)layer * 16 * 16 * C, m->conv_bias + (size_t)layer * C, n0, Ng, m->k, x_conv);
     }
     ARREAU_CHECK_HIP(hipGetLastError());
@@ -736,7 +738,7 @@ int arreau_launch_node_layer(const arreau_model* m, int layer, const float* kbuf
         return arreau_launch_mlp_bf16x6(m, layer, x_conv, x_in, x_out, xbar, vsum, N, s);
     }
     m->ran_mlp = 0;
-    hipLaunchKernelGGL((mlp_kernel<128, 512>), dim3((N + 3) / 4), dim3(256), 0, s, x_conv, x_in, x_out,
+    ARREAU_LAUNCH((mlp_kernel<128, 512>), dim3((N + 3) / 4), dim3(256), 0, s, x_conv, x_in, x_out,
                        m->ln_w + (size_t)layer * C, m->ln_b + (size_t)layer * C, m->mlp + (size_t)layer * mlp_layer,
                        m->mb1 + (size_t)layer * H, m->mb2 + (size_t)layer * C, m->ls + (size_t)layer * C,
                        m->ro_wT + (size_t)layer * C * (S + 4), m->ro_b + (size_t)layer * (S + 4), S, N,
@@ -982,23 +984,23 @@ int arreau_launch_readout(const arreau_model* m, const float* xbar, const float*
             static const int split_env = [] { const char* e = getenv("ARREAU_READOUT_SPLIT"); return e ? atoi(e) : -1; }();
             // small unsliced launch: one workgroup per output tile
             if (split_env >= 0 ? split_env != 0 : (whole && r.wg_cap == 0 && blocks32 < 64))
-                hipLaunchKernelGGL((readout_mfma_kernel<128, 3, 1>), dim3(blocks32, 3), dim3(64 * m->L), smem_m, s, xbar, vsum,
+                ARREAU_LAUNCH((readout_mfma_kernel<128, 3, 1>), dim3(blocks32, 3), dim3(64 * m->L), smem_m, s, xbar, vsum,
                                    m->ro_pack, m->ro_b, m->ori, m->S, m->L, N, n0, n1, eps, logits, gs, m->status);
             else
-                hipLaunchKernelGGL((readout_mfma_kernel<128, 3>), dim3(blocks32), dim3(64 * m->L), smem_m, s, xbar, vsum,
+                ARREAU_LAUNCH((readout_mfma_kernel<128, 3>), dim3(blocks32), dim3(64 * m->L), smem_m, s, xbar, vsum,
                                    m->ro_pack, m->ro_b, m->ori, m->S, m->L, N, n0, n1, eps, logits, gs, m->status);
         } else {
             if (!whole) {
                 arreau_set_error("read-out: range launches are implemented for the MFMA kernel only");
                 return ARREAU_EINVAL;
             }
-            hipLaunchKernelGGL(readout_nodes_kernel, dim3((N + RO_ATOMS - 1) / RO_ATOMS), dim3(RO_COLS * m->L), smem, s, xbar, vsum,
+            ARREAU_LAUNCH(readout_nodes_kernel, dim3((N + RO_ATOMS - 1) / RO_ATOMS), dim3(RO_COLS * m->L), smem, s, xbar, vsum,
                                m->ro_wT, m->ro_b, m->ori, m->S, m->C, m->L, N, eps, logits, gs, m->status);
         }
         ARREAU_CHECK_HIP(hipGetLastError());
     }
     if (b1 > b0 && len0 != nullptr)  // (len0 == nullptr: the caller pools the crystals itself -- the sampling loop's lattice update)
-        hipLaunchKernelGGL(readout_crystals_kernel, dim3((3 * (b1 - b0) + 127) / 128), dim3(128), 0, s, gs, offsets, b0, b1, len0);
+        ARREAU_LAUNCH(readout_crystals_kernel, dim3((3 * (b1 - b0) + 127) / 128), dim3(128), 0, s, gs, offsets, b0, b1, len0);
     ARREAU_CHECK_HIP(hipGetLastError());
     return ARREAU_OK;
 }

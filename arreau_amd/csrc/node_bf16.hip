@@ -182,7 +182,7 @@ int arreau_launch_mlp_bf16x6(const arreau_model* m, int layer, const float* x_co
     }
     const size_t layer_u32x4 = (size_t)2 * H * C * 3 * 2 / 16;  // bytes of W1 + W2 as 3 bf16 planes, in 16-byte units
     static const int dbg = [] { const char* e = getenv("ARREAU_MLP_DBG"); return e ? atoi(e) : 0; }();
-    hipLaunchKernelGGL((mlp_kernel_bf16x6<128, 512>), dim3((N + 7) / 8), dim3(256), 0, s, x_conv, x_in, x_out,
+    ARREAU_LAUNCH((mlp_kernel_bf16x6<128, 512>), dim3((N + 7) / 8), dim3(256), 0, s, x_conv, x_in, x_out,
                        m->ln_w + (size_t)layer * C, m->ln_b + (size_t)layer * C,
                        reinterpret_cast<const u32x4*>(m->mlp_bf16) + (size_t)layer * layer_u32x4,
                        m->mb1 + (size_t)layer * H, m->mb2 + (size_t)layer * C, m->ls + (size_t)layer * C,

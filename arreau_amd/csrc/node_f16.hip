@@ -204,7 +204,7 @@ int arreau_launch_mlp_f16x3(const arreau_model* m, int layer, const float* x_con
     constexpr int NW = 4;
     const size_t layer_u32x4 = (size_t)2 * H * C * 2 * 2 / 16;  // bytes of W1 + W2 as 2 fp16 planes, in 16-byte units
     const long long tiles = ((long long)N + 1) / 2;
-    hipLaunchKernelGGL((mlp_kernel_f16x3<128, 512, NW>), dim3((unsigned)((tiles + NW - 1) / NW)), dim3(64 * NW), 0, s,
+    ARREAU_LAUNCH((mlp_kernel_f16x3<128, 512, NW>), dim3((unsigned)((tiles + NW - 1) / NW)), dim3(64 * NW), 0, s,
                        x_conv, x_in, x_out, m->ln_w + (size_t)layer * C, m->ln_b + (size_t)layer * C,
                        reinterpret_cast<const u32x4*>(m->mlp_f16) + (size_t)layer * layer_u32x4,
                        m->mb1 + (size_t)layer * H, m->mb2 + (size_t)layer * C, m->ls + (size_t)layer * C,

@@ -510,7 +510,7 @@ int arreau_launch_mlp_f16x3_m16_split(const arreau_model* m, int layer, const fl
     }
     const size_t layer_u32x4 = (size_t)2 * H * C * 2 * 2 / 16;
     const u32x4* stream = reinterpret_cast<const u32x4*>(m->mlp_f16m) + (size_t)layer * layer_u32x4;
-    hipLaunchKernelGGL((mlp_kernel_f16x3_m16_split<128, 512>), dim3((unsigned)(n1 - n0)), dim3(512), 0, s, x_conv, x_in, x_out,
+    ARREAU_LAUNCH((mlp_kernel_f16x3_m16_split<128, 512>), dim3((unsigned)(n1 - n0)), dim3(512), 0, s, x_conv, x_in, x_out,
                        m->ln_w + (size_t)layer * C, m->ln_b + (size_t)layer * C, stream, m->mb1 + (size_t)layer * H,
                        m->mb2 + (size_t)layer * C, m->ls + (size_t)layer * C, m->ro_wv + (size_t)layer * C, m->ro_bv_host[layer],
                        n0, layer == 0 ? 1 : 0, xbar + (size_t)layer * Ntot * C, vsum);
@@ -565,7 +565,7 @@ int arreau_launch_mlp_f16x3_m16(const arreau_model* m, int layer, const float* x
     // per step, no gain -- the L2 -> LDS latency is already covered by one chunk of matrix work -- so the smaller one stays)
     static const int slots = [] { const char* e = getenv("ARREAU_MLP_SLOTS"); return e && atoi(e) == 4 ? 4 : 3; }();
     auto launch = [&](auto kernel) {
-        hipLaunchKernelGGL(kernel, grid, block, 0, s, x_conv, x_in, x_out, lnw, lnb, stream, m->mb1 + (size_t)layer * H,
+        ARREAU_LAUNCH(kernel, grid, block, 0, s, x_conv, x_in, x_out, lnw, lnb, stream, m->mb1 + (size_t)layer * H,
                            m->mb2 + (size_t)layer * C, m->ls + (size_t)layer * C, m->ro_wv + (size_t)layer * C,
                            m->ro_bv_host[layer], n0, n1, layer == 0 ? 1 : 0, xbar + (size_t)layer * Ntot * C, vsum);
     };

@@ -228,13 +228,13 @@ int arreau_launch_reverse(const arreau_model* m, float* d_frac, int32_t* d_types
                           const int32_t* d_batch) {
     const int n0 = r.n0, n1 = r.n1 < 0 ? N : r.n1, b0 = r.b0, b1 = r.b1 < 0 ? B : r.b1;
     if (b1 > b0) {
-        hipLaunchKernelGGL(reverse_lattice_kernel, dim3((4 * (b1 - b0) + 127) / 128), dim3(128), 0, s, d_lengths, d_angles, d_t, d_off,
+        ARREAU_LAUNCH(reverse_lattice_kernel, dim3((4 * (b1 - b0) + 127) / 128), dim3(128), 0, s, d_lengths, d_angles, d_t, d_off,
                            d_len0, noise, m->vp_alpha_bars, m->vp_betas, b1, m->T, d_lattice, d_fixed_lengths, m->status, b0,
                            d_gs_atoms, d_gs_atoms ? const_cast<float*>(d_len0) : nullptr);
         ARREAU_CHECK_HIP(hipGetLastError());
     }
     if (n1 > n0) {
-        hipLaunchKernelGGL(reverse_atoms_kernel, dim3((n1 - n0 + 3) / 4), dim3(256), 0, s, d_frac, d_types, d_t, d_off, B, n1,
+        ARREAU_LAUNCH(reverse_atoms_kernel, dim3((n1 - n0 + 3) / 4), dim3(256), 0, s, d_frac, d_types, d_t, d_off, B, n1,
                            d_eps, d_logits, noise, m->ve_sigmas, m->q1t, m->qmats, m->S, m->T, d_const_types, m->qmats_absorbing,
                            m->status, n0, d_batch);
         ARREAU_CHECK_HIP(hipGetLastError());
@@ -273,7 +273,7 @@ extern "C" int arreau_philox_fill(uint64_t seed, int32_t timestep, int32_t kind,
                                   void* stream) {
     ARREAU_REQUIRE((d_out || d_raw) && n >= 0 && kind >= 0 && kind <= 2, "arreau_philox_fill: bad argument");
     if (n == 0) return ARREAU_OK;
-    hipLaunchKernelGGL(philox_fill_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, seed,
+    ARREAU_LAUNCH(philox_fill_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, seed,
                        (uint32_t)timestep, (uint32_t)kind, n, d_out, d_raw);
     ARREAU_CHECK_HIP(hipGetLastError());
     return ARREAU_OK;

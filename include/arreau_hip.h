@@ -338,6 +338,12 @@ int arreau_train_conv_stats(arreau_model* model, float* d_stats, void* stream);
 int arreau_profile_edge_kernel(int32_t enable);
 int arreau_edge_kernel_time_ms(double* mean_ms, int64_t* launches);
 
+/* Debug aid, no reference counterpart: the "uninitialised-state probe".  pattern != 0: every kernel launch of the
+ * sampling path is preceded (same stream) by a kernel that fills every CU's LDS and vector registers with `pattern`;
+ * 0 switches it off.  A correct kernel's outputs do not depend on what the previous wave left on its CU, so results
+ * must be bit-identical for every pattern (eager launches only; process-wide).  tests/test_gpu_parity.py uses it. */
+int arreau_debug_set_pollution(uint32_t pattern);
+
 #ifdef __cplusplus
 }
 #endif

@@ -964,6 +964,58 @@ def test_sliced_multi_stream_execution_is_bitwise_the_whole_batch(dev, full_mode
     eng.check_status()
 
 
+@pytest.mark.parametrize("case", ["small-launch forms (3 crystals)", "throughput forms (ragged 64 crystals)", "large cells (2 x 64 atoms)"])
+def test_outputs_do_not_depend_on_leftover_lds_or_registers(dev, full_model, case):
+    """The uninitialised-state probe (arreau_debug_set_pollution): before EVERY kernel of the evaluation a polluter kernel
+    fills each CU's LDS and vector registers with a pattern, and the workspace in HBM is filled with another.  A kernel
+    that reads LDS, registers or workspace bytes it never wrote -- harmless and perfectly repeatable while it runs alone
+    (it finds its own kernel's leftovers), different as soon as another stream's or process's waves use the same CU,
+    which is the signature of the non-reproducibility of DESIGN.md section 8 -- shows up here on ONE stream, as outputs
+    that change with the pattern.  Scores, neighbour lists and three eager sampler steps must be bit-identical for every
+    pattern."""
+    from arreau_amd import _hip
+    from arreau_amd.diffusion.diffusion_helpers import crystal_offsets
+    m, _ = full_model
+    eng = m.engine()
+    rng = np.random.RandomState(11)
+    counts = {"small": [8, 5, 3], "throu": [int(v) for v in rng.randint(3, 21, size=64)], "large": [64, 64]}[case[:5]]
+    frac, types, lengths, angles, na = random_state(90, counts, 5, sampler_like=case[:5] != "large", cell=(6.0, 9.0))
+    B, N = len(counts), sum(counts)
+    d = lambda v: v.to(dev).contiguous()
+    off = crystal_offsets(na, dev)
+    t_c = torch.full((B,), 700, device=dev, dtype=torch.int32)
+
+    def evaluate(pattern, ws_fill):
+        _hip.check(_hip.lib().arreau_debug_set_pollution(pattern), "arreau_debug_set_pollution")
+        try:
+            eng.workspace(N, B).fill_(ws_fill)
+            eps, logits, len0, edges = eng.predict_scores(d(frac), d(types.to(torch.int32)), d(lengths), d(angles), t_c, off,
+                                                          return_edges=True)
+            deg = edges[0]
+            live = (torch.arange(eng.k, device=dev)[None, :] < deg[:, None])
+            graph = [deg, torch.where(live, edges[1], -7), torch.where(live[..., None], edges[2], 0.0),
+                     torch.where(live, edges[3], 0.0)]
+            eng.workspace(N, B).fill_(ws_fill)
+            f, ty, le, lat = d(frac.clone() % 1), d(types.to(torch.int32)), d(lengths.clone()), torch.zeros(B, 3, 3, device=dev)
+            eng.sample_loop(f, ty, le, d(angles), off, 999, 3, 77, None, lat, use_graph=False)
+            torch.cuda.synchronize()
+            return [eps, logits, len0] + graph + [f, ty, le, lat]
+        finally:
+            _hip.check(_hip.lib().arreau_debug_set_pollution(0), "arreau_debug_set_pollution")
+
+    names = ["eps", "logits", "len0", "deg", "src", "dir", "dist", "frac", "types", "lengths", "lattice"]
+    ref = evaluate(0, 0)
+    assert all(torch.isfinite(x.float()).all() for x in ref)
+    report = []
+    for pattern, ws_fill in ((0x7FC00000, 0xFF), (0x3F800000, 0x3F), (0xFFFFFFFF, 0x7F), (0x00000001, 0x80), (0x477FE000, 0x47)):
+        out = evaluate(pattern, ws_fill)
+        bad = [n for n, a, b in zip(names, ref, out) if not torch.equal(a, b)]
+        report.append((hex(pattern), hex(ws_fill), bad))
+    print(f"[pollution probe, {case}] (pattern, workspace fill, outputs that changed): {report}")
+    assert all(not bad for _, _, bad in report), report
+    eng.check_status()
+
+
 def test_graph_replay_matches_eager_loop(dev, small_model):
     """PONITA_DIFFUSION.sample: the hipGraph replay of the step follows the eager loop bit for bit (the noise is a
     function of (seed, timestep, element), not of how the step was launched)."""
