@@ -21,7 +21,7 @@ EXPORTS = [
     "arreau_model_status", "arreau_model_set_variant", "arreau_ponita_forward",
     "arreau_diffusion_noise", "arreau_diffusion_losses", "arreau_sample_loop", "arreau_philox_fill",
     "arreau_train_forward", "arreau_train_backward", "arreau_train_conv_stats", "arreau_model_update_train_weights",
-    "arreau_model_set_batch_layout", "arreau_debug_set_pollution",
+    "arreau_model_set_batch_layout", "arreau_debug_set_pollution", "arreau_debug_leftover_fraction",
 ]
 
 STATUS_NONFINITE, STATUS_BAD_TIMESTEP, STATUS_BAD_TYPE = 1, 2, 4
@@ -105,6 +105,7 @@ def lib():
     L.arreau_model_update_train_weights.argtypes = [c_void_p, POINTER(StateDict), c_void_p]
     L.arreau_model_set_batch_layout.argtypes = [c_void_p, c_void_p, c_int32, c_int32]
     L.arreau_debug_set_pollution.argtypes = [ctypes.c_uint32]
+    L.arreau_debug_leftover_fraction.argtypes = [ctypes.c_uint32, POINTER(c_double), POINTER(c_double), c_void_p]
     L.arreau_profile_edge_kernel.argtypes = [c_int32]
     L.arreau_edge_kernel_time_ms.argtypes = [POINTER(c_double), POINTER(c_int64)]
     for name in EXPORTS:

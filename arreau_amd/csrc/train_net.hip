@@ -13,6 +13,7 @@
 // the read-outs (ponita.py:126-155); the backward is what autograd derives from those (training_step,
 // lightning_wrappers/diffusion.py:108-118).  Gradients are returned in the state_dict layout (arreau_state_dict with
 // DEVICE pointers; non-trainable entries are ignored).
+#include <string.h>
 #include <algorithm>
 #include <vector>
 
@@ -744,6 +745,8 @@ static int ensure_ctx(arreau_model* m, int N, int B, hipStream_t s) {
         ARREAU_CHECK_HIP(hipStreamSynchronize(s));
         arreau_train_ctx_destroy(t);
         m->train = nullptr;
+        // a cached step graph of arreau_sample_loop (general path) points into the block just freed: never replay it
+        memset(m->graph_key, 0, sizeof(m->graph_key));
     }
     t = new arreau_train_ctx();
     t->capN = capN; t->capB = capB;

@@ -241,10 +241,10 @@ class DiffusionLoss(nn.Module):
         if (use_graph or fixed_cell) and noise != "philox":
             raise ValueError("graph replay and fixed-cell sampling need noise='philox' (the in-kernel generator)")
 
-        # One stream.  Running the batch as two pipelined slices on separate streams (arreau_model_set_batch_layout, kept as
-        # an opt-in: `pipelined_slices=2`) was 3 % faster at 256 x 20 on MI355X, but its results are not reproducible:
-        # in about one run in four one crystal differs at the 1e-5 level from the one-stream loop (DESIGN.md section 8:
-        # kernels of different slices sharing a CU), and parity comes first.
+        # One stream.  Running the batch as two pipelined slices on separate streams (`pipelined_slices=2`) was 3 % faster
+        # at 256 x 20 on MI355X, but its results are not reproducible -- in about one run in four one crystal differs at the
+        # 1e-5 level from the one-stream loop, cause unknown -- and parity comes first: the library
+        # refuses the mode unless ARREAU_ALLOW_MULTISTREAM=1 is set (an experiment, not a product mode).
         eng.set_batch_layout(num_atoms, groups=max(1, int(pipelined_slices)))
         if noise == "philox":
             if seed is None:

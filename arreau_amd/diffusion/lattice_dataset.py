@@ -131,10 +131,15 @@ def collate(items):
 def iterate_batches(dataset, batch_size: int, shuffle: bool = True, seed: int = 0, rank: int = 0, world_size: int = 1,
                     drop_last: bool = False):
     """One epoch of batches for data-parallel rank `rank` of `world_size`: every rank uses the same permutation (seeded)
-    and takes every world_size-th crystal, like DistributedSampler under Lightning's DDP (main_diffusion.py:293-303)."""
+    and takes every world_size-th crystal, like DistributedSampler under Lightning's DDP (main_diffusion.py:293-303).
+    With several ranks the permutation is first cut to a multiple of world_size (DistributedSampler's drop_last), so every
+    rank sees the same number of crystals and therefore of batches: a rank with one batch more than its peers would wait
+    for ever in that step's all-reduce."""
     order = np.arange(len(dataset))
     if shuffle:
         np.random.RandomState(seed).shuffle(order)
+    if world_size > 1:
+        order = order[:len(order) - len(order) % world_size]
     mine = order[rank::world_size]
     for s in range(0, len(mine), batch_size):
         idx = mine[s:s + batch_size]

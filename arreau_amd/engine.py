@@ -120,10 +120,10 @@ class HipEngine:
 
     def set_batch_layout(self, num_atoms, groups=0):
         """Tell the library the (host-side) atom count of every crystal of the batches that follow, so that it may run
-        the score network as `groups` crystal-aligned slices on separate streams (arreau_model_set_batch_layout;
-        groups = 0: the library's default, ARREAU_GROUPS or off).  Every slice computes what the whole-batch launches
-        compute for its atoms, but with more than one slice kernels of different slices share CUs, and on MI355X that was
-        seen to change a result at the 1e-5 level in rare evaluations: opt-in, off by default."""
+        the score network as `groups` crystal-aligned slices (arreau_model_set_batch_layout; groups = 0: the library's
+        default, ARREAU_GROUPS or off).  Slices on SEPARATE STREAMS are an experiment the library refuses unless
+        ARREAU_ALLOW_MULTISTREAM=1 is set: with kernels of two streams sharing CUs results were seen to change at the
+        1e-8 .. 1e-4 level in rare runs, cause unknown."""
         n = torch.as_tensor(num_atoms).to("cpu", torch.int64).reshape(-1)
         off = torch.zeros(n.numel() + 1, dtype=torch.int32)
         off[1:] = torch.cumsum(n, 0).to(torch.int32)

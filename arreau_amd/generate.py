@@ -98,7 +98,22 @@ def main():
         import numpy as np
         torch.manual_seed(args.seed + rank)
         np.random.seed(args.seed + rank)
-    fn = lambda n, b: model.sample(n, b, VisualizationSetting.NONE, False)
+    # ARREAU_GENERATE_GPU_LOCK=<file>: ranks that SHARE one device (the one-GPU rehearsal above) take turns on it -- a file
+    # lock held around each sampler call.  On a node every rank owns its GPU and the variable is not set.
+    lock_path = os.environ.get("ARREAU_GENERATE_GPU_LOCK")
+
+    def fn(n, b):
+        if not lock_path:
+            return model.sample(n, b, VisualizationSetting.NONE, False)
+        import fcntl
+        with open(lock_path, "a") as lock:
+            fcntl.flock(lock, fcntl.LOCK_EX)
+            try:
+                out = model.sample(n, b, VisualizationSetting.NONE, False)
+                torch.cuda.synchronize()
+                return out
+            finally:
+                fcntl.flock(lock, fcntl.LOCK_UN)
     res = generate_n_crystals(fn, args.num_crystals, args.num_atoms, args.batch, rank, world)
     if rank == 0:
         print("wrote", save_sample_results(res, args.out))

@@ -149,7 +149,19 @@ class PONITA_DIFFUSION(nn.Module):
         if all(bool(layer.conv.callibrated) for layer in layers):
             self._all_callibrated = True
             return
-        st = eng.conv_stats().cpu().double()
+        st = eng.conv_stats()
+        # Data-parallel training: every rank saw different crystals and noise, so its activation statistics differ; the
+        # replicas must apply ONE set of ratios or their weights diverge for good (only gradients are exchanged
+        # afterwards).  Rank 0's statistics are used everywhere -- what a single-GPU run of the reference computes.
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            if dist.get_backend() == "nccl":
+                dist.broadcast(st, src=0)
+            else:
+                host = st.cpu()
+                dist.broadcast(host, src=0)
+                st = host
+        st = st.cpu().double()
         with torch.no_grad():
             for l, layer in enumerate(layers):
                 if bool(layer.conv.callibrated):

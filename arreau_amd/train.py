@@ -123,6 +123,22 @@ def main():
     model = PONITA_DIFFUSION(net_args, ds.z_table).to(f"cuda:{local_rank}")
     torch.manual_seed(args.seed + 1000 + rank)  # different noise per rank
     train_epochs(model, ds, args.epochs, args.batch_size, rank, world, args.seed)
+    # data-parallel invariant: the replicas hold the same weights (same initial weights, same averaged gradients, ONE set
+    # of calibration ratios); a drift here means a rank applied something its peers did not
+    check = torch.stack([p.detach().double().sum() for p in model.parameters()]).sum().reshape(1)
+    if world > 1:
+        sums = [torch.zeros_like(check) for _ in range(world)]
+        if dist.get_backend() == "nccl":
+            dist.all_gather(sums, check)
+        else:
+            host = [s.cpu() for s in sums]
+            dist.all_gather(host, check.cpu())
+            sums = host
+        vals = [float(s) for s in sums]
+        if rank == 0:
+            print("replica parameter checksums:", " ".join(f"{v:.12e}" for v in vals))
+        if max(vals) - min(vals) > 1e-9 * max(1.0, abs(vals[0])):
+            raise SystemExit(f"rank {rank}: data-parallel replicas diverged: {vals}")
     if rank == 0 and args.out:
         print("wrote", save_lightning_checkpoint(args.out, model))
     if world > 1:

@@ -140,8 +140,8 @@ def parse_args(argv=None):
                     "statistics and PMC counters of whole-batch launches only); implies --eager-value")
     ap.add_argument("--eager-value", action="store_true", help="report the eager loop as `value` even where the product "
                     "defaults to graph replay")
-    ap.add_argument("--groups", type=int, default=0, help="opt-in: slices of the batch run on separate streams (0 = the product's "
-                    "default, one stream; 2 was 3 %% faster at 256 x 20 but is not run-to-run reproducible)")
+    ap.add_argument("--groups", type=int, default=0, help="experiment, needs ARREAU_ALLOW_MULTISTREAM=1: slices of the batch on separate streams "
+                    "(0 = the product: one stream; 2 was 3 %% faster at 256 x 20 but is not run-to-run reproducible)")
     args = ap.parse_args(argv)
     B, n, T = CONFIGS[args.config or "c2"]
     args.batch_per_gpu = args.batch_per_gpu or B
@@ -153,13 +153,38 @@ def parse_args(argv=None):
 # --------------------------------------------------------------------------------------------------------------
 # self-launch: `python bench.py --gpus N` (no torchrun) starts N rank processes, one per GPU
 # --------------------------------------------------------------------------------------------------------------
+def visible_gpu_count():
+    """GPUs this process could use, counted WITHOUT touching HIP (the launcher parent must stay a process that never
+    initialised the GPU runtime): KFD topology nodes with SIMDs (CPU nodes have simd_count 0), narrowed by the
+    *_VISIBLE_DEVICES lists a launcher may have set."""
+    import glob
+    n = 0
+    props = glob.glob("/sys/class/kfd/kfd/topology/nodes/*/properties")
+    if not props:  # no KFD topology in this mount namespace: one DRM render node per GPU
+        n = len(glob.glob("/dev/dri/renderD*"))
+    for prop in props:
+        try:
+            with open(prop) as fh:
+                for line in fh:
+                    key, _, val = line.partition(" ")
+                    if key == "simd_count":
+                        n += int(val) > 0
+                        break
+        except OSError:
+            pass
+    for var in ("ROCR_VISIBLE_DEVICES", "HIP_VISIBLE_DEVICES", "CUDA_VISIBLE_DEVICES"):
+        lst = os.environ.get(var)
+        if lst is not None:
+            n = min(n, len([x for x in lst.split(",") if x.strip() != ""]))
+    return n
+
+
 def launch_ranks(n, argv, stub=False):
     """Start `n` copies of this script as ranks 0..n-1 (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their
     environment) BEFORE this process touches a GPU; rank 0's stdout (the JSON line) is passed through.  Returns the
     exit code (non-zero if any rank failed; the others are then stopped by PID)."""
     if not stub and os.environ.get("ARREAU_BENCH_ONE_DEVICE", "0") != "1":  # (rehearsal mode shares one GPU)
-        import torch
-        have = torch.cuda.device_count()  # does not initialise the GPU runtime in this process
+        have = visible_gpu_count()  # sysfs + environment only: this parent never calls into HIP
         if have < n:
             log(f"--gpus {n} requested but only {have} GPU(s) are visible")
             return 2

@@ -149,8 +149,11 @@ int arreau_model_set_variant(arreau_model* model, int32_t edge_variant, int32_t 
  * synchronisation).  Crystals are independent and every kernel takes a node range over whole-batch arrays, so
  * every slice computes what the unsliced run computes for its atoms; the slices drift into different phases and the
  * HBM-bound message-passing kernel of one overlaps the matrix-bound edge / MLP kernels of another (3-5 % at 256 x 20).
- * OPT-IN, off by default: on MI355X kernels of different streams sharing a CU were seen to change a result at the 1e-5
- * level in rare evaluations, so a sliced run is not guaranteed bit-identical to the unsliced one.
+ * EXPERIMENT, refused by default (ARREAU_EINVAL for groups > 1 unless the environment holds ARREAU_ALLOW_MULTISTREAM=1):
+ * on MI355X, with kernels of two streams or two processes sharing CUs, one crystal in a few runs came out different at
+ * the 1e-8 .. 1e-4 level and the cause is not known, so a sliced multi-stream run is not
+ * guaranteed identical to the unsliced one.  ARREAU_SLICE_EAGER=serial runs the slices' range launches one after another
+ * on the caller's stream (bit-identical to the unsliced run; what the tests of the range launches use).
  * groups <= 0: the library's default (environment ARREAU_GROUPS, else 1 = off).  Used only with the default kernel set;
  * ignored otherwise. */
 int arreau_model_set_batch_layout(arreau_model* model, const int32_t* h_crystal_offsets, int32_t B, int32_t groups);
@@ -343,6 +346,9 @@ int arreau_edge_kernel_time_ms(double* mean_ms, int64_t* launches);
  * 0 switches it off.  A correct kernel's outputs do not depend on what the previous wave left on its CU, so results
  * must be bit-identical for every pattern (eager launches only; process-wide).  tests/test_gpu_parity.py uses it. */
 int arreau_debug_set_pollution(uint32_t pattern);
+/* The probe's positive control: one kernel per CU READS the whole LDS and 16 vector registers per lane without writing
+ * them first and reports the fraction of words equal to `pattern` (close to 1 right after a pollution with it). */
+int arreau_debug_leftover_fraction(uint32_t pattern, double* lds_fraction, double* reg_fraction, void* stream);
 
 #ifdef __cplusplus
 }

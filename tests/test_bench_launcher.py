@@ -29,11 +29,26 @@ def test_self_launch_two_ranks_stub():
 
 def test_self_launch_refuses_when_gpus_are_missing():
     """Without the stub, asking for more GPUs than are visible must fail loudly (never a silent 1-GPU run)."""
-    import torch
-    want = torch.cuda.device_count() + 2
+    sys.path.insert(0, ROOT)
+    import bench
+    want = bench.visible_gpu_count() + 2
     p = _run(["--gpus", str(want), "--steps", "1", "--warmup", "0"])
     assert p.returncode != 0
     assert "GPU(s) are visible" in p.stderr and not p.stdout.strip()
+
+
+def test_gpu_count_comes_from_sysfs_and_visibility_lists(monkeypatch):
+    """The launcher parent counts devices without calling into HIP: KFD topology + *_VISIBLE_DEVICES."""
+    sys.path.insert(0, ROOT)
+    import bench
+    base = bench.visible_gpu_count()
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "0")
+    assert bench.visible_gpu_count() == min(base, 1)
+    monkeypatch.setenv("HIP_VISIBLE_DEVICES", "")
+    assert bench.visible_gpu_count() == 0
+    src = open(BENCH).read()
+    body = src[src.index("def launch_ranks"):src.index("def main()")]
+    assert "import torch" not in body and "device_count" not in body
 
 
 def test_world_size_mismatch_is_an_error():

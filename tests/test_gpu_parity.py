@@ -22,20 +22,34 @@ GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 TOL = 1e-5
 
 
-def assert_scores_close(got, want, tag=""):
+def ulp32(x):
+    """Spacing of float32 numbers at magnitude x."""
+    return float(np.spacing(np.float32(abs(float(x)))))
+
+
+def pooled_bound(ref, atoms_per_crystal=20, ulps=4):
+    """Bound for a per-crystal pooled read-out (len0 / global_scalar): a SUM over the crystal's atoms, so its error is a
+    few fp32 ulps of the sum, not a fraction of 1e-5 of it -- 4 ulps of the largest value for crystals of up to 20 atoms
+    (measured: 3 ulps at |len0| ~ 58; the fp32 oracle is as far from fp64), growing with the square root of the atom
+    count; never below the plain 1e-5 of an order-one quantity."""
+    scale = max(1.0, (atoms_per_crystal / 20.0) ** 0.5)
+    return max(TOL, ulps * scale * ulp32(float(ref.abs().max())))
+
+
+def assert_scores_close(got, want, tag="", atoms_per_crystal=20):
     """The north-star bound -- per-step scores, type logits and lattice predictions within 1e-5 of the fp32 CPU path --
     as plain absolute 1e-5 wherever the quantity is of order one.  Measured (profiles/parity_r02.json, S = 90 model):
-    eps <= 2.3e-7, logits <= 2.6e-6 at |logits| ~ 6, len0 <= 1.2e-5 at |len0| ~ 58 (2 fp32 ulps of a sum over the
-    crystal's atoms; the fp32 oracle itself is that far from fp64).  A quantity larger than order one is allowed the
-    same RELATIVE error, each against its own magnitude only: logits 1e-5 * max(1, |logits|max / 8),
-    len0 1e-5 * max(1, |len0|max), eps 1e-5 * max(1, |eps|max)."""
+    eps <= 2.3e-7, logits <= 2.6e-6 at |logits| ~ 6, len0 <= 1.2e-5 at |len0| ~ 58.  A quantity larger than order one is
+    allowed the same RELATIVE error against its own magnitude: logits 1e-5 * max(1, |logits|max / 8), eps 1e-5 * max(1,
+    |eps|max); len0, a sum over the crystal's atoms, is bounded in fp32 ulps of that sum (pooled_bound: 4 ulps = 1.5e-5
+    at |len0| = 58, where round 2 allowed 5.8e-4)."""
     (eps, logits, len0), (eps_o, logits_o, len0_o) = got, want
     e = float((eps.detach().cpu() - eps_o).abs().max())
     l = float((logits.detach().cpu() - logits_o).abs().max())
     g = float((len0.detach().cpu() - len0_o).abs().max())
     assert e <= TOL * max(1.0, float(eps_o.abs().max())), (tag, "eps", e)
     assert l <= TOL * max(1.0, float(logits_o.abs().max()) / 8.0), (tag, "logits", l, float(logits_o.abs().max()))
-    assert g <= TOL * max(1.0, float(len0_o.abs().max())), (tag, "len0", g, float(len0_o.abs().max()))
+    assert g <= pooled_bound(len0_o, atoms_per_crystal), (tag, "len0", g, float(len0_o.abs().max()), pooled_bound(len0_o, atoms_per_crystal))
     return e, l, g
 
 
@@ -235,7 +249,7 @@ def test_forward_operator_seam(dev, small_model):
     assert vec_out.shape == (11, 1, 3) and gvec is None and edge_out == [None] * 5
     assert (logits.cpu() - logits_o).abs().max() <= TOL * max(1.0, float(logits_o.abs().max()))
     assert (vec_out.squeeze(1).cpu() - eps_o).abs().max() <= TOL * max(1.0, float(eps_o.abs().max()))
-    assert (gscalar.cpu() - len0_o).abs().max() <= TOL * 6 * max(1.0, float(len0_o.abs().max()))
+    assert (gscalar.cpu() - len0_o).abs().max() <= pooled_bound(len0_o, 6)
     # features outside the sampler's image
     g = torch.Generator().manual_seed(5)
     x2 = x.float().clone()
@@ -248,7 +262,7 @@ def test_forward_operator_seam(dev, small_model):
     logits, vec_out, gscalar, _, _ = m(mk(x2, vec2))
     assert (logits.cpu() - lo).abs().max() <= TOL * max(1.0, float(lo.abs().max()))
     assert (vec_out.cpu() - vo).abs().max() <= TOL * max(1.0, float(vo.abs().max()))
-    assert (gscalar.cpu() - go).abs().max() <= TOL * 6 * max(1.0, float(go.abs().max()))
+    assert (gscalar.cpu() - go).abs().max() <= pooled_bound(go, 6)
     assert (logits.cpu() - logits_o).abs().max() > 1e-3  # and it really is a different answer than the decoded state's
     with pytest.raises(ValueError):  # atoms of a crystal must be contiguous
         bad = mk(x, vec)
@@ -562,7 +576,7 @@ def test_generate_two_ranks_through_the_real_sampler(dev, tmp_path):
     """arreau_amd.generate (the role of main_diffusion_generate.py:52-94) driven end to end: a Lightning-format
     checkpoint on disk, two ranks (gloo, sharing this box's one GPU), the real PONITA_DIFFUSION.sample on each, results
     gathered on rank 0 in crystal order and written in the crystals.h5 layout.  Rank 0's crystals must equal, bit for
-    bit, the single-process run of the same slice under the same seed."""
+    bit, the single-process run of the same slice under the same seed (all three of them)."""
     import socket
     import subprocess
     import sys
@@ -571,7 +585,8 @@ def test_generate_two_ranks_through_the_real_sampler(dev, tmp_path):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     ckpt = save_lightning_checkpoint(str(tmp_path / "last.ckpt"), make_synthetic_model(S=12, seed=3, num_timesteps=30))
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
-    env.update(ARREAU_GENERATE_BACKEND="gloo", ARREAU_GENERATE_ONE_DEVICE="1", PYTHONPATH=root)
+    env.update(ARREAU_GENERATE_BACKEND="gloo", ARREAU_GENERATE_ONE_DEVICE="1", PYTHONPATH=root,
+               ARREAU_GENERATE_GPU_LOCK=str(tmp_path / "gpu.lock"))
     with socket.socket() as sk:
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
@@ -588,17 +603,40 @@ def test_generate_two_ranks_through_the_real_sampler(dev, tmp_path):
     assert two.frac_x.shape == (24, 3) and two.lattice.shape == (6, 3, 3)
     assert np.isfinite(two.frac_x).all() and (two.frac_x >= 0).all() and (two.frac_x <= 1).all()
     assert set(two.atomic_numbers.tolist()) <= set(float(z) for z in list(range(1, 12)) + [2001])
-    # rank 0's slice = the single-process run.  (The two ranks of this rehearsal share ONE GPU, so their kernels share CUs --
-    # the condition under which a result was seen to change at the 1e-5 level in rare evaluations; on a
-    # node every rank has its own GPU.  Required here: at least two of the three crystals bit for bit, all of them close.)
-    same = 0
+    # rank 0's slice = the single-process run, bit for bit.  (The two ranks of this rehearsal share the box's ONE GPU and
+    # take turns on it -- ARREAU_GENERATE_GPU_LOCK, a file lock around each sampler call -- because on a node every rank owns
+    # its GPU, and kernels of two processes sharing CUs are the condition of DESIGN.md section 8.)
     for i in range(3):
-        pairs = list(zip(get_one_crystal(two, i), get_one_crystal(one, i)))
-        same += all(np.array_equal(a, b) for a, b in pairs)
-        for a, b in pairs:
-            assert np.asarray(a).shape == np.asarray(b).shape
-    assert same >= 2, same
+        for a, b in zip(get_one_crystal(two, i), get_one_crystal(one, i)):
+            assert np.array_equal(a, b), i
     assert not np.array_equal(two.frac_x[:12], two.frac_x[12:])  # rank 1 sampled its own crystals
+
+
+def test_bench_self_launch_two_ranks_on_this_gpu(dev):
+    """`python bench.py --gpus 2` with no launcher around it, end to end on the real kernels: the parent starts two rank
+    processes (it never touches HIP itself), both share this box's one GPU (ARREAU_BENCH_ONE_DEVICE=1; RCCL cannot put two
+    ranks on one device, so the timing barrier runs on gloo), and rank 0 prints ONE JSON line with n_gpus = 2, one time per
+    rank and the whole-job rate = 2 x the crystals of a rank / the slower rank's time.  What the driver's 8-GPU run does
+    with eight devices (main_diffusion_generate.py:67-92: disjoint sub-batches, no exchange)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    env.update(ARREAU_BENCH_ONE_DEVICE="1", ARREAU_BENCH_BACKEND="gloo")
+    p = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                        "--batch-per-gpu", "64", "--no-cpu-baseline", "--no-fp32-variant", "--no-full-sampler"], env=env, cwd=root,
+                       capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0, p.stderr[-3000:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1, p.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and len(d["per_rank_ms"]) == 2 and d["scaling"] == "weak"
+    assert d["unit"] == "crystal-steps/s" and d["roofline"]["bound"] in ("mfma", "hbm") and d["vs_baseline"] is None
+    assert d["ms_per_step"] >= max(d["per_rank_ms"]) * 0.999
+    want = 2 * 64 / (d["ms_per_step"] * 1e-3)  # both ranks' crystals over the max-over-ranks time
+    assert abs(d["value"] - want) <= 1e-6 * want, (d["value"], want)
+    print(f"[bench --gpus 2 on one device] per-rank ms {d['per_rank_ms']}, value {d['value']:.0f} crystal-steps/s")
 
 
 def test_constant_atomic_symbols(dev, small_model):
@@ -624,13 +662,15 @@ def test_large_cell_regime_vs_oracle(dev, small_model):
     eps_o, logits_o, len0_o, (ei, _d, _dr, _c, _l) = _oracle_scores(om32, *state, 40)
     assert ei.shape[1] == 8 * 128  # saturated graph
     eps, logits, len0 = _engine_scores(m, dev, state, 40)
-    assert_scores_close((eps, logits, len0), (eps_o, logits_o, len0_o))
+    assert_scores_close((eps, logits, len0), (eps_o, logits_o, len0_o), atoms_per_crystal=64)
 
 
-@pytest.mark.parametrize("B,n", [(256, 20), (64, 64), (1024, 20)])
+@pytest.mark.parametrize("B,n", [(256, 20), (64, 64), (1024, 20), (1024, 64)])
 def test_full_size_batch_independence_and_determinism(dev, full_model, B, n):
     """At the benchmark sizes (config 2: 256 x 20; config 4 regime: 64 atoms per crystal; config 3's per-GPU share:
-    1024 x 20 = 8192 crystals over 8 GPUs) the oracle is too slow,
+    1024 x 20 = 8192 crystals over 8 GPUs; BASELINE configs[3] at FULL size: 1024 x 64 = 65,536 atoms, a 16 GB K stash
+    whose per-layer blocks lie beyond 2^32 bytes, the two-pass neighbour list and the XCD-aware receiver order all at
+    once) the oracle is too slow,
     so use size-independent properties: (1) two evaluations are bitwise identical (no atomics, fixed summation
     order); (2) crystals are independent -- a crystal evaluated inside the big batch gives bitwise the same
     scores as the same crystal evaluated alone; (3) that lone crystal matches the oracle to 1e-5."""
@@ -650,7 +690,8 @@ def test_full_size_batch_independence_and_determinism(dev, full_model, B, n):
         eps1, logits1, len01 = _engine_scores(m, dev, one, t)
         assert torch.equal(eps1, a[0][sl]) and torch.equal(logits1, a[1][sl]) and torch.equal(len01, a[2][ci:ci + 1])
     eps_o, logits_o, len0_o, _ = _oracle_scores(om32, *one, t)
-    assert_scores_close((eps1, logits1, len01), (eps_o, logits_o, len0_o))
+    assert_scores_close((eps1, logits1, len01), (eps_o, logits_o, len0_o), atoms_per_crystal=n)
+    m.engine().check_status()
 
 
 def test_atom_permutation_equivariance(dev, small_model):
@@ -724,7 +765,7 @@ def test_rotation_equivariance_through_the_kernels(dev, rot):
     assert (direction @ R - direction).abs().max() > 0.5  # the kernels really saw different inputs
     scale = max(1.0, float(logits_a.abs().max()))
     assert (logits_a - logits_b).abs().max() <= 2 * TOL * scale
-    assert (gs_a - gs_b).abs().max() <= 2 * TOL * 6 * max(1.0, float(gs_a.abs().max()))
+    assert (gs_a - gs_b).abs().max() <= 2 * pooled_bound(gs_a.cpu(), 6)
     assert (vec_a.squeeze(1) @ R.to(dev) - vec_b.squeeze(1)).abs().max() <= 2 * TOL * max(1.0, float(vec_a.abs().max()))
     assert (vec_a - vec_b).abs().max() > 1e-3 * float(vec_a.abs().max())  # and the vector output did rotate
 
@@ -806,7 +847,14 @@ def test_launch_geometry_switches_and_counted_waits_are_bitwise_neutral(dev):
     # significand bits: tools/exp/k_precision_study.py).
     for x, y in zip(outs["k3off"], outs["conv0"]):
         assert torch.equal(x, y), "conv0"
-    assert_scores_close(outs["default"], outs["k3off"])
+    # What the 3-byte stash costs, bounded by what tools/exp/k_precision_study.py measured for 16 significand bits in the
+    # oracle (profiles/r02g_k_precision_study.txt: eps 7e-8, logits 3.6e-7 -- the fp32 rounding floor): a narrower stash
+    # format cannot eat the remaining parity margin silently.
+    d_eps, d_logits, d_len0 = (float((a - b).abs().max()) for a, b in zip(outs["default"], outs["k3off"]))
+    print(f"[K stash] |3-byte - fp32| : eps {d_eps:.2e}  logits {d_logits:.2e} (|logits| {float(outs['k3off'][1].abs().max()):.1f})"
+          f"  len0 {d_len0:.2e} (|len0| {float(outs['k3off'][2].abs().max()):.1f})")
+    assert d_eps <= 3e-7 and d_logits <= 1e-6 * max(1.0, float(outs["k3off"][1].abs().max()) / 8.0)
+    assert d_len0 <= 2 * ulp32(float(outs["k3off"][2].abs().max()))
 
 
 def _philox_ref(ctr, key):
@@ -898,70 +946,107 @@ def test_sample_loop_is_the_per_step_path_with_philox_noise(dev, small_model):
         eng.sample_loop(f2, ty2, le2, an, off, 3, 5, seed, None, lat2)  # would run past timestep 1
 
 
-@pytest.mark.parametrize("groups", [2, 4])
-def test_sliced_multi_stream_execution_is_bitwise_the_whole_batch(dev, full_model, groups):
-    """arreau_model_set_batch_layout: the score network run as crystal-aligned slices (ragged batch, uneven slices): the
-    range launches of every kernel give bit for bit the whole-batch result for predict_scores; the sampling loop as a
-    one-stream graph is bit-identical; the opt-in multi-stream pipelined loop runs and agrees crystal by crystal (see
-    below)."""
+def _ragged_37(dev):
     from arreau_amd.diffusion.diffusion_helpers import crystal_offsets
-    m, _ = full_model
-    eng = m.engine()
     rng = np.random.RandomState(3)
     counts = [int(v) for v in rng.randint(3, 21, size=37)]
-    state = random_state(90, counts, 12, sampler_like=True)
-    frac, types, lengths, angles, na = state
-    B, N = len(counts), sum(counts)
+    frac, types, lengths, angles, na = random_state(90, counts, 12, sampler_like=True)
     d = lambda v: v.to(dev).contiguous()
     off = crystal_offsets(na, dev)
+    return counts, (frac, types, lengths, angles, na), d, off
+
+
+@pytest.mark.parametrize("groups", [2, 4])
+def test_range_launches_are_bitwise_the_whole_batch(dev, full_model, groups):
+    """Every kernel of the score network takes a node range over whole-batch arrays (NodeRange).  The batch cut into
+    crystal-aligned slices (ragged batch, uneven slices) and run slice after slice on ONE stream gives bit for bit the
+    whole-batch result; the sampling loop as a one-stream hipGraph replay is bit-identical to the eager loop; and slices on
+    SEPARATE streams are refused unless the caller opts in to the experiment (next test)."""
+    from arreau_amd import _hip
+    m, _ = full_model
+    eng = m.engine()
+    counts, (frac, types, lengths, angles, na), d, off = _ragged_37(dev)
+    B = len(counts)
     t_c = torch.full((B,), 700, device=dev, dtype=torch.int32)
     args = (d(frac), d(types.to(torch.int32)), d(lengths), d(angles), t_c, off)
     eng.set_batch_layout(na, groups=1)
     whole = eng.predict_scores(*args)
-    # the range launches of every kernel, slice after slice on ONE stream: bit for bit the whole-batch result
     os.environ["ARREAU_SLICE_EAGER"] = "serial"  # (read when the layout is set)
     try:
         eng.set_batch_layout(na, groups=groups)
+        sliced = eng.predict_scores(*args)
     finally:
         del os.environ["ARREAU_SLICE_EAGER"]
-    sliced = eng.predict_scores(*args)
+        eng.set_batch_layout(na, groups=1)
     for x, y in zip(whole, sliced):
         assert torch.equal(x, y)
-    # the same slices forked onto their own streams (kernels of different slices now share CUs: see below)
-    os.environ["ARREAU_SLICE_EAGER"] = "1"
-    try:
+    assert "ARREAU_ALLOW_MULTISTREAM" not in os.environ
+    with pytest.raises(_hip.ArreauHipError, match="ARREAU_ALLOW_MULTISTREAM"):
         eng.set_batch_layout(na, groups=groups)
-    finally:
-        del os.environ["ARREAU_SLICE_EAGER"]
-    forked = eng.predict_scores(*args)
-    assert_scores_close(forked, tuple(x.cpu() for x in whole), tag="fork-join slices")
 
     def loop(use_graph):
         f, ty, le, lat = d(frac.clone()), d(types.to(torch.int32)), d(lengths.clone()), torch.zeros(B, 3, 3, device=dev)
         eng.sample_loop(f, ty, le, d(angles), off, 999, 5, 4242, None, lat, use_graph=use_graph)
         return f, ty, le, lat
 
-    eng.set_batch_layout(na, groups=1)
     ref = loop(False)
     for x, y in zip(ref, loop(True)):  # one stream, graph replay: bit-identical
         assert torch.equal(x, y)
-    # Opt-in pipelined slices (own stream and step graph per slice, staggered, no per-step join): every slice computes what
-    # the whole batch computes for its crystals, but kernels of different slices then share CUs, and on MI355X that was
-    # seen to change one crystal at the 1e-5 level in rare runs (DESIGN.md section 8) -- which is why the mode is off by
-    # default.  Asserted here: the loop runs, all but at most two crystals are bit-identical, the rest agree closely.
-    eng.set_batch_layout(na, groups=groups)
-    offs = off.cpu().numpy()
-    for use_graph in (False, True, True):    # (the second graph run reuses the cached per-slice graphs)
-        out = loop(use_graph)
-        atom_bad = (ref[0] != out[0]).any(1).cpu().numpy()
-        crystals_bad = {int(np.searchsorted(offs, i, side="right") - 1) for i in np.nonzero(atom_bad)[0]}
-        crystals_bad |= set(np.nonzero((ref[2] != out[2]).any(1).cpu().numpy())[0].tolist())
-        assert len(crystals_bad) <= 2, (use_graph, sorted(crystals_bad))
-        assert (ref[0] - out[0]).abs().max() <= 1e-2 and (ref[2] - out[2]).abs().max() <= 1e-2
-        if not use_graph:
-            assert not crystals_bad  # (the eager loop is not sliced)
-    eng.set_batch_layout(na, groups=1)
     eng.check_status()
+
+
+def test_multi_stream_experiment_report(dev, full_model):
+    """The opt-in experiment (ARREAU_ALLOW_MULTISTREAM=1): the same slices forked onto their own streams, and the pipelined
+    sampling loop (own stream and step graph per slice, no per-step join).  Every slice computes what the whole batch
+    computes for its crystals, so the results SHOULD be bit-identical -- on MI355X, with kernels of two streams sharing CUs,
+    one crystal in a few runs was not (cause unknown; hazards, counted waits and leftover LDS /
+    register state ruled out).  This test asserts bit-equality; a mismatch is reported as an expected failure with the
+    number of crystals that differed -- the datum of this run -- instead of being tolerated."""
+    m, _ = full_model
+    eng = m.engine()
+    counts, (frac, types, lengths, angles, na), d, off = _ragged_37(dev)
+    B = len(counts)
+    offs = off.cpu().numpy()
+    t_c = torch.full((B,), 700, device=dev, dtype=torch.int32)
+    args = (d(frac), d(types.to(torch.int32)), d(lengths), d(angles), t_c, off)
+
+    def loop(use_graph):
+        f, ty, le, lat = d(frac.clone()), d(types.to(torch.int32)), d(lengths.clone()), torch.zeros(B, 3, 3, device=dev)
+        eng.sample_loop(f, ty, le, d(angles), off, 999, 5, 4242, None, lat, use_graph=use_graph)
+        return f, ty, le, lat
+
+    def crystals_differing(per_atom, per_crystal):
+        bad = {int(np.searchsorted(offs, i, side="right") - 1) for i in np.nonzero(per_atom.cpu().numpy())[0]}
+        return bad | set(np.nonzero(per_crystal.cpu().numpy())[0].tolist())
+
+    eng.set_batch_layout(na, groups=1)
+    whole = eng.predict_scores(*args)
+    ref = loop(False)
+    report = {}
+    os.environ["ARREAU_ALLOW_MULTISTREAM"] = "1"
+    try:
+        os.environ["ARREAU_SLICE_EAGER"] = "1"
+        try:
+            eng.set_batch_layout(na, groups=2)
+        finally:
+            del os.environ["ARREAU_SLICE_EAGER"]
+        forked = eng.predict_scores(*args)
+        report["fork-join scores"] = sorted(crystals_differing((whole[0] != forked[0]).any(1) | (whole[1] != forked[1]).any(1),
+                                                               (whole[2] != forked[2]).any(1)))
+        eng.set_batch_layout(na, groups=2)
+        for i in range(3):  # (the later graph runs reuse the cached per-slice graphs)
+            out = loop(True)
+            report[f"pipelined loop {i}"] = sorted(crystals_differing((ref[0] != out[0]).any(1) | (ref[1] != out[1]),
+                                                                      (ref[2] != out[2]).any(1)))
+            assert torch.isfinite(out[0]).all() and torch.isfinite(out[2]).all()
+    finally:
+        del os.environ["ARREAU_ALLOW_MULTISTREAM"]
+        eng.set_batch_layout(na, groups=1)
+    eng.check_status()
+    n_bad = sum(len(v) for v in report.values())
+    print(f"[multi-stream experiment] crystals that differ from the one-stream result, per run: {report}")
+    if n_bad:
+        pytest.xfail(f"multi-stream slices not bit-identical in this run: {report}")
 
 
 @pytest.mark.parametrize("case", ["small-launch forms (3 crystals)", "throughput forms (ragged 64 crystals)", "large cells (2 x 64 atoms)"])
@@ -1002,6 +1087,18 @@ def test_outputs_do_not_depend_on_leftover_lds_or_registers(dev, full_model, cas
             return [eps, logits, len0] + graph + [f, ty, le, lat]
         finally:
             _hip.check(_hip.lib().arreau_debug_set_pollution(0), "arreau_debug_set_pollution")
+
+    # positive control: a kernel that reads LDS / registers without writing them finds the pattern after a pollution
+    import ctypes
+    lds_f, reg_f = ctypes.c_double(), ctypes.c_double()
+    _hip.check(_hip.lib().arreau_debug_set_pollution(0x5EED5EED), "arreau_debug_set_pollution")
+    try:
+        _hip.check(_hip.lib().arreau_debug_leftover_fraction(0x5EED5EED, ctypes.byref(lds_f), ctypes.byref(reg_f),
+                                                             _hip.stream_ptr(dev)), "arreau_debug_leftover_fraction")
+    finally:
+        _hip.check(_hip.lib().arreau_debug_set_pollution(0), "arreau_debug_set_pollution")
+    print(f"[pollution probe] leftover words equal to the pattern: LDS {lds_f.value:.3f}, registers v96..v111 {reg_f.value:.3f}")
+    assert lds_f.value > 0.9 and reg_f.value > 0.9, (lds_f.value, reg_f.value)
 
     names = ["eps", "logits", "len0", "deg", "src", "dir", "dist", "frac", "types", "lengths", "lattice"]
     ref = evaluate(0, 0)

@@ -239,7 +239,8 @@ def test_optimizer_step_refreshes_training_weights_without_repacking(setup):
 def test_two_rank_training_loop_reduces_the_loss(tmp_path):
     """arreau_amd.train end to end: two data-parallel ranks (gloo, sharing this box's GPU), synthetic Alexandria-like
     crystals, forward + backward in the library, one flat all-reduce per step, Adam with the cosine warm-up schedule;
-    the ranks hold identical weights afterwards (checked through the written checkpoint) and the loss goes down."""
+    the ranks hold identical weights afterwards (parameter checksums of both replicas, printed by the driver) and the
+    epoch-mean loss goes down."""
     import os
     import socket
     import subprocess
@@ -252,14 +253,21 @@ def test_two_rank_training_loop_reduces_the_loss(tmp_path):
         port = sk.getsockname()[1]
     out = str(tmp_path / "trained.ckpt")
     p = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
-                        "127.0.0.1", "--master-port", str(port), "-m", "arreau_amd.train", "--num_synthetic", "96", "--epochs",
-                        "3", "--batch_size", "8", "--lr", "1e-3", "--out", out], env=env, cwd=root, capture_output=True,
+                        "127.0.0.1", "--master-port", str(port), "-m", "arreau_amd.train", "--num_synthetic", "99", "--epochs",
+                        "6", "--warmup", "1", "--batch_size", "8", "--lr", "2e-3", "--out", out], env=env, cwd=root, capture_output=True,
                        text=True, timeout=900)
     assert p.returncode == 0, p.stderr[-3000:]
     lines = [ln for ln in p.stdout.splitlines() if ln.startswith("epoch")]
-    assert len(lines) == 3, p.stdout
-    first, last = float(lines[0].split("last loss")[1].split(",")[0]), float(lines[-1].split("last loss")[1].split(",")[0])
+    assert len(lines) == 6, p.stdout
+    assert all(" 6 steps," in ln for ln in lines), lines  # 99 crystals -> 98 for two ranks -> 49 each -> 6 full batches of 8
+    mean = lambda ln: float(ln.split("loss per crystal")[1].split("(")[0])  # epoch mean over all ranks
+    first, last = mean(lines[0]), mean(lines[-1])
     assert np.isfinite(last) and os.path.exists(out)
+    assert last < 0.9 * first, (first, last)  # (epoch 0 runs at the warm-up's 1e-6 factor: it is the untrained loss)
+    sums = [ln for ln in p.stdout.splitlines() if ln.startswith("replica parameter checksums:")]
+    assert len(sums) == 1, p.stdout
+    a, b = (float(v) for v in sums[0].split(":")[1].split())
+    assert a == b, sums  # the two replicas hold the same weights (incl. the first-step calibration ratios)
     from arreau_amd.checkpoint import load_lightning_checkpoint
     ck = load_lightning_checkpoint(out)
     assert bool(ck["state_dict"]["model.interaction_layers.0.conv.callibrated"])

@@ -159,3 +159,53 @@ def test_optimizer_groups_and_cosine_warmup_schedule():
     for epoch in (0, 5, 10, 50, 100):
         want = 0.5 * (1 + np.cos(np.pi * epoch / 100)) * ((epoch + 1e-6) / (10 + 1e-6) if epoch <= 10 else 1.0)
         assert abs(sch.get_lr_factor(epoch) - want) < 1e-12
+
+
+def test_cosine_warmup_scheduler_matches_reference_values():
+    """The learning rates the reference's scheduler class hands to an optimizer of lr = 1, epoch by epoch
+    (tests/golden/scheduler.json, written by oracle/gen_golden_scheduler.py from the imported reference class): the
+    LambdaLR-based replacement steps through the same values, also after a state_dict round trip."""
+    import json
+    import os
+    from arreau_amd.lightning_wrappers.scheduler import CosineWarmupScheduler
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "scheduler.json")) as fh:
+        cases = json.load(fh)
+    assert len(cases) == 4
+    for case in cases:
+        p = torch.nn.Parameter(torch.zeros(1))
+        opt = torch.optim.Adam([p], lr=1.0)
+        sch = CosineWarmupScheduler(opt, case["warmup"], case["max_iters"])
+        for epoch, want in enumerate(case["lr_by_epoch"]):
+            assert abs(opt.param_groups[0]["lr"] - want) <= 1e-15 + 4e-16 * abs(want), (case["warmup"], epoch)
+            if epoch == 3:  # resume from a checkpointed schedule
+                state = sch.state_dict()
+                sch = CosineWarmupScheduler(opt, case["warmup"], case["max_iters"])
+                sch.load_state_dict(state)
+            opt.step()
+            sch.step()
+
+
+def test_every_rank_gets_the_same_number_of_batches():
+    """iterate_batches under data parallelism: a dataset whose size is not a multiple of world_size * batch_size must
+    still give every rank the same number of steps (one extra step on one rank = an all-reduce without partners = a hang).
+    len = 8 * 4 * 3 - 1: before the fix rank 7 got two batches of four and the others three."""
+    from types import SimpleNamespace
+    from arreau_amd.diffusion.lattice_dataset import iterate_batches
+
+    class Items:
+        def __len__(self):
+            return 8 * 4 * 3 - 1
+
+        def __getitem__(self, i):
+            one = torch.zeros(1, 3, dtype=torch.float64)
+            return SimpleNamespace(pos=one, X0=one, A0=torch.tensor([i]), L0=torch.zeros(3, 3, dtype=torch.float64), num_atoms=1)
+
+    for drop_last in (True, False):
+        seen, counts = [], []
+        for rank in range(8):
+            batches = list(iterate_batches(Items(), 4, shuffle=True, seed=3, rank=rank, world_size=8, drop_last=drop_last))
+            counts.append(len(batches))
+            seen += [int(a) for b in batches for a in b.A0]
+        assert len(set(counts)) == 1, (drop_last, counts)
+        assert len(seen) == len(set(seen))  # ranks take disjoint crystals
+    assert len(list(iterate_batches(Items(), 4, world_size=1))) == 24  # a single rank still sees everything
