@@ -12,24 +12,25 @@ import sys
 import time
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
-SOURCES = ["model.hip", "graph.hip", "edge.hip", "edge_bf16.hip", "edge_f16.hip", "node.hip", "node_bf16.hip", "node_f16.hip", "node_f16m.hip", "update.hip", "train.hip", "train_net.hip", "api.hip"]
+SOURCES = ["model.hip", "graph.hip", "edge.hip", "edge_bf16.hip", "edge_f16.hip", "node.hip", "node_bf16.hip", "node_f16.hip", "node_f16m.hip", "conv_proj.hip", "update.hip", "train.hip", "train_net.hip", "api.hip"]
 HEADERS = ["internal.h", "bf16x6.h", "f16x3.h", os.path.join("..", "..", "include", "arreau_hip.h"), "sgemm.h", "philox.h"]
 LIB = os.path.join(CSRC, "libarreau_hip.so")
 # Debug twin: the same sources with -DARREAU_DEBUG_WAIT_ALL (every hand-counted `s_waitcnt vmcnt(N)` becomes vmcnt(0)).
 # Its outputs must be bit-identical to the product library's (test_counted_waits_match_full_waits); only the sources
 # that contain counted waits are recompiled for it.
 LIB_DEBUG_WAIT = os.path.join(CSRC, "libarreau_hip_dbgwait.so")
-DEBUG_WAIT_SOURCES = ["edge_f16.hip", "node.hip", "node_f16m.hip"]
+DEBUG_WAIT_SOURCES = ["edge_f16.hip", "node.hip", "node_f16m.hip", "conv_proj.hip"]
 STAMP = os.path.join(CSRC, ".build_stamp")
 # Kernels that hand-count s_waitcnt vmcnt(N) or drain LDS-DMA copies with asm waits hipcc cannot see: a register spill
 # would put scratch loads/stores into the same in-order queue and silently break the protocol, so the build fails if
 # the compiler reports scratch for them.  source -> substrings of the (mangled) kernel names to check (None = all).
-NO_SCRATCH = {"edge_f16.hip": None, "node.hip": ["conv_kernel_streamed"], "node_f16.hip": None, "node_f16m.hip": None}
+NO_SCRATCH = {"edge_f16.hip": None, "node.hip": ["conv_kernel_streamed"], "node_f16.hip": None, "node_f16m.hip": None,
+              "conv_proj.hip": None}
 # Sources with inline asm: their device ISA is kept (-save-temps) and run through tools/isa_lint.py -- software wait
 # states around every asm instruction (store-data, VALU-written SGPR -> VMEM, M0 -> LDS-DMA, ...), asm loads' destination
 # registers untouched until their wait, no compiler use of M0, no unmodelled instruction kind inside asm.  hipcc pads and
 # counts none of that for inline asm; a violation fails the build.
-ASM_LINT = ("edge_f16.hip", "node.hip", "node_f16.hip", "node_f16m.hip", "graph.hip", "api.hip")
+ASM_LINT = ("edge_f16.hip", "node.hip", "node_f16.hip", "node_f16m.hip", "graph.hip", "api.hip", "conv_proj.hip")
 # -Wno-inline-asm: the lean LDS-DMA asm lists "m0" as clobbered (it overwrites M0 and does not restore it); clang warns
 # that reserved registers in a clobber list are not preserved for us -- which is what is declared, not asked for.  The
 # ISA check below verifies that the compiler itself never uses M0 in those kernels.

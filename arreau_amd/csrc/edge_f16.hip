@@ -78,7 +78,12 @@ extern "C" int arreau_debug_edge_ticks(unsigned long long* out8, int reset) {
 #define EDGE_TICK(i)
 #endif
 
-template <int C, int D, int EH_WAVES, bool K3 /* K tiles as 3-byte floats (internal.h) */>
+// PROJ = false ("basis form", round 3): the kernel stops after layer 2 and stores the windowed basis -- its two fp16 planes,
+// already in the B-operand fragment order of v_mfma_f32_16x16x32_f16 -- instead of running the L kernel projections and
+// storing their results: one 16 KiB block per edge slot ([k-block 0..7][plane][lane] x 16 bytes: whole 1 KiB, fully
+// coalesced store instructions), 1 KiB per (edge, orientation) row written ONCE, where the K stash writes L*C*3 = 1,920
+// bytes.  The projections move into the per-layer message kernel (conv_proj.hip), which streams those blocks through LDS.
+template <int C, int D, int EH_WAVES, bool K3 /* K tiles as 3-byte floats (internal.h) */, bool PROJ = true>
 __global__ __launch_bounds__(64 * EH_WAVES, 2) void edge_kernel_f16x3(
     const float* __restrict__ nbr_dir,   // [N][k][3]
     const float* __restrict__ nbr_dist,  // [N][k]
@@ -88,7 +93,7 @@ __global__ __launch_bounds__(64 * EH_WAVES, 2) void edge_kernel_f16x3(
     const float* __restrict__ ori,       // [16][3]
     const u32x4* __restrict__ stream,    // fp16x3 chunks: w1 (C/32 chunks) | w2 (D/32) | wk_l (L * C/32)
     const float* __restrict__ b1, const float* __restrict__ b2, float r_max, int N, int k, int L,
-    float* __restrict__ kbuf,            // [L][N*k*16][C]
+    float* __restrict__ kbuf,            // PROJ: [L][N*k*16][C];  basis form: [N*k][16 fragments][64 lanes] x 16 bytes
     int n0, int n1)                      // receivers of this launch: n0 .. n1-1 (N stays the batch size: it strides kbuf)
 {
     constexpr int TC = C / 32, TD = D / 32, TM = ARREAU_MONO_PAD / 32;
@@ -114,9 +119,20 @@ __global__ __launch_bounds__(64 * EH_WAVES, 2) void edge_kernel_f16x3(
     int sl = 0;  // ring slot of the current chunk
     constexpr unsigned SLOT_BYTES = NF3 * 1024u;
     auto slot_after = [](int s_, int n) { const int r = s_ + n; return r >= 3 ? r - 3 : r; };  // (s_ + n) % 3 for n <= 2
-    const int nchunks = L * TC;
+    const int nchunks = PROJ ? L * TC : 0;
     dma_wait();
     __syncthreads();
+    // basis form: stores this wave issued after its last weight copy (they are younger than the copy in the in-order
+    // queue, so the counted wait in front of a barrier leaves exactly that many operations in flight)
+    int pend = 0;
+    auto wait_copies = [&]() {
+        if constexpr (PROJ) dma_wait();
+        else {
+            if (pend == 0) dma_wait();
+            else if (pend == 2) dma_wait_but<2>();
+            else dma_wait_but<4>();
+        }
+    };
 
     for (int pair = blockIdx.x; pair < npairs; pair += gridDim.x) {
         // Everything derived from the lane / wave index is re-derived per pair from values the optimiser cannot see
@@ -151,10 +167,13 @@ __global__ __launch_bounds__(64 * EH_WAVES, 2) void edge_kernel_f16x3(
             } else if constexpr (q2 < TC + TD) {
                 dma_chunk_lean<NF2, EH_WAVES>(dma_src, lane16, wave, lds0 + dst * SLOT_BYTES);
                 dma_src += (size_t)NF2 * 64;
-            } else {  // first projection chunks (L * TC >= 2)
+            } else if constexpr (PROJ) {  // first projection chunks (L * TC >= 2)
                 dma_chunk_lean<NF3, EH_WAVES>(dma_src, lane16, wave, lds0 + dst * SLOT_BYTES);
                 dma_src += (size_t)NF3 * 64;
+            } else {  // basis form: the pair ends with layer 2 -- the next pair's first two chunks
+                if (has_next) dma_chunk<NF1, EH_WAVES>(stream + (size_t)(q2 - (TC + TD)) * NF1 * 64, lds[dst], wave, lane);
             }
+            pend = 0;
         };
         auto copy3 = [&](int cidx) {  // after SYNC of projection chunk cidx
             const int dst = slot_after(sl, 2);
@@ -260,7 +279,7 @@ __global__ __launch_bounds__(64 * EH_WAVES, 2) void edge_kernel_f16x3(
             MmaStream2<TM, 2 * TM> ms;
             ms.start(lds[sl], lane);
             if (go) ms.template run<0, TM>(acc, cross, bm);
-            dma_wait();
+            wait_copies();
             __syncthreads();
             if (u + 2 < TC) copy12(std::integral_constant<int, 0>{});          // an NF1 chunk
             else copy12(std::integral_constant<int, TC - 2>{});               // an NF2 chunk
@@ -295,10 +314,12 @@ __global__ __launch_bounds__(64 * EH_WAVES, 2) void edge_kernel_f16x3(
             MmaStream16<TC> ms;
             ms.start(lds[sl], lane);
             if (go) ms.template run<0, TC>(acc, h16);
-            dma_wait();
+            wait_copies();
             __syncthreads();
             if (u + 2 < TD) copy12(std::integral_constant<int, TC>{});         // an NF2 chunk
-            else copy12(std::integral_constant<int, TC + TD - 2>{});           // an NF3 chunk
+            else if constexpr (PROJ) copy12(std::integral_constant<int, TC + TD - 2>{});  // an NF3 chunk
+            else if (u + 2 == TD) copy12(std::integral_constant<int, TC + TD - 2>{});     // the next pair's chunk 0 ...
+            else copy12(std::integral_constant<int, TC + TD - 1>{});                      // ... and chunk 1
 #pragma unroll
             for (int nb = 0; nb < 2; ++nb) { b16[nb][u][0] = u32x4{0, 0, 0, 0}; b16[nb][u][1] = u32x4{0, 0, 0, 0}; }
             if (go) {
@@ -317,10 +338,28 @@ __global__ __launch_bounds__(64 * EH_WAVES, 2) void edge_kernel_f16x3(
                             b16[nb][u][1][2 * mt + pr] = lo;
                         }
                 }
+                if constexpr (!PROJ) {
+                    // the finished k-block of the basis leaves: fragment (u, plane) of slot 2 wn + nb, 1 KiB per instruction
+                    // (asm stores: a FIXED count per chunk, which wait_copies() relies on; wait states behind each: the
+                    // data registers of a VMEM store of more than 64 bits must not be rewritten at once)
+                    const bool full_b = 2 * wn + 1 < k;  // wave-uniform: the wave's second slot exists
+                    const char* blk = reinterpret_cast<const char*>(kbuf) + ((size_t)node * k + 2 * wn) * 16384 + 2048 * u;
+#pragma unroll
+                    for (int nb = 0; nb < 2; ++nb)
+#pragma unroll
+                        for (int plane = 0; plane < 2; ++plane)
+                            if (nb == 0 || full_b)
+                                asm volatile("global_store_dwordx4 %0, %1, %2" ARREAU_K_STORE_TAIL
+                                             :
+                                             : "v"(lane16), "v"(b16[nb][u][plane]), "s"(blk + 16384 * nb + 1024 * plane)
+                                             : "memory");
+                    pend += full_b ? 4 : 2;
+                }
             }
             sl = slot_after(sl, 1);
         }
         EDGE_TICK(2);
+        if constexpr (!PROJ) continue;  // basis form: the projections run in the message kernel of each layer (conv_proj.hip)
         // ---- per layer: kernel_l = Wk_l . basis  (conv.py:110), one output tile per chunk ---------------------
         constexpr int KB = K3 ? 3 : 4;  // bytes per K value
         const size_t layer_stride = (size_t)N * k * 16 * C;
@@ -692,7 +731,8 @@ int arreau_launch_edge_f16x3(const arreau_model* m, const float* dir, const floa
     // Inputs are identical from evaluation to evaluation; the cause is not found.  Slices exist for batches of thousands of
     // atoms, far above the switch-over, so nothing is lost by keeping the small-launch form to unsliced launches.
     const bool whole_batch = n0 == 0 && n1 == N && r.wg_cap == 0;
-    const bool use_split = split_ok && (split_env >= 0 ? split_env != 0 : (whole_batch && (n1 - n0) <= ARREAU_EDGE_SPLIT_MAX_NODES));
+    const bool use_split = split_ok && !arreau_basis_form(m, n1 - n0) &&
+                           (split_env >= 0 ? split_env != 0 : (whole_batch && (n1 - n0) <= ARREAU_EDGE_SPLIT_MAX_NODES));
     const bool k3 = arreau_k3(m);  // K tiles as 3-byte floats (the node-layer launcher reads the same decision)
     if (use_split) {
         auto launch = [&](auto kernel) {
@@ -707,6 +747,12 @@ int arreau_launch_edge_f16x3(const arreau_model* m, const float* dir, const floa
     const int npairs = (n1 - n0 + 1) / 2;
     int wgs = wgs_env > 0 ? (wgs_env < npairs ? wgs_env : npairs) : (npairs < n_cu ? npairs : n_cu);
     if (r.wg_cap > 0 && wgs > r.wg_cap) wgs = r.wg_cap;
+    if (arreau_basis_form(m, n1 - n0)) {  // stop after layer 2, store the basis planes (the node-layer launcher projects them)
+        ARREAU_LAUNCH((edge_kernel_f16x3<128, 256, 8, false, false>), dim3(wgs), dim3(512), 0, s, dir, dist, deg, batch, lattice, m->ori,
+                      reinterpret_cast<const u32x4*>(m->edge_f16), m->b1, m->b2, m->cfg.radius, N, m->k, m->L, kbuf, n0, n1);
+        ARREAU_CHECK_HIP(hipGetLastError());
+        return ARREAU_OK;
+    }
     auto launch = [&](auto kernel) {
         ARREAU_LAUNCH(kernel, dim3(wgs), dim3(512), 0, s, dir, dist, deg, batch, lattice, m->ori,
                            reinterpret_cast<const u32x4*>(m->edge_f16), m->b1, m->b2, m->cfg.radius, N, m->k, m->L, kbuf, n0, n1);

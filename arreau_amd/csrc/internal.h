@@ -298,6 +298,12 @@ __device__ __forceinline__ void arreau_unpack_k3(unsigned d0, unsigned d1, unsig
 }
 // the decision, shared by the edge and the node-layer launchers (both read the same model fields)
 bool arreau_k3(const arreau_model* m);
+// Basis form (round 3, the default for launches above the small-launch sizes): the edge kernel stores the windowed basis
+// planes instead of the L projected kernels, and each layer's message kernel projects them itself (conv_proj.hip) -- no K
+// stash.  The edge launcher and the node-layer launcher take the decision from the same fields and the same receiver count.
+bool arreau_basis_form(const arreau_model* m, int receivers);
+int arreau_launch_conv_proj(const arreau_model* m, int layer, const float* basis, const int32_t* deg, const int32_t* src,
+                            const float* x_in, float* x_conv, int N, hipStream_t s, NodeRange r = NodeRange());
 
 int arreau_launch_mlp_bf16x6(const arreau_model* m, int layer, const float* x_conv, const float* x_in, float* x_out,
                              float* xbar, float* vsum, int N, hipStream_t s);

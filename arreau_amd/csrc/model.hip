@@ -465,7 +465,7 @@ extern "C" int arreau_model_create(const arreau_config* cfg, const arreau_state_
     auto env_int = [](const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; };
     m->edge_variant = env_int("ARREAU_EDGE_VARIANT", 4);
     m->mlp_variant = env_int("ARREAU_MLP_VARIANT", 3);
-    m->conv_variant = env_int("ARREAU_CONV_VARIANT", 1);
+    m->conv_variant = env_int("ARREAU_CONV_VARIANT", 2);  // 2: basis form + conv_proj.hip; 1: K stash + streamed conv; 0: register conv
     m->readout_variant = env_int("ARREAU_READOUT_VARIANT", 1);
     m->ran_edge = m->ran_mlp = m->ran_conv = -1;
     m->fused = fused ? 1 : 0;

@@ -694,9 +694,13 @@ int arreau_launch_node_layer(const arreau_model* m, int layer, const float* kbuf
     const size_t mlp_layer = (size_t)2 * H * C;  // floats of W1 + W2, packed
     const int conv_blocks = N < 512 ? N : 512;   // persistent: 2 workgroups of 512 threads per CU (a multiple of 8: XCD-aware order)
     // conv variant: 1 (default, k = 8 only) = streamed form (K blocks by LDS-DMA, one workgroup per CU); 0 = register form
-    const int conv_variant = m->conv_variant;
-    m->ran_conv = (conv_variant == 1 && m->k == 8) ? 1 : 0;
-    if (conv_variant == 1 && m->k == 8) {
+    const bool basis_form = arreau_basis_form(m, Ng);
+    const int conv_variant = m->conv_variant == 2 ? 1 : m->conv_variant;  // (2 without the basis form = the streamed K pair)
+    m->ran_conv = basis_form ? 2 : (conv_variant == 1 && m->k == 8) ? 1 : 0;
+    if (basis_form) {
+        const int rc = arreau_launch_conv_proj(m, layer, kbuf, deg, src, x_in, x_conv, N, s, r);
+        if (rc) return rc;
+    } else if (conv_variant == 1 && m->k == 8) {
         int blocks = Ng < 256 ? Ng : 256;
         if (r.wg_cap > 0 && blocks > r.wg_cap) blocks = r.wg_cap;
         if (arreau_k3(m))  // (the edge launcher took the same decision: a row of K is 3 C bytes)
@@ -951,11 +955,21 @@ __global__ void readout_crystals_kernel(const float* __restrict__ gs, const int3
 // split-precision edge kernels (both forms) and the streamed conv kernel.  ARREAU_K3=0 keeps fp32 (A/B, tests).
 bool arreau_k3(const arreau_model* m) {
     static const int env = [] { const char* e = getenv("ARREAU_K3"); return e ? atoi(e) : 1; }();
+    // (conv_variant 2, the default, keeps K in fp32 wherever a launch is too small for the basis form: those launches are
+    // latency-bound, and an fp32 K makes them bit-identical to the basis form -- a crystal evaluated alone equals the same
+    // crystal inside a large batch)
     return env != 0 && m->edge_variant == 4 && m->f16_ok && m->conv_variant == 1 && m->k == 8 && m->C == 128 && m->D == 256;
 }
 
+// conv_variant 2 (default): basis form wherever it applies -- the fused shape, k = 8, fp16-representable weights, the
+// split-precision edge kernel -- and a launch large enough for the persistent kernels (small launches keep the
+// tile-per-workgroup forms of the edge / conv / ConvNext kernels, which are latency-bound and have their own K path).
+bool arreau_basis_form(const arreau_model* m, int receivers) {
+    return m->conv_variant == 2 && m->edge_variant == 4 && m->f16_ok && m->k == 8 && m->C == 128 && m->D == 256 && receivers > 240;
+}
+
 bool arreau_range_launches_supported(const arreau_model* m) {
-    return m->edge_variant == 4 && (m->mlp_variant == 3 || m->mlp_variant == 4) && m->f16_ok && m->conv_variant == 1 && m->k == 8 &&
+    return m->edge_variant == 4 && (m->mlp_variant == 3 || m->mlp_variant == 4) && m->f16_ok && (m->conv_variant == 1 || m->conv_variant == 2) && m->k == 8 &&
            m->readout_variant == 1 && m->S + 4 <= 96 && m->L <= 8 && m->C == 128;
 }
 
