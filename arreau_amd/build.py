@@ -24,8 +24,9 @@ STAMP = os.path.join(CSRC, ".build_stamp")
 # Kernels that hand-count s_waitcnt vmcnt(N) or drain LDS-DMA copies with asm waits hipcc cannot see: a register spill
 # would put scratch loads/stores into the same in-order queue and silently break the protocol, so the build fails if
 # the compiler reports scratch for them.  source -> substrings of the (mangled) kernel names to check (None = all).
-NO_SCRATCH = {"edge_f16.hip": None, "node.hip": ["conv_kernel_streamed"], "node_f16.hip": None, "node_f16m.hip": None,
-              "conv_proj.hip": None}
+# (conv_proj.hip is covered by the ISA lint instead: its projection role may spill -- it issues no asm memory operation
+# and hipcc counts its own scratch traffic --, its mix role, which hand-counts, must not share a path with a spill)
+NO_SCRATCH = {"edge_f16.hip": None, "node.hip": ["conv_kernel_streamed"], "node_f16.hip": None, "node_f16m.hip": None}
 # Sources with inline asm: their device ISA is kept (-save-temps) and run through tools/isa_lint.py -- software wait
 # states around every asm instruction (store-data, VALU-written SGPR -> VMEM, M0 -> LDS-DMA, ...), asm loads' destination
 # registers untouched until their wait, no compiler use of M0, no unmodelled instruction kind inside asm.  hipcc pads and

@@ -19,8 +19,8 @@
 //     the folded K tile is multiplied by the sender's feature rows (gathered through L2), and added to the running sum
 //     in slot order -- product rounded, then added, like messages -> index_add_ (and like the kernels this replaces:
 //     bit-identical to the edge / conv pair with an fp32 K stash).  The sum goes to an LDS tile.
-//   * waves 4-7, "mix": issue the LDS-DMA copies of the basis blocks SEVEN slots ahead (16 KiB per slot, ring of 8 slots =
-//     128 KiB: about 100 KiB of HBM requests in flight per CU without a single staging register), and meanwhile run the
+//   * waves 4-7, "mix": issue the LDS-DMA copies of the basis blocks EIGHT slots ahead (16 KiB per slot, ring of 9 slots =
+//     144 KiB: 96-112 KiB of HBM requests in flight per CU without a single staging register), and meanwhile run the
 //     depth-wise 16 x 16 orientation mix of the PREVIOUS receiver (fiber kernel slice in 128 registers per thread), two
 //     orientations per slot step, and store its result.
 //   One workgroup barrier per slot step, in the MIDDLE of the projection waves' MFMA stream (the ring protocol of
@@ -62,9 +62,14 @@ __device__ __forceinline__ void cp_wait_but() {
 }
 }  // namespace
 
-template <int C, int D>
-__global__ __launch_bounds__(512, 2) void conv_proj_kernel(
-    const u32x4* __restrict__ basis,     // [N*8 slots][16 fragments = (k-block, plane)][64 lanes] x 16 bytes
+// PW = projection waves (4: two 16-channel tiles per wave, 8 waves per workgroup; 8: one tile per wave, 12 waves per
+// workgroup = two projection waves per SIMD, which cover each other's LDS latency -- a lone projection wave per SIMD
+// waits for its B fragments in the open: measured 149 us per layer at 256 x 20 with PW = 4)
+// BFP8: the residual plane of the stashed basis is OCP fp8 e4m3 (edge_f16.hip): a slot block is 12 KiB -- eight 1 KiB hi
+// fragments, then eight 512 B lo fragments (8 bytes per lane), widened to fp16 in registers (exact) in front of their MFMAs.
+template <int C, int D, int PW, bool BFP8>
+__global__ __launch_bounds__(64 * (PW + 4), (PW + 4) / 4) void conv_proj_kernel(
+    const u32x4* __restrict__ basis,     // [N*8 slots][16 fragments = (k-block, plane)][64 lanes] x 16 bytes  (BFP8: see above)
     const u32x4* __restrict__ wchunks,   // this layer's projection chunks of the packed fp16x3 stream: [C/32][32][64]
     const int32_t* __restrict__ deg, const int32_t* __restrict__ src,
     const float* __restrict__ x_in,      // [N][16][C]
@@ -74,9 +79,14 @@ __global__ __launch_bounds__(512, 2) void conv_proj_kernel(
 {
     static_assert(C == 128 && D == 256, "roles and register budgets assume C = 128, D = 256");
     constexpr int K = 8, NKB = D / 32;
-    constexpr unsigned SLOT_BYTES = 16384;
-    __shared__ u32x4 ring[K][SLOT_BYTES / 16];                             // slot s of the current / next receiver
-    __shared__ __attribute__((aligned(16))) float tile[2][16 * CP_STR];   // x1 of the current / previous receiver
+    constexpr unsigned SLOT_BYTES = BFP8 ? 12288 : 16384;
+    constexpr int NC = SLOT_BYTES / 4096;  // 1 KiB copies per mix wave and slot
+    // NINE slot buffers (slot q of the workgroup's sequence lives in buffer q mod 9) + one tile = 152 KiB of the CU's 160:
+    // the stream's rate is bytes in flight over the loaded HBM latency (about 4.3 us: 80-96 KiB in flight per CU gave
+    // 4.7 TB/s with eight buffers), and an LDS-DMA byte in flight needs its landing place for the whole flight.
+    constexpr int RING = 9;
+    __shared__ u32x4 ring[RING][SLOT_BYTES / 16];
+    __shared__ __attribute__((aligned(16))) float tile[16 * CP_STR];      // x1 of the receiver just finished
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
 
@@ -95,36 +105,39 @@ __global__ __launch_bounds__(512, 2) void conv_proj_kernel(
     if (m >= n_iter) return;  // (workgroup-uniform: no barrier has been reached)
     int mn = next_valid(m + m_step);
 
-    if (wave < 4) {
+    constexpr int MT = 8 / PW;  // 16-channel tiles per projection wave
+    if (wave < PW) {
         // =========================================== projection role ===========================================
         const int c16 = lane & 15, g16 = lane >> 4;
-        u32x4 A1[2][NKB], A2[2][NKB];  // [16-channel tile mt][k-block]: the two fp16 planes of Wk_l rows 32 wave + 16 mt ..
+        u32x4 A1[MT][NKB], A2[MT][NKB];  // [16-channel tile][k-block]: the two fp16 planes of Wk_l rows 16 * (MT wave + mt) ..
         {
-            const u32x4* wc = wchunks + (size_t)wave * 32 * 64 + lane;  // fragment (kb, mt, plane) at ((kb * 2 + mt) * 2 + plane) * 64
+            // chunk u = 32 output channels; fragment (kb, tile-in-chunk, plane) at ((kb * 2 + tile) * 2 + plane) * 64
+            const u32x4* wc = wchunks + (size_t)((MT * wave) >> 1) * 32 * 64 + lane;
+            const int t0 = (MT * wave) & 1;
 #pragma unroll
             for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
-                for (int mt = 0; mt < 2; ++mt) {
-                    A1[mt][kb] = wc[((kb * 2 + mt) * 2 + 0) * 64];
-                    A2[mt][kb] = wc[((kb * 2 + mt) * 2 + 1) * 64];
+                for (int mt = 0; mt < MT; ++mt) {
+                    A1[mt][kb] = wc[((kb * 2 + t0 + mt) * 2 + 0) * 64];
+                    A2[mt][kb] = wc[((kb * 2 + t0 + mt) * 2 + 1) * 64];
                 }
             // wait for the weights HERE: left to their first use, the waits would sit inside the receiver loop, where every
             // pass would also wait for the sender rows requested two slots ahead
 #pragma unroll
             for (int kb = 0; kb < NKB; ++kb)
 #pragma unroll
-                for (int mt = 0; mt < 2; ++mt) asm volatile("" : "+v"(A1[mt][kb]), "+v"(A2[mt][kb]));
+                for (int mt = 0; mt < MT; ++mt) asm volatile("" : "+v"(A1[mt][kb]), "+v"(A2[mt][kb]));
         }
-        const unsigned cb = 32 * wave + 4 * g16;  // first channel of this lane's four (tile mt adds 16)
-        const u32x4* frag0 = &ring[0][0] + lane;
+        const unsigned cb = 16 * MT * wave + 4 * g16;  // first channel of this lane's four (tile mt adds 16)
         // sender rows: requested two slots ahead into four rotating register sets (hipcc counts these loads itself: this
         // role issues no asm memory operation), consumed slot by slot
-        f32x4v xv[4][2];
+        f32x4v xv[4][MT];
+        const unsigned x_off = (unsigned)c16 * C + cb;
         auto load_x = [&](const int32_t* srow, int s_, int buf) {
             const int sn = max(srow[s_], 0);  // unused slots: any valid row, dropped by the select below
-            const float* xr = x_in + ((size_t)sn * 16 + c16) * C + cb;
+            const float* xr = x_in + (size_t)sn * 16 * C;  // wave-uniform base + one 32-bit lane offset
 #pragma unroll
-            for (int mt = 0; mt < 2; ++mt) xv[buf][mt] = *reinterpret_cast<const f32x4v*>(xr + 16 * mt);
+            for (int mt = 0; mt < MT; ++mt) xv[buf][mt] = *reinterpret_cast<const f32x4v*>(xr + (x_off + 16 * mt));
         };
         {
             const int32_t* srow0 = src + (size_t)(n0 + local_of(m)) * K;
@@ -132,35 +145,84 @@ __global__ __launch_bounds__(512, 2) void conv_proj_kernel(
             load_x(srow0, 1, 1);
         }
         __syncthreads();  // SYNC_-1: slot 0 of the first receiver has landed
-        int par = 0;
+        // Every slot step has ONE barrier in the middle of its MFMA stream, so a step is as long as the longest dependent
+        // chain of a wave: the B fragments of a slot's first k-block are therefore requested during the previous slot's
+        // last k-step (the slot has been published by that slot's barrier) instead of behind its epilogue.
+        typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+        u32x4 b1[2], b2[2];
+        u32x2_t b8[2];  // BFP8: the lo fragment as stored (8 fp8 per lane)
+        const char* ring_b = reinterpret_cast<const char*>(&ring[0][0]);
+        const unsigned hi_off = 16u * lane, lo_off = 8192u + 8u * lane;
+        auto frag = [&](unsigned base /* byte offset of the slot buffer: wave-uniform */, int kb, int sl_) {
+            if constexpr (BFP8) {
+                b1[sl_] = *reinterpret_cast<const u32x4*>(ring_b + base + hi_off + 1024 * kb);
+                b8[sl_] = *reinterpret_cast<const u32x2_t*>(ring_b + base + lo_off + 512 * kb);
+            } else {
+                b1[sl_] = *reinterpret_cast<const u32x4*>(ring_b + base + hi_off + 2048 * kb);
+                b2[sl_] = *reinterpret_cast<const u32x4*>(ring_b + base + hi_off + 2048 * kb + 1024);
+            }
+        };
+        f32x4v am[1][MT], ax[1][MT];
+        f32x4v sum[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) sum[mt] = f32x4v{0.f, 0.f, 0.f, 0.f};
+        auto epilogue = [&](int set, int xbuf, bool on) {  // product rounded, then added in edge order (messages -> index_add_)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float kv = fmaf(ax[set][mt][r], F16X3_INV_SCALE, am[set][mt][r]);
+                    sum[mt][r] = on ? __fadd_rn(sum[mt][r], __fmul_rn(kv, xv[xbuf][mt][r])) : sum[mt][r];
+                }
+        };
+        auto write_tile = [&]() {
+            // (address re-derived from an opaque copy of the lane index right here: kept across the whole slot sequence it
+            // would cost registers the loop does not have)
+            int ln = lane;
+            asm volatile("" : "+v"(ln));
+            float* trow = &tile[(ln & 15) * CP_STR + 16 * MT * wave + 4 * (ln >> 4)];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                *reinterpret_cast<f32x4v*>(trow + 16 * mt) = sum[mt];
+                sum[mt] = f32x4v{0.f, 0.f, 0.f, 0.f};
+            }
+        };
+        int rb = 0;  // ring buffer of the current slot
+        frag(0u, 0, 0);
         while (true) {
             const int n = n0 + local_of(m);
             const bool has_next = mn < n_iter;
             const int nd = min(deg[n], K);
             const int32_t* srow = src + (size_t)n * K;
             const int32_t* srow_next = src + (size_t)(has_next ? n0 + local_of(mn) : n) * K;
-            f32x4v sum[2] = {f32x4v{0.f, 0.f, 0.f, 0.f}, f32x4v{0.f, 0.f, 0.f, 0.f}};
 #pragma unroll
             for (int s = 0; s < K; ++s) {
-                f32x4v am[2] = {f32x4v{0.f, 0.f, 0.f, 0.f}, f32x4v{0.f, 0.f, 0.f, 0.f}};
-                f32x4v ax[2] = {f32x4v{0.f, 0.f, 0.f, 0.f}, f32x4v{0.f, 0.f, 0.f, 0.f}};
+                constexpr int set = 0;
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) { am[set][mt] = f32x4v{0.f, 0.f, 0.f, 0.f}; ax[set][mt] = f32x4v{0.f, 0.f, 0.f, 0.f}; }
                 if (s + 2 < K) load_x(srow, s + 2, (s + 2) & 3);
                 else load_x(srow_next, s + 2 - K, (s + 2) & 3);  // (the last receiver re-reads its own rows: never used)
-                const u32x4* f = frag0 + (size_t)s * (SLOT_BYTES / 16);
-                u32x4 b1[2], b2[2];
-                b1[0] = f[0];
-                b2[0] = f[64];
+                const unsigned f = (unsigned)rb * SLOT_BYTES;
+                rb = rb == RING - 1 ? 0 : rb + 1;
+                const unsigned f_next = (unsigned)rb * SLOT_BYTES;
                 auto kstep = [&](int kb) {  // same product order per accumulator as MmaStream16 (edge_f16.hip)
                     const int slot = kb & 1, nslot = slot ^ 1;
-                    if (kb + 1 < NKB) {
-                        b1[nslot] = f[(size_t)(kb + 1) * 128];
-                        b2[nslot] = f[(size_t)(kb + 1) * 128 + 64];
+                    if (kb + 1 < NKB) frag(f, kb + 1, nslot);
+                    else frag(f_next, 0, nslot);  // k-block 0 of the next slot (published by this slot's barrier; at the very
+                                                  // end of the sequence: a buffer nobody writes any more, never used)
+                    const int s2 = BFP8 ? 0 : slot;  // (the widened fp8 fragment is made right in front of its MFMAs: one copy)
+                    if constexpr (BFP8) {
+#pragma unroll
+                        for (int w2 = 0; w2 < 2; ++w2) {
+                            b2[0][2 * w2] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(b8[slot][w2], 1.0f, false));
+                            b2[0][2 * w2 + 1] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(b8[slot][w2], 1.0f, true));
+                        }
                     }
 #pragma unroll
-                    for (int mt = 0; mt < 2; ++mt) {
-                        am[mt] = mfma16_f16(A1[mt][kb], b1[slot], am[mt]);
-                        ax[mt] = mfma16_f16(A1[mt][kb], b2[slot], ax[mt]);
-                        ax[mt] = mfma16_f16(A2[mt][kb], b1[slot], ax[mt]);
+                    for (int mt = 0; mt < MT; ++mt) {
+                        am[set][mt] = mfma16_f16(A1[mt][kb], b1[slot], am[set][mt]);
+                        ax[set][mt] = mfma16_f16(A1[mt][kb], b2[s2], ax[set][mt]);
+                        ax[set][mt] = mfma16_f16(A2[mt][kb], b1[slot], ax[set][mt]);
                     }
                 };
 #pragma unroll
@@ -168,18 +230,9 @@ __global__ __launch_bounds__(512, 2) void conv_proj_kernel(
                 __syncthreads();  // SYNC_q
 #pragma unroll
                 for (int kb = NKB / 2; kb < NKB; ++kb) kstep(kb);
-                const bool on = s < nd;  // product rounded, then added in edge order (messages -> index_add_)
-#pragma unroll
-                for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) {
-                        const float kv = fmaf(ax[mt][r], F16X3_INV_SCALE, am[mt][r]);
-                        sum[mt][r] = on ? __fadd_rn(sum[mt][r], __fmul_rn(kv, xv[s & 3][mt][r])) : sum[mt][r];
-                    }
+                epilogue(0, s & 3, s < nd);
             }
-#pragma unroll
-            for (int mt = 0; mt < 2; ++mt) *reinterpret_cast<f32x4v*>(&tile[par][c16 * CP_STR + cb + 16 * mt]) = sum[mt];
-            par ^= 1;
+            write_tile();  // (the mix waves took the previous receiver's tile into registers right behind SYNC of slot 0)
             if (!has_next) break;
             m = mn;
             mn = next_valid(mn + m_step);
@@ -189,9 +242,9 @@ __global__ __launch_bounds__(512, 2) void conv_proj_kernel(
     }
 
     // ================================================= mix role =================================================
-    const int t2 = tid - 256;
+    const int t2 = tid - 64 * PW;
     const int c = t2 & 127, ph = t2 >> 7;  // channel, half of the output orientations (p = 8 ph .. 8 ph + 7)
-    const int w4 = wave - 4;               // this wave copies fragments 4 w4 .. 4 w4 + 3 of every slot block
+    const int w4 = wave - PW;              // this wave copies fragments 4 w4 .. 4 w4 + 3 of every slot block
     float fkr[16][8];
     float bias = conv_bias[c];
     {
@@ -209,11 +262,13 @@ __global__ __launch_bounds__(512, 2) void conv_proj_kernel(
     }
     asm volatile("" : "+v"(bias));
     const unsigned lane16 = 16u * lane;
-    const unsigned ring0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)&ring[0][0]) + 4096u * w4;
-    auto copy_slot = [&](int n, int s) {  // this wave's quarter of slot s of receiver n -> ring[s]
-        const char* g = reinterpret_cast<const char*>(basis) + ((size_t)n * K + s) * SLOT_BYTES + 4096u * w4;
+    const unsigned ring0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)&ring[0][0]) + 1024u * NC * w4;
+    int wb = 0;  // ring buffer the next copy goes to (copies are issued in slot order)
+    auto copy_slot = [&](int n, int s) {  // this wave's quarter of slot s of receiver n -> the next ring buffer
+        const char* g = reinterpret_cast<const char*>(basis) + ((size_t)n * K + s) * SLOT_BYTES + 1024u * NC * w4;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) cp_glds16(lane16, g + 1024 * j, ring0 + s * SLOT_BYTES + 1024u * j);
+        for (int j = 0; j < NC; ++j) cp_glds16(lane16, g + 1024 * j, ring0 + wb * SLOT_BYTES + 1024u * j);
+        wb = wb == RING - 1 ? 0 : wb + 1;
     };
     const unsigned st_off = 4u * ((8 * ph) * C + c);
     auto store_out = [&](int n, float (&out)[8]) {
@@ -227,16 +282,17 @@ __global__ __launch_bounds__(512, 2) void conv_proj_kernel(
         cp_store4<24 * C>(xb, st_off, out[6] + bias);
         cp_store4<28 * C>(xb, st_off, out[7] + bias);
     };
-    // prologue: slots 0 .. 6 of the first receiver are requested, slot 0 is waited for (24 younger copies stay in flight)
+    // prologue: all eight slots of the first receiver are requested, slot 0 is waited for (the 7 NC younger copies stay in flight)
     {
         const int n = n0 + local_of(m);
 #pragma unroll
-        for (int s = 0; s < K - 1; ++s) copy_slot(n, s);
-        cp_wait_but<24>();
+        for (int s = 0; s < K; ++s) copy_slot(n, s);
+        cp_wait_but<7 * NC>();
         __syncthreads();  // SYNC_-1
     }
-    int i = 0, par = 0, n_prev = 0;
+    int i = 0, n_prev = 0;
     float out[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    float tv[16];  // x1[o][c] of the previous receiver
     while (true) {
         const int n = n0 + local_of(m);
         const bool has_next = mn < n_iter;
@@ -244,20 +300,25 @@ __global__ __launch_bounds__(512, 2) void conv_proj_kernel(
 #pragma unroll
         for (int s = 0; s < K; ++s) {
             // Before SYNC_q (q = 8 i + s) this wave's share of slot q + 1 must have landed.  Younger than that copy, in
-            // the in-order queue: the copies of slots q + 2 .. q + 6 (4 each) and -- when step q - 6 .. q - 1 contains a
-            // "phase 7" step that stored a receiver's result (s <= 5, from the third receiver on) -- those 8 stores.  The
+            // the in-order queue: the copies of slots q + 2 .. q + 7 (NC each) and -- when steps q - 7 .. q - 1 contain a
+            // "phase 7" step that stored a receiver's result (s <= 6, from the third receiver on) -- those 8 stores.  The
             // last receiver of the sequence has no full set of younger copies: it waits for everything.
             if (!has_next) cp_wait_but<0>();
-            else if (s <= 5 && i >= 2) cp_wait_but<28>();
-            else cp_wait_but<20>();
-            __syncthreads();  // SYNC_q
-            if (s == 0) copy_slot(n, K - 1);              // slot q + 7: this receiver's last slot ...
-            else if (has_next) copy_slot(n_next, s - 1);  // ... or slot s - 1 of the next receiver
+            else if (s <= 6 && i >= 2) cp_wait_but<6 * NC + 8>();
+            else cp_wait_but<6 * NC>();
+            __syncthreads();  // SYNC_q: slot q - 1's buffer is free
+            if (has_next) copy_slot(n_next, s);  // slot q + 8 = slot s of the next receiver
             if (i > 0) {  // orientation mix of the previous receiver, two input orientations per step (o ascending)
+                if (s == 0) {
+#pragma unroll
+                    for (int o = 0; o < 16; ++o) tv[o] = tile[o * CP_STR + c];
+#pragma unroll
+                    for (int o = 0; o < 16; ++o) asm volatile("" : "+v"(tv[o]));  // read before this wave meets SYNC_q+1
+                }
 #pragma unroll
                 for (int oo = 0; oo < 2; ++oo) {
                     const int o = 2 * s + oo;
-                    const float xo = tile[par ^ 1][o * CP_STR + c];
+                    const float xo = tv[o];
 #pragma unroll
                     for (int p = 0; p < 8; ++p) out[p] = fmaf(xo, fkr[o][p], out[p]);
                 }
@@ -269,7 +330,6 @@ __global__ __launch_bounds__(512, 2) void conv_proj_kernel(
             }
         }
         n_prev = n;
-        par ^= 1;
         ++i;
         if (!has_next) break;
         m = mn;
@@ -278,7 +338,7 @@ __global__ __launch_bounds__(512, 2) void conv_proj_kernel(
     __syncthreads();  // the last receiver's tile is complete
 #pragma unroll
     for (int o = 0; o < 16; ++o) {
-        const float xo = tile[par ^ 1][o * CP_STR + c];
+        const float xo = tile[o * CP_STR + c];
 #pragma unroll
         for (int p = 0; p < 8; ++p) out[p] = fmaf(xo, fkr[o][p], out[p]);
     }
@@ -307,8 +367,19 @@ int arreau_launch_conv_proj(const arreau_model* m, int layer, const float* basis
     constexpr int TC = 4, TD = 8, NF1 = 12, NF2 = 16, NF3 = 32;  // chunk geometry of the packed edge stream (edge_f16.hip)
     const u32x4* stream = reinterpret_cast<const u32x4*>(m->edge_f16);
     const u32x4* wchunks = stream + ((size_t)TC * NF1 + (size_t)TD * NF2 + (size_t)layer * TC * NF3) * 64;
-    ARREAU_LAUNCH((conv_proj_kernel<128, 256>), dim3(blocks), dim3(512), 0, s, reinterpret_cast<const u32x4*>(basis), wchunks, deg, src,
-                  x_in, m->fk + (size_t)layer * 16 * 16 * m->C, m->conv_bias + (size_t)layer * m->C, n0, Ng, x_conv);
+    static const int pw_env = [] { const char* e = getenv("ARREAU_CONV_PROJ_WAVES"); return e ? atoi(e) : 8; }();
+    auto launch = [&](auto kernel, int threads) {
+        ARREAU_LAUNCH(kernel, dim3(blocks), dim3(threads), 0, s, reinterpret_cast<const u32x4*>(basis), wchunks, deg, src, x_in,
+                      m->fk + (size_t)layer * 16 * 16 * m->C, m->conv_bias + (size_t)layer * m->C, n0, Ng, x_conv);
+    };
+    const bool fp8 = arreau_basis_fp8();
+    if (pw_env == 4) {
+        if (fp8) launch(conv_proj_kernel<128, 256, 4, true>, 512);
+        else launch(conv_proj_kernel<128, 256, 4, false>, 512);
+    } else {
+        if (fp8) launch(conv_proj_kernel<128, 256, 8, true>, 768);
+        else launch(conv_proj_kernel<128, 256, 8, false>, 768);
+    }
     ARREAU_CHECK_HIP(hipGetLastError());
     return ARREAU_OK;
 }

@@ -83,7 +83,12 @@ extern "C" int arreau_debug_edge_ticks(unsigned long long* out8, int reset) {
 // storing their results: one 16 KiB block per edge slot ([k-block 0..7][plane][lane] x 16 bytes: whole 1 KiB, fully
 // coalesced store instructions), 1 KiB per (edge, orientation) row written ONCE, where the K stash writes L*C*3 = 1,920
 // bytes.  The projections move into the per-layer message kernel (conv_proj.hip), which streams those blocks through LDS.
-template <int C, int D, int EH_WAVES, bool K3 /* K tiles as 3-byte floats (internal.h) */, bool PROJ = true>
+// BFP8 (basis form only): the residual plane leaves as OCP fp8 e4m3 instead of fp16 -- 3 bytes per basis value, a 12 KiB
+// block per slot ([8 k-blocks] x 1 KiB of hi fragments, then [8] x 512 B of lo fragments).  The basis then carries 11 + 4
+// significand bits; in the fp32 oracle that changes the network outputs by no more than the 4-byte form does (both at the
+// fp32 rounding floor: tools/exp/basis_precision_study.py, profiles/r03_basis_precision_study.txt), and it takes a quarter
+// off the only large stream of the step.
+template <int C, int D, int EH_WAVES, bool K3 /* K tiles as 3-byte floats (internal.h) */, bool PROJ = true, bool BFP8 = false>
 __global__ __launch_bounds__(64 * EH_WAVES, 2) void edge_kernel_f16x3(
     const float* __restrict__ nbr_dir,   // [N][k][3]
     const float* __restrict__ nbr_dist,  // [N][k]
@@ -343,16 +348,41 @@ __global__ __launch_bounds__(64 * EH_WAVES, 2) void edge_kernel_f16x3(
                     // (asm stores: a FIXED count per chunk, which wait_copies() relies on; wait states behind each: the
                     // data registers of a VMEM store of more than 64 bits must not be rewritten at once)
                     const bool full_b = 2 * wn + 1 < k;  // wave-uniform: the wave's second slot exists
-                    const char* blk = reinterpret_cast<const char*>(kbuf) + ((size_t)node * k + 2 * wn) * 16384 + 2048 * u;
+                    constexpr unsigned SLOT = BFP8 ? 12288u : 16384u;
+                    const char* blk = reinterpret_cast<const char*>(kbuf) + ((size_t)node * k + 2 * wn) * SLOT;
 #pragma unroll
-                    for (int nb = 0; nb < 2; ++nb)
+                    for (int nb = 0; nb < 2; ++nb) {
+                        if (nb == 1 && !full_b) continue;
+                        if constexpr (BFP8) {
+                            asm volatile("global_store_dwordx4 %0, %1, %2" ARREAU_K_STORE_TAIL
+                                         :
+                                         : "v"(lane16), "v"(b16[nb][u][0]), "s"(blk + SLOT * nb + 1024 * u)
+                                         : "memory");
+                            typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
+                            typedef short s2_t __attribute__((ext_vector_type(2)));
+                            unsigned lo8[2];
 #pragma unroll
-                        for (int plane = 0; plane < 2; ++plane)
-                            if (nb == 0 || full_b)
+                            for (int w2 = 0; w2 < 2; ++w2) {  // halves 4 w2 .. 4 w2 + 3 of the lane's eight -> one dword of fp8
+                                s2_t r = {0, 0};
+                                r = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(r, __builtin_bit_cast(h2_t, b16[nb][u][1][2 * w2]), 1.0f, false);
+                                r = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(r, __builtin_bit_cast(h2_t, b16[nb][u][1][2 * w2 + 1]), 1.0f, true);
+                                lo8[w2] = __builtin_bit_cast(unsigned, r);
+                            }
+                            typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+                            const u32x2_t lo = {lo8[0], lo8[1]};
+                            asm volatile("global_store_dwordx2 %0, %1, %2"
+                                         :
+                                         : "v"(lane16 >> 1), "v"(lo), "s"(blk + SLOT * nb + 8192 + 512 * u)
+                                         : "memory");
+                        } else {
+#pragma unroll
+                            for (int plane = 0; plane < 2; ++plane)
                                 asm volatile("global_store_dwordx4 %0, %1, %2" ARREAU_K_STORE_TAIL
                                              :
-                                             : "v"(lane16), "v"(b16[nb][u][plane]), "s"(blk + 16384 * nb + 1024 * plane)
+                                             : "v"(lane16), "v"(b16[nb][u][plane]), "s"(blk + SLOT * nb + 2048 * u + 1024 * plane)
                                              : "memory");
+                        }
+                    }
                     pend += full_b ? 4 : 2;
                 }
             }
@@ -748,8 +778,12 @@ int arreau_launch_edge_f16x3(const arreau_model* m, const float* dir, const floa
     int wgs = wgs_env > 0 ? (wgs_env < npairs ? wgs_env : npairs) : (npairs < n_cu ? npairs : n_cu);
     if (r.wg_cap > 0 && wgs > r.wg_cap) wgs = r.wg_cap;
     if (arreau_basis_form(m, n1 - n0)) {  // stop after layer 2, store the basis planes (the node-layer launcher projects them)
-        ARREAU_LAUNCH((edge_kernel_f16x3<128, 256, 8, false, false>), dim3(wgs), dim3(512), 0, s, dir, dist, deg, batch, lattice, m->ori,
-                      reinterpret_cast<const u32x4*>(m->edge_f16), m->b1, m->b2, m->cfg.radius, N, m->k, m->L, kbuf, n0, n1);
+        if (arreau_basis_fp8())
+            ARREAU_LAUNCH((edge_kernel_f16x3<128, 256, 8, false, false, true>), dim3(wgs), dim3(512), 0, s, dir, dist, deg, batch, lattice, m->ori,
+                          reinterpret_cast<const u32x4*>(m->edge_f16), m->b1, m->b2, m->cfg.radius, N, m->k, m->L, kbuf, n0, n1);
+        else
+            ARREAU_LAUNCH((edge_kernel_f16x3<128, 256, 8, false, false, false>), dim3(wgs), dim3(512), 0, s, dir, dist, deg, batch, lattice, m->ori,
+                          reinterpret_cast<const u32x4*>(m->edge_f16), m->b1, m->b2, m->cfg.radius, N, m->k, m->L, kbuf, n0, n1);
         ARREAU_CHECK_HIP(hipGetLastError());
         return ARREAU_OK;
     }

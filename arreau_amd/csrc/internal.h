@@ -302,6 +302,7 @@ bool arreau_k3(const arreau_model* m);
 // planes instead of the L projected kernels, and each layer's message kernel projects them itself (conv_proj.hip) -- no K
 // stash.  The edge launcher and the node-layer launcher take the decision from the same fields and the same receiver count.
 bool arreau_basis_form(const arreau_model* m, int receivers);
+bool arreau_basis_fp8();  // residual plane of the stashed basis as fp8 e4m3 (default; ARREAU_BASIS_FP8=0: fp16, bit-identical to the K pair)
 int arreau_launch_conv_proj(const arreau_model* m, int layer, const float* basis, const int32_t* deg, const int32_t* src,
                             const float* x_in, float* x_conv, int N, hipStream_t s, NodeRange r = NodeRange());
 

@@ -968,6 +968,11 @@ bool arreau_basis_form(const arreau_model* m, int receivers) {
     return m->conv_variant == 2 && m->edge_variant == 4 && m->f16_ok && m->k == 8 && m->C == 128 && m->D == 256 && receivers > 240;
 }
 
+bool arreau_basis_fp8() {
+    static const int env = [] { const char* e = getenv("ARREAU_BASIS_FP8"); return e ? atoi(e) : 1; }();
+    return env != 0;
+}
+
 bool arreau_range_launches_supported(const arreau_model* m) {
     return m->edge_variant == 4 && (m->mlp_variant == 3 || m->mlp_variant == 4) && m->f16_ok && (m->conv_variant == 1 || m->conv_variant == 2) && m->k == 8 &&
            m->readout_variant == 1 && m->S + 4 <= 96 && m->L <= 8 && m->C == 128;

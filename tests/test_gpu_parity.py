@@ -828,7 +828,7 @@ def test_launch_geometry_switches_and_counted_waits_are_bitwise_neutral(dev):
     outs = {}
     with tempfile.TemporaryDirectory() as d:
         for tag, env in (("default", {}), ("k3off", {"ARREAU_CONV_VARIANT": "1", "ARREAU_K3": "0"}), ("conv0", {"ARREAU_CONV_VARIANT": "0"}),
-                         ("pair", {"ARREAU_CONV_VARIANT": "1"}),
+                         ("pair", {"ARREAU_CONV_VARIANT": "1"}), ("basis16", {"ARREAU_BASIS_FP8": "0"}),
                          ("wgs", {"ARREAU_EDGE_WGS": "100000"}),
                          ("dbgwait", {"ARREAU_HIP_LIB": LIB_DEBUG_WAIT}), ("nb1", {"ARREAU_MLP_NB": "1"}),
                          ("nb2", {"ARREAU_MLP_NB": "2"}), ("slots4", {"ARREAU_MLP_SLOTS": "4"}),
@@ -848,9 +848,18 @@ def test_launch_geometry_switches_and_counted_waits_are_bitwise_neutral(dev):
     # (ARREAU_K3=0), which in turn is bit-identical to the register form of the conv kernel (ARREAU_CONV_VARIANT=0).  The
     # round-2 default, the same pair with K as 3-byte floats, agrees to the parity tolerance (K rounded to 16 significand
     # bits: tools/exp/k_precision_study.py).
+    # The default stash holds the basis' residual plane as fp8 e4m3 (3 bytes per value); ARREAU_BASIS_FP8=0 keeps both
+    # planes in fp16 (4 bytes), which makes the whole chain the SAME arithmetic as the round-2 kernels.
     for tag in ("k3off", "conv0"):
-        for x, y in zip(outs["default"], outs[tag]):
+        for x, y in zip(outs["basis16"], outs[tag]):
             assert torch.equal(x, y), tag
+    # what the fp8 residual plane costs (11 + 4 significand bits of the basis): bounded like the K stash below, by what
+    # tools/exp/basis_precision_study.py measured in the oracle (eps 7e-8, logits 3.6e-7 at |logits| = 2: the rounding floor)
+    b_eps, b_logits, b_len0 = (float((a - b).abs().max()) for a, b in zip(outs["default"], outs["basis16"]))
+    print(f"[basis stash] |fp16 + fp8 - fp16 + fp16| : eps {b_eps:.2e}  logits {b_logits:.2e} (|logits| {float(outs['basis16'][1].abs().max()):.1f})"
+          f"  len0 {b_len0:.2e} (|len0| {float(outs['basis16'][2].abs().max()):.1f})")
+    assert b_eps <= 3e-7 and b_logits <= 4e-7 * max(1.0, float(outs["basis16"][1].abs().max()))
+    assert b_len0 <= 3 * ulp32(float(outs["basis16"][2].abs().max()))
     # What the 3-byte stash costs, bounded by what tools/exp/k_precision_study.py measured for 16 significand bits in the
     # oracle (profiles/r02g_k_precision_study.txt: eps 7e-8, logits 3.6e-7 at |logits| <= 2, i.e. about 2e-7 of the
     # largest logit -- the fp32 rounding floor) and what this comparison measures on the GPU (eps 1.3e-7, logits 1.9e-6 at

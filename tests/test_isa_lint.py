@@ -95,6 +95,17 @@ def test_mfma_result_read_by_asm(lint, tmp_path):
     assert run(lint, tmp_path, mfma + "\ts_nop 7\n" + store) == []
 
 
+def test_spills_must_not_share_a_path_with_counted_waits(lint, tmp_path):
+    spill = "\tscratch_store_dword off, v0, off\n"
+    wait = ASM % "\ts_waitcnt vmcnt(4)"
+    assert run(lint, tmp_path, spill + wait) == ["scratch-before-counted-wait"]
+    assert run(lint, tmp_path, wait + spill) == ["scratch-after-counted-wait"]
+    assert run(lint, tmp_path, spill + ASM % "\ts_waitcnt vmcnt(0)") == []  # a full wait is not a count
+    # two roles that never meet: one spills, the other counts
+    roles = ("\ts_cbranch_scc1 .LBB0_5\n" + spill + "\ts_endpgm\n.LBB0_5:\n" + wait)
+    assert run(lint, tmp_path, roles) == []
+
+
 def test_unmodelled_instruction_inside_asm_is_reported(lint, tmp_path):
     assert run(lint, tmp_path, ASM % "\tv_permlane32_swap_b32 v1, v2") == ["unmodelled-asm"]
 

@@ -18,6 +18,8 @@ contains inline asm):
     in front of it cover the load; the claim itself is checked on the GPU by the debug-wait twin library (every counted
     wait -> vmcnt(0), outputs bit-identical).  What the lint proves is the part no test can: that the COMPILER did not
     copy, spill or re-use the destination registers between the load and that point;
+  * register spills (scratch_*) must not share a control-flow path with an inline-asm counted wait `vmcnt(N > 0)` (they
+    are VMEM operations in the same in-order queue); a role of waves that never counts may spill;
   * M0: in a function whose asm writes M0, every compiler instruction naming m0 is a violation (the asm does not
     restore it);
   * `--all` applies the table to compiler-only pairs too: it must report nothing (self-check of the table and of the
@@ -490,6 +492,40 @@ def check_modelled(name, code):
     return [(name, "unmodelled-asm", 0, 0, i, i, []) for i in code if i.in_asm and not _ASM_MODELLED.match(i.mn)]
 
 
+def check_scratch(name, code, succs):
+    """Register spills (scratch_load / scratch_store) are VMEM operations: in a wave that hand-counts `s_waitcnt vmcnt(N)`
+    they would sit in the same in-order queue and silently shift the count.  A kernel may spill in one role (a branch of
+    waves that never executes a counted wait -- hipcc counts its own scratch traffic correctly there) but not on any path
+    that also meets an inline-asm counted wait: no asm `vmcnt(N > 0)` may be reachable from a scratch instruction, nor a
+    scratch instruction from such a wait."""
+    scratch = [i for i in code if i.mn.startswith("scratch_")]
+    waits = [i for i in code if i.in_asm and i.vmcnt is not None and i.vmcnt > 0]
+    if not scratch or not waits:
+        return []
+
+    def reach(starts):
+        seen, stack = set(), [x.idx for x in starts]
+        while stack:
+            i = stack.pop()
+            for nxt in succs[i]:
+                if nxt not in seen:
+                    seen.add(nxt)
+                    stack.append(nxt)
+        return seen
+
+    from_scratch, from_waits = reach(scratch), reach(waits)
+    out = []
+    for w in waits:
+        if w.idx in from_scratch:
+            out.append((name, "scratch-before-counted-wait", 0, 0, scratch[0], w, []))
+            break
+    for x in scratch:
+        if x.idx in from_waits:
+            out.append((name, "scratch-after-counted-wait", 0, 0, waits[0], x, []))
+            break
+    return out
+
+
 _M0_OK = (re.compile(r"^s_mov_b32 m0, s\d+$"), re.compile(r"^s_add_u32 m0, s\d+, (0x[0-9a-f]+|\d+|s\d+)$"),
           re.compile(r"^s_mov_b32 s\d+, m0$"))
 
@@ -514,6 +550,7 @@ def lint_file(path, all_pairs=False):
         out += check_asm_loads(name, code, succs)
         out += check_m0(name, code)
         out += check_modelled(name, code)
+        out += check_scratch(name, code, succs)
     return out
 
 
