@@ -145,12 +145,15 @@ __global__ __launch_bounds__(64 * (PW + 4), (PW + 4) / 4) void conv_proj_kernel(
             load_x(srow0, 1, 1);
         }
         __syncthreads();  // SYNC_-1: slot 0 of the first receiver has landed
-        // Every slot step has ONE barrier in the middle of its MFMA stream, so a step is as long as the longest dependent
-        // chain of a wave: the B fragments of a slot's first k-block are therefore requested during the previous slot's
-        // last k-step (the slot has been published by that slot's barrier) instead of behind its epilogue.
+        // B fragments travel LDS -> registers DIST k-steps ahead of their MFMAs, through NBUF rotating register sets, across
+        // barriers and slot boundaries (a slot's first fragments are requested during the previous slot's last k-steps: that
+        // slot has been published by the barrier in the middle of the previous slot).  hipcc, left alone, sinks every
+        // ds_read to within one or two MFMAs of its use -- measured: the LDS latency exposed at each of the 64 k-steps of a
+        // receiver, a matrix pipe busy 45 % of the time -- so the issue order is pinned with sched_group_barrier below.
+        constexpr int DIST = PW == 4 ? 2 : 1, NBUF = PW == 4 ? 4 : 2;
         typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
-        u32x4 b1[2], b2[2];
-        u32x2_t b8[2];  // BFP8: the lo fragment as stored (8 fp8 per lane)
+        u32x4 b1[NBUF], b2[NBUF];
+        u32x2_t b8[NBUF];  // BFP8: the lo fragment as stored (8 fp8 per lane)
         const char* ring_b = reinterpret_cast<const char*>(&ring[0][0]);
         const unsigned hi_off = 16u * lane, lo_off = 8192u + 8u * lane;
         auto frag = [&](unsigned base /* byte offset of the slot buffer: wave-uniform */, int kb, int sl_) {
@@ -188,7 +191,8 @@ __global__ __launch_bounds__(64 * (PW + 4), (PW + 4) / 4) void conv_proj_kernel(
             }
         };
         int rb = 0;  // ring buffer of the current slot
-        frag(0u, 0, 0);
+#pragma unroll
+        for (int kb = 0; kb < DIST; ++kb) frag(0u, kb, kb);
         while (true) {
             const int n = n0 + local_of(m);
             const bool has_next = mn < n_iter;
@@ -206,10 +210,11 @@ __global__ __launch_bounds__(64 * (PW + 4), (PW + 4) / 4) void conv_proj_kernel(
                 rb = rb == RING - 1 ? 0 : rb + 1;
                 const unsigned f_next = (unsigned)rb * SLOT_BYTES;
                 auto kstep = [&](int kb) {  // same product order per accumulator as MmaStream16 (edge_f16.hip)
-                    const int slot = kb & 1, nslot = slot ^ 1;
-                    if (kb + 1 < NKB) frag(f, kb + 1, nslot);
-                    else frag(f_next, 0, nslot);  // k-block 0 of the next slot (published by this slot's barrier; at the very
-                                                  // end of the sequence: a buffer nobody writes any more, never used)
+                    const int slot = kb % NBUF, kk = kb + DIST;
+                    if (kk < NKB) frag(f, kk, kk % NBUF);
+                    else frag(f_next, kk - NKB, kk % NBUF);  // first k-blocks of the next slot (published by this slot's barrier;
+                                                             // at the very end of the sequence: a buffer nobody writes any
+                                                             // more, never used)
                     const int s2 = BFP8 ? 0 : slot;  // (the widened fp8 fragment is made right in front of its MFMAs: one copy)
                     if constexpr (BFP8) {
 #pragma unroll
@@ -225,11 +230,20 @@ __global__ __launch_bounds__(64 * (PW + 4), (PW + 4) / 4) void conv_proj_kernel(
                         ax[set][mt] = mfma16_f16(A2[mt][kb], b1[slot], ax[set][mt]);
                     }
                 };
+                auto pin = [&]() {  // issue order of one half slot: per k-step its fragment requests, then its MFMAs (vector work floats)
+#pragma unroll
+                    for (int i = 0; i < NKB / 2; ++i) {
+                        __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);                 // DS reads of k-step + DIST
+                        __builtin_amdgcn_sched_group_barrier(0x008, 3 * MT, 0);           // MFMAs of this k-step
+                    }
+                };
 #pragma unroll
                 for (int kb = 0; kb < NKB / 2; ++kb) kstep(kb);
+                pin();
                 __syncthreads();  // SYNC_q
 #pragma unroll
                 for (int kb = NKB / 2; kb < NKB; ++kb) kstep(kb);
+                pin();
                 epilogue(0, s & 3, s < nd);
             }
             write_tile();  // (the mix waves took the previous receiver's tile into registers right behind SYNC of slot 0)
@@ -367,7 +381,7 @@ int arreau_launch_conv_proj(const arreau_model* m, int layer, const float* basis
     constexpr int TC = 4, TD = 8, NF1 = 12, NF2 = 16, NF3 = 32;  // chunk geometry of the packed edge stream (edge_f16.hip)
     const u32x4* stream = reinterpret_cast<const u32x4*>(m->edge_f16);
     const u32x4* wchunks = stream + ((size_t)TC * NF1 + (size_t)TD * NF2 + (size_t)layer * TC * NF3) * 64;
-    static const int pw_env = [] { const char* e = getenv("ARREAU_CONV_PROJ_WAVES"); return e ? atoi(e) : 8; }();
+    static const int pw_env = [] { const char* e = getenv("ARREAU_CONV_PROJ_WAVES"); return e ? atoi(e) : 4; }();
     auto launch = [&](auto kernel, int threads) {
         ARREAU_LAUNCH(kernel, dim3(blocks), dim3(threads), 0, s, reinterpret_cast<const u32x4*>(basis), wchunks, deg, src, x_in,
                       m->fk + (size_t)layer * 16 * 16 * m->C, m->conv_bias + (size_t)layer * m->C, n0, Ng, x_conv);

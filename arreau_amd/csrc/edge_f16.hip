@@ -88,6 +88,18 @@ extern "C" int arreau_debug_edge_ticks(unsigned long long* out8, int reset) {
 // significand bits; in the fp32 oracle that changes the network outputs by no more than the 4-byte form does (both at the
 // fp32 rounding floor: tools/exp/basis_precision_study.py, profiles/r03_basis_precision_study.txt), and it takes a quarter
 // off the only large stream of the step.
+// The residual plane of a basis value pair rounded to fp8 e4m3 and widened back (exact): what the basis form stores.  The
+// kernels that project IN PLACE (PROJ = true: small launches, the round-2 pair) apply the same rounding to their B operand
+// when BFP8 is set, so that every path evaluates the same numbers -- a crystal alone (small-launch kernels) equals, bit for
+// bit, the same crystal inside a large batch (basis form).
+__device__ __forceinline__ unsigned round_lo_fp8(unsigned lo_pair) {
+    typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
+    typedef short s2_t __attribute__((ext_vector_type(2)));
+    s2_t r = {0, 0};
+    r = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(r, __builtin_bit_cast(h2_t, lo_pair), 1.0f, false);
+    return __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(__builtin_bit_cast(unsigned, r), 1.0f, false));
+}
+
 template <int C, int D, int EH_WAVES, bool K3 /* K tiles as 3-byte floats (internal.h) */, bool PROJ = true, bool BFP8 = false>
 __global__ __launch_bounds__(64 * EH_WAVES, 2) void edge_kernel_f16x3(
     const float* __restrict__ nbr_dir,   // [N][k][3]
@@ -339,6 +351,7 @@ __global__ __launch_bounds__(64 * EH_WAVES, 2) void edge_kernel_f16x3(
                                                    f32x2{acc.m[mt][nb][2 * pr], acc.m[mt][nb][2 * pr + 1]});
                             unsigned hi, lo;
                             split_pair2<false>(gelu_fast2(pre) * splat2(win16[nb]), hi, lo);  // |window| <= 1
+                            if constexpr (PROJ && BFP8) lo = round_lo_fp8(lo);
                             b16[nb][u][0][2 * mt + pr] = hi;
                             b16[nb][u][1][2 * mt + pr] = lo;
                         }
@@ -363,9 +376,12 @@ __global__ __launch_bounds__(64 * EH_WAVES, 2) void edge_kernel_f16x3(
                             unsigned lo8[2];
 #pragma unroll
                             for (int w2 = 0; w2 < 2; ++w2) {  // halves 4 w2 .. 4 w2 + 3 of the lane's eight -> one dword of fp8
+                                // (element copies first: __builtin_bit_cast applied to a vector-element lvalue reads element
+                                // 0 whatever the index -- hipcc 7.2)
+                                const unsigned p0 = b16[nb][u][1][2 * w2], p1 = b16[nb][u][1][2 * w2 + 1];
                                 s2_t r = {0, 0};
-                                r = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(r, __builtin_bit_cast(h2_t, b16[nb][u][1][2 * w2]), 1.0f, false);
-                                r = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(r, __builtin_bit_cast(h2_t, b16[nb][u][1][2 * w2 + 1]), 1.0f, true);
+                                r = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(r, __builtin_bit_cast(h2_t, p0), 1.0f, false);
+                                r = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(r, __builtin_bit_cast(h2_t, p1), 1.0f, true);
                                 lo8[w2] = __builtin_bit_cast(unsigned, r);
                             }
                             typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
@@ -498,7 +514,7 @@ __global__ __launch_bounds__(64 * EH_WAVES, 2) void edge_kernel_f16x3(
 // measured on MI355X (tools/gpu_edge_split_sweep.sh): 60 / 120 / 200 / 260 / 380 receivers: 19.8 / 31.8 / 56.9 / 71.0 / 88.1 us
 // against 65.9 / 67.0 / 69.0 / 71.8 / 74.0 us of the persistent form
 #define ARREAU_EDGE_SPLIT_MAX_NODES 240
-template <int C, int D, bool K3>
+template <int C, int D, bool K3, bool BFP8>
 __global__ __launch_bounds__(512) void edge_kernel_f16x3_split(
     const float* __restrict__ nbr_dir, const float* __restrict__ nbr_dist, const int32_t* __restrict__ deg,
     const int32_t* __restrict__ batch, const float* __restrict__ lattice, const float* __restrict__ ori,
@@ -638,6 +654,7 @@ __global__ __launch_bounds__(512) void edge_kernel_f16x3_split(
                                            f32x2{acc.m[mt][nb][2 * pr], acc.m[mt][nb][2 * pr + 1]});
                     unsigned hi, lo;
                     split_pair2<false>(gelu_fast2(pre) * splat2(win16[nb]), hi, lo);  // |window| <= 1
+                    if constexpr (BFP8) lo = round_lo_fp8(lo);
                     hi4[2 * mt + pr] = hi;
                     lo4[2 * mt + pr] = lo;
                 }
@@ -769,8 +786,11 @@ int arreau_launch_edge_f16x3(const arreau_model* m, const float* dir, const floa
             ARREAU_LAUNCH(kernel, dim3((unsigned)(n1 - n0) * 4), dim3(512), 0, s, dir, dist, deg, batch, lattice, m->ori,
                                reinterpret_cast<const u32x4*>(m->edge_f16), m->b1, m->b2, m->cfg.radius, N, m->k, m->L, kbuf, n0);
         };
-        if (k3) launch(edge_kernel_f16x3_split<128, 256, true>);
-        else launch(edge_kernel_f16x3_split<128, 256, false>);
+        const bool bq = arreau_basis_fp8();
+        if (k3 && bq) launch(edge_kernel_f16x3_split<128, 256, true, true>);
+        else if (k3) launch(edge_kernel_f16x3_split<128, 256, true, false>);
+        else if (bq) launch(edge_kernel_f16x3_split<128, 256, false, true>);
+        else launch(edge_kernel_f16x3_split<128, 256, false, false>);
         ARREAU_CHECK_HIP(hipGetLastError());
         return ARREAU_OK;
     }
@@ -791,8 +811,11 @@ int arreau_launch_edge_f16x3(const arreau_model* m, const float* dir, const floa
         ARREAU_LAUNCH(kernel, dim3(wgs), dim3(512), 0, s, dir, dist, deg, batch, lattice, m->ori,
                            reinterpret_cast<const u32x4*>(m->edge_f16), m->b1, m->b2, m->cfg.radius, N, m->k, m->L, kbuf, n0, n1);
     };
-    if (k3) launch(edge_kernel_f16x3<128, 256, 8, true>);
-    else launch(edge_kernel_f16x3<128, 256, 8, false>);
+    const bool bq = arreau_basis_fp8();
+    if (k3 && bq) launch(edge_kernel_f16x3<128, 256, 8, true, true, true>);
+    else if (k3) launch(edge_kernel_f16x3<128, 256, 8, true, true, false>);
+    else if (bq) launch(edge_kernel_f16x3<128, 256, 8, false, true, true>);
+    else launch(edge_kernel_f16x3<128, 256, 8, false, true, false>);
     ARREAU_CHECK_HIP(hipGetLastError());
     return ARREAU_OK;
 }

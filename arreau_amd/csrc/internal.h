@@ -302,7 +302,10 @@ bool arreau_k3(const arreau_model* m);
 // planes instead of the L projected kernels, and each layer's message kernel projects them itself (conv_proj.hip) -- no K
 // stash.  The edge launcher and the node-layer launcher take the decision from the same fields and the same receiver count.
 bool arreau_basis_form(const arreau_model* m, int receivers);
-bool arreau_basis_fp8();  // residual plane of the stashed basis as fp8 e4m3 (default; ARREAU_BASIS_FP8=0: fp16, bit-identical to the K pair)
+// Numerics switch of the split-precision edge path: the residual plane of the windowed basis is rounded to fp8 e4m3 (11 + 4
+// significand bits; default) -- what the basis form stores (3 bytes per value), applied by every fp16x3 edge kernel so that all
+// launch sizes evaluate the same numbers.  ARREAU_BASIS_FP8=0: both planes fp16 everywhere (the round-2 arithmetic).
+bool arreau_basis_fp8();
 int arreau_launch_conv_proj(const arreau_model* m, int layer, const float* basis, const int32_t* deg, const int32_t* src,
                             const float* x_in, float* x_conv, int N, hipStream_t s, NodeRange r = NodeRange());
 

@@ -848,18 +848,21 @@ def test_launch_geometry_switches_and_counted_waits_are_bitwise_neutral(dev):
     # (ARREAU_K3=0), which in turn is bit-identical to the register form of the conv kernel (ARREAU_CONV_VARIANT=0).  The
     # round-2 default, the same pair with K as 3-byte floats, agrees to the parity tolerance (K rounded to 16 significand
     # bits: tools/exp/k_precision_study.py).
-    # The default stash holds the basis' residual plane as fp8 e4m3 (3 bytes per value); ARREAU_BASIS_FP8=0 keeps both
-    # planes in fp16 (4 bytes), which makes the whole chain the SAME arithmetic as the round-2 kernels.
+    # Same products in the same order: the basis form (default) is bit-identical to the round-2 pair on an fp32 K stash and
+    # to the register form of the conv kernel -- every fp16x3 edge kernel rounds the basis' residual plane to fp8 e4m3, the
+    # form the stash holds (3 bytes per value).
     for tag in ("k3off", "conv0"):
-        for x, y in zip(outs["basis16"], outs[tag]):
+        for x, y in zip(outs["default"], outs[tag]):
             assert torch.equal(x, y), tag
-    # what the fp8 residual plane costs (11 + 4 significand bits of the basis): bounded like the K stash below, by what
-    # tools/exp/basis_precision_study.py measured in the oracle (eps 7e-8, logits 3.6e-7 at |logits| = 2: the rounding floor)
+    # What that rounding costs (11 + 4 significand bits of the basis; ARREAU_BASIS_FP8=0 keeps both planes in fp16 = the
+    # round-2 arithmetic).  In the fp32 oracle it is invisible (tools/exp/basis_precision_study.py: both forms at the
+    # rounding floor, eps 7e-8 / logits 3.6e-7 at |logits| = 2); measured here: eps 1.3e-7, logits 1.9e-6 at |logits| = 6.8
+    # (2.8e-7 relative), len0 4 ulps.  Bounded so that a coarser format cannot eat the parity margin silently.
     b_eps, b_logits, b_len0 = (float((a - b).abs().max()) for a, b in zip(outs["default"], outs["basis16"]))
     print(f"[basis stash] |fp16 + fp8 - fp16 + fp16| : eps {b_eps:.2e}  logits {b_logits:.2e} (|logits| {float(outs['basis16'][1].abs().max()):.1f})"
           f"  len0 {b_len0:.2e} (|len0| {float(outs['basis16'][2].abs().max()):.1f})")
     assert b_eps <= 3e-7 and b_logits <= 4e-7 * max(1.0, float(outs["basis16"][1].abs().max()))
-    assert b_len0 <= 3 * ulp32(float(outs["basis16"][2].abs().max()))
+    assert b_len0 <= 6 * ulp32(float(outs["basis16"][2].abs().max()))
     # What the 3-byte stash costs, bounded by what tools/exp/k_precision_study.py measured for 16 significand bits in the
     # oracle (profiles/r02g_k_precision_study.txt: eps 7e-8, logits 3.6e-7 at |logits| <= 2, i.e. about 2e-7 of the
     # largest logit -- the fp32 rounding floor) and what this comparison measures on the GPU (eps 1.3e-7, logits 1.9e-6 at
@@ -870,6 +873,48 @@ def test_launch_geometry_switches_and_counted_waits_are_bitwise_neutral(dev):
           f"  len0 {d_len0:.2e} (|len0| {float(outs['k3off'][2].abs().max()):.1f})")
     assert d_eps <= 3e-7 and d_logits <= 4e-7 * max(1.0, float(outs["k3off"][1].abs().max()))
     assert d_len0 <= 3 * ulp32(float(outs["k3off"][2].abs().max()))
+
+
+def test_basis_stash_holds_fp16_and_e4m3_planes(dev, full_model):
+    """The stash the edge kernel writes in the basis form, read back from the workspace: per edge slot a 12 KiB block of
+    eight 1 KiB hi fragments (fp16, [k-block][lane][8 halves]) and eight 512 B lo fragments (OCP fp8 e4m3).  Against the
+    4-byte form (ARREAU_BASIS_FP8=0, both planes fp16) of the same evaluation, run in a second process: the hi planes are
+    identical and every fp8 byte is torch's float8_e4m3fn rounding (nearest even) of the fp16 residual.  (Found with this
+    comparison in round 3: a __builtin_bit_cast on a vector-element lvalue that read element 0 for every index.)"""
+    import subprocess
+    import sys
+    import tempfile
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    B, n, k, C = 24, 20, 8, 128
+    N = B * n
+    code = ("import sys, torch\nsys.path.insert(0, %r)\n"
+            "from arreau_amd.checkpoint import make_synthetic_model\nfrom arreau_amd.diffusion.diffusion_helpers import crystal_offsets\n"
+            "from tests.helpers import random_state\n"
+            "dev = torch.device('cuda', 0)\nm = make_synthetic_model(S=90, seed=1234).to(dev)\n"
+            "frac, types, lengths, angles, na = random_state(90, [%d] * %d, 5, sampler_like=True)\nd = lambda v: v.to(dev).contiguous()\n"
+            "t_c = torch.full((%d,), 500, device=dev, dtype=torch.int32)\neng = m.engine()\n"
+            "eng.predict_scores(d(frac), d(types.to(torch.int32)), d(lengths), d(angles), t_c, crystal_offsets(na, dev))\n"
+            "torch.cuda.synchronize()\ntorch.save(eng.workspace(%d, %d).cpu(), sys.argv[1])\n" % (root, n, B, B, N, B))
+    off = 0
+    for nbytes in (B * 9 * 4, N * 3 * 4, B * C * 4, N * 4, N * 4, N * k * 4, N * k * 4, N * k * 3 * 4, N * k * 4, 0):  # api.hip: carve()
+        off = (off + 255) & ~255
+        k0 = off
+        off += nbytes
+    ws = {}
+    with tempfile.TemporaryDirectory() as d:
+        for tag, env in (("fp8", {}), ("f16", {"ARREAU_BASIS_FP8": "0"})):
+            path = os.path.join(d, tag + ".pt")
+            subprocess.run([sys.executable, "-c", code, path], check=True, env={**os.environ, **env}, timeout=300)
+            ws[tag] = torch.load(path)
+    slots = N * k
+    a = ws["fp8"][k0:k0 + slots * 12288].view(slots, 12288)
+    b16 = ws["f16"][k0:k0 + slots * 16384].contiguous().view(torch.float16).view(slots, 8, 2, 64, 8)  # [slot][k-block][plane][lane][8]
+    hi = a[:, :8192].contiguous().view(torch.float16).view(slots, 8, 64, 8)
+    lo = a[:, 8192:].contiguous().view(torch.uint8).view(slots, 8, 64, 8)
+    assert torch.isfinite(b16.float()).all() and float(b16[:, :, 0].float().abs().max()) > 0.1  # every slot was written (k = 8 everywhere)
+    assert torch.equal(hi.view(torch.int16), b16[:, :, 0].contiguous().view(torch.int16))
+    want = b16[:, :, 1].float().to(torch.float8_e4m3fn).view(torch.uint8)
+    assert int((want != lo).sum()) == 0
 
 
 def _philox_ref(ctr, key):
