@@ -17,7 +17,7 @@ EXPORTS = [
     "arreau_last_error", "arreau_version", "arreau_model_create", "arreau_model_destroy",
     "arreau_model_config", "arreau_workspace_bytes", "arreau_lattice_from_params", "arreau_frac_to_cart",
     "arreau_radius_graph_pbc", "arreau_compact_edges", "arreau_edges_to_slots", "arreau_predict_scores",
-    "arreau_reverse_step", "arreau_profile_edge_kernel", "arreau_edge_kernel_time_ms",
+    "arreau_reverse_step", "arreau_profile_edge_kernel", "arreau_edge_kernel_time_ms", "arreau_conv_kernel_time_ms",
     "arreau_model_status", "arreau_model_set_variant", "arreau_ponita_forward",
     "arreau_diffusion_noise", "arreau_diffusion_losses", "arreau_sample_loop", "arreau_philox_fill",
     "arreau_train_forward", "arreau_train_backward", "arreau_train_conv_stats", "arreau_model_update_train_weights",
@@ -108,6 +108,7 @@ def lib():
     L.arreau_debug_leftover_fraction.argtypes = [ctypes.c_uint32, POINTER(c_double), POINTER(c_double), c_void_p]
     L.arreau_profile_edge_kernel.argtypes = [c_int32]
     L.arreau_edge_kernel_time_ms.argtypes = [POINTER(c_double), POINTER(c_int64)]
+    L.arreau_conv_kernel_time_ms.argtypes = [POINTER(c_double), POINTER(c_int64)]
     for name in EXPORTS:
         fn = getattr(L, name)
         if fn.restype is ctypes.c_int:

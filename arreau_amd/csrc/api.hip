@@ -144,7 +144,31 @@ struct EdgeProfile {
     bool enabled = false;
     std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
 } g_prof;
+// the same for the per-layer message kernel of the basis form (conv_proj.hip), the dominant kernel since round 3
+EdgeProfile g_prof_conv;
 }  // namespace
+
+// called by arreau_launch_conv_proj around its launch (internal.h)
+void arreau_prof_conv(int end, hipStream_t s) {
+    static thread_local hipEvent_t e0 = nullptr;
+    {
+        std::lock_guard<std::mutex> lock(g_prof_conv.mu);
+        if (!g_prof_conv.enabled) return;
+    }
+    if (!end) {
+        if (hipEventCreate(&e0) != hipSuccess) { e0 = nullptr; return; }
+        (void)hipEventRecord(e0, s);
+        return;
+    }
+    if (!e0) return;
+    hipEvent_t e1 = nullptr;
+    if (hipEventCreate(&e1) == hipSuccess) {
+        (void)hipEventRecord(e1, s);
+        std::lock_guard<std::mutex> lock(g_prof_conv.mu);
+        g_prof_conv.events.emplace_back(e0, e1);
+    }
+    e0 = nullptr;
+}
 
 extern "C" size_t arreau_workspace_bytes(const arreau_config* cfg, int64_t max_atoms, int64_t max_crystals) {
     if (!cfg || max_atoms < 0 || max_crystals < 0) return 0;
@@ -152,13 +176,32 @@ extern "C" size_t arreau_workspace_bytes(const arreau_config* cfg, int64_t max_a
 }
 
 extern "C" int arreau_profile_edge_kernel(int32_t enable) {
-    std::lock_guard<std::mutex> lock(g_prof.mu);
-    for (auto& ev : g_prof.events) {
-        (void)hipEventDestroy(ev.first);
-        (void)hipEventDestroy(ev.second);
+    for (EdgeProfile* p : {&g_prof, &g_prof_conv}) {
+        std::lock_guard<std::mutex> lock(p->mu);
+        for (auto& ev : p->events) {
+            (void)hipEventDestroy(ev.first);
+            (void)hipEventDestroy(ev.second);
+        }
+        p->events.clear();
+        p->enabled = enable != 0;
     }
-    g_prof.events.clear();
-    g_prof.enabled = enable != 0;
+    return ARREAU_OK;
+}
+
+extern "C" int arreau_conv_kernel_time_ms(double* mean_ms, int64_t* launches) {
+    ARREAU_REQUIRE(mean_ms && launches, "arreau_conv_kernel_time_ms: null pointer");
+    std::lock_guard<std::mutex> lock(g_prof_conv.mu);
+    double tot = 0.0;
+    int64_t n = 0;
+    for (auto& ev : g_prof_conv.events) {
+        ARREAU_CHECK_HIP(hipEventSynchronize(ev.second));
+        float ms = 0.f;
+        ARREAU_CHECK_HIP(hipEventElapsedTime(&ms, ev.first, ev.second));
+        tot += ms;
+        ++n;
+    }
+    *mean_ms = n ? tot / (double)n : 0.0;
+    *launches = n;
     return ARREAU_OK;
 }
 

@@ -387,6 +387,7 @@ int arreau_launch_conv_proj(const arreau_model* m, int layer, const float* basis
                       m->fk + (size_t)layer * 16 * 16 * m->C, m->conv_bias + (size_t)layer * m->C, n0, Ng, x_conv);
     };
     const bool fp8 = arreau_basis_fp8();
+    arreau_prof_conv(0, s);
     if (pw_env == 4) {
         if (fp8) launch(conv_proj_kernel<128, 256, 4, true>, 512);
         else launch(conv_proj_kernel<128, 256, 4, false>, 512);
@@ -394,6 +395,7 @@ int arreau_launch_conv_proj(const arreau_model* m, int layer, const float* basis
         if (fp8) launch(conv_proj_kernel<128, 256, 8, true>, 768);
         else launch(conv_proj_kernel<128, 256, 8, false>, 768);
     }
+    arreau_prof_conv(1, s);
     ARREAU_CHECK_HIP(hipGetLastError());
     return ARREAU_OK;
 }

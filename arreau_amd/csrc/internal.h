@@ -306,6 +306,7 @@ bool arreau_basis_form(const arreau_model* m, int receivers);
 // significand bits; default) -- what the basis form stores (3 bytes per value), applied by every fp16x3 edge kernel so that all
 // launch sizes evaluate the same numbers.  ARREAU_BASIS_FP8=0: both planes fp16 everywhere (the round-2 arithmetic).
 bool arreau_basis_fp8();
+void arreau_prof_conv(int end, hipStream_t s);  // api.hip: hipEvents around the message kernel while bench.py profiles
 int arreau_launch_conv_proj(const arreau_model* m, int layer, const float* basis, const int32_t* deg, const int32_t* src,
                             const float* x_in, float* x_conv, int N, hipStream_t s, NodeRange r = NodeRange());
 

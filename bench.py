@@ -53,6 +53,18 @@ def edge_kernel_flops_per_row(C=128, D=256, L=5):
     return 2 * (258 * C + C * D) + 2 * L * D * C
 
 
+def conv_proj_bytes_per_launch(rows, N, C=128, O=16, stash_bytes_per_row=768):
+    """Algorithmic HBM bytes of ONE launch of the per-layer message kernel (conv_proj_kernel, the dominant kernel of the
+    default path since round 3): the stashed basis of every (edge, orientation) row read once (3 bytes per value: fp16 +
+    fp8 e4m3 plane, 256 values), every node feature row read once, the convolved rows written once."""
+    return rows * stash_bytes_per_row + 2 * N * O * C * 4
+
+
+def conv_proj_flops_per_row(C=128, D=256):
+    """Algorithmic FLOPs of the kernel projection of one layer per (edge, orientation) row (conv.py:110)."""
+    return 2 * D * C
+
+
 def step_flops_per_atom(k=8, S=90, C=128, D=256, L=5, O=16, W=4):
     """F = E*O*[2(258C + CD) + 2L*DC + 2LC] + N*O*[L(2OC + 4W C^2) + 2(S+78)C + 2LC(S+4)]
     per atom with E = k edges per atom  (= 83.0 MFLOP at the defaults)."""
@@ -67,15 +79,17 @@ def config_label(B, n):
             (1024, 64): "BASELINE configs[3]"}.get((B, n), "custom size")
 
 
-def measured_traffic(B, n):
-    """HBM bytes per launch of the edge kernel from the committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE,
-    separate runs, gfx950 FETCH correction applied) -- only valid for the workload they were taken on."""
+def measured_traffic(B, n, key="edge_kernel_hbm_bytes_per_launch"):
+    """HBM bytes per launch of a kernel from the committed rocprofv3 PMC passes (FETCH_SIZE / WRITE_SIZE, separate runs,
+    gfx950 FETCH correction applied) -- only valid for the workload they were taken on: profiles/hbm_traffic_pmc.json
+    holds one entry per (crystals per GPU, atoms per crystal)."""
     path = os.path.join(ROOT, "profiles", "hbm_traffic_pmc.json")
     try:
         with open(path) as fh:
             d = json.load(fh)
-        if d.get("crystals_per_gpu") == B and d.get("atoms_per_crystal") == n:
-            return d["edge_kernel_hbm_bytes_per_launch"]
+        for entry in (d if isinstance(d, list) else [d]):
+            if entry.get("crystals_per_gpu") == B and entry.get("atoms_per_crystal") == n:
+                return entry.get(key)
     except (OSError, ValueError, KeyError):
         pass
     return None
@@ -379,6 +393,8 @@ def run_rank(args, rank, local_rank, world):
     el_eager = timed_loop(args.steps)
     mean_ms, launches = ctypes.c_double(), ctypes.c_int64()
     _hip.check(_hip.lib().arreau_edge_kernel_time_ms(ctypes.byref(mean_ms), ctypes.byref(launches)), "edge time")
+    conv_ms, conv_launches = ctypes.c_double(), ctypes.c_int64()
+    _hip.check(_hip.lib().arreau_conv_kernel_time_ms(ctypes.byref(conv_ms), ctypes.byref(conv_launches)), "conv time")
     _hip.check(_hip.lib().arreau_profile_edge_kernel(0), "profile off")
     e_end = degree_sum()
     status = eng.check_status()  # raises on non-finite outputs / clamped indices; names the kernels that really ran
@@ -473,6 +489,44 @@ def run_rank(args, rank, local_rank, world):
             edge_peak = MFMA_F32_PEAK_TFLOPS
             edge_peak_note = "fp32-input MFMA peak"
         edge_traffic = measured_traffic(B, n)
+        edge_roof = {
+            "kernel": edge_kernel_name,
+            "bound": "mfma", "achieved": edge_tflops, "peak": edge_peak, "unit": "TFLOP/s",
+            "frac": edge_tflops / edge_peak, "traffic": edge_traffic,
+            "peak_note": edge_peak_note, "frac_of_fp32_mfma_peak": edge_tflops / MFMA_F32_PEAK_TFLOPS,
+            "avg_launch_ms": mean_ms.value, "launches_timed": int(launches.value),
+            "algorithmic_flops_per_launch": edge_flops,
+        }
+        roofline = edge_roof
+        if status.get("conv_variant") == 2 and conv_launches.value > 0:
+            # Default path since round 3: the edge kernel stops after the basis (it stores the two planes, 3 bytes per
+            # value) and every layer's message kernel projects them itself.  That kernel, L launches per step, is where
+            # the step's time is: a stream of the stash through LDS under the projection's MFMAs -- priced against HBM.
+            rows = e_mean * 16 / launches_per_step
+            cbytes = conv_proj_bytes_per_launch(rows, N / launches_per_step)
+            cflops = rows * conv_proj_flops_per_row()
+            t = conv_ms.value * 1e-3
+            front_flops = rows * 2 * (258 * 128 + 128 * 256)
+            edge_roof = dict(edge_roof, kernel="edge_kernel_f16x3<128,256,PROJ=false> (pair invariants + basis MLP; stores the basis "
+                             "planes: fp16 + fp8 e4m3, 768 B per row)", achieved=front_flops / (mean_ms.value * 1e-3) / 1e12,
+                             algorithmic_flops_per_launch=front_flops)
+            edge_roof["frac"] = edge_roof["achieved"] / edge_peak
+            edge_roof["frac_of_fp32_mfma_peak"] = edge_roof["achieved"] / MFMA_F32_PEAK_TFLOPS
+            edge_roof["traffic"] = measured_traffic(B, n, "edge_kernel_hbm_bytes_per_launch")
+            roofline = {
+                "kernel": "conv_proj_kernel<128,256> x L per step (kernel projection of the layer on fp16x3 MFMAs from the stashed "
+                          "basis + message passing + spherical convolution; conv.py:110-127)",
+                "bound": "hbm", "achieved": cbytes / t / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": cbytes / t / 1e9 / HBM_PEAK_GBS, "traffic": measured_traffic(B, n, "conv_proj_hbm_bytes_per_launch"),
+                "avg_launch_ms": conv_ms.value, "launches_timed": int(conv_launches.value),
+                "launches_per_step": int(round(conv_launches.value / args.steps)),
+                "algorithmic_bytes_per_launch": cbytes,
+                "bytes_note": "stash 768 B per (edge, orientation) row read once + node feature rows read once + convolved rows written once",
+                "mfma": {"achieved": cflops / t / 1e12, "peak": edge_peak, "unit": "TFLOP/s", "frac": cflops / t / 1e12 / edge_peak,
+                         "algorithmic_flops_per_launch": cflops, "peak_note": edge_peak_note},
+                "share_of_step": conv_ms.value * round(conv_launches.value / args.steps) / (1e3 * el_eager / args.steps),
+                "edge_kernel": edge_roof,
+            }
         out = {
             "metric": "denoising steps/sec (crystal-steps, whole node)",
             "value": crystal_steps_per_s,
@@ -489,10 +543,12 @@ def run_rank(args, rank, local_rank, world):
             "dtype_note": "fp32 inputs/outputs/accumulation; kernels that ran (reported by the library, "
                           f"arreau_model_status): edge={status['edge_kernel']}, mlp={status['mlp_kernel']}.  fp16x3 = each "
                           "fp32 product of the dense layers as 3 fp16 MFMA products (two 11-bit operand planes, f16x3.h); "
-                          "the per-layer edge-kernel stash K between the edge and conv kernels is held as 3-byte floats "
-                          "(16 significand bits; ARREAU_K3=0: fp32) unless the environment says otherwise: "
-                          f"ARREAU_K3={os.environ.get('ARREAU_K3', '1')}; "
-                          "measured deviations from the fp32 / fp64 CPU oracle: profiles/parity_r02.json; "
+                          f"message path (conv kernel variant {status.get('conv_variant')}): 2 = no K stash -- the edge kernel "
+                          "stores the windowed basis once (fp16 plane + residual plane rounded to fp8 e4m3: 3 bytes per value, "
+                          "11 + 4 significand bits; ARREAU_BASIS_FP8=0: both planes fp16) and every layer's message kernel "
+                          "projects it; 1 = the round-2 pair with a K stash of 3-byte floats; environment: "
+                          f"ARREAU_BASIS_FP8={os.environ.get('ARREAU_BASIS_FP8', '1')} ARREAU_CONV_VARIANT={os.environ.get('ARREAU_CONV_VARIANT', '2')}; "
+                          "measured deviations from the fp32 / fp64 CPU oracle: profiles/parity_r03.json; "
                           "roofline.fp32_mfma_variant = the same step on the plain fp32-MFMA kernels",
             "data": "synthetic",
             "config": {
@@ -511,15 +567,7 @@ def run_rank(args, rank, local_rank, world):
             "batch_steps_per_sec": world * args.steps / elapsed,
             "crystals_per_min": 60.0 * crystal_steps_per_s / (T - 1),
             "step_tflops_algorithmic": world * step_flops / (ms_per_step * 1e-3) / 1e12,
-            "roofline": {
-                "kernel": edge_kernel_name,
-                "bound": "mfma", "achieved": edge_tflops, "peak": edge_peak, "unit": "TFLOP/s",
-                "frac": edge_tflops / edge_peak, "traffic": edge_traffic,
-                "peak_note": edge_peak_note, "frac_of_fp32_mfma_peak": edge_tflops / MFMA_F32_PEAK_TFLOPS,
-                "avg_launch_ms": mean_ms.value, "launches_timed": int(launches.value),
-                "algorithmic_flops_per_launch": edge_flops,
-                "fp32_mfma_variant": fp32_variant,
-            },
+            "roofline": dict(roofline, fp32_mfma_variant=fp32_variant),
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(model, B, n, T, args.cpu_steps)

@@ -340,6 +340,9 @@ int arreau_train_conv_stats(arreau_model* model, float* d_stats, void* stream);
  * recorded since then (synchronises the events) and the count. */
 int arreau_profile_edge_kernel(int32_t enable);
 int arreau_edge_kernel_time_ms(double* mean_ms, int64_t* launches);
+/* The same for the per-layer message kernel of the default path since round 3 (conv_proj_kernel: kernel projection +
+ * message passing + spherical convolution, ponita/nn/conv.py:110-127): L launches per evaluation. */
+int arreau_conv_kernel_time_ms(double* mean_ms, int64_t* launches);
 
 /* Debug aid, no reference counterpart: the "uninitialised-state probe".  pattern != 0: every kernel launch of the
  * sampling path is preceded (same stream) by a kernel that fills every CU's LDS and vector registers with `pattern`;

@@ -1,34 +1,48 @@
 #!/bin/bash
-# usage: tools/hbm_traffic.sh   (GPU box).  Two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) over the bench workload
-# -> gpurun_out/hbm_traffic_pmc.json in the layout bench.py reads from profiles/hbm_traffic_pmc.json.
+# usage: tools/hbm_traffic.sh [config]   (GPU box; config = c2 (default) | c3 | c4).  Two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE)
+# over the bench workload -> gpurun_out/hbm_traffic_pmc_<config>.json, one entry of the list bench.py reads from
+# profiles/hbm_traffic_pmc.json.
+cfg=${1:-c2}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout -k 10 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d gpurun_out/pmc_traffic_$c -- python bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-graph-loop --no-full-sampler --no-fp32-variant > gpurun_out/pmc_traffic_$c.json 2> gpurun_out/pmc_traffic_$c.err || exit 1
+  rm -rf gpurun_out/pmc_traffic_${cfg}_$c
+  timeout -k 10 400 rocprofv3 --kernel-trace --pmc $c --output-format csv -d gpurun_out/pmc_traffic_${cfg}_$c -- python3 bench.py --config $cfg --steps 4 --warmup 2 --no-cpu-baseline --no-graph-loop --no-full-sampler --no-fp32-variant > gpurun_out/pmc_traffic_${cfg}_$c.json 2> gpurun_out/pmc_traffic_${cfg}_$c.err || exit 1
 done
-python - <<'PY'
-import csv, glob, json, collections
+python3 - $cfg <<'PY'
+import csv, glob, json, collections, sys
+cfg = sys.argv[1]
+B, n = {"c2": (256, 20), "c3": (1024, 20), "c4": (1024, 64)}[cfg]
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for c in ("FETCH_SIZE", "WRITE_SIZE"):
-    for f in glob.glob("gpurun_out/pmc_traffic_%s/*/*counter_collection.csv" % c):
+    for f in glob.glob("gpurun_out/pmc_traffic_%s_%s/*/*counter_collection.csv" % (cfg, c)):
         for r in csv.DictReader(open(f)):
             if r["Counter_Name"] == c:
                 acc[r["Kernel_Name"].split("(")[0]][c].append(float(r["Counter_Value"]))
-out = {"note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, tools/hbm_traffic.sh), `python bench.py --steps 6 "
-               "--warmup 2 --no-cpu-baseline --no-graph-loop --no-full-sampler`, C2 workload. KB per launch (mean). gfx950 correction (MI355X_MICROARCH.md, HBM): "
-               "FETCH_SIZE counts wide coalesced reads at 1/2 -> doubled in hbm_bytes_corrected.",
-       "crystals_per_gpu": 256, "atoms_per_crystal": 20, "kernels": {}}
-edge = None
+out = {"note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, tools/hbm_traffic.sh), `python bench.py --config %s --steps 4 "
+               "--warmup 2 --no-cpu-baseline --no-graph-loop --no-full-sampler --no-fp32-variant`. KB per launch (mean). gfx950 correction "
+               "(MI355X_MICROARCH.md, HBM): FETCH_SIZE counts wide coalesced reads at 1/2 -> doubled in hbm_bytes_corrected." % cfg,
+       "config": cfg, "crystals_per_gpu": B, "atoms_per_crystal": n, "kernels": {}}
+step = 0.0
 for k, v in acc.items():
     f = sum(v["FETCH_SIZE"]) / max(1, len(v["FETCH_SIZE"]))
     w = sum(v["WRITE_SIZE"]) / max(1, len(v["WRITE_SIZE"]))
-    out["kernels"][k] = {"FETCH_SIZE_KB": f, "WRITE_SIZE_KB": w, "hbm_bytes_corrected": (2 * f + w) * 1024}
-    if "edge_kernel_f16x3" in k:
-        edge = k
-out["edge_kernel"] = edge
-out["edge_kernel_hbm_bytes_per_launch"] = out["kernels"][edge]["hbm_bytes_corrected"]
-json.dump(out, open("gpurun_out/hbm_traffic_pmc.json", "w"), indent=1)
-for k in ("edge_kernel", "conv_kernel", "mlp_kernel"):
-    for n, v in out["kernels"].items():
-        if k in n:
-            print(n, "%.1f MB per launch" % (v["hbm_bytes_corrected"] / 1e6))
+    out["kernels"][k] = {"FETCH_SIZE_KB": f, "WRITE_SIZE_KB": w, "hbm_bytes_corrected": (2 * f + w) * 1024, "launches_seen": len(v["FETCH_SIZE"])}
+per_step = {"edge_kernel_f16x3": 1, "conv_proj_kernel": 5, "conv_kernel_streamed": 5, "mlp_kernel": 5, "readout": 1, "neighbor_kernel": 1, "embed_kernel": 1,
+            "prep_kernel": 1, "reverse_": 1}
+for name, key in (("edge_kernel_f16x3", "edge_kernel_hbm_bytes_per_launch"), ("conv_proj_kernel", "conv_proj_hbm_bytes_per_launch"),
+                  ("conv_kernel_streamed", "conv_kernel_hbm_bytes_per_launch"), ("mlp_kernel", "mlp_kernel_hbm_bytes_per_launch")):
+    hit = [k for k in out["kernels"] if name in k]
+    out[key] = out["kernels"][hit[0]]["hbm_bytes_corrected"] if hit else None
+for k, v in out["kernels"].items():
+    for name, mult in per_step.items():
+        if name in k:
+            step += mult * v["hbm_bytes_corrected"]
+            break
+out["hbm_bytes_per_step_sampling_kernels"] = step
+json.dump(out, open("gpurun_out/hbm_traffic_pmc_%s.json" % cfg, "w"), indent=1)
+for k in ("edge_kernel", "conv_proj", "conv_kernel", "mlp_kernel"):
+    for nme, v in out["kernels"].items():
+        if k in nme:
+            print(nme[:60], "%.1f MB per launch" % (v["hbm_bytes_corrected"] / 1e6))
+print("sampling kernels, per step: %.3f GB" % (step / 1e9))
 PY
