@@ -427,10 +427,6 @@ __global__ __launch_bounds__(64 * EH_WAVES, 2) void edge_kernel_f16x3(
                     for (int r = 0; r < 4; ++r) v[r] = fmaf(a.x[mt][nb][r], F16X3_INV_SCALE, a.m[mt][nb][r]);
                     // asm store: the counted wait at SYNC assumes exactly 4 (or 2) store instructions per tile
                     // (scalar base + one per-lane 32-bit offset + immediate: no 64-bit vector address arithmetic)
-#if ARREAU_EXP & 1
-                    asm volatile("" : : "v"(v), "v"(st_off));  // timing experiment: K tiles computed, not stored
-                    if (false)
-#endif
                     if (nb == 0 || full) {
                         if constexpr (K3) {
                             const u32x3_k d = arreau_pack_k3(v[0], v[1], v[2], v[3]);

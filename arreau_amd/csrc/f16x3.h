@@ -59,18 +59,9 @@ __device__ __forceinline__ f32x2 splat2(float v) { return f32x2{v, v}; }
 // polynomial from turning upwards.  Non-finite inputs stay loud: x = +-inf -> NaN / -inf, NaN -> NaN (nothing is
 // clamped to the fp16 range: a value >= 65520 overflows its fp16 plane to inf, propagates to the network outputs and
 // sets ARREAU_STATUS_NONFINITE in the read-out kernel).
-// Timing-only builds (tools/exp/build_exp.sh ... "-DARREAU_EXP=<bits>"; WRONG results on purpose, never shipped): what a
-// kernel's time is made of is measured by removing parts of it (profiles/r02g_remove_parts_timing.txt).
-//   1 edge kernel: K tiles computed, not stored      2 GELU -> max(x, 0)            4 no plane split (low plane = high plane)
-//   8 ConvNext kernel: no ring barrier              16 ... no DMA waits            32 ... no DMA copies
-//  64 ConvNext kernel: no LDS fragment reads       128 ... no MFMAs             256 ... no x_conv loads     512 ... no x_in loads / x_out stores
-#ifndef ARREAU_EXP
-#define ARREAU_EXP 0
-#endif
+// (The timing-only "remove a part" hooks of round 2 -- -DARREAU_EXP=<bits>, wrong results on purpose -- are no longer in the
+// product sources: tools/exp/arreau_exp_hooks.patch holds them and tools/exp/build_exp.sh applies it to a scratch copy.)
 __device__ __forceinline__ f32x2 gelu_fast2(f32x2 x) {
-#if ARREAU_EXP & 2
-    return f32x2{fmaxf(x.x, 0.f), fmaxf(x.y, 0.f)};
-#endif
     const float ax = fabsf(x.x), ay = fabsf(x.y);
     // (v_med3 / v_max / v_min co-execute with the partner wave's MFMAs, tools/exp/coexec.hip, coexec2.hip)
     const f32x2 a = f32x2{__builtin_amdgcn_fmed3f(ax, -INFINITY, 12.0f), __builtin_amdgcn_fmed3f(ay, -INFINITY, 12.0f)};
@@ -99,10 +90,6 @@ template <bool CLAMP = true>
 __device__ __forceinline__ void split_pair2(f32x2 v, unsigned& hi, unsigned& lo) {
     // (CLAMP is kept in the signature for the callers; no clamp is applied -- see gelu_fast2: overflow is loud)
     hi = __builtin_bit_cast(unsigned, cvt_f16x2(v));
-#if ARREAU_EXP & 4
-    lo = hi ^ 0x00010001u;
-    return;
-#endif
     const f32x2 sc = v * splat2(F16X3_SCALE);
     const float neg_scale = -F16X3_SCALE;
     asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(lo) : "v"(hi), "s"(neg_scale), "v"(sc.x));
@@ -276,12 +263,7 @@ __device__ __forceinline__ void mma16_range(f32x4v (&am)[2][NB], f32x4v (&ax)[2]
                                             const u32x4 (&b)[NB][NKB][2], int lane) {
     const u32x4* f = buf + lane;
     u32x4 a1[2], a2[2];
-#if ARREAU_EXP & 64
-    a1[0] = a1[1] = a2[0] = a2[1] = b[0][0][0];
-    auto frag = [&](u32x4& d, const u32x4&) { asm volatile("" : "+v"(d)); };
-#else
     auto frag = [&](u32x4& d, const u32x4& src) { d = src; };
-#endif
     frag(a1[ST0 & 1], f[(size_t)ST0 * 128]);
     frag(a2[ST0 & 1], f[(size_t)ST0 * 128 + 64]);
 #pragma unroll
@@ -294,13 +276,9 @@ __device__ __forceinline__ void mma16_range(f32x4v (&am)[2][NB], f32x4v (&ax)[2]
         const int kb = st >> 1, mt = st & 1;
 #pragma unroll
         for (int nb = 0; nb < NB; ++nb) {
-#if ARREAU_EXP & 128
-            asm volatile("" : "+v"(am[mt][nb]), "+v"(ax[mt][nb]) : "v"(a1[slot]), "v"(a2[slot]));
-#else
             am[mt][nb] = mfma16_f16(a1[slot], b[nb][kb][0], am[mt][nb]);
             ax[mt][nb] = mfma16_f16(a1[slot], b[nb][kb][1], ax[mt][nb]);
             ax[mt][nb] = mfma16_f16(a2[slot], b[nb][kb][0], ax[mt][nb]);
-#endif
         }
     }
     __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);

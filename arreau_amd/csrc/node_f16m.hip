@@ -119,11 +119,7 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_kernel_f16x3_m16(
         for (int kb = 0; kb < KC; ++kb)
 #pragma unroll
             for (int hf = 0; hf < 2; ++hf) {
-#if ARREAU_EXP & 256
-                const f32x4 v = {0.25f * cp, -0.5f, 0.125f * gp, 1.0f};  // timing experiment: no x_conv loads
-#else
                 const f32x4 v = *reinterpret_cast<const f32x4*>(rowp + 32 * kb + 16 * hf);
-#endif
 #pragma unroll
                 for (int r = 0; r < 4; ++r) x[kb][4 * hf + r] = v[r];
                 sum += (v[0] + v[1]) + (v[2] + v[3]);
@@ -174,14 +170,10 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_kernel_f16x3_m16(
     constexpr int NCHUNK = 8 * 4;
     auto sync = [&]() {
         const int younger = min(max(NCHUNK - 2 - q, 0), P - 2);
-#if !(ARREAU_EXP & 16)
         if (P == 3 && younger == 1) dma_wait_but<PER>();
         else dma_wait();
-#endif
-#if !(ARREAU_EXP & 8)
         __syncthreads();
-#endif
-        if (!(ARREAU_EXP & 32) && q + P < NCHUNK) dma_chunk_lean<NF, NW>(dma_src, lane16, wave, lds0 + (unsigned)(sl == 0 ? NSLOT - 1 : sl - 1) * (NF * 1024u));
+        if (q + P < NCHUNK) dma_chunk_lean<NF, NW>(dma_src, lane16, wave, lds0 + (unsigned)(sl == 0 ? NSLOT - 1 : sl - 1) * (NF * 1024u));
         dma_src += (size_t)NF * 64;
         ++q;
     };
@@ -267,15 +259,11 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_kernel_f16x3_m16(
 #pragma unroll
             for (int nb = 0; nb < NB; ++nb) {
                 const size_t off = ((size_t)nrow[nb] * 16 + c) * C + c0;
-#if ARREAU_EXP & 512
-                const f32x4 xi = {0.5f, 0.25f, -0.5f, 1.0f};  // timing experiment: no x_in loads, no x_out stores
-#else
                 const f32x4 xi = *reinterpret_cast<const f32x4*>(x_in + off);
-#endif
                 f32x4 xo;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) xo[r] = (acc_o[u][mt][nb][r] + b2v[r]) * lsv[r] + xi[r];
-                if (valid[nb] && !(ARREAU_EXP & 512)) *reinterpret_cast<f32x4*>(x_out + off) = xo;
+                if (valid[nb]) *reinterpret_cast<f32x4*>(x_out + off) = xo;
 #pragma unroll
                 for (int r = 0; r < 4; ++r) vdot[nb] += xo[r] * wvv[r];
                 f32x4 sum;
