@@ -1055,6 +1055,50 @@ def test_range_launches_are_bitwise_the_whole_batch(dev, full_model, groups):
     eng.check_status()
 
 
+def test_range_launches_of_the_basis_form(dev, full_model):
+    """The same property for slices large enough to take the basis form themselves (more than 240 receivers each: the edge
+    kernel stores the basis planes for receivers n0 .. n1-1 into the whole-batch stash, conv_proj_kernel walks that range
+    with absolute indices): three uneven slices of a ragged 1,500-atom batch, one after another on one stream, against the
+    whole-batch launch -- bit for bit -- and a degree-starved batch (huge cells: most receivers have no or few in-edges)."""
+    from arreau_amd.diffusion.diffusion_helpers import crystal_offsets
+    m, _ = full_model
+    eng = m.engine()
+    rng = np.random.RandomState(8)
+    for cell, t in (((4.0, 8.0), 600), ((14.0, 22.0), 5)):
+        counts = [int(v) for v in rng.randint(5, 21, size=120)]
+        frac, types, lengths, angles, na = random_state(90, counts, 31, cell=cell)
+        B, N = len(counts), sum(counts)
+        assert N > 3 * 260
+        d = lambda v: v.to(dev).contiguous()
+        off = crystal_offsets(na, dev)
+        t_c = torch.full((B,), t, device=dev, dtype=torch.int32)
+        args = (d(frac), d(types.to(torch.int32)), d(lengths), d(angles), t_c, off)
+        eng.set_batch_layout(na, groups=1)
+        whole = eng.predict_scores(*args, return_edges=True)
+        deg = whole[3][0]
+        if cell[0] > 10:
+            assert int((deg == 0).sum()) > 0 and int(deg.max()) <= 8  # receivers without in-edges are in the batch
+        os.environ["ARREAU_SLICE_EAGER"] = "serial"
+        try:
+            eng.set_batch_layout(na, groups=3)
+            sliced = eng.predict_scores(*args)
+        finally:
+            del os.environ["ARREAU_SLICE_EAGER"]
+            eng.set_batch_layout(na, groups=1)
+        for x, y in zip(whole[:3], sliced):
+            assert torch.isfinite(x).all() and torch.equal(x, y)
+        st = eng.check_status()
+        assert st["conv_variant"] == 2  # the message kernel of the basis form really ran
+    # just above the switch-over: 260 receivers = one receiver per workgroup (every workgroup's first receiver is its last:
+    # the prologue / drain paths of the ring protocol only), against the oracle and against the K pair
+    m2, om32 = full_model
+    state = random_state(90, [20] * 13, 77, cell=(4.0, 8.0))
+    eps_o, logits_o, len0_o, _ = _oracle_scores(om32, *state, 300)
+    got = _engine_scores(m2, dev, state, 300)
+    assert eng.check_status()["conv_variant"] == 2
+    assert_scores_close(got, (eps_o, logits_o, len0_o), tag="260 receivers")
+
+
 def test_multi_stream_experiment_report(dev, full_model):
     """The opt-in experiment (ARREAU_ALLOW_MULTISTREAM=1): the same slices forked onto their own streams, and the pipelined
     sampling loop (own stream and step graph per slice, no per-step join).  Every slice computes what the whole batch

@@ -21,5 +21,10 @@ for c in ("c2", "c1", "c3", "c4", "c5", "c5_hidden200"):
           "frac", round(d["roofline"]["frac"], 4), "cpu", (d.get("cpu_baseline") or {}).get("value"), "full", (d.get("full_sampler_measured") or {}).get("crystals_per_min"))
 PY
 tools/prof_bench.sh ${tag}_c2 --no-fp32-variant || exit 1
-tools/hbm_traffic.sh > gpurun_out/${tag}_hbm.txt 2>&1 || { tail -n 20 gpurun_out/${tag}_hbm.txt; exit 1; }
-cat gpurun_out/${tag}_hbm.txt
+for c in c2 c4; do
+  tools/hbm_traffic.sh $c > gpurun_out/${tag}_hbm_$c.txt 2>&1 || { tail -n 20 gpurun_out/${tag}_hbm_$c.txt; exit 1; }
+  cat gpurun_out/${tag}_hbm_$c.txt
+  cp gpurun_out/hbm_traffic_pmc_$c.json gpurun_out/${tag}_hbm_traffic_pmc_$c.json
+done
+timeout -k 10 600 python3 tools/parity_report.py --out gpurun_out/${tag}_parity.json > gpurun_out/${tag}_parity.log 2>&1 || { tail -n 20 gpurun_out/${tag}_parity.log; exit 1; }
+tail -n 6 gpurun_out/${tag}_parity.log
