@@ -1,9 +1,10 @@
 #!/bin/bash
-# usage (GPU box): tools/gpu_final.sh <tag>  -- everything a round's record needs, in one call: GPU suite + smoke, bench.py as
+# usage (GPU box): tools/gpu_final.sh <tag> [benches|profiles]  (two calls when one would exceed a box's time limit) -- everything a round's record needs, in one call: GPU suite + smoke, bench.py as
 # the driver runs it (c2) and at the other BASELINE configurations, kernel statistics and HBM-traffic PMC passes at c2
-tag=$1
+tag=$1; part=${2:-all}
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-timeout -k 10 1000 python3 -m pytest tests -m gpu -x -q > gpurun_out/${tag}_pytest.log 2>&1; rc=$?
+if [ $part != profiles ]; then
+timeout -k 10 1000 python3 -m pytest tests -m gpu -x -q -s > gpurun_out/${tag}_pytest.log 2>&1; rc=$?
 tail -n 3 gpurun_out/${tag}_pytest.log
 [ $rc -eq 0 ] || exit $rc
 timeout -k 10 300 python3 -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -n 1 || exit 1
@@ -20,6 +21,8 @@ for c in ("c2", "c1", "c3", "c4", "c5", "c5_hidden200"):
     print(c, "value", round(d["value"], 1), "ms_per_step", round(d["ms_per_step"], 4), d.get("loop_mode", ""), "eager", (d.get("eager_loop") or {}).get("ms_per_step"),
           "frac", round(d["roofline"]["frac"], 4), "cpu", (d.get("cpu_baseline") or {}).get("value"), "full", (d.get("full_sampler_measured") or {}).get("crystals_per_min"))
 PY
+fi
+[ $part = benches ] && exit 0
 tools/prof_bench.sh ${tag}_c2 --no-fp32-variant || exit 1
 for c in c2 c4; do
   tools/hbm_traffic.sh $c > gpurun_out/${tag}_hbm_$c.txt 2>&1 || { tail -n 20 gpurun_out/${tag}_hbm_$c.txt; exit 1; }
