@@ -962,10 +962,17 @@ bool arreau_k3(const arreau_model* m) {
 }
 
 // conv_variant 2 (default): basis form wherever it applies -- the fused shape, k = 8, fp16-representable weights, the
-// split-precision edge kernel -- and a launch large enough for the persistent kernels (small launches keep the
-// tile-per-workgroup forms of the edge / conv / ConvNext kernels, which are latency-bound and have their own K path).
+// split-precision edge kernel -- and a launch large enough for it to pay: measured at n = 20 (graph replay, one box), the
+// basis form against the K pair on fp32 K: 960 receivers 0.436 / 0.421 ms per step, 1920: 0.655 / 0.656, 2560: 0.852 /
+// 0.870, 3520: 1.059 / 1.078, 5120: 1.35 / 1.48 -- so it takes over from 2,000 receivers (ARREAU_BASIS_MIN_RECEIVERS
+// moves the switch: the tests set 240 to run the basis form on small batches).  Below that the K pair runs on an fp32 K
+// buffer (and at most 240 receivers: the tile-per-workgroup kernels); all of them evaluate the same numbers.
 bool arreau_basis_form(const arreau_model* m, int receivers) {
-    return m->conv_variant == 2 && m->edge_variant == 4 && m->f16_ok && m->k == 8 && m->C == 128 && m->D == 256 && receivers > 240;
+    const char* e = getenv("ARREAU_BASIS_MIN_RECEIVERS");
+    const int min_receivers = e ? atoi(e) : 2000;
+    // (L >= 2: the stash -- 96 or 128 KiB per atom -- lives in the workspace region sized for L per-layer K buffers of 64 KiB per atom)
+    return m->conv_variant == 2 && m->edge_variant == 4 && m->f16_ok && m->k == 8 && m->C == 128 && m->D == 256 && m->L >= 2 &&
+           receivers > (min_receivers > 240 ? min_receivers : 240);
 }
 
 bool arreau_basis_fp8() {

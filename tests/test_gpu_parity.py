@@ -706,10 +706,15 @@ def test_atom_permutation_equivariance(dev, small_model):
     assert_scores_close((b[0], b[1], b[2]), (a[0][perm].cpu(), a[1][perm].cpu(), a[2].cpu()))
 
 
-def test_many_ragged_crystals_persistent_edge_workgroups(dev, small_model):
-    """More receiver pairs than CUs, with degrees from 0 to the cap: every persistent edge-kernel workgroup walks
+@pytest.mark.parametrize("message_path", ["K pair (the product's choice at this size)", "basis form"])
+def test_many_ragged_crystals_persistent_edge_workgroups(dev, small_model, message_path, monkeypatch):
+    """(Both message paths: below 2,000 receivers the product runs the K pair; ARREAU_BASIS_MIN_RECEIVERS=240 puts the same
+    batch through the basis form -- idle waves that store nothing, receivers of every degree in conv_proj_kernel.)
+    More receiver pairs than CUs, with degrees from 0 to the cap: every persistent edge-kernel workgroup walks
     several pairs (the weight ring wraps from one pair into the next) and mixes waves that have slots with waves
     that only keep the ring turning.  The network (edges teacher-forced) against the oracle."""
+    if message_path == "basis form":
+        monkeypatch.setenv("ARREAU_BASIS_MIN_RECEIVERS", "240")
     m, om32, _ = small_model
     rng = np.random.RandomState(5)
     num_atoms = [int(v) for v in rng.randint(1, 7, size=420)]  # about 1470 atoms -> about 735 pairs on 256 CUs
@@ -723,6 +728,7 @@ def test_many_ragged_crystals_persistent_edge_workgroups(dev, small_model):
     edges = tuple(x.to(dev).contiguous() for x in (deg, src, sdir, sdist))
     eps, logits, len0 = _engine_scores(m, dev, state, 60, edges=edges)
     assert_scores_close((eps, logits, len0), (eps_o, logits_o, len0_o))
+    assert m.engine().check_status()["conv_variant"] == (2 if message_path == "basis form" else 1)
 
 
 def _rotation(axis, angle):
@@ -834,7 +840,10 @@ def test_launch_geometry_switches_and_counted_waits_are_bitwise_neutral(dev):
                          ("nb2", {"ARREAU_MLP_NB": "2"}), ("slots4", {"ARREAU_MLP_SLOTS": "4"}),
                          ("edgesplit", {"ARREAU_EDGE_SPLIT": "1", "ARREAU_READOUT_SPLIT": "1", "ARREAU_MLP_SPLIT": "1"})):
             path = os.path.join(d, tag + ".pt")
-            subprocess.run([sys.executable, "-c", code, path], check=True, env={**os.environ, **env}, timeout=300)
+            # (ARREAU_BASIS_MIN_RECEIVERS=240: this 1,920-receiver batch takes the basis form, which the product uses from
+            # 2,000 receivers on)
+            subprocess.run([sys.executable, "-c", code, path], check=True,
+                           env={**os.environ, "ARREAU_BASIS_MIN_RECEIVERS": "240", **env}, timeout=300)
             outs[tag] = torch.load(path)
     # nb1 / nb2: the MLP kernel on 16-row (one node) and 32-row (two nodes) wave tiles -- the small-batch geometry
     # slots4: the MLP kernel's weight ring with four slots instead of three (another set of counted waits)
@@ -904,7 +913,8 @@ def test_basis_stash_holds_fp16_and_e4m3_planes(dev, full_model):
     with tempfile.TemporaryDirectory() as d:
         for tag, env in (("fp8", {}), ("f16", {"ARREAU_BASIS_FP8": "0"})):
             path = os.path.join(d, tag + ".pt")
-            subprocess.run([sys.executable, "-c", code, path], check=True, env={**os.environ, **env}, timeout=300)
+            subprocess.run([sys.executable, "-c", code, path], check=True,
+                           env={**os.environ, "ARREAU_BASIS_MIN_RECEIVERS": "240", **env}, timeout=300)
             ws[tag] = torch.load(path)
     slots = N * k
     a = ws["fp8"][k0:k0 + slots * 12288].view(slots, 12288)
@@ -1055,12 +1065,13 @@ def test_range_launches_are_bitwise_the_whole_batch(dev, full_model, groups):
     eng.check_status()
 
 
-def test_range_launches_of_the_basis_form(dev, full_model):
+def test_range_launches_of_the_basis_form(dev, full_model, monkeypatch):
     """The same property for slices large enough to take the basis form themselves (more than 240 receivers each: the edge
     kernel stores the basis planes for receivers n0 .. n1-1 into the whole-batch stash, conv_proj_kernel walks that range
     with absolute indices): three uneven slices of a ragged 1,500-atom batch, one after another on one stream, against the
     whole-batch launch -- bit for bit -- and a degree-starved batch (huge cells: most receivers have no or few in-edges)."""
     from arreau_amd.diffusion.diffusion_helpers import crystal_offsets
+    monkeypatch.setenv("ARREAU_BASIS_MIN_RECEIVERS", "240")  # (read per launch; the product's switch is at 2,000 receivers)
     m, _ = full_model
     eng = m.engine()
     rng = np.random.RandomState(8)
