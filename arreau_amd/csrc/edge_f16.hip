@@ -100,6 +100,13 @@ __device__ __forceinline__ unsigned round_lo_fp8(unsigned lo_pair) {
     return __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(__builtin_bit_cast(unsigned, r), 1.0f, false));
 }
 
+// Re-layout pad (32x32 accumulator layout -> two 16-column blocks): 16-byte cell (row, slot) of a plane, row = 0 .. 31,
+// slot = 0 .. 3.  Writers walk the rows lane by lane at a fixed slot, readers too: with cells in plain row-major order
+// (64 bytes per row) eight consecutive lanes hit two of the eight 16-byte bank groups -- 9.2 M bank-conflict cycles per
+// launch at 256 x 20 (PMC, round 3).  The slot index is therefore XOR-swizzled with bits 1-2 of the row: eight
+// consecutive rows cover all eight groups for writers and readers alike.
+__device__ __forceinline__ int relayout_cell(int plane, int row, int slot) { return 128 * plane + 4 * row + (slot ^ ((row >> 1) & 3)); }
+
 template <int C, int D, int EH_WAVES, bool K3 /* K tiles as 3-byte floats (internal.h) */, bool PROJ = true, bool BFP8 = false>
 __global__ __launch_bounds__(64 * EH_WAVES, 2) void edge_kernel_f16x3(
     const float* __restrict__ nbr_dir,   // [N][k][3]
@@ -276,8 +283,8 @@ __global__ __launch_bounds__(64 * EH_WAVES, 2) void edge_kernel_f16x3(
         auto relayout_write = [&](const Planes2& pl) {
 #pragma unroll
             for (int plane = 0; plane < 2; ++plane) {
-                pad16[128 * plane + (j * 2 + h) * 2 + 0] = pl.p[plane][0];
-                pad16[128 * plane + (j * 2 + h) * 2 + 1] = pl.p[plane][1];
+                pad16[relayout_cell(plane, j, 2 * h + 0)] = pl.p[plane][0];
+                pad16[relayout_cell(plane, j, 2 * h + 1)] = pl.p[plane][1];
             }
         };
         auto relayout_read = [&](int u) {
@@ -285,7 +292,7 @@ __global__ __launch_bounds__(64 * EH_WAVES, 2) void edge_kernel_f16x3(
             for (int plane = 0; plane < 2; ++plane)
 #pragma unroll
                 for (int nb = 0; nb < 2; ++nb)
-                    h16[nb][u][plane] = pad16[128 * plane + ((16 * nb + c16) * 2 + (g16 >> 1)) * 2 + (g16 & 1)];
+                    h16[nb][u][plane] = pad16[relayout_cell(plane, 16 * nb + c16, g16)];
         };
         // ---- layer 1: h = GELU(W1f . mono + b1) -------------------------------------------------------------
 #pragma unroll
@@ -599,8 +606,8 @@ __global__ __launch_bounds__(512) void edge_kernel_f16x3_split(
         const Planes2 pl = gelu_split_tile2(acc, cross, 1.0f);
 #pragma unroll
         for (int plane = 0; plane < 2; ++plane) {
-            hpad[wave][128 * plane + (j * 2 + h) * 2 + 0] = pl.p[plane][0];
-            hpad[wave][128 * plane + (j * 2 + h) * 2 + 1] = pl.p[plane][1];
+            hpad[wave][relayout_cell(plane, j, 2 * h + 0)] = pl.p[plane][0];
+            hpad[wave][relayout_cell(plane, j, 2 * h + 1)] = pl.p[plane][1];
         }
     }
     __syncthreads();
@@ -627,7 +634,7 @@ __global__ __launch_bounds__(512) void edge_kernel_f16x3_split(
             for (int nb = 0; nb < 2; ++nb)
 #pragma unroll
                 for (int plane = 0; plane < 2; ++plane)
-                    hq[nb][plane] = hpad[kb][128 * plane + ((16 * nb + c16) * 2 + (g16 >> 1)) * 2 + (g16 & 1)];
+                    hq[nb][plane] = hpad[kb][relayout_cell(plane, 16 * nb + c16, g16)];
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
