@@ -285,10 +285,16 @@ int run_network(const arreau_model* m, const Workspace& w, bool given, int32_t* 
     // sampling loop uses the pipelined form (arreau_sample_loop).
     const bool sliced = p && p->eager && p->G > 1 && p->B == B && p->N == N && arreau_range_launches_supported(m);
     if (!sliced) {
-        if (!given && (rc = arreau_launch_neighbor(w.cart, w.lattice, d_off, w.batch, B, N, m->cfg.radius, m->k, deg, src, w.cell, dir, dist, s)))
-            return rc;
-        if ((rc = run_edge_kernel(m, dir, dist, deg, w, N, s))) return rc;
-        if ((rc = arreau_launch_embed(m, d_frac, d_types, w.lattice, w.batch, w.cvec, N, w.xa, s))) return rc;
+        if (!given) {
+            // neighbour list and embedding side by side in one launch (both need prep_kernel's outputs only)
+            if ((rc = arreau_launch_neighbor_embed(m, w.cart, w.lattice, d_off, w.batch, B, N, deg, src, w.cell, dir, dist, d_frac, d_types,
+                                                   w.cvec, w.xa, s)))
+                return rc;
+            if ((rc = run_edge_kernel(m, dir, dist, deg, w, N, s))) return rc;
+        } else {
+            if ((rc = run_edge_kernel(m, dir, dist, deg, w, N, s))) return rc;
+            if ((rc = arreau_launch_embed(m, d_frac, d_types, w.lattice, w.batch, w.cvec, N, w.xa, s))) return rc;
+        }
         return run_layers_and_readout(m, w, deg, src, d_off, B, N, d_eps, d_logits, d_len0, s);
     }
     static const int n_cu = [] {
@@ -429,12 +435,11 @@ int enqueue_slice_step(const arreau_model* m, float* d_frac, int32_t* d_types, f
     if ((rc = arreau_launch_prep(m, d_frac, d_lengths, d_angles, nullptr, d_off, B, N, w.lattice, w.cart, w.batch, w.cvec, s,
                                  w.t_next, w.t_cur, r)))
         return rc;
-    if ((rc = arreau_launch_neighbor(w.cart, w.lattice, d_off, w.batch, B, N, m->cfg.radius, m->k, w.deg, w.src, w.cell, w.dir,
-                                     w.dist, s, r)))
+    if ((rc = arreau_launch_neighbor_embed(m, w.cart, w.lattice, d_off, w.batch, B, N, w.deg, w.src, w.cell, w.dir, w.dist, d_frac,
+                                           d_types, w.cvec, w.xa, s, r)))
         return rc;
     if ((rc = run_edge_kernel(m, w.dir, w.dist, w.deg, w, N, s, r))) return rc;
     if (after_edge) ARREAU_CHECK_HIP(hipEventRecord(after_edge, s));
-    if ((rc = arreau_launch_embed(m, d_frac, d_types, w.lattice, w.batch, w.cvec, N, w.xa, s, r))) return rc;
     // (the per-crystal pooling of the lattice read-out happens inside the lattice update: no launch of its own)
     if ((rc = run_layers_and_readout(m, w, w.deg, w.src, d_off, B, N, w.eps, w.logits, nullptr, s, r))) return rc;
     return arreau_launch_reverse(m, d_frac, d_types, d_lengths, d_angles, w.t_cur, d_off, B, N, w.eps, w.logits, w.len0,

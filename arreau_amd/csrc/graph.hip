@@ -1,5 +1,6 @@
 // Lattice algebra and the periodic-boundary neighbour list (HBM/latency-bound integer+fp32 work).
 #include "internal.h"
+#include "embed_dev.h"
 
 // ---------------------------------------------------------------------------------------------
 // lattice_from_params (diffusion/lattice_helpers.py:55-105): rows a, b, c of the cell.
@@ -84,30 +85,59 @@ extern "C" int arreau_frac_to_cart(const float* d_frac, const float* d_lattice, 
 // ---------------------------------------------------------------------------------------------
 struct Cand { float dx, dy, dz, d2; };
 
-__device__ __forceinline__ Cand arreau_candidate(const float* __restrict__ cart, int first, int c,
-                                                 const float* Lm, float pix, float piy, float piz) {
+// offset of periodic image `ci` (0..26, itertools.product((-1,0,1),repeat=3) order) = lattice^T @ cell (:391-393); products
+// with -1/0/1 are exact
+__device__ __forceinline__ void arreau_image_offset(int ci, const float* Lm, float* o) {
+    const float cx = (float)(ci / 9 - 1), cy = (float)((ci / 3) % 3 - 1), cz = (float)(ci % 3 - 1);
+    o[0] = __fadd_rn(__fadd_rn(__fmul_rn(cx, Lm[0]), __fmul_rn(cy, Lm[3])), __fmul_rn(cz, Lm[6]));
+    o[1] = __fadd_rn(__fadd_rn(__fmul_rn(cx, Lm[1]), __fmul_rn(cy, Lm[4])), __fmul_rn(cz, Lm[7]));
+    o[2] = __fadd_rn(__fadd_rn(__fmul_rn(cx, Lm[2]), __fmul_rn(cy, Lm[5])), __fmul_rn(cz, Lm[8]));
+}
+
+// candidate c = 27 * sender + image: `pos` holds the senders' positions (of the crystal when first == 0, else of the batch),
+// `img` the wave's table of the 27 image offsets (LDS)
+__device__ __forceinline__ Cand arreau_candidate(const float* __restrict__ pos, int first, int c, const float* img,
+                                                 float pix, float piy, float piz) {
     const int j = c / 27;
     const int ci = c - 27 * j;
-    const float cx = (float)(ci / 9 - 1), cy = (float)((ci / 3) % 3 - 1), cz = (float)(ci % 3 - 1);
-    // image offset = lattice^T @ cell (:391-393); products with -1/0/1 are exact
-    const float ox = __fadd_rn(__fadd_rn(__fmul_rn(cx, Lm[0]), __fmul_rn(cy, Lm[3])), __fmul_rn(cz, Lm[6]));
-    const float oy = __fadd_rn(__fadd_rn(__fmul_rn(cx, Lm[1]), __fmul_rn(cy, Lm[4])), __fmul_rn(cz, Lm[7]));
-    const float oz = __fadd_rn(__fadd_rn(__fmul_rn(cx, Lm[2]), __fmul_rn(cy, Lm[5])), __fmul_rn(cz, Lm[8]));
-    const float* pj = cart + 3 * (size_t)(first + j);
+    const float* pj = pos + 3 * (size_t)(first + j);
+    const float* o = img + 3 * ci;
     Cand r;
-    r.dx = __fsub_rn(__fadd_rn(pj[0], ox), pix);  // (pos2 + offset) - pos1  (:404-408)
-    r.dy = __fsub_rn(__fadd_rn(pj[1], oy), piy);
-    r.dz = __fsub_rn(__fadd_rn(pj[2], oz), piz);
+    r.dx = __fsub_rn(__fadd_rn(pj[0], o[0]), pix);  // (pos2 + offset) - pos1  (:404-408)
+    r.dy = __fsub_rn(__fadd_rn(pj[1], o[1]), piy);
+    r.dz = __fsub_rn(__fadd_rn(pj[2], o[2]), piz);
     r.d2 = __fadd_rn(__fadd_rn(__fmul_rn(r.dx, r.dx), __fmul_rn(r.dy, r.dy)), __fmul_rn(r.dz, r.dz));
     return r;
 }
 
-__global__ __launch_bounds__(256) void neighbor_kernel(
-    const float* __restrict__ cart, const float* __restrict__ lattice, const int32_t* __restrict__ offsets,
+// Wave-wide minimum of a double, the same value in every lane.  Round 3: the butterfly of __shfl_xor (two ds_bpermute round
+// trips through the LDS crossbar per step, six steps, on the critical path of each of the k selection rounds) became DPP moves
+// inside each row of 16 lanes -- quad_perm xor 1, xor 2, row_half_mirror, row_mirror -- then row_bcast15 / row_bcast31 across
+// the rows and a read of lane 63.  An exact minimum either way: the selection is unchanged.
+__device__ __forceinline__ double arreau_wave_min_f64(double v) {
+#define ARREAU_DPP_MIN(ctrl, rows)                                                                              \
+    {                                                                                                             \
+        const int lo = __double2loint(v), hi = __double2hiint(v);                                                 \
+        const int lo2 = __builtin_amdgcn_update_dpp(lo, lo, ctrl, rows, 0xf, false);                              \
+        const int hi2 = __builtin_amdgcn_update_dpp(hi, hi, ctrl, rows, 0xf, false);                              \
+        v = fmin(v, __hiloint2double(hi2, lo2));                                                                  \
+    }
+    ARREAU_DPP_MIN(0xB1, 0xf)   // quad_perm [1,0,3,2]
+    ARREAU_DPP_MIN(0x4E, 0xf)   // quad_perm [2,3,0,1]
+    ARREAU_DPP_MIN(0x141, 0xf)  // row_half_mirror: the other quad of the 8
+    ARREAU_DPP_MIN(0x140, 0xf)  // row_mirror: the other half of the row
+    ARREAU_DPP_MIN(0x142, 0xa)  // row_bcast15 into rows 1 and 3
+    ARREAU_DPP_MIN(0x143, 0xc)  // row_bcast31 into rows 2 and 3: lane 63 now holds the minimum of the wave
+#undef ARREAU_DPP_MIN
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 63), __builtin_amdgcn_readlane(__double2loint(v), 63));
+}
+
+__device__ __forceinline__ void arreau_neighbor_body(
+    unsigned blk /* workgroup of the neighbour part: four receivers */, const float* __restrict__ cart, const float* __restrict__ lattice, const int32_t* __restrict__ offsets,
     const int32_t* __restrict__ batch /* [N] crystal of atom, or null */, int B,
     int n0, int N /* receivers n0 .. N-1 */, float r2, int k, int32_t* __restrict__ deg, int32_t* __restrict__ src,
     int32_t* __restrict__ cell, float* __restrict__ dir, float* __restrict__ dist) {
-    const int i = n0 + (int)((blockIdx.x * (unsigned)blockDim.x + threadIdx.x) >> 6);
+    const int i = n0 + (int)((blk * (unsigned)blockDim.x + threadIdx.x) >> 6);
     const int lane = threadIdx.x & 63;
     if (i >= N) return;  // wave-uniform
     // the crystal of the receiver: one load when the caller has the atom -> crystal map (prep_kernel writes it),
@@ -119,6 +149,29 @@ __global__ __launch_bounds__(256) void neighbor_kernel(
 #pragma unroll
     for (int q = 0; q < 9; ++q) Lm[q] = lattice[9 * b + q];
     const float pix = cart[3 * (size_t)i], piy = cart[3 * (size_t)i + 1], piz = cart[3 * (size_t)i + 2];
+    // Round 3: the wave first copies the Cartesian positions of its crystal into LDS (crystals of up to NBR_LDS_ATOMS atoms;
+    // wave-uniform test) and the candidates read them from there.  Before, every candidate evaluation waited for three global
+    // loads under its own lane mask, a dozen dependent L2 round trips per receiver.  Same values, same arithmetic.
+    // The 27 image offsets are likewise computed once per wave (lanes 0..26) into an LDS table instead of once per candidate:
+    // the kernel is bound by the VALU work of the candidate evaluations.
+    constexpr int NBR_LDS_ATOMS = 128;
+    __shared__ float cpos[4][3 * NBR_LDS_ATOMS];
+    __shared__ float cimg[4][27 * 3 + 3];
+    float* mypos = cpos[(threadIdx.x >> 6) & 3];
+    float* myimg = cimg[(threadIdx.x >> 6) & 3];
+    const bool staged = ncand <= 27 * NBR_LDS_ATOMS;
+    if (lane < 27) {
+        float o[3];
+        arreau_image_offset(lane, Lm, o);
+        myimg[3 * lane] = o[0]; myimg[3 * lane + 1] = o[1]; myimg[3 * lane + 2] = o[2];
+    }
+    if (staged)
+        for (int a = lane; a < ncand / 9; a += 64) mypos[a] = cart[3 * (size_t)first + a];  // ncand / 9 = 3 * atoms
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_wave_barrier();
+    auto candidate = [&](int c) -> Cand {
+        return staged ? arreau_candidate(mypos, 0, c, myimg, pix, piy, piz) : arreau_candidate(cart, first, c, myimg, pix, piy, piz);
+    };
 
     // Crystals of up to 64 * NBR_KEYS / 27 = 28 atoms (wave-uniform test): every lane evaluates its candidates once
     // and keeps their keys in registers; each of the k selection rounds is then a scan of those keys.  Larger
@@ -130,6 +183,7 @@ __global__ __launch_bounds__(256) void neighbor_kernel(
     constexpr double KEY_NONE = 1.0e300;
     auto make_key = [](float d2, int c) { return (double)__float_as_uint(d2) * 2097152.0 + (double)c; };
     bool cached = ncand <= 64 * NBR_KEYS;
+    int nkeys = ncand;  // wave-uniform: keys[q] beyond 64 q >= nkeys are KEY_NONE, the rounds skip them
     double keys[NBR_KEYS];
     if (cached) {
 #pragma unroll
@@ -137,7 +191,7 @@ __global__ __launch_bounds__(256) void neighbor_kernel(
             const int c = lane + 64 * q;
             keys[q] = KEY_NONE;
             if (c < ncand) {
-                const Cand cd = arreau_candidate(cart, first, c, Lm, pix, piy, piz);
+                const Cand cd = candidate(c);
                 if (cd.d2 <= r2 && cd.d2 > 0.0001f) keys[q] = make_key(cd.d2, c);
             }
         }
@@ -149,20 +203,21 @@ __global__ __launch_bounds__(256) void neighbor_kernel(
         //   pass 2: the candidates with key <= T -- at least k, rarely many more -- are compacted into a per-wave LDS list
         //           (wave ballot + lane prefix count; the order in the list does not matter, the keys are unique) and
         //           become the register-resident key set of the rounds below.
-        // Should more than 64 * NBR_KEYS candidates pass (massive exact ties), the re-evaluating rounds remain.  Same keys,
+        // Should more than 64 * NBR_LIST candidates pass (massive exact ties), the re-evaluating rounds remain.  Same keys,
         // same selection, same output as before.
-        __shared__ double klist[4][64 * NBR_KEYS];
+        // (the list holds 64 * NBR_LIST keys: T leaves k .. a few dozen of them; a longer list would only cost LDS, i.e. resident
+        // waves -- with 64 * NBR_KEYS entries the kernel was limited to 5 workgroups per CU)
+        constexpr int NBR_LIST = 6;
+        __shared__ double klist[4][64 * NBR_LIST];
         double* mylist = klist[(threadIdx.x >> 6) & 3];
         double lmin = KEY_NONE;
         for (int c = lane; c < ncand; c += 64) {
-            const Cand cd = arreau_candidate(cart, first, c, Lm, pix, piy, piz);
+            const Cand cd = candidate(c);
             if (cd.d2 <= r2 && cd.d2 > 0.0001f) lmin = fmin(lmin, make_key(cd.d2, c));
         }
         double T = KEY_NONE, below = -1.0;
         for (int s = 0; s < k; ++s) {
-            double best = lmin > below ? lmin : KEY_NONE;
-#pragma unroll
-            for (int off = 32; off >= 1; off >>= 1) best = fmin(best, __shfl_xor(best, off, 64));
+            const double best = arreau_wave_min_f64(lmin > below ? lmin : KEY_NONE);
             T = best;
             if (best == KEY_NONE) break;  // wave-uniform: fewer than k lanes hold a candidate -> everything in range passes
             below = best;
@@ -173,7 +228,7 @@ __global__ __launch_bounds__(256) void neighbor_kernel(
             bool in = false;
             double key = KEY_NONE;
             if (c < ncand) {
-                const Cand cd = arreau_candidate(cart, first, c, Lm, pix, piy, piz);
+                const Cand cd = candidate(c);
                 if (cd.d2 <= r2 && cd.d2 > 0.0001f) {
                     key = make_key(cd.d2, c);
                     in = key <= T;
@@ -181,15 +236,16 @@ __global__ __launch_bounds__(256) void neighbor_kernel(
             }
             const unsigned long long m = __ballot(in);
             const int pos = total + (int)__builtin_amdgcn_mbcnt_hi((unsigned)(m >> 32), __builtin_amdgcn_mbcnt_lo((unsigned)m, 0u));
-            if (in && pos < 64 * NBR_KEYS) mylist[pos] = key;
+            if (in && pos < 64 * NBR_LIST) mylist[pos] = key;
             total += __builtin_popcountll(m);
         }
-        if (total <= 64 * NBR_KEYS) {
+        if (total <= 64 * NBR_LIST) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the wave's own list writes, before its reads
             __builtin_amdgcn_wave_barrier();
 #pragma unroll
-            for (int q = 0; q < NBR_KEYS; ++q) keys[q] = lane + 64 * q < total ? mylist[lane + 64 * q] : KEY_NONE;
+            for (int q = 0; q < NBR_KEYS; ++q) keys[q] = q < NBR_LIST && lane + 64 * q < total ? mylist[lane + 64 * q] : KEY_NONE;
             cached = true;
+            nkeys = total;
         }
     }
     double last = -1.0, mine = KEY_NONE;
@@ -198,18 +254,18 @@ __global__ __launch_bounds__(256) void neighbor_kernel(
         double best = KEY_NONE;
         if (cached) {
 #pragma unroll
-            for (int q = 0; q < NBR_KEYS; ++q) best = fmin(best, keys[q] > last ? keys[q] : KEY_NONE);
+            for (int q = 0; q < NBR_KEYS; ++q)
+                if (64 * q < nkeys) best = fmin(best, keys[q] > last ? keys[q] : KEY_NONE);
         } else {
             for (int c = lane; c < ncand; c += 64) {
-                const Cand cd = arreau_candidate(cart, first, c, Lm, pix, piy, piz);
+                const Cand cd = candidate(c);
                 if (cd.d2 <= r2 && cd.d2 > 0.0001f) {
                     const double key = make_key(cd.d2, c);
                     best = fmin(best, key > last ? key : KEY_NONE);
                 }
             }
         }
-#pragma unroll
-        for (int off = 32; off >= 1; off >>= 1) best = fmin(best, __shfl_xor(best, off, 64));
+        best = arreau_wave_min_f64(best);
         if (best == KEY_NONE) break;  // wave-uniform: fewer than k candidates
         last = best;
         if (lane == s) mine = best;
@@ -220,14 +276,14 @@ __global__ __launch_bounds__(256) void neighbor_kernel(
     const unsigned myc = index_of(mine);
     int rank = 0;
     for (int s = 0; s < count; ++s) {
-        const unsigned oc = index_of(__shfl(mine, s, 64));
+        const unsigned oc = (unsigned)__builtin_amdgcn_readlane((int)myc, s);  // s is wave-uniform
         rank += (oc < myc) ? 1 : 0;
     }
     if (lane == 0) deg[i] = count;
     if (lane < k) {
         const size_t base = (size_t)i * k;
         if (lane < count) {
-            const Cand cd = arreau_candidate(cart, first, (int)myc, Lm, pix, piy, piz);
+            const Cand cd = candidate((int)myc);
             const size_t o = base + rank;
             src[o] = first + (int)(myc / 27u);
             cell[o] = (int)(myc % 27u);
@@ -242,6 +298,29 @@ __global__ __launch_bounds__(256) void neighbor_kernel(
     }
 }
 
+__global__ __launch_bounds__(256) void neighbor_kernel(
+    const float* __restrict__ cart, const float* __restrict__ lattice, const int32_t* __restrict__ offsets,
+    const int32_t* __restrict__ batch, int B, int n0, int N, float r2, int k, int32_t* __restrict__ deg, int32_t* __restrict__ src,
+    int32_t* __restrict__ cell, float* __restrict__ dir, float* __restrict__ dist) {
+    arreau_neighbor_body(blockIdx.x, cart, lattice, offsets, batch, B, n0, N, r2, k, deg, src, cell, dir, dist);
+}
+
+// Round 3: the sampler's step builds the neighbour list and the embedded node features in ONE launch.  Both depend on prep_kernel
+// only and not on each other; the embedding is bound by its HBM writes (16 rows of C floats per atom), the neighbour list by
+// latency and VALU work, so side by side they take the time of the longer one.  The first `embed_blocks` workgroups embed.
+__global__ __launch_bounds__(256) void neighbor_embed_kernel(
+    unsigned embed_blocks, const float* __restrict__ cart, const float* __restrict__ lattice, const int32_t* __restrict__ offsets,
+    const int32_t* __restrict__ batch, int B, int n0, int N, float r2, int k, int32_t* __restrict__ deg, int32_t* __restrict__ src,
+    int32_t* __restrict__ cell, float* __restrict__ dir, float* __restrict__ dist, const float* __restrict__ frac,
+    const int32_t* __restrict__ types, const float* __restrict__ cvec, const float* __restrict__ ori, const float* __restrict__ embT,
+    int S, int C, float* __restrict__ x0, int32_t* __restrict__ status) {
+    if (blockIdx.x < embed_blocks) {
+        arreau_embed_body(blockIdx.x * blockDim.x + threadIdx.x, frac, types, lattice, batch, cvec, ori, embT, S, C, n0, N, x0, status);
+        return;
+    }
+    arreau_neighbor_body(blockIdx.x - embed_blocks, cart, lattice, offsets, batch, B, n0, N, r2, k, deg, src, cell, dir, dist);
+}
+
 int arreau_launch_neighbor(const float* cart, const float* lattice, const int32_t* offsets, const int32_t* batch,
                            int B, int N, float radius, int k, int32_t* deg, int32_t* src, int32_t* cell, float* dir, float* dist,
                            hipStream_t s, NodeRange r) {
@@ -251,6 +330,26 @@ int arreau_launch_neighbor(const float* cart, const float* lattice, const int32_
     const int waves_per_block = 4;
     ARREAU_LAUNCH(neighbor_kernel, dim3((n1 - n0 + waves_per_block - 1) / waves_per_block), dim3(64 * waves_per_block),
                        0, s, cart, lattice, offsets, batch, B, n0, n1, r2, k, deg, src, cell, dir, dist);
+    ARREAU_CHECK_HIP(hipGetLastError());
+    return ARREAU_OK;
+}
+
+int arreau_launch_neighbor_embed(const arreau_model* m, const float* cart, const float* lattice, const int32_t* offsets,
+                                 const int32_t* batch, int B, int N, int32_t* deg, int32_t* src, int32_t* cell, float* dir,
+                                 float* dist, const float* frac, const int32_t* types, const float* cvec, float* x0, hipStream_t s,
+                                 NodeRange r) {
+    const int n0 = r.n0, n1 = r.n1 < 0 ? N : r.n1;
+    if (n1 <= n0) return ARREAU_OK;
+    ARREAU_REQUIRE(batch != nullptr, "neighbour list + embedding: the atom -> crystal map is required");
+    const float r2 = (float)((double)m->cfg.radius * (double)m->cfg.radius);
+    const long long pairs = (long long)(n1 - n0) * (m->C / 4);
+    if (pairs >= (1ll << 31)) {
+        arreau_set_error("embed kernel: more than 2^31 (atom, channel group) pairs in one launch");
+        return ARREAU_EINVAL;
+    }
+    const unsigned embed_blocks = (unsigned)((pairs + 255) / 256), nbr_blocks = (unsigned)((n1 - n0 + 3) / 4);
+    ARREAU_LAUNCH(neighbor_embed_kernel, dim3(embed_blocks + nbr_blocks), dim3(256), 0, s, embed_blocks, cart, lattice, offsets, batch,
+                  B, n0, n1, r2, m->k, deg, src, cell, dir, dist, frac, types, cvec, m->ori, m->embT, m->S, m->C, x0, m->status);
     ARREAU_CHECK_HIP(hipGetLastError());
     return ARREAU_OK;
 }

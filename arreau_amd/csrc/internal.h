@@ -250,6 +250,11 @@ int arreau_launch_fiber_precompute(arreau_model* m, hipStream_t s);
 int arreau_launch_neighbor(const float* cart, const float* lattice, const int32_t* offsets, const int32_t* batch, int B, int N,
                            float radius, int k, int32_t* deg, int32_t* src, int32_t* cell, float* dir, float* dist,
                            hipStream_t s, NodeRange r = NodeRange());
+// neighbour list + embedding of the sampler's node features in one launch (graph.hip; both read prep_kernel's outputs only)
+int arreau_launch_neighbor_embed(const arreau_model* m, const float* cart, const float* lattice, const int32_t* offsets,
+                                 const int32_t* batch, int B, int N, int32_t* deg, int32_t* src, int32_t* cell, float* dir,
+                                 float* dist, const float* frac, const int32_t* types, const float* cvec, float* x0, hipStream_t s,
+                                 NodeRange r = NodeRange());
 int arreau_launch_prep(const arreau_model* m, const float* frac, const float* lengths, const float* angles,
                        const int32_t* t, const int32_t* offsets, int B, int N, float* lattice, float* cart,
                        int32_t* batch, float* cvec, hipStream_t s, int32_t* t_next = nullptr, int32_t* t_cur = nullptr,

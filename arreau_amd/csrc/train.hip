@@ -78,7 +78,7 @@ __global__ __launch_bounds__(256) void noise_atoms_kernel(
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int i = blockIdx.x * 4 + wave;
     if (i >= N) return;
-    int lo = 0, hi = B;  // crystal of this atom (64-ary search, see reverse_atoms_kernel)
+    int lo = 0, hi = B;  // crystal of this atom (64-ary search, see reverse_atoms_body in update.hip)
     while (hi - lo > 1) {
         const int span = hi - lo, step = (span + 63) >> 6;
         const int probe = lo + lane * step;

@@ -7,7 +7,7 @@
 
 // VP_lattice.reverse_given_x0 (diffusion_helpers.py:185-199) on lengths, then lattice_from_params.
 // Note the reference adds `variance * z` (not sqrt(variance)) and zeroes z when t <= 1.
-__global__ void reverse_lattice_kernel(float* __restrict__ lengths, const float* __restrict__ angles,
+__device__ __forceinline__ void reverse_lattice_body(int gt /* global thread of the lattice part */, float* __restrict__ lengths, const float* __restrict__ angles,
                                        const int32_t* __restrict__ tstep, const int32_t* __restrict__ offsets,
                                        const float* __restrict__ len0, StepNoiseSrc noise,
                                        const float* __restrict__ alpha_bars, const float* __restrict__ betas, int B,
@@ -17,7 +17,6 @@ __global__ void reverse_lattice_kernel(float* __restrict__ lengths, const float*
                                        // readout_crystals_kernel) instead of a launch of its own; len0_out receives it
                                        const float* __restrict__ gs_atoms, float* __restrict__ len0_out) {
     // four lanes per crystal: lane i < 3 owns length component i (pooling, update), lane 0 then writes the cell
-    const int gt = blockIdx.x * blockDim.x + threadIdx.x;
     const int b = b0 + (gt >> 2), i = gt & 3;
     const bool live = b < B;  // (whole groups of four are live or not; the shuffles below need every lane)
     const int bc = live ? b : B - 1;
@@ -86,8 +85,8 @@ __device__ __forceinline__ float remainder_one(float x) {
 
 // One wave per atom: VE_pbc.reverse on the fractional coordinates (diffusion_helpers.py:65-81) and
 // D3PM.reverse on the atom type (d3pm.py:74-110, 198-215).  Lanes span the S classes (2 per lane).
-__global__ __launch_bounds__(256) void reverse_atoms_kernel(
-    float* __restrict__ frac, int32_t* __restrict__ types, const int32_t* __restrict__ tstep,
+__device__ __forceinline__ void reverse_atoms_body(
+    int blk /* block of the atom part */, float* __restrict__ frac, int32_t* __restrict__ types, const int32_t* __restrict__ tstep,
     const int32_t* __restrict__ offsets, int B, int N, const float* __restrict__ eps,
     const float* __restrict__ logits, StepNoiseSrc noise,
     const float* __restrict__ ve_sigmas, const float* __restrict__ q1t, const float* __restrict__ qmats, int S,
@@ -96,7 +95,7 @@ __global__ __launch_bounds__(256) void reverse_atoms_kernel(
     const float* __restrict__ z_frac = noise.z_frac;
     const float* __restrict__ u_types = noise.u_types;
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int i = n0 + blockIdx.x * 4 + wave;  // atoms n0 .. N-1
+    const int i = n0 + blk * 4 + wave;  // atoms n0 .. N-1
     if (i >= N) return;  // wave-uniform; no block-level barrier below
     // crystal of this atom = largest b with offsets[b] <= i: a 64-ary search by the whole wave (each level one
     // load per lane + a ballot) instead of log2(B) dependent loads
@@ -221,22 +220,40 @@ __global__ __launch_bounds__(256) void reverse_atoms_kernel(
     if (lane == 0) types[i] = const_types ? const_types[i] : besti;
 }
 
+// ONE launch for the four updates of a step (round 3; they were two): the first `lat_blocks` workgroups (256 threads = 64
+// crystals, four lanes each) run the lattice update, the others the atom update, one wave per atom.  The two parts touch
+// disjoint data (lengths / lattice / pooled read-out against coordinates / types), so nothing orders them.
+__global__ __launch_bounds__(256) void reverse_kernel(
+    int lat_blocks, float* __restrict__ lengths, const float* __restrict__ angles, const int32_t* __restrict__ tstep,
+    const int32_t* __restrict__ offsets, const float* __restrict__ len0, StepNoiseSrc noise, const float* __restrict__ alpha_bars,
+    const float* __restrict__ betas, int B_lat, int T, float* __restrict__ lattice, const float* __restrict__ fixed_lengths,
+    int32_t* __restrict__ status, int b0, const float* __restrict__ gs_atoms, float* __restrict__ len0_out,
+    float* __restrict__ frac, int32_t* __restrict__ types, int B, int N, const float* __restrict__ eps,
+    const float* __restrict__ logits, const float* __restrict__ ve_sigmas, const float* __restrict__ q1t,
+    const float* __restrict__ qmats, int S, const int32_t* __restrict__ const_types, int absorbing, int n0,
+    const int32_t* __restrict__ batch) {
+    if ((int)blockIdx.x < lat_blocks) {
+        reverse_lattice_body(blockIdx.x * blockDim.x + threadIdx.x, lengths, angles, tstep, offsets, len0, noise, alpha_bars, betas, B_lat, T,
+                             lattice, fixed_lengths, status, b0, gs_atoms, len0_out);
+        return;
+    }
+    reverse_atoms_body((int)blockIdx.x - lat_blocks, frac, types, tstep, offsets, B, N, eps, logits, noise, ve_sigmas, q1t, qmats, S, T,
+                       const_types, absorbing, status, n0, batch);
+}
+
 int arreau_launch_reverse(const arreau_model* m, float* d_frac, int32_t* d_types, float* d_lengths, const float* d_angles,
                           const int32_t* d_t, const int32_t* d_off, int B, int N, const float* d_eps,
                           const float* d_logits, const float* d_len0, StepNoiseSrc noise, const int32_t* d_const_types,
                           float* d_lattice, hipStream_t s, const float* d_fixed_lengths, NodeRange r, const float* d_gs_atoms,
                           const int32_t* d_batch) {
     const int n0 = r.n0, n1 = r.n1 < 0 ? N : r.n1, b0 = r.b0, b1 = r.b1 < 0 ? B : r.b1;
-    if (b1 > b0) {
-        ARREAU_LAUNCH(reverse_lattice_kernel, dim3((4 * (b1 - b0) + 127) / 128), dim3(128), 0, s, d_lengths, d_angles, d_t, d_off,
-                           d_len0, noise, m->vp_alpha_bars, m->vp_betas, b1, m->T, d_lattice, d_fixed_lengths, m->status, b0,
-                           d_gs_atoms, d_gs_atoms ? const_cast<float*>(d_len0) : nullptr);
-        ARREAU_CHECK_HIP(hipGetLastError());
-    }
-    if (n1 > n0) {
-        ARREAU_LAUNCH(reverse_atoms_kernel, dim3((n1 - n0 + 3) / 4), dim3(256), 0, s, d_frac, d_types, d_t, d_off, B, n1,
-                           d_eps, d_logits, noise, m->ve_sigmas, m->q1t, m->qmats, m->S, m->T, d_const_types, m->qmats_absorbing,
-                           m->status, n0, d_batch);
+    const int lat_blocks = b1 > b0 ? (4 * (b1 - b0) + 255) / 256 : 0;
+    const int atom_blocks = n1 > n0 ? (n1 - n0 + 3) / 4 : 0;
+    if (lat_blocks + atom_blocks > 0) {
+        ARREAU_LAUNCH(reverse_kernel, dim3(lat_blocks + atom_blocks), dim3(256), 0, s, lat_blocks, d_lengths, d_angles, d_t, d_off, d_len0,
+                      noise, m->vp_alpha_bars, m->vp_betas, b1, m->T, d_lattice, d_fixed_lengths, m->status, b0, d_gs_atoms,
+                      d_gs_atoms ? const_cast<float*>(d_len0) : nullptr, d_frac, d_types, B, n1, d_eps, d_logits, m->ve_sigmas, m->q1t,
+                      m->qmats, m->S, d_const_types, m->qmats_absorbing, n0, d_batch);
         ARREAU_CHECK_HIP(hipGetLastError());
     }
     return ARREAU_OK;

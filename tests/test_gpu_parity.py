@@ -134,7 +134,9 @@ def test_radius_graph_matches_reference_fixture(dev, i):
     ([2] * 5, (9.0, 12.0), 3), ([33], (2.5, 4.0), 4),
     # crystals beyond the register-resident candidate set: in-range keys compacted through LDS (relaxed cells) and the
     # re-evaluating rounds (more than 768 candidates inside the cutoff)
-    ([48, 64, 29, 57], (7.0, 11.0), 5), ([64], (2.0, 3.0), 6), ([40, 40], (3.5, 5.0), 7)])
+    ([48, 64, 29, 57], (7.0, 11.0), 5), ([64], (2.0, 3.0), 6), ([40, 40], (3.5, 5.0), 7),
+    # a crystal beyond the LDS copy of the positions (more than 128 atoms: candidates read from global memory), next to one inside it
+    ([150, 3, 128, 129], (8.0, 12.0), 8)])
 def test_radius_graph_vs_oracle_random(dev, num_atoms, cell, seed):
     """Larger ragged / dense / sparse cases against the oracle's radius_graph_pbc (fp32).  Edges whose
     d^2 is within 1e-5 (relative) of the receiver's selection threshold may legitimately differ; none do
