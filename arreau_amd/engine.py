@@ -4,6 +4,7 @@ Host-side plumbing only: tensors are allocated with torch, every arithmetic step
 state runs in libarreau_hip.so.
 """
 import ctypes
+import math
 import os
 
 import torch
@@ -234,12 +235,19 @@ class HipEngine:
         cfg = self.cfg
         S, C, D, L, W = self.S, cfg.hidden_dim, cfg.basis_dim, cfg.num_layers, cfg.widening_factor
         H = W * C
-        z = lambda *shape: torch.zeros(shape, device=dev, dtype=torch.float32)
-        g = {"basis_w1": z(C, 258), "basis_b1": z(C), "basis_w2": z(D, C), "basis_b2": z(D), "fiber_w1": z(C, 3),
-             "fiber_b1": z(C), "fiber_w2": z(D, C), "fiber_b2": z(D), "x_embedder_w": z(C, S + 78),
-             "conv_kernel_w": z(L, C, D), "conv_fiber_w": z(L, C, D), "conv_bias": z(L, C), "norm_w": z(L, C),
-             "norm_b": z(L, C), "linear1_w": z(L, H, C), "linear1_b": z(L, H), "linear2_w": z(L, C, H),
-             "linear2_b": z(L, C), "layer_scale": z(L, C), "readout_w": z(L, S + 4, C), "readout_b": z(L, S + 4)}
+        shapes = {"basis_w1": (C, 258), "basis_b1": (C,), "basis_w2": (D, C), "basis_b2": (D,), "fiber_w1": (C, 3),
+                  "fiber_b1": (C,), "fiber_w2": (D, C), "fiber_b2": (D,), "x_embedder_w": (C, S + 78),
+                  "conv_kernel_w": (L, C, D), "conv_fiber_w": (L, C, D), "conv_bias": (L, C), "norm_w": (L, C),
+                  "norm_b": (L, C), "linear1_w": (L, H, C), "linear1_b": (L, H), "linear2_w": (L, C, H),
+                  "linear2_b": (L, C), "layer_scale": (L, C), "readout_w": (L, S + 4, C), "readout_b": (L, S + 4)}
+        # one zero-filled buffer per step, the gradients are views of it (21 fill launches were 0.1 ms of the step); every
+        # view starts on a 16-byte boundary (the kernels write some of them as float4 columns)
+        sizes = {k: -(-math.prod(v) // 4) * 4 for k, v in shapes.items()}
+        flat = torch.zeros(sum(sizes.values()), device=dev, dtype=torch.float32)
+        g, o = {}, 0
+        for k, shp in shapes.items():
+            g[k] = flat[o:o + math.prod(shp)].view(shp)
+            o += sizes[k]
         csd = _hip.StateDict()
         for name in _hip._SD_FIELDS:
             t = g.get(name)
