@@ -319,6 +319,10 @@ int arreau_launch_mlp_bf16x6(const arreau_model* m, int layer, const float* x_co
                              float* xbar, float* vsum, int N, hipStream_t s);
 int arreau_launch_mlp_f16x3_m16(const arreau_model* m, int layer, const float* x_conv, const float* x_in, float* x_out,
                                 float* xbar, float* vsum, int N, hipStream_t s, NodeRange r = NodeRange());
+// one launch per layer for small unsliced launches (node_f16m.hip): conv_kernel_streamed<128, false> + the split MLP form
+bool arreau_small_layer_fusable(const arreau_model* m, int N, NodeRange r);
+int arreau_launch_small_layer(const arreau_model* m, int layer, const float* kbuf, const int32_t* deg, const int32_t* src,
+                              const float* x_in, float* x_out, float* xbar, float* vsum, int Ntot, hipStream_t s);
 int arreau_launch_mlp_f16x3_m16_split(const arreau_model* m, int layer, const float* x_conv, const float* x_in, float* x_out,
                                       float* xbar, float* vsum, int N, hipStream_t s, NodeRange r = NodeRange());
 int arreau_launch_mlp_f16x3(const arreau_model* m, int layer, const float* x_conv, const float* x_in, float* x_out,

@@ -665,6 +665,10 @@ int arreau_launch_node_layer(const arreau_model* m, int layer, const float* kbuf
     const bool basis_form = arreau_basis_form(m, Ng);
     const int conv_variant = m->conv_variant == 2 ? 1 : m->conv_variant;  // (2 without the basis form = the streamed K pair)
     m->ran_conv = basis_form ? 2 : (conv_variant == 1 && m->k == 8) ? 1 : 0;
+    if (arreau_small_layer_fusable(m, N, r)) {  // small launch: both halves of the layer in one kernel (bit-identical)
+        m->ran_mlp = 3;
+        return arreau_launch_small_layer(m, layer, kbuf, deg, src, x_in, x_out, xbar, vsum, N, s);
+    }
     if (basis_form) {
         const int rc = arreau_launch_conv_proj(m, layer, kbuf, deg, src, x_in, x_conv, N, s, r);
         if (rc) return rc;

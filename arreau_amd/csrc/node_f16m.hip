@@ -313,16 +313,25 @@ __device__ __forceinline__ void load_steps(u32x4 (&w)[2 * NST], const u32x4* __r
 }
 }  // namespace
 
-template <int C, int H>
+// FUSE (round 3): the workgroup first evaluates its node's message passing + spherical convolution itself -- the arithmetic
+// of conv_kernel / conv_kernel_streamed (node.hip) on an fp32 K block, same thread roles (512 threads), same order of the
+// rounded products and of the mix -- and keeps the 16 convolved rows in LDS instead of reading them back from x_conv: one
+// launch per layer instead of two where launches, not bytes, are what a step costs (1 x 8: 15 -> 10 launches per step).
+template <int C, int H, bool FUSE = false>
 __global__ __launch_bounds__(512) void mlp_kernel_f16x3_m16_split(
     const float* __restrict__ x_conv, const float* __restrict__ x_in, float* __restrict__ x_out,
     const float* __restrict__ ln_w, const float* __restrict__ ln_b, const u32x4* __restrict__ stream,
     const float* __restrict__ mb1, const float* __restrict__ mb2, const float* __restrict__ ls,
-    const float* __restrict__ wv, float bv, int n0, int first_layer, float* __restrict__ xbar, float* __restrict__ vsum) {
+    const float* __restrict__ wv, float bv, int n0, int first_layer, float* __restrict__ xbar, float* __restrict__ vsum,
+    const float* __restrict__ kl /* FUSE: this layer's kernels [N*8*16][C] fp32 */, const int32_t* __restrict__ deg,
+    const int32_t* __restrict__ src, const float* __restrict__ fk /* [16][16][C] */, const float* __restrict__ conv_bias) {
     static_assert(C == 128 && H == 512, "chunking below assumes C = 128, H = 512");
     constexpr int KC = C / 32, HQ = H / 4;
+    constexpr int TS = 132;             // row stride of the two conv tiles (node.hip: CONV_LDS_STRIDE)
     __shared__ u32x4 hidx[16][2][64];   // hidden chunk (quarter * 4 + u) as B operand: [chunk][plane][lane], 32 KiB
     __shared__ f32x4 xo_s[8][64];       // the eight output tiles' x_out values, for the vector read-out chain
+    __shared__ __attribute__((aligned(16))) float ctile[FUSE ? 16 * TS : 4];  // FUSE: messages summed per orientation row
+    __shared__ __attribute__((aligned(16))) float xc_s[FUSE ? 16 * TS : 4];   // FUSE: the node's 16 convolved rows
 
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int q = wave >> 1, e = wave & 1;     // phase 1: hidden quarter, half of the quarter
@@ -342,10 +351,56 @@ __global__ __launch_bounds__(512) void mlp_kernel_f16x3_m16_split(
     const f32x4 ep_ls = *reinterpret_cast<const f32x4*>(ls + ep_c0);
     const f32x4 ep_xi = *reinterpret_cast<const f32x4*>(x_in + ep_off);
 
+    if constexpr (FUSE) {
+        // conv.py:111,131-133 + index_add_ over the in-edges, then the depth-wise orientation mix (conv.py:113-127): node.hip's
+        // conv_kernel, for this workgroup's node
+        const int tid = threadIdx.x;
+        const int c = tid & 127, pq = tid >> 7;     // mix role: channel, quarter of the output orientations
+        const int c4 = tid & 31, o_row = tid >> 5;  // gather role: float4 column, orientation row
+        constexpr int K = 8;
+        const int nd = min(deg[n], K);
+        const int32_t* srow = src + (size_t)n * K;
+        const size_t kbase = ((size_t)n * K * 16 + o_row) * C + 4 * c4;
+        f32x4 kv[K], xv[K];
+#pragma unroll
+        for (int s_ = 0; s_ < K; ++s_) {  // unused slots: any valid row, dropped by the select below (their K rows may be uninitialised)
+            const int sn = max(srow[s_], 0);
+            kv[s_] = *reinterpret_cast<const f32x4*>(kl + kbase + (size_t)s_ * 16 * C);
+            xv[s_] = *reinterpret_cast<const f32x4*>(x_in + ((size_t)sn * 16 + o_row) * C + 4 * c4);
+        }
+        float fkr[16][4];
+#pragma unroll
+        for (int o = 0; o < 16; ++o)
+#pragma unroll
+            for (int p = 0; p < 4; ++p) fkr[o][p] = fk[((size_t)o * 16 + (4 * pq + p)) * C + c];
+        const float cbias = conv_bias[c];
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int s_ = 0; s_ < K; ++s_) {
+            const bool on = s_ < nd;  // product rounded, then added in edge order (messages -> index_add_)
+            acc[0] = on ? __fadd_rn(acc[0], __fmul_rn(kv[s_][0], xv[s_][0])) : acc[0];
+            acc[1] = on ? __fadd_rn(acc[1], __fmul_rn(kv[s_][1], xv[s_][1])) : acc[1];
+            acc[2] = on ? __fadd_rn(acc[2], __fmul_rn(kv[s_][2], xv[s_][2])) : acc[2];
+            acc[3] = on ? __fadd_rn(acc[3], __fmul_rn(kv[s_][3], xv[s_][3])) : acc[3];
+        }
+        *reinterpret_cast<f32x4*>(&ctile[o_row * TS + 4 * c4]) = acc;
+        __syncthreads();
+        float out[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int o = 0; o < 16; ++o) {
+            const float xo = ctile[o * TS + c];
+#pragma unroll
+            for (int p = 0; p < 4; ++p) out[p] += xo * fkr[o][p];
+        }
+#pragma unroll
+        for (int p = 0; p < 4; ++p) xc_s[(4 * pq + p) * TS + c] = out[p] + cbias;
+        __syncthreads();
+    }
+
     // ---- the node's 16 rows in B-operand layout, LayerNorm (eps 1e-5, biased variance), split (as in the kernel above) ----
     u32x4 xn[KC][2];
     {
-        const float* rowp = x_conv + ((size_t)n * 16 + cp) * C + 4 * gp;
+        const float* rowp = FUSE ? xc_s + cp * TS + 4 * gp : x_conv + ((size_t)n * 16 + cp) * C + 4 * gp;
         float x[KC][8];
         float sum = 0.f;
 #pragma unroll
@@ -487,6 +542,7 @@ __global__ __launch_bounds__(512) void mlp_kernel_f16x3_m16_split(
     }
 }
 
+#define ARREAU_MLP_SPLIT_MAX_NODES 512
 int arreau_launch_mlp_f16x3_m16_split(const arreau_model* m, int layer, const float* x_conv, const float* x_in, float* x_out,
                                       float* xbar, float* vsum, int Ntot, hipStream_t s, NodeRange r) {
     const int n0 = r.n0, n1 = r.n1 < 0 ? Ntot : r.n1;
@@ -501,12 +557,39 @@ int arreau_launch_mlp_f16x3_m16_split(const arreau_model* m, int layer, const fl
     ARREAU_LAUNCH((mlp_kernel_f16x3_m16_split<128, 512>), dim3((unsigned)(n1 - n0)), dim3(512), 0, s, x_conv, x_in, x_out,
                        m->ln_w + (size_t)layer * C, m->ln_b + (size_t)layer * C, stream, m->mb1 + (size_t)layer * H,
                        m->mb2 + (size_t)layer * C, m->ls + (size_t)layer * C, m->ro_wv + (size_t)layer * C, m->ro_bv_host[layer],
-                       n0, layer == 0 ? 1 : 0, xbar + (size_t)layer * Ntot * C, vsum);
+                       n0, layer == 0 ? 1 : 0, xbar + (size_t)layer * Ntot * C, vsum, (const float*)nullptr, (const int32_t*)nullptr,
+                       (const int32_t*)nullptr, (const float*)nullptr, (const float*)nullptr);
     ARREAU_CHECK_HIP(hipGetLastError());
     return ARREAU_OK;
 }
 
-#define ARREAU_MLP_SPLIT_MAX_NODES 512
+// Message passing + spherical convolution + ConvNext block of one layer in ONE launch (small unsliced launches on an fp32 K
+// buffer with k = 8; see the kernel): what conv_kernel_streamed<128, false> followed by the launch above computes, bit for bit.
+bool arreau_small_layer_fusable(const arreau_model* m, int N, NodeRange r) {
+    const char* e = getenv("ARREAU_FUSE_SMALL");  // 0: two launches per layer (A/B, tests); read per call
+    static const int split_env = [] { const char* v = getenv("ARREAU_MLP_SPLIT"); return v ? atoi(v) : -1; }();
+    const int n0 = r.n0, n1 = r.n1 < 0 ? N : r.n1;
+    const bool whole_batch = n0 == 0 && n1 == N && r.wg_cap == 0;
+    return (e == nullptr || atoi(e) != 0) && split_env < 0 && whole_batch && N <= ARREAU_MLP_SPLIT_MAX_NODES && m->mlp_variant == 3 &&
+           m->f16_ok && m->k == 8 && m->C == 128 && m->H == 512 && (m->conv_variant == 1 || m->conv_variant == 2) && !arreau_k3(m) &&
+           !arreau_basis_form(m, n1 - n0);
+}
+int arreau_launch_small_layer(const arreau_model* m, int layer, const float* kbuf, const int32_t* deg, const int32_t* src,
+                              const float* x_in, float* x_out, float* xbar, float* vsum, int Ntot, hipStream_t s) {
+    if (Ntot <= 0) return ARREAU_OK;
+    const int C = m->C, H = m->H;
+    const size_t layer_u32x4 = (size_t)2 * H * C * 2 * 2 / 16;
+    const u32x4* stream = reinterpret_cast<const u32x4*>(m->mlp_f16m) + (size_t)layer * layer_u32x4;
+    const size_t layer_stride = (size_t)Ntot * m->k * 16 * C;
+    ARREAU_LAUNCH((mlp_kernel_f16x3_m16_split<128, 512, true>), dim3((unsigned)Ntot), dim3(512), 0, s, (const float*)nullptr, x_in, x_out,
+                       m->ln_w + (size_t)layer * C, m->ln_b + (size_t)layer * C, stream, m->mb1 + (size_t)layer * H,
+                       m->mb2 + (size_t)layer * C, m->ls + (size_t)layer * C, m->ro_wv + (size_t)layer * C, m->ro_bv_host[layer],
+                       0, layer == 0 ? 1 : 0, xbar + (size_t)layer * Ntot * C, vsum, kbuf + layer_stride * layer, deg, src,
+                       m->fk + (size_t)layer * 16 * 16 * C, m->conv_bias + (size_t)layer * C);
+    ARREAU_CHECK_HIP(hipGetLastError());
+    return ARREAU_OK;
+}
+
 int arreau_launch_mlp_f16x3_m16(const arreau_model* m, int layer, const float* x_conv, const float* x_in, float* x_out,
                                 float* xbar, float* vsum, int Ntot, hipStream_t s, NodeRange r) {
     const int n0 = r.n0, n1 = r.n1 < 0 ? Ntot : r.n1;

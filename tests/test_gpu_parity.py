@@ -1342,11 +1342,14 @@ def test_small_launch_kernels_are_bit_identical_to_the_throughput_forms(dev):
     with tempfile.TemporaryDirectory() as d:
         # (the read-out kernel has the same kind of small-launch form -- one workgroup per output tile -- switched along)
         for tag, env in (("default", {}), ("persistent", {"ARREAU_EDGE_SPLIT": "0", "ARREAU_READOUT_SPLIT": "0", "ARREAU_MLP_SPLIT": "0"}),
-                         ("split", {"ARREAU_EDGE_SPLIT": "1", "ARREAU_READOUT_SPLIT": "1", "ARREAU_MLP_SPLIT": "1"})):
+                         ("split", {"ARREAU_EDGE_SPLIT": "1", "ARREAU_READOUT_SPLIT": "1", "ARREAU_MLP_SPLIT": "1"}),
+                         # round 3: the default for these sizes evaluates a layer's message passing + spherical convolution inside
+                         # the ConvNext launch (k = 8); this is the two-launch form
+                         ("two_launches", {"ARREAU_FUSE_SMALL": "0"})):
             path = os.path.join(d, tag + ".pt")
             subprocess.run([sys.executable, "-c", code, path], check=True, env={**os.environ, **env}, timeout=300)
             outs[tag] = torch.load(path)
     assert len(outs["default"]) == 24 and all(torch.isfinite(x).all() for x in outs["default"])
-    for tag in ("persistent", "split"):
+    for tag in ("persistent", "split", "two_launches"):
         for x, y in zip(outs["default"], outs[tag]):
             assert torch.equal(x, y), tag
