@@ -447,10 +447,31 @@ int enqueue_slice_step(const arreau_model* m, float* d_frac, int32_t* d_types, f
                                  w.gs, w.batch);
 }
 
+// The single-stream product loop runs WITHOUT a prep launch per step (round 3) when it can: the update launch of step i
+// leaves the lattice and the per-crystal embedding of step i + 1 behind (reverse_crystal_block), the neighbour-list waves form
+// the Cartesian positions themselves and advance the device-side timestep (neighbor_embed_kernel<LOOP>), and ONE prep launch
+// in front of the loop (arreau_sample_loop) supplies the first step.  ARREAU_LOOP_PREP=1 keeps the prep launch in every step
+// (A/B, tests: the two loops are bit-identical).
+bool loop_without_prep(const arreau_model* m) {
+    const char* e = getenv("ARREAU_LOOP_PREP");
+    const arreau_partition* p = m->part;
+    return !(e && atoi(e) != 0) && !arreau_general_path(m) && !(p && p->eager && p->G > 1);
+}
+
 int enqueue_sample_step(const arreau_model* m, float* d_frac, int32_t* d_types, float* d_lengths, const float* d_angles,
                         const int32_t* d_off, int B, int N, uint64_t seed, const int32_t* d_const_types,
-                        const float* d_fixed_lengths, float* d_lattice, const Workspace& w, hipStream_t s) {
+                        const float* d_fixed_lengths, float* d_lattice, const Workspace& w, hipStream_t s, bool no_prep) {
     int rc;
+    if (no_prep) {
+        if ((rc = arreau_launch_neighbor_embed(m, nullptr, w.lattice, d_off, w.batch, B, N, w.deg, w.src, w.cell, w.dir, w.dist, d_frac,
+                                               d_types, w.cvec, w.xa, s, NodeRange(), w.t_cur)))
+            return rc;
+        if ((rc = run_edge_kernel(m, w.dir, w.dist, w.deg, w, N, s))) return rc;
+        if ((rc = run_layers_and_readout(m, w, w.deg, w.src, d_off, B, N, w.eps, w.logits, nullptr, s))) return rc;
+        return arreau_launch_reverse(m, d_frac, d_types, d_lengths, d_angles, w.t_cur, d_off, B, N, w.eps, w.logits, w.len0,
+                                     StepNoiseSrc{nullptr, nullptr, nullptr, seed}, d_const_types, d_lattice, s, d_fixed_lengths,
+                                     NodeRange(), w.gs, w.batch, w.lattice, w.cvec);
+    }
     if ((rc = arreau_launch_prep(m, d_frac, d_lengths, d_angles, nullptr, d_off, B, N, w.lattice, w.cart, w.batch, w.cvec, s,
                                  w.t_next, w.t_cur)))
         return rc;
@@ -482,12 +503,25 @@ extern "C" int arreau_sample_loop(arreau_model* m, float* d_frac, int32_t* d_typ
     }
     if (n_steps == 0) return ARREAU_OK;
     hipStream_t s = (hipStream_t)stream;
-    ARREAU_LAUNCH(fill_i32_kernel, dim3((B + 255) / 256), dim3(256), 0, s, w.t_next, t_start, B);
-    ARREAU_CHECK_HIP(hipGetLastError());
     int rc;
+    // (slices on their own streams -- the opt-in experiment below -- keep the prep launch per step)
+    const bool sliced_loop = use_graph && n_steps >= 3 && m->part && m->part->G > 1 && m->part->eager != 2 && m->part->B == B &&
+                             m->part->N == N && arreau_range_launches_supported(m);
+    const bool no_prep = !sliced_loop && loop_without_prep(m);
+    if (no_prep) {
+        // t_cur holds the timestep of the step in progress; every step's first launch advances it, so it starts one above
+        ARREAU_LAUNCH(fill_i32_kernel, dim3((B + 255) / 256), dim3(256), 0, s, w.t_cur, t_start + 1, B);
+        ARREAU_CHECK_HIP(hipGetLastError());
+        if ((rc = arreau_launch_prep(m, d_frac, d_lengths, d_angles, w.t_cur, d_off, B, N, w.lattice, w.cart, w.batch, w.cvec, s, nullptr,
+                                     nullptr, NodeRange(), -1)))
+            return rc;
+    } else {
+        ARREAU_LAUNCH(fill_i32_kernel, dim3((B + 255) / 256), dim3(256), 0, s, w.t_next, t_start, B);
+        ARREAU_CHECK_HIP(hipGetLastError());
+    }
     if (!use_graph || n_steps < 3) {
         for (int i = 0; i < n_steps; ++i)
-            if ((rc = enqueue_sample_step(m, d_frac, d_types, d_lengths, d_angles, d_off, B, N, seed, d_const_types, d_fixed_lengths, d_lattice, w, s)))
+            if ((rc = enqueue_sample_step(m, d_frac, d_types, d_lengths, d_angles, d_off, B, N, seed, d_const_types, d_fixed_lengths, d_lattice, w, s, no_prep)))
                 return rc;
         return ARREAU_OK;
     }
@@ -575,22 +609,22 @@ extern "C" int arreau_sample_loop(arreau_model* m, float* d_frac, int32_t* d_typ
     ARREAU_CHECK_HIP(hipStreamWaitEvent(s, ev, 0));
     // The executable graph is kept with the model and reused while the next call names the same buffers, sizes and seed
     // (a sampler drawing sub-batch after sub-batch through the caching allocator does): capture + instantiation, about
-    // 2 ms, are then paid once.  The timestep is not part of the graph (it lives in t_next, set above).
+    // 2 ms, are then paid once.  The timestep is not part of the graph (it lives in t_next / t_cur, set above).
     const uint64_t key[12] = {(uint64_t)d_frac, (uint64_t)d_types, (uint64_t)d_lengths, (uint64_t)d_angles, (uint64_t)d_off,
                               ((uint64_t)(uint32_t)B << 32) | (uint32_t)N, seed, (uint64_t)d_const_types, (uint64_t)d_fixed_lengths,
                               (uint64_t)d_lattice, (uint64_t)d_workspace,
-                              ((uint64_t)(uint32_t)m->edge_variant << 32) | (uint32_t)m->mlp_variant};
+                              ((uint64_t)(uint32_t)(m->edge_variant | (no_prep ? 0x10000 : 0)) << 32) | (uint32_t)m->mlp_variant};
     hipGraphExec_t exec = (hipGraphExec_t)m->retired_graph;
     int first_replay = 0;
     hipError_t e = hipSuccess;
     if (!exec || memcmp(key, m->graph_key, sizeof(key)) != 0) {
         // The first step runs eagerly (it also forces lazy module loading, which must not happen inside a capture).
-        if ((rc = enqueue_sample_step(m, d_frac, d_types, d_lengths, d_angles, d_off, B, N, seed, d_const_types, d_fixed_lengths, d_lattice, w, s)))
+        if ((rc = enqueue_sample_step(m, d_frac, d_types, d_lengths, d_angles, d_off, B, N, seed, d_const_types, d_fixed_lengths, d_lattice, w, s, no_prep)))
             return rc;
         first_replay = 1;
         hipGraph_t graph = nullptr;
         ARREAU_CHECK_HIP(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
-        rc = enqueue_sample_step(m, d_frac, d_types, d_lengths, d_angles, d_off, B, N, seed, d_const_types, d_fixed_lengths, d_lattice, w, s);
+        rc = enqueue_sample_step(m, d_frac, d_types, d_lengths, d_angles, d_off, B, N, seed, d_const_types, d_fixed_lengths, d_lattice, w, s, no_prep);
         e = hipStreamEndCapture(s, &graph);
         if (rc) {
             if (graph) (void)hipGraphDestroy(graph);

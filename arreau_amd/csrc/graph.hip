@@ -96,11 +96,26 @@ __device__ __forceinline__ void arreau_image_offset(int ci, const float* Lm, flo
 
 // candidate c = 27 * sender + image: `pos` holds the senders' positions (of the crystal when first == 0, else of the batch),
 // `img` the wave's table of the 27 image offsets (LDS)
+// frac_to_cart_coords of one atom (diffusion_helpers.py:223-230), the expression of prep_kernel / arreau_frac_to_cart
+__device__ __forceinline__ float arreau_cart_component(const float* __restrict__ frac, const float* Lm, size_t atom, int d) {
+    const float f0 = frac[3 * atom], f1 = frac[3 * atom + 1], f2 = frac[3 * atom + 2];
+    return (f0 * Lm[d] + f1 * Lm[3 + d]) + f2 * Lm[6 + d];
+}
+
+template <bool FROM_FRAC = false>
 __device__ __forceinline__ Cand arreau_candidate(const float* __restrict__ pos, int first, int c, const float* img,
-                                                 float pix, float piy, float piz) {
+                                                 float pix, float piy, float piz, const float* Lm = nullptr) {
     const int j = c / 27;
     const int ci = c - 27 * j;
-    const float* pj = pos + 3 * (size_t)(first + j);
+    float pjv[3];
+    if constexpr (FROM_FRAC) {  // `pos` holds fractional coordinates: form the sender's position here
+#pragma unroll
+        for (int d = 0; d < 3; ++d) pjv[d] = arreau_cart_component(pos, Lm, (size_t)(first + j), d);
+    } else {
+        const float* pj = pos + 3 * (size_t)(first + j);
+        pjv[0] = pj[0]; pjv[1] = pj[1]; pjv[2] = pj[2];
+    }
+    const float* pj = pjv;
     const float* o = img + 3 * ci;
     Cand r;
     r.dx = __fsub_rn(__fadd_rn(pj[0], o[0]), pix);  // (pos2 + offset) - pos1  (:404-408)
@@ -132,6 +147,7 @@ __device__ __forceinline__ double arreau_wave_min_f64(double v) {
     return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 63), __builtin_amdgcn_readlane(__double2loint(v), 63));
 }
 
+template <bool FROM_FRAC = false /* `cart` holds FRACTIONAL coordinates; positions are formed here (sampling loop: no prep launch) */>
 __device__ __forceinline__ void arreau_neighbor_body(
     unsigned blk /* workgroup of the neighbour part: four receivers */, const float* __restrict__ cart, const float* __restrict__ lattice, const int32_t* __restrict__ offsets,
     const int32_t* __restrict__ batch /* [N] crystal of atom, or null */, int B,
@@ -148,7 +164,9 @@ __device__ __forceinline__ void arreau_neighbor_body(
     float Lm[9];
 #pragma unroll
     for (int q = 0; q < 9; ++q) Lm[q] = lattice[9 * b + q];
-    const float pix = cart[3 * (size_t)i], piy = cart[3 * (size_t)i + 1], piz = cart[3 * (size_t)i + 2];
+    const float pix = FROM_FRAC ? arreau_cart_component(cart, Lm, (size_t)i, 0) : cart[3 * (size_t)i];
+    const float piy = FROM_FRAC ? arreau_cart_component(cart, Lm, (size_t)i, 1) : cart[3 * (size_t)i + 1];
+    const float piz = FROM_FRAC ? arreau_cart_component(cart, Lm, (size_t)i, 2) : cart[3 * (size_t)i + 2];
     // Round 3: the wave first copies the Cartesian positions of its crystal into LDS (crystals of up to NBR_LDS_ATOMS atoms;
     // wave-uniform test) and the candidates read them from there.  Before, every candidate evaluation waited for three global
     // loads under its own lane mask, a dozen dependent L2 round trips per receiver.  Same values, same arithmetic.
@@ -166,11 +184,12 @@ __device__ __forceinline__ void arreau_neighbor_body(
         myimg[3 * lane] = o[0]; myimg[3 * lane + 1] = o[1]; myimg[3 * lane + 2] = o[2];
     }
     if (staged)
-        for (int a = lane; a < ncand / 9; a += 64) mypos[a] = cart[3 * (size_t)first + a];  // ncand / 9 = 3 * atoms
+        for (int a = lane; a < ncand / 9; a += 64)  // ncand / 9 = 3 * atoms
+            mypos[a] = FROM_FRAC ? arreau_cart_component(cart, Lm, (size_t)first + a / 3, a % 3) : cart[3 * (size_t)first + a];
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     __builtin_amdgcn_wave_barrier();
     auto candidate = [&](int c) -> Cand {
-        return staged ? arreau_candidate(mypos, 0, c, myimg, pix, piy, piz) : arreau_candidate(cart, first, c, myimg, pix, piy, piz);
+        return staged ? arreau_candidate(mypos, 0, c, myimg, pix, piy, piz) : arreau_candidate<FROM_FRAC>(cart, first, c, myimg, pix, piy, piz, Lm);
     };
 
     // Crystals of up to 64 * NBR_KEYS / 27 = 28 atoms (wave-uniform test): every lane evaluates its candidates once
@@ -308,17 +327,26 @@ __global__ __launch_bounds__(256) void neighbor_kernel(
 // Round 3: the sampler's step builds the neighbour list and the embedded node features in ONE launch.  Both depend on prep_kernel
 // only and not on each other; the embedding is bound by its HBM writes (16 rows of C floats per atom), the neighbour list by
 // latency and VALU work, so side by side they take the time of the longer one.  The first `embed_blocks` workgroups embed.
+// LOOP (sampling loop, round 3): no prep launch in the step.  `cart` holds the fractional coordinates (positions are formed by
+// the waves that need them, with prep_kernel's expression); the lattice and the per-crystal embedding were left by the
+// previous step's update launch (reverse_crystal_block) or by the one prep launch in front of the loop; and the first
+// workgroups advance the device-side timestep of every crystal by one (`tick`: read only by the update launch).
+template <bool LOOP = false>
 __global__ __launch_bounds__(256) void neighbor_embed_kernel(
     unsigned embed_blocks, const float* __restrict__ cart, const float* __restrict__ lattice, const int32_t* __restrict__ offsets,
     const int32_t* __restrict__ batch, int B, int n0, int N, float r2, int k, int32_t* __restrict__ deg, int32_t* __restrict__ src,
     int32_t* __restrict__ cell, float* __restrict__ dir, float* __restrict__ dist, const float* __restrict__ frac,
     const int32_t* __restrict__ types, const float* __restrict__ cvec, const float* __restrict__ ori, const float* __restrict__ embT,
-    int S, int C, float* __restrict__ x0, int32_t* __restrict__ status) {
+    int S, int C, float* __restrict__ x0, int32_t* __restrict__ status, int32_t* __restrict__ tick, int tick_b0, int tick_b1) {
+    if constexpr (LOOP) {
+        const int b = tick_b0 + (int)(blockIdx.x * blockDim.x + threadIdx.x);
+        if (b < tick_b1) tick[b] -= 1;  // (nobody else reads or writes it in this launch)
+    }
     if (blockIdx.x < embed_blocks) {
         arreau_embed_body(blockIdx.x * blockDim.x + threadIdx.x, frac, types, lattice, batch, cvec, ori, embT, S, C, n0, N, x0, status);
         return;
     }
-    arreau_neighbor_body(blockIdx.x - embed_blocks, cart, lattice, offsets, batch, B, n0, N, r2, k, deg, src, cell, dir, dist);
+    arreau_neighbor_body<LOOP>(blockIdx.x - embed_blocks, cart, lattice, offsets, batch, B, n0, N, r2, k, deg, src, cell, dir, dist);
 }
 
 int arreau_launch_neighbor(const float* cart, const float* lattice, const int32_t* offsets, const int32_t* batch,
@@ -337,9 +365,9 @@ int arreau_launch_neighbor(const float* cart, const float* lattice, const int32_
 int arreau_launch_neighbor_embed(const arreau_model* m, const float* cart, const float* lattice, const int32_t* offsets,
                                  const int32_t* batch, int B, int N, int32_t* deg, int32_t* src, int32_t* cell, float* dir,
                                  float* dist, const float* frac, const int32_t* types, const float* cvec, float* x0, hipStream_t s,
-                                 NodeRange r) {
+                                 NodeRange r, int32_t* tick) {
     const int n0 = r.n0, n1 = r.n1 < 0 ? N : r.n1;
-    if (n1 <= n0) return ARREAU_OK;
+    if (n1 <= n0 && tick == nullptr) return ARREAU_OK;
     ARREAU_REQUIRE(batch != nullptr, "neighbour list + embedding: the atom -> crystal map is required");
     const float r2 = (float)((double)m->cfg.radius * (double)m->cfg.radius);
     const long long pairs = (long long)(n1 - n0) * (m->C / 4);
@@ -348,8 +376,18 @@ int arreau_launch_neighbor_embed(const arreau_model* m, const float* cart, const
         return ARREAU_EINVAL;
     }
     const unsigned embed_blocks = (unsigned)((pairs + 255) / 256), nbr_blocks = (unsigned)((n1 - n0 + 3) / 4);
-    ARREAU_LAUNCH(neighbor_embed_kernel, dim3(embed_blocks + nbr_blocks), dim3(256), 0, s, embed_blocks, cart, lattice, offsets, batch,
-                  B, n0, n1, r2, m->k, deg, src, cell, dir, dist, frac, types, cvec, m->ori, m->embT, m->S, m->C, x0, m->status);
+    if (tick != nullptr) {
+        // sampling loop: positions from `frac` (the `cart` argument is not read), timesteps of crystals b0 .. b1-1 advanced
+        const int b0 = r.b0, b1 = r.b1 < 0 ? B : r.b1;
+        const unsigned tick_blocks = (unsigned)((b1 - b0 + 255) / 256);
+        const unsigned grid = embed_blocks + nbr_blocks > tick_blocks ? embed_blocks + nbr_blocks : tick_blocks;  // (extra workgroups only tick)
+        ARREAU_LAUNCH(neighbor_embed_kernel<true>, dim3(grid), dim3(256), 0, s, embed_blocks, frac, lattice, offsets, batch, B, n0, n1, r2,
+                      m->k, deg, src, cell, dir, dist, frac, types, cvec, m->ori, m->embT, m->S, m->C, x0, m->status, tick, b0, b1);
+    } else {
+        ARREAU_LAUNCH(neighbor_embed_kernel<false>, dim3(embed_blocks + nbr_blocks), dim3(256), 0, s, embed_blocks, cart, lattice, offsets,
+                      batch, B, n0, n1, r2, m->k, deg, src, cell, dir, dist, frac, types, cvec, m->ori, m->embT, m->S, m->C, x0, m->status,
+                      (int32_t*)nullptr, 0, 0);
+    }
     ARREAU_CHECK_HIP(hipGetLastError());
     return ARREAU_OK;
 }

@@ -254,17 +254,19 @@ int arreau_launch_neighbor(const float* cart, const float* lattice, const int32_
 int arreau_launch_neighbor_embed(const arreau_model* m, const float* cart, const float* lattice, const int32_t* offsets,
                                  const int32_t* batch, int B, int N, int32_t* deg, int32_t* src, int32_t* cell, float* dir,
                                  float* dist, const float* frac, const int32_t* types, const float* cvec, float* x0, hipStream_t s,
-                                 NodeRange r = NodeRange());
+                                 NodeRange r = NodeRange(), int32_t* tick = nullptr /* sampling loop without a prep launch: see the kernel */);
 int arreau_launch_prep(const arreau_model* m, const float* frac, const float* lengths, const float* angles,
                        const int32_t* t, const int32_t* offsets, int B, int N, float* lattice, float* cart,
                        int32_t* batch, float* cvec, hipStream_t s, int32_t* t_next = nullptr, int32_t* t_cur = nullptr,
-                       NodeRange r = NodeRange());
+                       NodeRange r = NodeRange(), int t_offset = 0);
 int arreau_launch_reverse(const arreau_model* m, float* d_frac, int32_t* d_types, float* d_lengths, const float* d_angles,
                           const int32_t* d_t, const int32_t* d_off, int B, int N, const float* d_eps,
                           const float* d_logits, const float* d_len0, StepNoiseSrc noise, const int32_t* d_const_types,
                           float* d_lattice, hipStream_t s, const float* d_fixed_lengths = nullptr, NodeRange r = NodeRange(),
                           const float* d_gs_atoms = nullptr /* pool these per-atom read-outs into d_len0 first */,
-                          const int32_t* d_batch = nullptr /* crystal index of each atom, if the caller has it */);
+                          const int32_t* d_batch = nullptr /* crystal index of each atom, if the caller has it */,
+                          float* d_lattice_ws = nullptr, float* d_cvec_next = nullptr /* sampling loop: also prepare the next step
+                          (workspace lattice + per-crystal embedding for timestep t - 1), see reverse_crystal_block */);
 int arreau_launch_edge(const arreau_model* m, const float* dir, const float* dist, const int32_t* deg,
                        const int32_t* batch, const float* lattice, int N, float* kbuf, hipStream_t s, NodeRange r = NodeRange());
 int arreau_launch_edge_bf16x6(const arreau_model* m, const float* dir, const float* dist, const int32_t* deg,

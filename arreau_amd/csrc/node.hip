@@ -4,6 +4,7 @@
 
 #include "internal.h"
 #include "embed_dev.h"
+#include "prep_dev.h"
 
 // ---------------------------------------------------------------------------------------------
 // K0 prep: per crystal lattice, Cartesian coordinates, node->crystal map, and the part of the
@@ -15,24 +16,13 @@
 // (position_orientation_graph.py:82-86).  Everything except the one-hot column and the 4 vector
 // channels is constant inside a crystal, so it is reduced once per crystal to cvec[b][C].
 // ---------------------------------------------------------------------------------------------
-__device__ __forceinline__ void cell_from_params(const float* len, const float* ang, float* Lm) {
-    const float a = len[0], b = len[1], c = len[2];
-    const float ca = cosf(ang[0]), cb = cosf(ang[1]), cg = cosf(ang[2]);
-    const float sa = sinf(ang[0]), sb = sinf(ang[1]);
-    float val = (ca * cb - cg) / (sa * sb);
-    val = fminf(fmaxf(val, -1.0f), 1.0f);
-    const float gs = acosf(val);
-    Lm[0] = a * sb;             Lm[1] = 0.0f;               Lm[2] = a * cb;
-    Lm[3] = -b * sa * cosf(gs); Lm[4] = b * sa * sinf(gs);  Lm[5] = b * ca;
-    Lm[6] = 0.0f;               Lm[7] = 0.0f;               Lm[8] = c;
-}
-
 __global__ __launch_bounds__(128) void prep_kernel(
     const float* __restrict__ frac, const float* __restrict__ lengths, const float* __restrict__ angles,
     const int32_t* __restrict__ tstep, const int32_t* __restrict__ offsets, const float* __restrict__ betas,
     const float* __restrict__ t_emb_w, const float* __restrict__ embT, int S, int C, int T,
     float* __restrict__ lattice, float* __restrict__ cart, int32_t* __restrict__ batch, float* __restrict__ cvec,
-    int32_t* __restrict__ status, int32_t* __restrict__ t_next, int32_t* __restrict__ t_cur, int b0) {
+    int32_t* __restrict__ status, int32_t* __restrict__ t_next, int32_t* __restrict__ t_cur, int b0,
+    int t_offset /* added to the timestep read (the sampling loop's first set-up: -1, see arreau_sample_loop) */) {
     __shared__ float feat[ARREAU_T_EMB_DIM + ARREAU_N_CRYSTAL_FEATS];
     // Sampling loop on device time (arreau_sample_loop): this workgroup is the only reader of its crystal's entry of
     // t_next in this launch; it publishes the timestep of the step in t_cur (read by the later kernels of the step) and
@@ -55,33 +45,10 @@ __global__ __launch_bounds__(128) void prep_kernel(
     const float* ang = angles + 3 * b;
     if (threadIdx.x == 0) {
         float tmp[9];
-        cell_from_params(len, ang, tmp);
+        arreau_prep_cell(len, ang, tmp);
         for (int i = 0; i < 9; ++i) { Lm[i] = tmp[i]; lattice[9 * b + i] = tmp[i]; }
     }
-    if (threadIdx.x < 32) {
-        // GaussianFourierProjection of betas[t] (diffusion_helpers.py:23-25; diffusion_loss.py:126-127)
-        int t = t_sh;
-        if ((t < 0 || t > T) && threadIdx.x == 0) atomicOr(status, ARREAU_STATUS_BAD_TIMESTEP);  // clamped, but flagged
-        t = t < 0 ? 0 : (t > T ? T : t);
-        const float proj = ((betas[t] * t_emb_w[threadIdx.x]) * 2.0f) * 3.14159265358979323846f;
-        feat[threadIdx.x] = sinf(proj);
-        feat[32 + threadIdx.x] = cosf(proj);
-    } else if (threadIdx.x < 32 + ARREAU_N_CRYSTAL_FEATS) {
-        const int i = threadIdx.x - 32;
-        float v;
-        if (i == 0) v = (float)n;
-        else if (i < 4) v = len[i - 1];
-        else if (i < 7) v = ang[i - 4];
-        else v = fabsf(len[i - 7] / (float)n);
-        feat[ARREAU_T_EMB_DIM + i] = v;
-    }
-    __syncthreads();
-    for (int c = threadIdx.x; c < C; c += blockDim.x) {
-        float acc = 0.0f;
-#pragma unroll 37  // 74 rows: two batches of independent loads in flight instead of one L2 round trip per row
-        for (int i = 0; i < ARREAU_T_EMB_DIM + ARREAU_N_CRYSTAL_FEATS; ++i) acc += feat[i] * embT[(size_t)(S + i) * C + c];
-        cvec[(size_t)b * C + c] = acc;
-    }
+    arreau_prep_cvec(t_sh + t_offset, n, len, ang, betas, t_emb_w, embT, S, C, T, feat, cvec + (size_t)b * C, status);  // (barriers inside)
     for (int a = threadIdx.x; a < n; a += blockDim.x) {
         const size_t i = (size_t)first + a;
         const float f0 = frac[3 * i], f1 = frac[3 * i + 1], f2 = frac[3 * i + 2];
@@ -93,11 +60,11 @@ __global__ __launch_bounds__(128) void prep_kernel(
 
 int arreau_launch_prep(const arreau_model* m, const float* frac, const float* lengths, const float* angles,
                        const int32_t* t, const int32_t* offsets, int B, int N, float* lattice, float* cart,
-                       int32_t* batch, float* cvec, hipStream_t s, int32_t* t_next, int32_t* t_cur, NodeRange r) {
+                       int32_t* batch, float* cvec, hipStream_t s, int32_t* t_next, int32_t* t_cur, NodeRange r, int t_offset) {
     const int b0 = r.b0, b1 = r.b1 < 0 ? B : r.b1;
     if (b1 <= b0) return ARREAU_OK;
     ARREAU_LAUNCH(prep_kernel, dim3(b1 - b0), dim3(128), 0, s, frac, lengths, angles, t, offsets, m->vp_betas,
-                       m->t_emb_w, m->embT, m->S, m->C, m->T, lattice, cart, batch, cvec, m->status, t_next, t_cur, b0);
+                       m->t_emb_w, m->embT, m->S, m->C, m->T, lattice, cart, batch, cvec, m->status, t_next, t_cur, b0, t_offset);
     ARREAU_CHECK_HIP(hipGetLastError());
     return ARREAU_OK;
 }

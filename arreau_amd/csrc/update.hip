@@ -1,9 +1,50 @@
 // K6: the reverse updates of one denoising step (diffusion/diffusion_loss.py:338-347).
 #include "internal.h"
 #include "philox.h"
+#include "prep_dev.h"
 
 #define D3PM_EPS 1e-6f  // d3pm.py:23
 
+
+// One component of the length update of crystal b at timestep t (VP_lattice.reverse_given_x0; the per-atom read-out is pooled
+// here when gs_atoms is given: the ordered sum of readout_crystals_kernel).  Writes lengths[3 b + i] and returns it.
+__device__ __forceinline__ float reverse_length_component(int b, int i, int t, int first, int last, float* __restrict__ lengths,
+                                                          const float* __restrict__ len0, StepNoiseSrc noise,
+                                                          const float* __restrict__ alpha_bars, const float* __restrict__ betas,
+                                                          const float* __restrict__ fixed_lengths, const float* __restrict__ gs_atoms,
+                                                          float* __restrict__ len0_out) {
+    const float* __restrict__ z = noise.z_lattice;
+    const float n = (float)(last - first);
+    const float ab_t = alpha_bars[t], ab_p = alpha_bars[t - 1], beta = betas[t];
+    const float denom = 1.0f - ab_t;
+    const float alpha_t = 1.0f - beta;
+    const float c0 = sqrtf(ab_p) * beta;
+    const float c1 = sqrtf(alpha_t) * (1.0f - ab_p);
+    const float variance = (1.0f - ab_p) * beta / denom;
+    float pooled;
+    if (gs_atoms != nullptr) {
+        pooled = 0.f;  // the ordered sum of readout_crystals_kernel, four loads in flight at a time
+        int a = first;
+        for (; a + 3 < last; a += 4) {
+            const float v0 = gs_atoms[(size_t)a * 3 + i], v1 = gs_atoms[(size_t)(a + 1) * 3 + i];
+            const float v2 = gs_atoms[(size_t)(a + 2) * 3 + i], v3 = gs_atoms[(size_t)(a + 3) * 3 + i];
+            pooled = (((pooled + v0) + v1) + v2) + v3;
+        }
+        for (; a < last; ++a) pooled += gs_atoms[(size_t)a * 3 + i];
+        len0_out[3 * b + i] = pooled;
+    } else {
+        pooled = len0[3 * b + i];
+    }
+    const float x0 = pooled * n;  // pred_lengths_0 * num_atoms (diffusion_loss.py:338)
+    const float xt = lengths[3 * b + i];
+    const float mean = (c0 * x0 + c1 * xt) / denom;
+    const float zdraw = z ? z[3 * b + i] : philox_normal(noise.seed, (uint32_t)t, ARREAU_DRAW_Z_LATTICE, 3u * b + i);
+    const float zz = t > 1 ? zdraw : 0.0f;
+    // fixed-cell sampling (arreau_sample_loop, d_fixed_lengths): the given lengths are re-imposed after the update
+    const float mylen = fixed_lengths ? fixed_lengths[3 * b + i] : mean + variance * zz;
+    lengths[3 * b + i] = mylen;
+    return mylen;
+}
 
 // VP_lattice.reverse_given_x0 (diffusion_helpers.py:185-199) on lengths, then lattice_from_params.
 // Note the reference adds `variance * z` (not sqrt(variance)) and zeroes z when t <= 1.
@@ -20,43 +61,12 @@ __device__ __forceinline__ void reverse_lattice_body(int gt /* global thread of 
     const int b = b0 + (gt >> 2), i = gt & 3;
     const bool live = b < B;  // (whole groups of four are live or not; the shuffles below need every lane)
     const int bc = live ? b : B - 1;
-    const float* __restrict__ z = noise.z_lattice;
     int t = tstep[bc];
     if (live && i == 0 && (t < 1 || t > T)) atomicOr(status, ARREAU_STATUS_BAD_TIMESTEP);  // clamped, but flagged
     t = t < 1 ? 1 : (t > T ? T : t);
     const int first = offsets[bc], last = offsets[bc + 1];
-    const float n = (float)(last - first);
-    const float ab_t = alpha_bars[t], ab_p = alpha_bars[t - 1], beta = betas[t];
-    const float denom = 1.0f - ab_t;
-    const float alpha_t = 1.0f - beta;
-    const float c0 = sqrtf(ab_p) * beta;
-    const float c1 = sqrtf(alpha_t) * (1.0f - ab_p);
-    const float variance = (1.0f - ab_p) * beta / denom;
     float mylen = 0.f;
-    if (live && i < 3) {
-        float pooled;
-        if (gs_atoms != nullptr) {
-            pooled = 0.f;  // the ordered sum of readout_crystals_kernel, four loads in flight at a time
-            int a = first;
-            for (; a + 3 < last; a += 4) {
-                const float v0 = gs_atoms[(size_t)a * 3 + i], v1 = gs_atoms[(size_t)(a + 1) * 3 + i];
-                const float v2 = gs_atoms[(size_t)(a + 2) * 3 + i], v3 = gs_atoms[(size_t)(a + 3) * 3 + i];
-                pooled = (((pooled + v0) + v1) + v2) + v3;
-            }
-            for (; a < last; ++a) pooled += gs_atoms[(size_t)a * 3 + i];
-            len0_out[3 * b + i] = pooled;
-        } else {
-            pooled = len0[3 * b + i];
-        }
-        const float x0 = pooled * n;  // pred_lengths_0 * num_atoms (diffusion_loss.py:338)
-        const float xt = lengths[3 * b + i];
-        const float mean = (c0 * x0 + c1 * xt) / denom;
-        const float zdraw = z ? z[3 * b + i] : philox_normal(noise.seed, (uint32_t)t, ARREAU_DRAW_Z_LATTICE, 3u * b + i);
-        const float zz = t > 1 ? zdraw : 0.0f;
-        // fixed-cell sampling (arreau_sample_loop, d_fixed_lengths): the given lengths are re-imposed after the update
-        mylen = fixed_lengths ? fixed_lengths[3 * b + i] : mean + variance * zz;
-        lengths[3 * b + i] = mylen;
-    }
+    if (live && i < 3) mylen = reverse_length_component(b, i, t, first, last, lengths, len0, noise, alpha_bars, betas, fixed_lengths, gs_atoms, len0_out);
     const int base = (threadIdx.x & 63) & ~3;
     float newlen[3];
 #pragma unroll
@@ -220,6 +230,40 @@ __device__ __forceinline__ void reverse_atoms_body(
     if (lane == 0) types[i] = const_types ? const_types[i] : besti;
 }
 
+// Sampling loop (round 3): the lattice update of a crystal by ONE workgroup that then also prepares the crystal's NEXT step --
+// what prep_kernel (node.hip) would compute at the top of that step from the lengths just written: the cell (into the
+// caller's lattice AND the workspace copy the network reads) and the per-crystal part of the embedding for timestep t - 1.
+// The step then needs no prep launch (the Cartesian positions, prep's other product, are formed by the neighbour-list waves
+// from the fractional coordinates).  Same arithmetic as reverse_lattice_body + prep_kernel, thread for thread.
+__device__ __forceinline__ void reverse_crystal_block(int b, float* __restrict__ lengths, const float* __restrict__ angles,
+                                                      const int32_t* __restrict__ tstep, const int32_t* __restrict__ offsets,
+                                                      const float* __restrict__ len0, StepNoiseSrc noise,
+                                                      const float* __restrict__ alpha_bars, const float* __restrict__ betas, int T,
+                                                      float* __restrict__ lattice, const float* __restrict__ fixed_lengths,
+                                                      int32_t* __restrict__ status, const float* __restrict__ gs_atoms,
+                                                      float* __restrict__ len0_out, float* __restrict__ lattice_ws,
+                                                      float* __restrict__ cvec_next, const float* __restrict__ t_emb_w,
+                                                      const float* __restrict__ embT, int S, int C) {
+    __shared__ float newlen[3];
+    __shared__ float feat[ARREAU_T_EMB_DIM + ARREAU_N_CRYSTAL_FEATS];
+    const int t_raw = tstep[b];
+    if (threadIdx.x == 0 && (t_raw < 1 || t_raw > T)) atomicOr(status, ARREAU_STATUS_BAD_TIMESTEP);  // clamped, but flagged
+    const int t = t_raw < 1 ? 1 : (t_raw > T ? T : t_raw);
+    const int first = offsets[b], last = offsets[b + 1];
+    if (threadIdx.x < 3)
+        newlen[threadIdx.x] = reverse_length_component(b, threadIdx.x, t, first, last, lengths, len0, noise, alpha_bars, betas, fixed_lengths,
+                                                       gs_atoms, len0_out);
+    __syncthreads();
+    const float* ang = angles + 3 * b;
+    if (threadIdx.x == 0) {
+        float Lm[9];
+        arreau_prep_cell(newlen, ang, Lm);  // lattice_from_params (lattice_helpers.py:55-105)
+#pragma unroll
+        for (int q = 0; q < 9; ++q) { lattice[9 * b + q] = Lm[q]; lattice_ws[9 * b + q] = Lm[q]; }
+    }
+    arreau_prep_cvec(t_raw - 1, last - first, newlen, ang, betas, t_emb_w, embT, S, C, T, feat, cvec_next + (size_t)b * C, status);
+}
+
 // ONE launch for the four updates of a step (round 3; they were two): the first `lat_blocks` workgroups (256 threads = 64
 // crystals, four lanes each) run the lattice update, the others the atom update, one wave per atom.  The two parts touch
 // disjoint data (lengths / lattice / pooled read-out against coordinates / types), so nothing orders them.
@@ -231,7 +275,14 @@ __global__ __launch_bounds__(256) void reverse_kernel(
     float* __restrict__ frac, int32_t* __restrict__ types, int B, int N, const float* __restrict__ eps,
     const float* __restrict__ logits, const float* __restrict__ ve_sigmas, const float* __restrict__ q1t,
     const float* __restrict__ qmats, int S, const int32_t* __restrict__ const_types, int absorbing, int n0,
-    const int32_t* __restrict__ batch) {
+    const int32_t* __restrict__ batch,
+    // sampling loop: the lattice part is one workgroup per crystal, which also prepares the next step (reverse_crystal_block)
+    float* __restrict__ lattice_ws, float* __restrict__ cvec_next, const float* __restrict__ t_emb_w, const float* __restrict__ embT, int C) {
+    if ((int)blockIdx.x < lat_blocks && cvec_next != nullptr) {  // (kernel argument: uniform)
+        reverse_crystal_block(b0 + (int)blockIdx.x, lengths, angles, tstep, offsets, len0, noise, alpha_bars, betas, T, lattice, fixed_lengths,
+                              status, gs_atoms, len0_out, lattice_ws, cvec_next, t_emb_w, embT, S, C);
+        return;
+    }
     if ((int)blockIdx.x < lat_blocks) {
         reverse_lattice_body(blockIdx.x * blockDim.x + threadIdx.x, lengths, angles, tstep, offsets, len0, noise, alpha_bars, betas, B_lat, T,
                              lattice, fixed_lengths, status, b0, gs_atoms, len0_out);
@@ -245,15 +296,17 @@ int arreau_launch_reverse(const arreau_model* m, float* d_frac, int32_t* d_types
                           const int32_t* d_t, const int32_t* d_off, int B, int N, const float* d_eps,
                           const float* d_logits, const float* d_len0, StepNoiseSrc noise, const int32_t* d_const_types,
                           float* d_lattice, hipStream_t s, const float* d_fixed_lengths, NodeRange r, const float* d_gs_atoms,
-                          const int32_t* d_batch) {
+                          const int32_t* d_batch, float* d_lattice_ws, float* d_cvec_next) {
     const int n0 = r.n0, n1 = r.n1 < 0 ? N : r.n1, b0 = r.b0, b1 = r.b1 < 0 ? B : r.b1;
-    const int lat_blocks = b1 > b0 ? (4 * (b1 - b0) + 255) / 256 : 0;
+    const bool prep_next = d_cvec_next != nullptr;  // one workgroup per crystal, which also prepares the next step
+    ARREAU_REQUIRE(!prep_next || d_lattice_ws != nullptr, "reverse update: the next step's set-up needs the workspace lattice");
+    const int lat_blocks = b1 > b0 ? (prep_next ? b1 - b0 : (4 * (b1 - b0) + 255) / 256) : 0;
     const int atom_blocks = n1 > n0 ? (n1 - n0 + 3) / 4 : 0;
     if (lat_blocks + atom_blocks > 0) {
         ARREAU_LAUNCH(reverse_kernel, dim3(lat_blocks + atom_blocks), dim3(256), 0, s, lat_blocks, d_lengths, d_angles, d_t, d_off, d_len0,
                       noise, m->vp_alpha_bars, m->vp_betas, b1, m->T, d_lattice, d_fixed_lengths, m->status, b0, d_gs_atoms,
                       d_gs_atoms ? const_cast<float*>(d_len0) : nullptr, d_frac, d_types, B, n1, d_eps, d_logits, m->ve_sigmas, m->q1t,
-                      m->qmats, m->S, d_const_types, m->qmats_absorbing, n0, d_batch);
+                      m->qmats, m->S, d_const_types, m->qmats_absorbing, n0, d_batch, d_lattice_ws, d_cvec_next, m->t_emb_w, m->embT, m->C);
         ARREAU_CHECK_HIP(hipGetLastError());
     }
     return ARREAU_OK;

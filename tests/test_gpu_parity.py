@@ -1018,6 +1018,38 @@ def test_sample_loop_is_the_per_step_path_with_philox_noise(dev, small_model):
         eng.sample_loop(f2, ty2, le2, an, off, 3, 5, seed, None, lat2)  # would run past timestep 1
 
 
+@pytest.mark.parametrize("counts", [[4, 7, 2], [150, 5, 129]])
+def test_sample_loop_without_and_with_a_prep_launch_per_step(dev, small_model, monkeypatch, counts):
+    """Round 3: the loop's steps carry no prep launch (the update launch prepares the next step, the neighbour-list waves form
+    the Cartesian positions -- from LDS copies, or per candidate for crystals above 128 atoms -- and advance the timestep).
+    ARREAU_LOOP_PREP=1 keeps the round-2 form, one prep launch per step; both forms, eager and replayed, leave the same
+    bits, after the last timestep (t = 1, where the next step's set-up is for the unused timestep 0) as well."""
+    from arreau_amd.diffusion.diffusion_helpers import crystal_offsets
+    m, _, _ = small_model
+    eng = m.engine()
+    S, seed = 12, 24681357
+    frac, types, lengths, angles, na = random_state(S, counts, 17, sampler_like=True)
+    B = len(counts)
+    d = lambda v: v.to(dev).contiguous()
+    off, an = crystal_offsets(na, dev), d(angles)
+    results = {}
+    for form, env in (("no_prep", None), ("prep_per_step", "1")):
+        if env is None:
+            monkeypatch.delenv("ARREAU_LOOP_PREP", raising=False)
+        else:
+            monkeypatch.setenv("ARREAU_LOOP_PREP", env)
+        for use_graph in (False, True):
+            for t_start, n_steps in ((99, 5), (3, 3)):
+                f, ty, le, lat = d(frac.clone()), d(types.to(torch.int32)), d(lengths.clone()), torch.zeros(B, 3, 3, device=dev)
+                eng.sample_loop(f, ty, le, an, off, t_start, n_steps, seed, None, lat, use_graph=use_graph)
+                results[(form, use_graph, t_start)] = (f, ty, le, lat)
+    eng.check_status()
+    for key, val in results.items():
+        ref = results[("prep_per_step", False, key[2])]
+        for a, b in zip(val, ref):
+            assert torch.equal(a, b), key
+
+
 def _ragged_37(dev):
     from arreau_amd.diffusion.diffusion_helpers import crystal_offsets
     rng = np.random.RandomState(3)
