@@ -78,10 +78,13 @@ extern "C" int arreau_frac_to_cart(const float* d_frac, const float* d_lattice, 
 // c = 27*j_local + cell (the reference's order: sender-minor inside a receiver, 27 images in
 // itertools.product((-1,0,1),repeat=3) order, :377-402).  A candidate survives when
 // 1e-4 < d2 <= R^2 (:432-436).  The k smallest by (d2, c) are found by k rounds of a wave-wide
-// arg-min over a 64-bit key (d2 bits << 32 | c): deterministic, no LDS, no atomics.  Slots are
-// written in ascending c, i.e. the order the reference's masked_select leaves them in.
-// fp32 arithmetic mirrors the reference's op order without FMA contraction so that the selected
-// set equals the fp32 CPU path's on tie-free input.
+// arg-min over a key that orders (d2 bits, c) lexicographically (held as a double, see below; the
+// wave minimum by DPP): deterministic, no atomics.  Slots are written in ascending c, i.e. the
+// order the reference's masked_select leaves them in.  fp32 arithmetic mirrors the reference's
+// op order without FMA contraction so that the selected set equals the fp32 CPU path's on
+// tie-free input.  Per wave, LDS holds a copy of the crystal's positions (up to 128 atoms) and
+// the table of the 27 image offsets (round 3: the kernel is bound by the vector work of the
+// candidate evaluations and of the selection rounds, not by memory).
 // ---------------------------------------------------------------------------------------------
 struct Cand { float dx, dy, dz, d2; };
 
