@@ -169,9 +169,12 @@ __device__ __forceinline__ void reverse_atoms_body(
             f2a = fmaf(p0, d0, 0.f);
             f2b = fmaf(p1, d1, 0.f);
             float fm = 0.f;
-            for (int c = 0; c < S; ++c) {  // wave-uniform
-                const float pc = c < 64 ? __shfl(p0, c, 64) : __shfl(p1, c - 64, 64);
-                const float qc = c < 64 ? __shfl(c0, c, 64) : __shfl(c1, c - 64, 64);
+            // (c is wave-uniform: the broadcasts are v_readlane, not LDS-crossbar permutes -- round 3: the 2 S permutes per atom
+            // were most of this kernel's time)
+            auto lane_value = [](float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); };
+            for (int c = 0; c < S; ++c) {
+                const float pc = c < 64 ? lane_value(p0, c) : lane_value(p1, c - 64);
+                const float qc = c < 64 ? lane_value(c0, c) : lane_value(c1, c - 64);
                 fm = fmaf(pc, qc, fm);
             }
             if (s0 == mask) f2a = fm;
@@ -190,7 +193,8 @@ __device__ __forceinline__ void reverse_atoms_body(
 #pragma unroll
             for (int i = 0; i < 16; ++i) {
                 const int c = c0 + i;  // wave-uniform
-                float sc = c < 64 ? __shfl(p0, c, 64) : __shfl(p1, c - 64, 64);
+                float sc = c < 64 ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(p0), c))
+                                  : __int_as_float(__builtin_amdgcn_readlane(__float_as_int(p1), c - 64));
                 sc = c < S ? sc : 0.f;
                 f2a = fmaf(sc, qa[i], f2a);
                 f2b = fmaf(sc, qb[i], f2b);
