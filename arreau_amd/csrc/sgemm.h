@@ -27,15 +27,20 @@ template <int VEC, int WM, int WN, int BK>
 __global__ __launch_bounds__(256) void sgemm_kernel(int M, int N, int K, const float* __restrict__ A, long as0, long as1,
                                                     const float* __restrict__ B, long bs0, long bs1, float* __restrict__ C,
                                                     int ldc, float alpha, float beta, int kchunk,
-                                                    float* __restrict__ partial) {
+                                                    float* __restrict__ partial, int splits /* k-slices per product */,
+                                                    long a_bs, long b_bs, long c_bs /* batch strides: blockIdx.z = batch * splits + slice */) {
     constexpr int TM = 64 * WM, TN = 64 * WN;
+    const int bi = (int)blockIdx.z / splits, zi = (int)blockIdx.z - bi * splits;
+    A += (long)bi * a_bs;
+    B += (long)bi * b_bs;
+    C += (long)bi * c_bs;
     constexpr int KP = BK / 4;                              // 16-byte pieces per k-row of a tile
     constexpr int PA = WM * BK / 16, PB = WN * BK / 16;     // pieces per thread (VEC); elements per thread = 4 x that
     __shared__ __attribute__((aligned(16))) float As[BK][TM + 4], Bs[BK][TN + 4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int h = lane >> 5, j = lane & 31, wm = (wave >> 1) * (32 * WM), wn = (wave & 1) * (32 * WN);
     const int m0 = blockIdx.y * TM, n0 = blockIdx.x * TN;
-    const int kbeg = blockIdx.z * kchunk, kend = min(K, kbeg + kchunk);
+    const int kbeg = zi * kchunk, kend = min(K, kbeg + kchunk);
     f32x16 acc[WM][WN];
 #pragma unroll
     for (int a = 0; a < WM; ++a)
@@ -143,15 +148,17 @@ __global__ __launch_bounds__(256) void sgemm_kernel(int M, int N, int K, const f
             for (int r = 0; r < 16; ++r) {
                 const int m = m0 + wm + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * h, n = n0 + wn + 32 * b + j;
                 if (m < M && n < N) {
-                    if (gridDim.z > 1) partial[((size_t)blockIdx.z * M + m) * N + n] = acc[a][b][r];
+                    if (splits > 1) partial[((size_t)blockIdx.z * M + m) * N + n] = acc[a][b][r];  // [batch][slice][M][N]
                     else C[(size_t)m * ldc + n] = alpha * acc[a][b][r] + (beta != 0.f ? beta * C[(size_t)m * ldc + n] : 0.f);
                 }
             }
 }
 __global__ void splitk_reduce_kernel(const float* __restrict__ partial, int Z, int M, int N, float* __restrict__ C, int ldc,
-                                     float alpha, float beta) {
+                                     float alpha, float beta, long c_bs /* blockIdx.y = product of the batch */) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (long)M * N) return;
+    partial += (size_t)blockIdx.y * Z * M * N;
+    C += (long)blockIdx.y * c_bs;
     float s = 0.f;
     for (int z = 0; z < Z; ++z) s += partial[(size_t)z * M * N + i];
     const int m = (int)(i / N), n = (int)(i % N);
@@ -159,10 +166,14 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ partial, int Z, i
 }
 }  // namespace arreau_sgemm_detail
 
+// batch > 1: `batch` products of the same shape in one launch (operands a_bs / b_bs / c_bs floats apart; a stride of 0 shares an
+// operand): the weight gradients of the L layers, which nothing in the backward pass waits for, leave the chip idle one by one
+// (16 tiles each) and fill it together.
 inline int arreau_sgemm(hipStream_t s, float* partial, int M, int N, int K, const float* A, long as0, long as1, const float* B,
-                        long bs0, long bs1, float* C, int ldc, float alpha = 1.f, float beta = 0.f) {
+                        long bs0, long bs1, float* C, int ldc, float alpha = 1.f, float beta = 0.f, int batch = 1, long a_bs = 0,
+                        long b_bs = 0, long c_bs = 0) {
     using namespace arreau_sgemm_detail;
-    if (M == 0 || N == 0) return ARREAU_OK;
+    if (M == 0 || N == 0 || batch <= 0) return ARREAU_OK;
     // Tile size.  The kernel is bound by the matrix pipe of the busiest CU, so what matters is how evenly the tiles divide
     // over the 256 CUs: 268 tiles of 128 x 128 (8512 x 512 outputs) leave 12 CUs with two workgroups and everybody waits for
     // them (measured 304 us at K = 2048: half the rate of four times the rows); as 64 x 64 tiles the same product is 1064
@@ -174,22 +185,24 @@ inline int arreau_sgemm(hipStream_t s, float* partial, int M, int N, int K, cons
     const int T = small ? 64 : 128;
     const int gm = (M + T - 1) / T, gn = (N + T - 1) / T;
     int Z = 1;
-    const int tiles = gm * gn;
+    const int tiles = gm * gn * batch;
     if (tiles < 128 && K >= 256) {
         const int fill = (256 + tiles - 1) / tiles;
         Z = min(64, min(max(fill, K / 1024), K / 128));
-        while (Z > 1 && (size_t)Z * M * N > ARREAU_SGEMM_PARTIAL_FLOATS) --Z;
+    } else if (batch > 1 && tiles < 512 && K >= 2048) {
+        Z = min(8, K / 1024);  // a batch of long reductions over few tiles: still about four workgroups per CU
     }
+    while (Z > 1 && (size_t)batch * Z * M * N > ARREAU_SGEMM_PARTIAL_FLOATS) --Z;
     const int BK = small ? 32 : 16;
     const int kchunk = ((K + Z - 1) / Z + BK - 1) / BK * BK;
     Z = (K + kchunk - 1) / kchunk;
     // 16-byte operand fetches need the contiguous dimension and the leading dimension to be multiples of four floats
     const bool a_ok = (as1 == 1 && as0 % 4 == 0 && K % 4 == 0) || (as0 == 1 && as1 % 4 == 0 && M % 4 == 0);
     const bool b_ok = (bs1 == 1 && bs0 % 4 == 0 && N % 4 == 0) || (bs0 == 1 && bs1 % 4 == 0 && K % 4 == 0);
-    const bool vec = a_ok && b_ok && ((size_t)A % 16 == 0) && ((size_t)B % 16 == 0);
+    const bool vec = a_ok && b_ok && ((size_t)A % 16 == 0) && ((size_t)B % 16 == 0) && a_bs % 4 == 0 && b_bs % 4 == 0;
     auto launch = [&](auto kernel) {
-        hipLaunchKernelGGL(kernel, dim3(gn, gm, Z), dim3(256), 0, s, M, N, K, A, as0, as1, B, bs0, bs1, C, ldc, alpha, beta, kchunk,
-                           partial);
+        hipLaunchKernelGGL(kernel, dim3(gn, gm, Z * batch), dim3(256), 0, s, M, N, K, A, as0, as1, B, bs0, bs1, C, ldc, alpha, beta, kchunk,
+                           partial, Z, a_bs, b_bs, c_bs);
     };
     if (small) {
         if (vec) launch(sgemm_kernel<1, 1, 1, 32>); else launch(sgemm_kernel<0, 1, 1, 32>);
@@ -198,7 +211,8 @@ inline int arreau_sgemm(hipStream_t s, float* partial, int M, int N, int K, cons
     }
     ARREAU_CHECK_HIP(hipGetLastError());
     if (Z > 1) {
-        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)(((long)M * N + 255) / 256)), dim3(256), 0, s, partial, Z, M, N, C, ldc, alpha, beta);
+        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)(((long)M * N + 255) / 256), batch), dim3(256), 0, s, partial, Z, M, N, C, ldc,
+                           alpha, beta, c_bs);
         ARREAU_CHECK_HIP(hipGetLastError());
     }
     return ARREAU_OK;

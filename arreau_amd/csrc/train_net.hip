@@ -94,12 +94,18 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ a
 // gradients: enough bytes in flight to cover the HBM latency) and a second small launch adds the chunk rows: 32 row
 // phases per column in a fixed order, then the phases in order.  Deterministic.
 constexpr int COLSUM4_MAX_CHUNKS = 1024;
+constexpr int COLSUM4_MAX_BATCH = 8;  // matrices per batched call (the layers of the network)
 __global__ __launch_bounds__(256) void colsum4_partial_kernel(const f32x4* __restrict__ a, const f32x4* __restrict__ b, long rows,
                                                               int cols4, long rows_per_chunk,
-                                                              f32x4* __restrict__ part,   // [chunks][cols4]
-                                                              f32x4* __restrict__ part2)  // plain sums of a (or null)
+                                                              f32x4* __restrict__ part,   // [batch][chunks][cols4]
+                                                              f32x4* __restrict__ part2,  // plain sums of a (or null)
+                                                              long a_bs4, long b_bs4)     // blockIdx.y = matrix of the batch (strides in float4)
 {
     __shared__ f32x4 sh[256];
+    a += (long)blockIdx.y * a_bs4;
+    if (b) b += (long)blockIdx.y * b_bs4;
+    part += (size_t)blockIdx.y * gridDim.x * cols4;
+    if (part2) part2 += (size_t)blockIdx.y * gridDim.x * cols4;
     const int P = 256 / cols4;
     const int c4 = threadIdx.x % cols4, ph = threadIdx.x / cols4;
     const bool act = ph < P;
@@ -144,8 +150,13 @@ __global__ __launch_bounds__(256) void colsum4_partial_kernel(const f32x4* __res
 __global__ __launch_bounds__(256) void colsum4_final_kernel(const f32x4* __restrict__ part, const f32x4* __restrict__ part2,
                                                             int chunks, int cols4, float scale, int accumulate,
                                                             float* __restrict__ out, float* __restrict__ out2,
-                                                            const float* __restrict__ colscale2) {
+                                                            const float* __restrict__ colscale2,
+                                                            long out_bs, long out2_bs) {  // blockIdx.y = matrix of the batch
     __shared__ f32x4 sh[256];
+    part += (size_t)blockIdx.y * chunks * cols4;
+    if (part2) part2 += (size_t)blockIdx.y * chunks * cols4;
+    out += (long)blockIdx.y * out_bs;
+    if (out2) out2 += (long)blockIdx.y * out2_bs;
     const int cl = threadIdx.x & 7, ph = threadIdx.x >> 3;
     const int c4 = blockIdx.x * 8 + cl;
     const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
@@ -587,6 +598,8 @@ struct arreau_train_ctx {
     float *x, *x1, *xhat, *rstd, *xn, *hpre, *h, *out, *fk, *rbar, *gs, *kern;
     // backward temporaries
     float *dx, *dtmp, *dh, *drbar, *dx1, *dkern, *dkb, *dh1, *dfk, *dfkb, *dfh1, *dw1f, *partial, *scratch_cols, *colpart;
+    float *dxn_all, *dx2_all;  // [L][M][C]: d(LayerNorm output) and d(spherical conv output), for the batched bias / norm gradients
+    float *xn_all, *dout_all, *dfk_all;  // [L][...]: LayerNorm outputs (forward), d(out) and d(fiber kernel) (backward), for the batched weight gradients
     int32_t* colcount;  // colsum_kernel's arrival counters (one per 64-column group; zero between launches)
     const int32_t *tstep, *offsets, *types;
     const float *frac, *lengths, *angles;
@@ -622,11 +635,13 @@ size_t layout(arreau_train_ctx& t, const arreau_model* m, int N, int B, float* b
     t.rstd = c.take<float>(L * M); t.xn = c.take<float>(M * C); t.hpre = c.take<float>(L * M * H); t.h = c.take<float>(L * M * H);
     t.out = c.take<float>(L * M * C); t.fk = c.take<float>(L * 256 * C); t.rbar = c.take<float>(M * RO); t.gs = c.take<float>(N * 3);
     t.kern = c.take<float>(R * L * C);   // all layers' spatial kernels, [R][L*C] (one GEMM: the basis is layer-independent)
-    t.dx = c.take<float>(M * C); t.dtmp = c.take<float>(M * C); t.dh = c.take<float>(M * H); t.drbar = c.take<float>(M * RO);
+    t.dx = c.take<float>(M * C); t.dtmp = c.take<float>(M * C); t.dh = c.take<float>(L * M * H); t.drbar = c.take<float>(M * RO);
+    t.xn_all = c.take<float>(L * M * C); t.dout_all = c.take<float>(L * M * C); t.dfk_all = c.take<float>(L * 256 * C);
+    t.dxn_all = c.take<float>(L * M * C); t.dx2_all = c.take<float>(L * M * C);  // kept per layer for the batched weight gradients
     t.dx1 = c.take<float>(M * C); t.dkern = c.take<float>(R * L * C); t.dkb = c.take<float>(R * D); t.dh1 = c.take<float>(R * C);
     t.dfk = c.take<float>(256 * C); t.dfkb = c.take<float>(256 * D); t.dfh1 = c.take<float>(256 * C);
     t.dw1f = c.take<float>(C * ARREAU_MONO_PAD); t.partial = c.take<float>(PARTIAL_FLOATS); t.scratch_cols = c.take<float>(1024);
-    t.colpart = c.take<float>((size_t)2 * COLSUM4_MAX_CHUNKS * 1024);  // (two results per pass)
+    t.colpart = c.take<float>((size_t)2 * COLSUM4_MAX_BATCH * COLSUM4_MAX_CHUNKS * 1024);  // (two results per pass, up to eight matrices per call)
     t.colcount = c.take<int32_t>(COLCOUNT_INTS);
     return c.off;
 }
@@ -645,31 +660,51 @@ int linear_dx(hipStream_t s, arreau_train_ctx& t, long rows, int in, int out, co
               float alpha = 1.f, float beta = 0.f) {
     return gemm(s, t, (int)rows, in, out, dY, out, 1, W, in, 1, dX, in, alpha, beta);
 }
+// the same for `batch` layers in one launch (dY / X / dW of consecutive layers dy_bs / x_bs / out * in floats apart; 0 = shared)
+int linear_dw_batched(hipStream_t s, arreau_train_ctx& t, int batch, long rows, int in, int out, const float* dY, long dy_bs,
+                      const float* X, long x_bs, float* dW, float alpha = 1.f) {
+    return arreau_sgemm(s, t.partial, out, in, (int)rows, dY, 1, out, X, in, 1, dW, in, alpha, 0.f, batch, dy_bs, x_bs, (long)out * in);
+}
 // dW[out][in] = alpha * dY[rows][out]^T . X[rows][in]
 int linear_dw(hipStream_t s, arreau_train_ctx& t, long rows, int in, int out, const float* dY, const float* X, float* dW,
               float alpha = 1.f) {
     return gemm(s, t, out, in, (int)rows, dY, 1, out, X, in, 1, dW, in, alpha, 0.f);
 }
+// `batch` > 1: the same sums for `batch` matrices (a / b a_bs / b_bs floats apart, results out_bs / out2_bs apart) in the two
+// launches of one -- the bias gradients of the L layers (16-byte columns only).
 int colsum(hipStream_t s, arreau_train_ctx& t, const float* a, const float* b, long rows, int cols, float scale, float* out,
-           int accumulate = 0, float* out2 = nullptr, const float* colscale2 = nullptr) {
+           int accumulate = 0, float* out2 = nullptr, const float* colscale2 = nullptr, int batch = 1, long a_bs = 0, long b_bs = 0,
+           long out_bs = 0, long out2_bs = 0) {
     if (cols > 1024) {
         arreau_set_error("colsum: more than 1024 columns");
         return ARREAU_EINVAL;
     }
-    if (cols % 4 == 0 && (size_t)a % 16 == 0 && (b == nullptr || (size_t)b % 16 == 0)) {
+    if (cols % 4 == 0 && (size_t)a % 16 == 0 && (b == nullptr || (size_t)b % 16 == 0) && a_bs % 4 == 0 && b_bs % 4 == 0) {
         const int chunks = (int)std::min<long>(COLSUM4_MAX_CHUNKS, std::max<long>(1, rows / 16));
         const long rpc = (rows + chunks - 1) / chunks;
+        if (batch > COLSUM4_MAX_BATCH) {
+            arreau_set_error("colsum: batch beyond the partial-sum scratch");
+            return ARREAU_EINVAL;
+        }
         f32x4* part = reinterpret_cast<f32x4*>(t.colpart);
-        f32x4* part2 = b && out2 ? part + (size_t)COLSUM4_MAX_CHUNKS * 256 : nullptr;
-        hipLaunchKernelGGL(colsum4_partial_kernel, dim3(chunks), dim3(256), 0, s, reinterpret_cast<const f32x4*>(a),
-                           reinterpret_cast<const f32x4*>(b), rows, cols / 4, rpc, part, part2);
+        f32x4* part2 = b && out2 ? part + (size_t)COLSUM4_MAX_BATCH * COLSUM4_MAX_CHUNKS * 256 : nullptr;
+        hipLaunchKernelGGL(colsum4_partial_kernel, dim3(chunks, batch), dim3(256), 0, s, reinterpret_cast<const f32x4*>(a),
+                           reinterpret_cast<const f32x4*>(b), rows, cols / 4, rpc, part, part2, a_bs / 4, b_bs / 4);
         ARREAU_CHECK_HIP(hipGetLastError());
-        hipLaunchKernelGGL(colsum4_final_kernel, dim3((cols / 4 + 7) / 8), dim3(256), 0, s, part, part2, chunks, cols / 4, scale,
-                           accumulate, out, part2 ? out2 : nullptr, colscale2);
+        hipLaunchKernelGGL(colsum4_final_kernel, dim3((cols / 4 + 7) / 8, batch), dim3(256), 0, s, part, part2, chunks, cols / 4, scale,
+                           accumulate, out, part2 ? out2 : nullptr, colscale2, out_bs, out2_bs);
         ARREAU_CHECK_HIP(hipGetLastError());
         if (out2 && !b) {
             arreau_set_error("colsum: a second result needs a second operand");
             return ARREAU_EINVAL;
+        }
+        return ARREAU_OK;
+    }
+    if (batch > 1) {  // element-wise path (columns not a multiple of four): one matrix after the other
+        for (int i = 0; i < batch; ++i) {
+            const int rc = colsum(s, t, a + (long)i * a_bs, b ? b + (long)i * b_bs : nullptr, rows, cols, scale, out + (long)i * out_bs, accumulate,
+                                  out2 ? out2 + (long)i * out2_bs : nullptr, colscale2);
+            if (rc) return rc;
         }
         return ARREAU_OK;
     }
@@ -799,11 +834,11 @@ int arreau_general_network(arreau_model* m, const arreau_graph_view& g, const in
         TRY(linear(s, t, 256, D, C, t.fkb, m->fiber_wk + (size_t)l * C * D, fk));
         LAUNCH(mix_forward_kernel, dim3(blocks(M * C)), dim3(256), x1, fk, m->conv_bias + (size_t)l * C, N, C, t.dtmp);
         LAUNCH(ln_forward_kernel, dim3(blocks(M, 4)), dim3(256), t.dtmp, m->ln_w + (size_t)l * C, m->ln_b + (size_t)l * C, M, C,
-               t.xhat + (size_t)l * M * C, t.rstd + (size_t)l * M, t.xn);
+               t.xhat + (size_t)l * M * C, t.rstd + (size_t)l * M, t.xn_all + (size_t)l * M * C);
         float* hpre = t.hpre + (size_t)l * M * H;
         float* h = t.h + (size_t)l * M * H;
         float* out = t.out + (size_t)l * M * C;
-        TRY(linear(s, t, M, C, H, t.xn, t.lin1 + (size_t)l * H * C, hpre));
+        TRY(linear(s, t, M, C, H, t.xn_all + (size_t)l * M * C, t.lin1 + (size_t)l * H * C, hpre));
         TRY(launch_bias_gelu(s, hpre, m->mb1 + (size_t)l * H, (const float*)nullptr, M, H, h));
         TRY(linear(s, t, M, H, C, h, t.lin2 + (size_t)l * C * H, out));
         LAUNCH(bias_scale_residual_kernel, dim3(blocks(M * C)), dim3(256), out, m->mb2 + (size_t)l * C, m->ls + (size_t)l * C, xl, M, C, xnext);
@@ -872,8 +907,7 @@ extern "C" int arreau_train_backward(arreau_model* m, const float* d_g_eps, cons
         const float* hpre = t.hpre + (size_t)l * M * H;
         const float* h = t.h + (size_t)l * M * H;
         const float* out = t.out + (size_t)l * M * C;
-        // read-out (ponita.py:105,108)
-        TRY(linear_dw(s, t, M, C, RO, t.drbar, xnext, W(g->readout_w) + (size_t)l * RO * C, invL));
+        // read-out (ponita.py:105,108); its weight gradient: one batched product over the layers, below the loop
         if (l == L - 1) TRY(colsum(s, t, t.drbar, nullptr, M, RO, invL, W(g->readout_b) + (size_t)l * RO));
         else  // every layer's read-out sees the same d(rbar): the bias gradients are equal
             ARREAU_CHECK_HIP(hipMemcpyAsync(W(g->readout_b) + (size_t)l * RO, g->readout_b + (size_t)(L - 1) * RO, RO * sizeof(float),
@@ -883,38 +917,44 @@ extern "C" int arreau_train_backward(arreau_model* m, const float* d_g_eps, cons
         // d(layer_scale) = sum_rows dx * out and d(linear_2.bias) = sum_rows dout = ls * sum_rows dx, in one pass over dx
         if (m->cfg.has_layer_scale)
             TRY(colsum(s, t, t.dx, out, M, C, 1.0f, W(g->layer_scale) + (size_t)l * C, 0, W(g->linear2_b) + (size_t)l * C, m->ls + (size_t)l * C));
-        LAUNCH(scale_cols_kernel, dim3(blocks(M * C)), dim3(256), t.dx, m->ls + (size_t)l * C, M, C, t.dtmp);   // dout
-        TRY(linear_dw(s, t, M, H, C, t.dtmp, h, W(g->linear2_w) + (size_t)l * C * H));
-        if (!m->cfg.has_layer_scale) TRY(colsum(s, t, t.dtmp, nullptr, M, C, 1.0f, W(g->linear2_b) + (size_t)l * C));
-        TRY(linear_dx(s, t, M, H, C, t.dtmp, t.lin2 + (size_t)l * C * H, t.dh));
-        TRY(launch_gelu_backward(s, t.dh, hpre, (const float*)nullptr, M, H));      // dhpre
-        // xn = xhat * g + b (recomputed)
-        LAUNCH(affine_cols_kernel, dim3(blocks(M * C)), dim3(256), xhat, m->ln_w + (size_t)l * C, m->ln_b + (size_t)l * C, M, C, t.xn);
-        TRY(linear_dw(s, t, M, C, H, t.dh, t.xn, W(g->linear1_w) + (size_t)l * H * C));
-        TRY(colsum(s, t, t.dh, nullptr, M, H, 1.0f, W(g->linear1_b) + (size_t)l * H));
-        TRY(linear_dx(s, t, M, C, H, t.dh, t.lin1 + (size_t)l * H * C, t.dtmp));                                     // dxn
-        // d(norm.weight) = sum_rows dxn * xhat and d(norm.bias) = sum_rows dxn, in one pass over dxn
-        TRY(colsum(s, t, t.dtmp, xhat, M, C, 1.0f, W(g->norm_w) + (size_t)l * C, 0, W(g->norm_b) + (size_t)l * C));
-        LAUNCH(ln_backward_kernel, dim3(blocks(M, 4)), dim3(256), t.dtmp, xhat, t.rstd + (size_t)l * M, m->ln_w + (size_t)l * C, M, C,
-               t.xn);                                                                                                // dx2 (in xn)
+        // (the weight gradients of linear_2, linear_1, the read-out and the fiber kernel are products nothing below waits for:
+        // their operands are kept per layer and each kind runs as ONE batched product after the loop)
+        float* dout = t.dout_all + (size_t)l * M * C;
+        float* dh = t.dh + (size_t)l * M * H;
+        LAUNCH(scale_cols_kernel, dim3(blocks(M * C)), dim3(256), t.dx, m->ls + (size_t)l * C, M, C, dout);   // dout
+        if (!m->cfg.has_layer_scale) TRY(colsum(s, t, dout, nullptr, M, C, 1.0f, W(g->linear2_b) + (size_t)l * C));
+        TRY(linear_dx(s, t, M, H, C, dout, t.lin2 + (size_t)l * C * H, dh));
+        TRY(launch_gelu_backward(s, dh, hpre, (const float*)nullptr, M, H));      // dhpre
+        float* dxn = t.dxn_all + (size_t)l * M * C;
+        float* dx2 = t.dx2_all + (size_t)l * M * C;
+        TRY(linear_dx(s, t, M, C, H, dh, t.lin1 + (size_t)l * H * C, dxn));                                          // dxn
+        LAUNCH(ln_backward_kernel, dim3(blocks(M, 4)), dim3(256), dxn, xhat, t.rstd + (size_t)l * M, m->ln_w + (size_t)l * C, M, C, dx2);
         // spherical conv: x2 = mix(x1, fk) / 16 + bias
-        TRY(colsum(s, t, t.xn, nullptr, M, C, 1.0f, W(g->conv_bias) + (size_t)l * C));
-        LAUNCH(mix_backward_x_kernel, dim3(blocks(M * C)), dim3(256), t.xn, fk, N, C, t.dx1);
+        LAUNCH(mix_backward_x_kernel, dim3(blocks(M * C)), dim3(256), dx2, fk, N, C, t.dx1);
         {
             const int chunks = (N + MIX_CHUNK - 1) / MIX_CHUNK;  // partial sums live in the split-K scratch (free here)
             if ((size_t)chunks * 256 * C > PARTIAL_FLOATS) {
                 arreau_set_error("arreau_train_backward: batch too large for the fiber-kernel gradient scratch");
                 return ARREAU_ECAPACITY;
             }
-            LAUNCH(mix_backward_fk_partial_kernel, dim3(256, chunks), dim3(128), x1, t.xn, N, C, t.partial);
-            LAUNCH(mix_backward_fk_final_kernel, dim3(blocks(256L * C)), dim3(256), t.partial, chunks, C, t.dfk);
+            LAUNCH(mix_backward_fk_partial_kernel, dim3(256, chunks), dim3(128), x1, dx2, N, C, t.partial);
+            LAUNCH(mix_backward_fk_final_kernel, dim3(blocks(256L * C)), dim3(256), t.partial, chunks, C, t.dfk_all + (size_t)l * 256 * C);
         }
-        TRY(linear_dw(s, t, 256, D, C, t.dfk, t.fkb, W(g->conv_fiber_w) + (size_t)l * C * D));
-        TRY(linear_dx(s, t, 256, D, C, t.dfk, m->fiber_wk + (size_t)l * C * D, t.dfkb, 1.0f, 1.0f));
+        TRY(linear_dx(s, t, 256, D, C, t.dfk_all + (size_t)l * 256 * C, m->fiber_wk + (size_t)l * C * D, t.dfkb, 1.0f, 1.0f));
         // spatial conv: x1 = sum_s kern * x_l[src]; the residual path already sits in dx (= d x_l so far)
         LAUNCH(conv_backward_kernel, dim3(blocks(R * C)), dim3(256), t.kern + (size_t)l * C, L * C, xl, t.dx1, t.deg, t.src, N, k, C,
                t.dkern + (size_t)l * C, t.dx);
     }
+    // the layers' weight gradients, one batched product per kind (operands kept per layer above / by the forward pass)
+    TRY(linear_dw_batched(s, t, L, M, C, RO, t.drbar, 0, t.x + (size_t)M * C, (long)M * C, W(g->readout_w), invL));         // x_{l+1}
+    TRY(linear_dw_batched(s, t, L, M, H, C, t.dout_all, (long)M * C, t.h, (long)M * H, W(g->linear2_w)));
+    TRY(linear_dw_batched(s, t, L, M, C, H, t.dh, (long)M * H, t.xn_all, (long)M * C, W(g->linear1_w)));
+    TRY(linear_dw_batched(s, t, L, 256, D, C, t.dfk_all, 256L * C, t.fkb, 0, W(g->conv_fiber_w)));
+    // ... and the column sums: d(linear_1.bias) = sum_rows dhpre; d(norm.weight) = sum_rows dxn * xhat and d(norm.bias) = sum_rows dxn
+    // in one pass over dxn; d(conv.bias) = sum_rows dx2
+    TRY(colsum(s, t, t.dh, nullptr, M, H, 1.0f, W(g->linear1_b), 0, nullptr, nullptr, L, (long)M * H, 0, H, 0));
+    TRY(colsum(s, t, t.dxn_all, t.xhat, M, C, 1.0f, W(g->norm_w), 0, W(g->norm_b), nullptr, L, (long)M * C, (long)M * C, C, C));
+    TRY(colsum(s, t, t.dx2_all, nullptr, M, C, 1.0f, W(g->conv_bias), 0, nullptr, nullptr, L, (long)M * C, 0, C, 0));
     // kernel projections of all layers at once: dWk [L*C][D] = dkern^T . kb,  dkb = dkern . Wk
     TRY(linear_dw(s, t, R, D, L * C, t.dkern, t.kb, W(g->conv_kernel_w)));
     TRY(linear_dx(s, t, R, D, L * C, t.dkern, t.wk, t.dkb));
