@@ -395,6 +395,10 @@ __global__ void mix_backward_fk_partial_kernel(const float* __restrict__ x1, con
                                                float* __restrict__ part /*[chunks][256][C]*/) {
     const int op = blockIdx.x, o = op >> 4, p = op & 15;
     const int n0 = blockIdx.y * MIX_CHUNK, n1 = min(N, n0 + MIX_CHUNK);
+    // blockIdx.z = layer (the layers' x1 / dx2 / partial sums lie N * 16 * C, resp. chunks * 256 * C floats apart)
+    x1 += (size_t)blockIdx.z * N * 16 * C;
+    dx2 += (size_t)blockIdx.z * N * 16 * C;
+    part += (size_t)blockIdx.z * gridDim.y * 256 * C;
     for (int c = threadIdx.x; c < C; c += blockDim.x) {
         float acc = 0.f;
         for (int n = n0; n < n1; ++n) acc += x1[((size_t)n * 16 + o) * C + c] * dx2[((size_t)n * 16 + p) * C + c];
@@ -404,6 +408,8 @@ __global__ void mix_backward_fk_partial_kernel(const float* __restrict__ x1, con
 __global__ void mix_backward_fk_final_kernel(const float* __restrict__ part, int chunks, int C, float* __restrict__ dfk) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= 256 * C) return;
+    part += (size_t)blockIdx.y * chunks * 256 * C;  // blockIdx.y = layer
+    dfk += (size_t)blockIdx.y * 256 * C;
     float acc = 0.f;
     for (int q = 0; q < chunks; ++q) acc += part[(size_t)q * 256 * C + i];
     dfk[i] = acc * (1.0f / 16.0f);
@@ -825,13 +831,14 @@ int arreau_general_network(arreau_model* m, const arreau_graph_view& g, const in
     ARREAU_CHECK_HIP(hipMemsetAsync(t.rbar, 0, (size_t)M * RO * sizeof(float), s));
     // kernel_l = kb . Wk_l^T for all layers in one product (conv.py:110; conv.kernel.weight stacked [L*C][D])
     TRY(linear(s, t, R, D, L * C, t.kb, t.wk, t.kern));
+    // fiber kernels of all layers: fk_l = fkb . Wfk_l^T (conv.py:113-116), one batched product
+    TRY(arreau_sgemm(s, t.partial, 256, C, D, t.fkb, D, 1, m->fiber_wk, 1, D, t.fk, C, 1.f, 0.f, L, 0, (long)C * D, 256L * C));
     for (int l = 0; l < L; ++l) {
         const float* xl = t.x + (size_t)l * M * C;
         float* xnext = t.x + (size_t)(l + 1) * M * C;
         float* x1 = t.x1 + (size_t)l * M * C;
         float* fk = t.fk + (size_t)l * 256 * C;
         LAUNCH(conv_forward_kernel, dim3(blocks(M * C)), dim3(256), t.kern + (size_t)l * C, L * C, xl, g.deg, g.src, N, k, C, x1);
-        TRY(linear(s, t, 256, D, C, t.fkb, m->fiber_wk + (size_t)l * C * D, fk));
         LAUNCH(mix_forward_kernel, dim3(blocks(M * C)), dim3(256), x1, fk, m->conv_bias + (size_t)l * C, N, C, t.dtmp);
         LAUNCH(ln_forward_kernel, dim3(blocks(M, 4)), dim3(256), t.dtmp, m->ln_w + (size_t)l * C, m->ln_b + (size_t)l * C, M, C,
                t.xhat + (size_t)l * M * C, t.rstd + (size_t)l * M, t.xn_all + (size_t)l * M * C);
@@ -931,19 +938,22 @@ extern "C" int arreau_train_backward(arreau_model* m, const float* d_g_eps, cons
         LAUNCH(ln_backward_kernel, dim3(blocks(M, 4)), dim3(256), dxn, xhat, t.rstd + (size_t)l * M, m->ln_w + (size_t)l * C, M, C, dx2);
         // spherical conv: x2 = mix(x1, fk) / 16 + bias
         LAUNCH(mix_backward_x_kernel, dim3(blocks(M * C)), dim3(256), dx2, fk, N, C, t.dx1);
-        {
-            const int chunks = (N + MIX_CHUNK - 1) / MIX_CHUNK;  // partial sums live in the split-K scratch (free here)
-            if ((size_t)chunks * 256 * C > PARTIAL_FLOATS) {
-                arreau_set_error("arreau_train_backward: batch too large for the fiber-kernel gradient scratch");
-                return ARREAU_ECAPACITY;
-            }
-            LAUNCH(mix_backward_fk_partial_kernel, dim3(256, chunks), dim3(128), x1, dx2, N, C, t.partial);
-            LAUNCH(mix_backward_fk_final_kernel, dim3(blocks(256L * C)), dim3(256), t.partial, chunks, C, t.dfk_all + (size_t)l * 256 * C);
-        }
-        TRY(linear_dx(s, t, 256, D, C, t.dfk_all + (size_t)l * 256 * C, m->fiber_wk + (size_t)l * C * D, t.dfkb, 1.0f, 1.0f));
         // spatial conv: x1 = sum_s kern * x_l[src]; the residual path already sits in dx (= d x_l so far)
         LAUNCH(conv_backward_kernel, dim3(blocks(R * C)), dim3(256), t.kern + (size_t)l * C, L * C, xl, t.dx1, t.deg, t.src, N, k, C,
                t.dkern + (size_t)l * C, t.dx);
+    }
+    // d(fiber kernel) of every layer = sum over nodes of x1 (x) dx2 / 16: one batched pair of launches (both operands were kept
+    // per layer), then its two uses
+    {
+        const int chunks = (N + MIX_CHUNK - 1) / MIX_CHUNK;  // partial sums live in the split-K scratch (free here)
+        if ((size_t)L * chunks * 256 * C > PARTIAL_FLOATS) {
+            arreau_set_error("arreau_train_backward: batch too large for the fiber-kernel gradient scratch");
+            return ARREAU_ECAPACITY;
+        }
+        LAUNCH(mix_backward_fk_partial_kernel, dim3(256, chunks, L), dim3(128), t.x1, t.dx2_all, N, C, t.partial);
+        LAUNCH(mix_backward_fk_final_kernel, dim3(blocks(256L * C), L), dim3(256), t.partial, chunks, C, t.dfk_all);
+        for (int l = L - 1; l >= 0; --l)  // (accumulated in the order of the layer loop)
+            TRY(linear_dx(s, t, 256, D, C, t.dfk_all + (size_t)l * 256 * C, m->fiber_wk + (size_t)l * C * D, t.dfkb, 1.0f, 1.0f));
     }
     // the layers' weight gradients, one batched product per kind (operands kept per layer above / by the forward pass)
     TRY(linear_dw_batched(s, t, L, M, C, RO, t.drbar, 0, t.x + (size_t)M * C, (long)M * C, W(g->readout_w), invL));         // x_{l+1}
