@@ -45,7 +45,8 @@ class Config(Structure):
 
 
 class Status(Structure):
-    _fields_ = [("flags", c_int32), ("edge_kernel", c_int32), ("mlp_kernel", c_int32), ("conv_kernel", c_int32)]
+    _fields_ = [("flags", c_int32), ("edge_kernel", c_int32), ("mlp_kernel", c_int32), ("conv_kernel", c_int32),
+                ("basis_row_bytes", c_int32)]
 
 
 _SD_FIELDS = [

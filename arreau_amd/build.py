@@ -27,7 +27,7 @@ STAMP = os.path.join(CSRC, ".build_stamp")
 # (conv_proj.hip is covered by the ISA lint instead: its projection role may spill -- it issues no asm memory operation
 # and hipcc counts its own scratch traffic --, its mix role, which hand-counts, must not share a path with a spill)
 NO_SCRATCH = {"edge_f16.hip": None, "node.hip": ["conv_kernel_streamed"], "node_f16.hip": None, "node_f16m.hip": None}
-# Sources with inline asm: their device ISA is kept (-save-temps) and run through tools/isa_lint.py -- software wait
+# Sources with inline asm: their device ISA is kept (-save-temps) and run through arreau_amd/_isa_lint.py -- software wait
 # states around every asm instruction (store-data, VALU-written SGPR -> VMEM, M0 -> LDS-DMA, ...), asm loads' destination
 # registers untouched until their wait, no compiler use of M0, no unmodelled instruction kind inside asm.  hipcc pads and
 # counts none of that for inline asm; a violation fails the build.
@@ -44,7 +44,7 @@ FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++20", "-fPIC", "-Wall", "-Wno-u
 
 def _digest():
     h = hashlib.sha256()
-    for f in SOURCES + HEADERS + [os.path.join("..", "..", "tools", "isa_lint.py")]:
+    for f in SOURCES + HEADERS + [os.path.join("..", "_isa_lint.py")]:
         with open(os.path.join(CSRC, f), "rb") as fh:
             h.update(fh.read())
     h.update(" ".join(FLAGS).encode())
@@ -104,12 +104,8 @@ def _drop_remarks(diag):
 
 
 def _isa_lint():
-    """tools/isa_lint.py as a module (the repository's tools/ directory is not a package)."""
-    import importlib.util
-    path = os.path.join(CSRC, "..", "..", "tools", "isa_lint.py")
-    spec = importlib.util.spec_from_file_location("arreau_isa_lint", path)
-    mod = importlib.util.module_from_spec(spec)
-    spec.loader.exec_module(mod)
+    """The ISA hazard lint (arreau_amd/_isa_lint.py; tools/isa_lint.py is its command-line wrapper)."""
+    from arreau_amd import _isa_lint as mod
     return mod
 
 
@@ -139,7 +135,7 @@ def _compile_all(hipcc, sources, objdir, extra_flags, verbose):
                 bad = lint.lint_file(isa[0]) if isa else None
                 if bad is None or bad:
                     failed = True
-                    sys.stderr.write(f"[arreau_amd.build] {src}: ISA hazard lint (tools/isa_lint.py): "
+                    sys.stderr.write(f"[arreau_amd.build] {src}: ISA hazard lint (arreau_amd/_isa_lint.py): "
                                      f"{'device ISA not found' if bad is None else str(len(bad)) + ' violation(s)'}\n")
                     for v in (bad or [])[:8]:
                         sys.stderr.write("  " + lint.format_violation(v) + "\n")

@@ -110,13 +110,16 @@ def default_args(**overrides):
     return argparse.Namespace(**d)
 
 
-def make_synthetic_model(S=90, seed=1234, trained_like=True, ori_grid=None, **arg_overrides):
+def make_synthetic_model(S=90, seed=1234, trained_like=True, ori_grid=None, pooled_readout_scale=None, **arg_overrides):
     """Random-weight PONITA_DIFFUSION in the reference's layout (the real checkpoint is a download
     that is unavailable offline).  Default PyTorch initialisers under torch.manual_seed(seed), like
     the reference constructors.  `trained_like=True` additionally randomises the tensors whose
     initial values hide the network from a parity test (layer_scale = 1e-6 scales every ConvNext
     branch to nothing; zero conv bias; unit LayerNorm): layer_scale ~ U(0.1, 1), conv.bias ~ N(0, 0.1),
-    norm.weight ~ U(0.5, 1.5), norm.bias ~ N(0, 0.1)."""
+    norm.weight ~ U(0.5, 1.5), norm.bias ~ N(0, 0.1).  `pooled_readout_scale` multiplies the read-out rows (and biases) of
+    the three per-crystal scalars (split order [S, 1, 0, 3], ponita.py:108-117): random rows make the pooled prediction
+    `pred_lengths_0` a sum of ~n values of order 3 (|len0| ~ 58 at 20 atoms), whereas a trained model predicts lengths / n =
+    O(1) (diffusion_loss.py:264-267); e.g. 1/32 gives a model whose three outputs are all of order one."""
     from .lightning_wrappers.diffusion import PONITA_DIFFUSION
     state = torch.random.get_rng_state()
     try:
@@ -131,6 +134,11 @@ def make_synthetic_model(S=90, seed=1234, trained_like=True, ori_grid=None, **ar
                     layer.conv.bias.normal_(0.0, 0.1)
                     layer.norm.weight.uniform_(0.5, 1.5)
                     layer.norm.bias.normal_(0.0, 0.1)
+        if pooled_readout_scale is not None:
+            with torch.no_grad():
+                for ro in model.model.read_out_layers:
+                    ro.weight[S + 1:S + 4] *= float(pooled_readout_scale)
+                    ro.bias[S + 1:S + 4] *= float(pooled_readout_scale)
     finally:
         torch.random.set_rng_state(state)
     return model

@@ -613,7 +613,13 @@ extern "C" int arreau_sample_loop(arreau_model* m, float* d_frac, int32_t* d_typ
     const uint64_t key[12] = {(uint64_t)d_frac, (uint64_t)d_types, (uint64_t)d_lengths, (uint64_t)d_angles, (uint64_t)d_off,
                               ((uint64_t)(uint32_t)B << 32) | (uint32_t)N, seed, (uint64_t)d_const_types, (uint64_t)d_fixed_lengths,
                               (uint64_t)d_lattice, (uint64_t)d_workspace,
-                              ((uint64_t)(uint32_t)(m->edge_variant | (no_prep ? 0x10000 : 0)) << 32) | (uint32_t)m->mlp_variant};
+                              ((uint64_t)(uint32_t)(m->edge_variant | (no_prep ? 0x10000 : 0) |
+                                                    // which kernels a capture holds also depends on switches read per call
+                                                    // (ARREAU_BASIS_MIN_RECEIVERS, ARREAU_FUSE_SMALL) and on the conv variant:
+                                                    // a changed switch must not replay the stale graph
+                                                    (arreau_basis_form(m, N) ? 0x20000 : 0) | (arreau_basis_fp8() ? 0x40000 : 0) |
+                                                    (arreau_small_layer_fusable(m, N, NodeRange()) ? 0x80000 : 0) |
+                                                    ((m->conv_variant & 3) << 20)) << 32) | (uint32_t)m->mlp_variant};
     hipGraphExec_t exec = (hipGraphExec_t)m->retired_graph;
     int first_replay = 0;
     hipError_t e = hipSuccess;

@@ -781,7 +781,7 @@ int arreau_launch_edge_f16x3(const arreau_model* m, const float* dir, const floa
     // Inputs are identical from evaluation to evaluation; the cause is not found.  Slices exist for batches of thousands of
     // atoms, far above the switch-over, so nothing is lost by keeping the small-launch form to unsliced launches.
     const bool whole_batch = n0 == 0 && n1 == N && r.wg_cap == 0;
-    const bool use_split = split_ok && !arreau_basis_form(m, n1 - n0) &&
+    const bool use_split = split_ok && !arreau_basis_form(m, N) &&
                            (split_env >= 0 ? split_env != 0 : (whole_batch && (n1 - n0) <= ARREAU_EDGE_SPLIT_MAX_NODES));
     const bool k3 = arreau_k3(m);  // K tiles as 3-byte floats (the node-layer launcher reads the same decision)
     if (use_split) {
@@ -800,7 +800,9 @@ int arreau_launch_edge_f16x3(const arreau_model* m, const float* dir, const floa
     const int npairs = (n1 - n0 + 1) / 2;
     int wgs = wgs_env > 0 ? (wgs_env < npairs ? wgs_env : npairs) : (npairs < n_cu ? npairs : n_cu);
     if (r.wg_cap > 0 && wgs > r.wg_cap) wgs = r.wg_cap;
-    if (arreau_basis_form(m, n1 - n0)) {  // stop after layer 2, store the basis planes (the node-layer launcher projects them)
+    // (decided from the WHOLE batch, not from this launch's range: the two forms lay the shared kbuf region out differently,
+    // so slices of one batch on either side of the threshold must not mix them -- ADVICE round 3)
+    if (arreau_basis_form(m, N)) {  // stop after layer 2, store the basis planes (the node-layer launcher projects them)
         if (arreau_basis_fp8())
             ARREAU_LAUNCH((edge_kernel_f16x3<128, 256, 8, false, false, true>), dim3(wgs), dim3(512), 0, s, dir, dist, deg, batch, lattice, m->ori,
                           reinterpret_cast<const u32x4*>(m->edge_f16), m->b1, m->b2, m->cfg.radius, N, m->k, m->L, kbuf, n0, n1);

@@ -544,6 +544,7 @@ extern "C" int arreau_model_status(const arreau_model* model, arreau_status* out
     out->edge_kernel = model->ran_edge;
     out->mlp_kernel = model->ran_mlp;
     out->conv_kernel = model->ran_conv;
+    out->basis_row_bytes = model->ran_conv == 2 ? (arreau_basis_fp8() ? 768 : 1024) : 0;
     return ARREAU_OK;
 }
 

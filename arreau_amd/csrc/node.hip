@@ -629,7 +629,7 @@ int arreau_launch_node_layer(const arreau_model* m, int layer, const float* kbuf
     const size_t mlp_layer = (size_t)2 * H * C;  // floats of W1 + W2, packed
     const int conv_blocks = N < 512 ? N : 512;   // persistent: 2 workgroups of 512 threads per CU (a multiple of 8: XCD-aware order)
     // conv variant: 1 (default, k = 8 only) = streamed form (K blocks by LDS-DMA, one workgroup per CU); 0 = register form
-    const bool basis_form = arreau_basis_form(m, Ng);
+    const bool basis_form = arreau_basis_form(m, N);  // whole-batch decision (one kbuf layout per evaluation)
     const int conv_variant = m->conv_variant == 2 ? 1 : m->conv_variant;  // (2 without the basis form = the streamed K pair)
     m->ran_conv = basis_form ? 2 : (conv_variant == 1 && m->k == 8) ? 1 : 0;
     if (arreau_small_layer_fusable(m, N, r)) {  // small launch: both halves of the layer in one kernel (bit-identical)

@@ -572,7 +572,7 @@ bool arreau_small_layer_fusable(const arreau_model* m, int N, NodeRange r) {
     const bool whole_batch = n0 == 0 && n1 == N && r.wg_cap == 0;
     return (e == nullptr || atoi(e) != 0) && split_env < 0 && whole_batch && N <= ARREAU_MLP_SPLIT_MAX_NODES && m->mlp_variant == 3 &&
            m->f16_ok && m->k == 8 && m->C == 128 && m->H == 512 && (m->conv_variant == 1 || m->conv_variant == 2) && !arreau_k3(m) &&
-           !arreau_basis_form(m, n1 - n0);
+           !arreau_basis_form(m, N);
 }
 int arreau_launch_small_layer(const arreau_model* m, int layer, const float* kbuf, const int32_t* deg, const int32_t* src,
                               const float* x_in, float* x_out, float* xbar, float* vsum, int Ntot, hipStream_t s) {

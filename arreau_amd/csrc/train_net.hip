@@ -344,12 +344,57 @@ __global__ void conv_forward_kernel(const float* __restrict__ kern, int ldk, con
     }
     x1[i] = acc;
 }
-// dkern[(n,s,o),c] = dx1[n,o,c] * x[src,o,c];  dx[src,o,c] += kern[(n,s,o),c] * dx1[n,o,c]  (atomic: several receivers
-// share a sender)
-__global__ void conv_backward_kernel(const float* __restrict__ kern, int ldk, const float* __restrict__ x,
-                                     const float* __restrict__ dx1, const int32_t* __restrict__ deg,
-                                     const int32_t* __restrict__ src, int N, int k, int C, float* __restrict__ dkern,
-                                     float* __restrict__ dx) {
+// Sender-side adjacency of the batch (round 4; it replaces an fp32 atomicAdd scatter, so the weight gradients are now bit
+// for bit reproducible).  Edges never leave a crystal, so crystal b's reversed lists live in the k * n_b entries behind
+// rev_idx[k * off[b]]: one workgroup per crystal; thread j (a sender) scans the crystal's receiver slots in (receiver, slot)
+// order -- the order the forward pass adds messages in -- counts its own, takes its place by an ordered scan over the
+// crystal's senders, and writes the slot indices.  O(k n_b^2) integer compares per crystal, once per training step.
+__global__ __launch_bounds__(256) void reverse_adjacency_kernel(const int32_t* __restrict__ off, const int32_t* __restrict__ deg,
+                                                                const int32_t* __restrict__ src, int k,
+                                                                int32_t* __restrict__ rev_start /*[N]*/, int32_t* __restrict__ rev_cnt /*[N]*/,
+                                                                int32_t* __restrict__ rev_idx /*[N*k]: slot index (n * k + s)*/) {
+    const int b = blockIdx.x, a0 = off[b], a1 = off[b + 1], nb = a1 - a0;
+    __shared__ int32_t base_of_pass;
+    if (threadIdx.x == 0) base_of_pass = a0 * k;
+    __syncthreads();
+    for (int j0 = 0; j0 < nb; j0 += blockDim.x) {  // senders in passes of blockDim (crystals above 256 atoms take several)
+        const int j = a0 + j0 + threadIdx.x;
+        int cnt = 0;
+        if (j < a1)
+            for (int n = a0; n < a1; ++n) {
+                const int nd = min(deg[n], k);
+                for (int s = 0; s < nd; ++s) cnt += src[(size_t)n * k + s] == j;
+            }
+        // exclusive scan over the pass (Hillis-Steele through LDS; 256 entries)
+        __shared__ int32_t sc[256];
+        sc[threadIdx.x] = cnt;
+        __syncthreads();
+        for (int d = 1; d < 256; d <<= 1) {
+            const int v = threadIdx.x >= d ? sc[threadIdx.x - d] : 0;
+            __syncthreads();
+            sc[threadIdx.x] += v;
+            __syncthreads();
+        }
+        const int start = base_of_pass + sc[threadIdx.x] - cnt;
+        const int total = sc[255];
+        if (j < a1) {
+            rev_start[j] = start;
+            rev_cnt[j] = cnt;
+            int w = start;
+            for (int n = a0; n < a1; ++n) {
+                const int nd = min(deg[n], k);
+                for (int s = 0; s < nd; ++s)
+                    if (src[(size_t)n * k + s] == j) rev_idx[w++] = n * k + s;
+            }
+        }
+        __syncthreads();
+        if (threadIdx.x == 0) base_of_pass += total;
+        __syncthreads();
+    }
+}
+// dkern[(n,s,o),c] = dx1[n,o,c] * x[src,o,c]   (receiver side, one thread per element of the kernel matrix)
+__global__ void conv_backward_kern_kernel(const float* __restrict__ x, const float* __restrict__ dx1, const int32_t* __restrict__ deg,
+                                          const int32_t* __restrict__ src, int N, int k, int C, int ldk, float* __restrict__ dkern) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (long)N * k * 16 * C) return;
     const int c = (int)(i % C);
@@ -360,9 +405,25 @@ __global__ void conv_backward_kernel(const float* __restrict__ kern, int ldk, co
     const size_t ik = (size_t)row * ldk + c;  // same position in the [R][L*C] matrices
     if (s >= min(deg[n], k)) { dkern[ik] = 0.f; return; }
     const int j = src[e];
-    const float g = dx1[((size_t)n * 16 + o) * C + c];
-    dkern[ik] = g * x[((size_t)j * 16 + o) * C + c];
-    atomicAdd(dx + ((size_t)j * 16 + o) * C + c, kern[ik] * g);
+    dkern[ik] = dx1[((size_t)n * 16 + o) * C + c] * x[((size_t)j * 16 + o) * C + c];
+}
+// dx[j,o,c] += sum over the edges (n, s) that j sends, in (receiver, slot) order, of kern[(n,s,o),c] * dx1[n,o,c]
+// (sender side: one thread owns one element of dx -- a segmented sum in a fixed order, no atomics)
+__global__ void conv_backward_dx_kernel(const float* __restrict__ kern, int ldk, const float* __restrict__ dx1,
+                                        const int32_t* __restrict__ rev_start, const int32_t* __restrict__ rev_cnt,
+                                        const int32_t* __restrict__ rev_idx, int N, int k, int C, float* __restrict__ dx) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)N * 16 * C) return;
+    const int c = (int)(i % C);
+    const long row = i / C;
+    const int o = (int)(row & 15), j = (int)(row >> 4);
+    const int st = rev_start[j], cnt = rev_cnt[j];
+    float acc = 0.f;
+    for (int q = 0; q < cnt; ++q) {
+        const int e = rev_idx[st + q], n = e / k;
+        acc += kern[((size_t)e * 16 + o) * ldk + c] * dx1[((size_t)n * 16 + o) * C + c];
+    }
+    dx[i] += acc;
 }
 // x2[n,p,c] = sum_o x1[n,o,c] fk[o,p,c] / 16 + bias[c]   (conv.py:113-127)
 __global__ void mix_forward_kernel(const float* __restrict__ x1, const float* __restrict__ fk, const float* __restrict__ bias,
@@ -392,9 +453,9 @@ __global__ void mix_backward_x_kernel(const float* __restrict__ dx2, const float
 // order (deterministic)
 constexpr int MIX_CHUNK = 32;
 __global__ void mix_backward_fk_partial_kernel(const float* __restrict__ x1, const float* __restrict__ dx2, int N, int C,
-                                               float* __restrict__ part /*[chunks][256][C]*/) {
+                                               float* __restrict__ part /*[chunks][256][C]*/, int chunk = MIX_CHUNK) {
     const int op = blockIdx.x, o = op >> 4, p = op & 15;
-    const int n0 = blockIdx.y * MIX_CHUNK, n1 = min(N, n0 + MIX_CHUNK);
+    const int n0 = blockIdx.y * chunk, n1 = min(N, n0 + chunk);
     // blockIdx.z = layer (the layers' x1 / dx2 / partial sums lie N * 16 * C, resp. chunks * 256 * C floats apart)
     x1 += (size_t)blockIdx.z * N * 16 * C;
     dx2 += (size_t)blockIdx.z * N * 16 * C;
@@ -598,7 +659,7 @@ struct arreau_train_ctx {
     // plain row-major weights (in the model blob): [C][96], [D][C], [L][C][D], [L][H][C], [L][C][H], [L][S+4][C]
     const float *w1f, *w2, *wk, *lin1, *lin2, *ro_w;
     // forward state
-    int32_t *batch, *deg, *src, *cell;
+    int32_t *batch, *deg, *src, *cell, *rev_start, *rev_cnt, *rev_idx;
     float *lattice, *cart, *cvec, *dir, *dist;
     float *mono, *window, *h1pre, *h1, *h2pre, *kb, *fpoly, *fh1pre, *fh1, *fh2pre, *fkb, *F;
     float *x, *x1, *xhat, *rstd, *xn, *hpre, *h, *out, *fk, *rbar, *gs, *kern;
@@ -631,6 +692,7 @@ size_t layout(arreau_train_ctx& t, const arreau_model* m, int N, int B, float* b
     const size_t R = (size_t)N * k * 16, M = (size_t)N * 16;
     t.w1f = m->t_w1f; t.w2 = m->t_w2; t.wk = m->t_wk; t.lin1 = m->t_lin1; t.lin2 = m->t_lin2; t.ro_w = m->t_ro_w;
     t.batch = c.take<int32_t>(N); t.deg = c.take<int32_t>(N); t.src = c.take<int32_t>(N * k); t.cell = c.take<int32_t>(N * k);
+    t.rev_start = c.take<int32_t>(N); t.rev_cnt = c.take<int32_t>(N); t.rev_idx = c.take<int32_t>(N * k);
     t.lattice = c.take<float>(B * 9); t.cart = c.take<float>(N * 3); t.cvec = c.take<float>(B * C);
     t.dir = c.take<float>(N * k * 3); t.dist = c.take<float>(N * k);
     t.mono = c.take<float>(R * ARREAU_MONO_PAD); t.window = c.take<float>(R);
@@ -905,6 +967,8 @@ extern "C" int arreau_train_backward(arreau_model* m, const float* d_g_eps, cons
     ARREAU_CHECK_HIP(hipMemsetAsync(t.dx, 0, (size_t)M * C * sizeof(float), s));
     ARREAU_CHECK_HIP(hipMemsetAsync(t.dfkb, 0, (size_t)256 * D * sizeof(float), s));
     const float invL = 1.0f / (float)L;
+    // sender-side adjacency of this step's graph (for the ordered, atomic-free d(x_l) of the spatial conv)
+    LAUNCH(reverse_adjacency_kernel, dim3((unsigned)t.B), dim3(256), t.offsets, t.deg, t.src, k, t.rev_start, t.rev_cnt, t.rev_idx);
     for (int l = L - 1; l >= 0; --l) {
         const float* xl = t.x + (size_t)l * M * C;
         const float* xnext = t.x + (size_t)(l + 1) * M * C;
@@ -939,19 +1003,26 @@ extern "C" int arreau_train_backward(arreau_model* m, const float* d_g_eps, cons
         // spherical conv: x2 = mix(x1, fk) / 16 + bias
         LAUNCH(mix_backward_x_kernel, dim3(blocks(M * C)), dim3(256), dx2, fk, N, C, t.dx1);
         // spatial conv: x1 = sum_s kern * x_l[src]; the residual path already sits in dx (= d x_l so far)
-        LAUNCH(conv_backward_kernel, dim3(blocks(R * C)), dim3(256), t.kern + (size_t)l * C, L * C, xl, t.dx1, t.deg, t.src, N, k, C,
-               t.dkern + (size_t)l * C, t.dx);
+        LAUNCH(conv_backward_kern_kernel, dim3(blocks(R * C)), dim3(256), xl, t.dx1, t.deg, t.src, N, k, C, L * C, t.dkern + (size_t)l * C);
+        LAUNCH(conv_backward_dx_kernel, dim3(blocks(M * C)), dim3(256), t.kern + (size_t)l * C, L * C, t.dx1, t.rev_start, t.rev_cnt,
+               t.rev_idx, N, k, C, t.dx);
     }
     // d(fiber kernel) of every layer = sum over nodes of x1 (x) dx2 / 16: one batched pair of launches (both operands were kept
     // per layer), then its two uses
     {
-        const int chunks = (N + MIX_CHUNK - 1) / MIX_CHUNK;  // partial sums live in the split-K scratch (free here)
-        if ((size_t)L * chunks * 256 * C > PARTIAL_FLOATS) {
-            arreau_set_error("arreau_train_backward: batch too large for the fiber-kernel gradient scratch");
-            return ARREAU_ECAPACITY;
+        // partial sums live in the split-K scratch (free here): as many layers per pair of launches as fit it -- all L at the
+        // bench's 64 crystals, one at the reference's `make train` preset (batch 270, hidden_dim 200: ~2,200 atoms) -- and
+        // atom chunks that grow with the batch once a single layer's partial sums would not fit
+        int chunk = MIX_CHUNK;
+        while ((size_t)((N + chunk - 1) / chunk) * 256 * C > PARTIAL_FLOATS) chunk *= 2;
+        const int chunks = (N + chunk - 1) / chunk;
+        const int Lg = (int)std::min<size_t>((size_t)L, PARTIAL_FLOATS / ((size_t)chunks * 256 * C));
+        for (int l0 = 0; l0 < L; l0 += Lg) {
+            const int nl = std::min(Lg, L - l0);
+            LAUNCH(mix_backward_fk_partial_kernel, dim3(256, chunks, nl), dim3(128), t.x1 + (size_t)l0 * N * 16 * C,
+                   t.dx2_all + (size_t)l0 * N * 16 * C, N, C, t.partial, chunk);
+            LAUNCH(mix_backward_fk_final_kernel, dim3(blocks(256L * C), nl), dim3(256), t.partial, chunks, C, t.dfk_all + (size_t)l0 * 256 * C);
         }
-        LAUNCH(mix_backward_fk_partial_kernel, dim3(256, chunks, L), dim3(128), t.x1, t.dx2_all, N, C, t.partial);
-        LAUNCH(mix_backward_fk_final_kernel, dim3(blocks(256L * C), L), dim3(256), t.partial, chunks, C, t.dfk_all);
         for (int l = L - 1; l >= 0; --l)  // (accumulated in the order of the layer loop)
             TRY(linear_dx(s, t, 256, D, C, t.dfk_all + (size_t)l * 256 * C, m->fiber_wk + (size_t)l * C * D, t.dfkb, 1.0f, 1.0f));
     }

@@ -100,7 +100,8 @@ class HipEngine:
                                                    _hip.stream_ptr(self.device)), "arreau_model_status")
         return {"flags": int(st.flags), "edge_kernel": _hip.EDGE_KERNELS.get(st.edge_kernel, "none"),
                 "mlp_kernel": _hip.MLP_KERNELS.get(st.mlp_kernel, "none"), "edge_variant": int(st.edge_kernel),
-                "mlp_variant": int(st.mlp_kernel), "conv_variant": int(st.conv_kernel)}
+                "mlp_variant": int(st.mlp_kernel), "conv_variant": int(st.conv_kernel),
+                "basis_row_bytes": int(st.basis_row_bytes)}
 
     def check_status(self, reset=True):
         """Raise if a kernel flagged a condition under which its results must not be trusted."""

@@ -53,11 +53,24 @@ def edge_kernel_flops_per_row(C=128, D=256, L=5):
     return 2 * (258 * C + C * D) + 2 * L * D * C
 
 
-def conv_proj_bytes_per_launch(rows, N, C=128, O=16, stash_bytes_per_row=768):
-    """Algorithmic HBM bytes of ONE launch of the per-layer message kernel (conv_proj_kernel, the dominant kernel of the
-    default path since round 3): the stashed basis of every (edge, orientation) row read once (3 bytes per value: fp16 +
-    fp8 e4m3 plane, 256 values), every node feature row read once, the convolved rows written once."""
-    return rows * stash_bytes_per_row + 2 * N * O * C * 4
+def conv_pass_bytes(N, C=128, O=16):
+    """ALGORITHMIC HBM bytes of one conv pass ("each layer = one conv pass (read x, write x_1) + one node
+    pass"; edge kernels never materialised): 2 * N * O * C * 4.  What the message kernel moves beyond that -- the stashed
+    basis it streams, the sender rows it gathers -- is the design's own traffic and is reported as such, not as work."""
+    return 2 * N * O * C * 4
+
+
+def step_bytes(N, E, B, S=90, C=128, L=5, O=16):
+    """algorithmic bytes of one step = 4 * [(5L + 1) N O C + 2 E 6 + N (S + 4) + 4 N + 6 B]
+    (213.8 KB per atom-step at E = 8 N: 1.095 GB at 256 x 20)."""
+    return 4 * ((5 * L + 1) * N * O * C + 2 * E * 6 + N * (S + 4) + 4 * N + 6 * B)
+
+
+def stash_bytes_per_launch(N, row_bytes, k=8, O=16):
+    """Bytes of the stashed basis one launch of the message kernel streams: ALL k slots of every receiver (the kernel
+    copies a receiver's whole block; unused slots included), row_bytes per (slot, orientation) row as the library reports
+    it (arreau_model_status: 768 = fp16 + fp8 e4m3 plane, 1024 = two fp16 planes)."""
+    return N * k * O * row_bytes
 
 
 def conv_proj_flops_per_row(C=128, D=256):
@@ -271,13 +284,49 @@ def run_stub(args, rank, world):
         dist.all_gather(gathered, tt)
         per_rank = [float(g[0]) for g in gathered]
         elapsed = max(float(g[1]) for g in gathered)
+    ranks = {"backend": dist.get_backend() if world > 1 else None, "world_size": dist.get_world_size() if world > 1 else 1,
+             "data_path_collectives": 0,
+             "per_rank": gather_json(dist if world > 1 else None, "cpu", world, {"rank": rank, "pid": os.getpid(),
+                                                                               "hostname": socket.gethostname()})}
     if rank == 0:
         emit({"metric": "stub", "value": world * args.batch_per_gpu * args.steps / elapsed, "n_gpus": world,
               "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
-              "per_rank_ms": [1e3 * e / args.steps for e in per_rank]})
+              "per_rank_ms": [1e3 * e / args.steps for e in per_rank], "ranks": ranks})
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def device_identity(torch, dev):
+    """Name, UUID and PCI address of this rank's GPU (what distinguishes N MI355X of one node in the record)."""
+    p = torch.cuda.get_device_properties(dev)
+    out = {"device": p.name, "device_index": dev.index, "hostname": socket.gethostname(),
+           "visible_devices": os.environ.get("HIP_VISIBLE_DEVICES") or os.environ.get("ROCR_VISIBLE_DEVICES")}
+    for key in ("uuid", "pci_bus_id", "pci_device_id", "pci_domain_id", "gcnArchName", "multi_processor_count"):
+        v = getattr(p, key, None)
+        if v is not None:
+            out[key] = str(v) if key == "uuid" else v
+    return out
+
+
+def gather_json(dist, where, world, obj, cap=2048):
+    """every rank's small record on every rank (fixed-size byte tensors through all_gather: works on RCCL and gloo alike)"""
+    if dist is None:
+        return [obj]
+    import torch
+    raw = json.dumps(obj).encode()[:cap]
+    buf = torch.zeros(cap + 4, dtype=torch.uint8)
+    buf[:4] = torch.tensor(list(len(raw).to_bytes(4, "little")), dtype=torch.uint8)
+    buf[4:4 + len(raw)] = torch.tensor(list(raw), dtype=torch.uint8)
+    buf = buf.to(where)
+    got = [torch.zeros_like(buf) for _ in range(world)]
+    dist.all_gather(got, buf)
+    out = []
+    for g in got:
+        g = g.cpu()
+        n = int.from_bytes(bytes(g[:4].tolist()), "little")
+        out.append(json.loads(bytes(g[4:4 + n].tolist()).decode()))
+    return out
 
 
 def run_rank(args, rank, local_rank, world):
@@ -397,7 +446,11 @@ def run_rank(args, rank, local_rank, world):
     _hip.check(_hip.lib().arreau_conv_kernel_time_ms(ctypes.byref(conv_ms), ctypes.byref(conv_launches)), "conv time")
     _hip.check(_hip.lib().arreau_profile_edge_kernel(0), "profile off")
     e_end = degree_sum()
-    status = eng.check_status()  # raises on non-finite outputs / clamped indices; names the kernels that really ran
+    # (ARREAU_BENCH_TIMING_ONLY=1: builder experiments with libraries that compute wrong numbers on purpose -- tools/exp --;
+    # the status word is read but not enforced and the line says so: such a line is not a result)
+    timing_only = os.environ.get("ARREAU_BENCH_TIMING_ONLY", "0") == "1"
+    check = (lambda: eng.status(reset=True)) if timing_only else eng.check_status
+    status = check()  # raises on non-finite outputs / clamped indices; names the kernels that really ran
     per_rank_eager, el_eager = gather(local_elapsed[0], el_eager)
 
     # Loop 2, hipGraph replay of the captured step (arreau_sample_loop use_graph = 1) on one stream: bit-identical results,
@@ -409,7 +462,7 @@ def run_rank(args, rank, local_rank, world):
         run_steps(3, use_graph=True)  # warm-up of the graph path (capture, instantiation, stream / event creation)
         el_graph = timed_loop(args.steps, use_graph=True)
         per_rank_graph, el_graph = gather(local_elapsed[0], el_graph)
-        eng.check_status()
+        check()
 
     # `value` is the loop the product runs for THIS configuration: the same policy as DiffusionLoss.sample's default
     # (graph replay from 200 sampler steps on; the 100-step single-crystal config runs eagerly).
@@ -454,7 +507,7 @@ def run_rank(args, rank, local_rank, world):
         m32, l32 = ctypes.c_double(), ctypes.c_int64()
         _hip.check(_hip.lib().arreau_edge_kernel_time_ms(ctypes.byref(m32), ctypes.byref(l32)), "edge time")
         _hip.check(_hip.lib().arreau_profile_edge_kernel(0), "profile off")
-        st32 = eng.check_status()
+        st32 = check()
         eng.set_variant(4, args.mlp_variant)
         e32 = degree_sum()
         fl32 = e32 * 16 * edge_kernel_flops_per_row()
@@ -463,6 +516,15 @@ def run_rank(args, rank, local_rank, world):
                         "edge_tflops": fl32 / (m32.value * 1e-3) / 1e12 if m32.value > 0 else 0.0,
                         "frac_of_157.3": (fl32 / (m32.value * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS) if m32.value > 0 else 0.0}
 
+    # What lets the record prove N ranks on N distinct devices (and which library carried the barrier): every rank reports
+    # its device identity and the work it really processed; no collective touches the data path.
+    ranks_info = {"backend": (dist.get_backend() if dist is not None else None),
+                  "world_size": (dist.get_world_size() if dist is not None else 1),
+                  "data_path_collectives": 0,
+                  "note": "the process group carries only the timing barriers and the gathers of these records",
+                  "per_rank": gather_json(dist, dev if backend == "nccl" else "cpu", world,
+                                          dict(device_identity(torch, dev), rank=rank, local_rank=local_rank, pid=os.getpid(),
+                                               degree_sum_start=e_start, degree_sum_end=e_end, crystals=B, atoms=N))}
     if rank == 0:
         log(f"timed region: {args.steps} steps in {elapsed:.3f} s")
         ms_per_step = 1e3 * elapsed / args.steps
@@ -498,35 +560,59 @@ def run_rank(args, rank, local_rank, world):
             "algorithmic_flops_per_launch": edge_flops,
         }
         roofline = edge_roof
+        Nl = N / launches_per_step
         if status.get("conv_variant") == 2 and conv_launches.value > 0:
-            # Default path since round 3: the edge kernel stops after the basis (it stores the two planes, 3 bytes per
-            # value) and every layer's message kernel projects them itself.  That kernel, L launches per step, is where
-            # the step's time is: a stream of the stash through LDS under the projection's MFMAs -- priced against HBM.
+            # Default path since round 3: the edge kernel stops after the basis and every layer's message kernel projects it
+            # itself.  That kernel, L launches per step, is where the step's time is.  It is a dense contraction (2 D C FLOP per
+            # (edge, orientation) row, SURVEY.md 8(d) "kernel projection 50.5 %"), so the headline fraction is the MFMA one;
+            # its ALGORITHMIC bytes are those of 8(d)'s conv pass (read x, write x_1).  The basis stash it streams is traffic the
+            # design adds: reported beside the PMC figure, never as achieved work.
             rows = e_mean * 16 / launches_per_step
-            cbytes = conv_proj_bytes_per_launch(rows, N / launches_per_step)
+            row_bytes = int(status.get("basis_row_bytes") or 768)
+            cbytes = conv_pass_bytes(Nl)
             cflops = rows * conv_proj_flops_per_row()
             t = conv_ms.value * 1e-3
             front_flops = rows * 2 * (258 * 128 + 128 * 256)
             edge_roof = dict(edge_roof, kernel="edge_kernel_f16x3<128,256,PROJ=false> (pair invariants + basis MLP; stores the basis "
-                             "planes: fp16 + fp8 e4m3, 768 B per row)", achieved=front_flops / (mean_ms.value * 1e-3) / 1e12,
+                             f"planes, {row_bytes} B per row)", achieved=front_flops / (mean_ms.value * 1e-3) / 1e12,
                              algorithmic_flops_per_launch=front_flops)
             edge_roof["frac"] = edge_roof["achieved"] / edge_peak
             edge_roof["frac_of_fp32_mfma_peak"] = edge_roof["achieved"] / MFMA_F32_PEAK_TFLOPS
             edge_roof["traffic"] = measured_traffic(B, n, "edge_kernel_hbm_bytes_per_launch")
+            pmc = measured_traffic(B, n, "conv_proj_hbm_bytes_per_launch")
             roofline = {
                 "kernel": "conv_proj_kernel<128,256> x L per step (kernel projection of the layer on fp16x3 MFMAs from the stashed "
                           "basis + message passing + spherical convolution; conv.py:110-127)",
-                "bound": "hbm", "achieved": cbytes / t / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": cbytes / t / 1e9 / HBM_PEAK_GBS, "traffic": measured_traffic(B, n, "conv_proj_hbm_bytes_per_launch"),
+                "bound": "mfma", "achieved": cflops / t / 1e12, "peak": edge_peak, "unit": "TFLOP/s",
+                "frac": cflops / t / 1e12 / edge_peak, "traffic": pmc,
+                "peak_note": edge_peak_note, "frac_of_fp32_mfma_peak": cflops / t / 1e12 / MFMA_F32_PEAK_TFLOPS,
                 "avg_launch_ms": conv_ms.value, "launches_timed": int(conv_launches.value),
                 "launches_per_step": int(round(conv_launches.value / args.steps)),
+                "algorithmic_flops_per_launch": cflops,
+                "flops_note": "2 D C FLOP per (edge, orientation) row, rows = (sum of in-degrees measured on the device) x 16",
                 "algorithmic_bytes_per_launch": cbytes,
-                "bytes_note": "stash 768 B per (edge, orientation) row read once + node feature rows read once + convolved rows written once",
-                "mfma": {"achieved": cflops / t / 1e12, "peak": edge_peak, "unit": "TFLOP/s", "frac": cflops / t / 1e12 / edge_peak,
-                         "algorithmic_flops_per_launch": cflops, "peak_note": edge_peak_note},
+                "bytes_note": "SURVEY.md 8(d): one conv pass = read x + write x_1 = 2 N O C 4 bytes; the stash is NOT in it",
+                "hbm": {"achieved": cbytes / t / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": cbytes / t / 1e9 / HBM_PEAK_GBS},
+                "stash_bytes_per_launch": stash_bytes_per_launch(Nl, row_bytes),
+                "stash_note": f"design-added stream: {row_bytes} B per (slot, orientation) row, all 8 slots of every receiver "
+                              "(written once by the edge kernel, read once per layer); counted in `traffic`, not in `achieved`",
+                "traffic_over_algorithmic_bytes": (pmc / cbytes) if pmc else None,
                 "share_of_step": conv_ms.value * round(conv_launches.value / args.steps) / (1e3 * el_eager / args.steps),
                 "edge_kernel": edge_roof,
             }
+        # both step-level fractions, from the algorithmic figures
+        sb = step_bytes(N, e_mean, B)
+        step_traffic = measured_traffic(B, n, "hbm_bytes_per_step_sampling_kernels")
+        step_roof = {
+            "algorithmic_flops": step_flops, "algorithmic_bytes": sb,
+            "achieved_flops": step_flops / (ms_per_step * 1e-3) / (MFMA_F32_PEAK_TFLOPS * 1e12),
+            "achieved_flops_of_split_scheme_roof": step_flops / (ms_per_step * 1e-3) / (edge_peak * 1e12),
+            "achieved_hbm": sb / (ms_per_step * 1e-3) / (HBM_PEAK_GBS * 1e9),
+            "traffic": step_traffic, "traffic_over_algorithmic_bytes": (step_traffic / sb) if step_traffic else None,
+            "note": "achieved_flops = F / (t x 157.3e12) (can exceed 1: the dense layers run as 3 fp16 MFMA products per fp32 "
+                    f"product; against that scheme's roof, {edge_peak:.0f} TFLOP/s: achieved_flops_of_split_scheme_roof); achieved_hbm = "
+                    "Bytes / (t x 8e12); per GPU; traffic = PMC bytes per step of the committed rocprofv3 passes",
+        }
         out = {
             "metric": "denoising steps/sec (crystal-steps, whole node)",
             "value": crystal_steps_per_s,
@@ -567,8 +653,11 @@ def run_rank(args, rank, local_rank, world):
             "batch_steps_per_sec": world * args.steps / elapsed,
             "crystals_per_min": 60.0 * crystal_steps_per_s / (T - 1),
             "step_tflops_algorithmic": world * step_flops / (ms_per_step * 1e-3) / 1e12,
-            "roofline": dict(roofline, fp32_mfma_variant=fp32_variant),
+            "roofline": dict(roofline, step=step_roof, fp32_mfma_variant=fp32_variant),
+            "ranks": ranks_info,
         }
+        if timing_only:
+            out["INVALID_timing_only_experiment"] = True
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(model, B, n, T, args.cpu_steps)
         emit(out)
@@ -656,6 +745,13 @@ def run_rank_c5(args, rank, local_rank, world):
         model.training_step(batches[i % len(batches)])
     torch.cuda.synchronize(dev)
     fb_ms = 1e3 * (time.perf_counter() - t1) / args.steps
+    ranks_info = {"backend": (dist.get_backend() if dist is not None else None),
+                  "world_size": (dist.get_world_size() if dist is not None else 1),
+                  "data_path_collectives": 1 if world > 1 else 0,
+                  "note": "one all-reduce of the flat fp32 gradient bucket per step (arreau_amd.train.optimizer_step); RCCL when the backend is nccl",
+                  "per_rank": gather_json(dist, dev if backend == "nccl" else "cpu", world,
+                                          dict(device_identity(torch, dev), rank=rank, local_rank=local_rank, pid=os.getpid(),
+                                               mean_atoms_per_batch=n_atoms))}
     if rank == 0:
         ms = 1e3 * elapsed / args.steps
         flops = 3.0 * step_flops_per_atom(C=args.hidden_dim) * n_atoms  # forward + backward ~ 3 x forward
@@ -670,6 +766,7 @@ def run_rank_c5(args, rank, local_rank, world):
                        "crystals_per_gpu": B, "mean_atoms_per_batch": n_atoms, "hidden_dim": args.hidden_dim,
                        "parallelism": f"data parallel x{world}: one all-reduce of the {n_params / 1e6:.2f}M-parameter fp32 gradient per step"},
             "last_loss": float(loss),
+            "ranks": ranks_info,
             "forward_backward_ms": fb_ms,
             "roofline": {"kernel": "training step, forward + backward (sgemm_kernel + elementwise kernels of train_net.hip)",
                          "bound": "mfma", "achieved": flops / (fb_ms * 1e-3) / 1e12, "peak": MFMA_F32_PEAK_TFLOPS,

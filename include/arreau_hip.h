@@ -130,6 +130,8 @@ typedef struct arreau_status {
     int32_t edge_kernel;
     int32_t mlp_kernel;
     int32_t conv_kernel;
+    int32_t basis_row_bytes; /* conv_kernel == 2: bytes of the stashed basis per (edge, orientation) row the kernels really used
+                              * (768: fp16 plane + fp8 e4m3 residual plane; 1024: two fp16 planes); 0 otherwise */
 } arreau_status;
 /* Reads (and with reset != 0 clears) the status word; synchronises `stream`. */
 int arreau_model_status(const arreau_model* model, arreau_status* out, int32_t reset, void* stream);

@@ -25,6 +25,10 @@ def test_self_launch_two_ranks_stub():
     assert d["n_gpus"] == 2 and d["steps"] == 5 and len(d["per_rank_ms"]) == 2
     assert d["per_rank_ms"][1] > d["per_rank_ms"][0]  # the stub's rank 1 is slower ...
     assert d["ms_per_step"] >= max(d["per_rank_ms"])  # ... and the reported time covers the slowest rank
+    # the line proves its ranks: backend and size as the process group sees them, one record per rank from distinct processes
+    r = d["ranks"]
+    assert r["backend"] == "gloo" and r["world_size"] == 2 and r["data_path_collectives"] == 0
+    assert [x["rank"] for x in r["per_rank"]] == [0, 1] and len({x["pid"] for x in r["per_rank"]}) == 2
 
 
 def test_self_launch_refuses_when_gpus_are_missing():

@@ -133,7 +133,7 @@ def test_general_shape_training_step_matches_oracle_autograd(dev, odd_model):
             continue
         err = float((got[name].cpu() - w).abs().max())
         scale = max(float(w.abs().max()), 1e-7)
-        assert err <= 2e-3 * scale + 1e-7, (name, err, scale)
+        assert err <= 1e-4 * scale + 1e-7, (name, err, scale)
         checked += 1
     assert checked >= 9 + 10 * len(mm.model.interaction_layers)
     # after an optimiser step the SAME engine keeps sampling (plain weights are refreshed on the device; nothing is packed)

@@ -341,6 +341,89 @@ def test_full_size_architecture_parity(dev, full_model):
         assert err_split <= 2 * err_exact + ulp, (name, err_split, err_exact)
 
 
+def test_plain_tolerance_on_a_model_with_order_one_outputs(dev):
+    """The north-star bound as a PLAIN absolute 1e-5 on all three outputs, no magnitude scaling.  The default synthetic
+    checkpoint's random read-out rows make the pooled lattice prediction a sum of ~n values of order 3 (|len0| ~ 58 at 20
+    atoms), which is why assert_scores_close bounds it in ulps of that sum; a trained model predicts lengths / n = O(1)
+    (diffusion_loss.py:264-267).  This model's pooled read-out rows are scaled by 1/32 (make_synthetic_model), so eps,
+    logits and len0 are all of order one -- and all three must meet 1e-5 as written, teacher-forced and with the
+    library's own neighbour list, uniform and ragged batches, first / middle / last timesteps."""
+    from arreau_amd.checkpoint import make_synthetic_model
+    m = make_synthetic_model(S=90, seed=1234, pooled_readout_scale=1.0 / 32.0).to(dev)
+    om32 = oracle_from_module(m, torch.float32)
+    eng = m.engine()
+    worst = [0.0, 0.0, 0.0]
+    for counts, seed, t in (([20, 20], 7, 999), ([20] * 8, 3, 500), ([13, 20, 7, 20, 1, 16], 5, 2), ([20] * 4, 9, 1)):
+        state = random_state(90, counts, seed, sampler_like=True)
+        eps_o, logits_o, len0_o, (ei, dists, direction, _c, _l) = _oracle_scores(om32, *state, t)
+        assert float(len0_o.abs().max()) < 8.0 and float(logits_o.abs().max()) < 16.0  # order one: nothing to scale by
+        N, B = sum(counts), len(counts)
+        deg, src, sdir, sdist = slots_from_edges(ei, dists, direction, N, 8)
+        f, ty, le, an, off = _to_dev(dev, *state)
+        t_c = torch.full((B,), t, device=dev, dtype=torch.int32)
+        forced = eng.predict_scores(f, ty, le, an, t_c, off, edges=tuple(x.to(dev).contiguous() for x in (deg, src, sdir, sdist)))
+        own = eng.predict_scores(f, ty, le, an, t_c, off)
+        for tag, got in (("teacher-forced", forced), ("own neighbour list", own)):
+            for i, (name, a, b) in enumerate((("eps", got[0], eps_o), ("logits", got[1], logits_o), ("len0", got[2], len0_o))):
+                err = float((a.cpu() - b).abs().max())
+                worst[i] = max(worst[i], err)
+                assert err <= TOL, (counts, t, tag, name, err, float(b.abs().max()))
+    eng.check_status()
+    print(f"\n[plain 1e-5] worst eps / logits / len0 deviation from the fp32 oracle: {worst[0]:.2e} / {worst[1]:.2e} / {worst[2]:.2e}")
+    eng.close()
+
+
+def test_loop_at_the_benchmark_size_is_bitwise_across_eager_graph_and_per_step(dev, full_model):
+    """The exact path bench.py's `value` is measured on -- 256 crystals x 20 atoms, S = 90, T = 1000, basis form of the
+    message path, in-kernel Philox noise, no prep launch per step, hipGraph replay -- compared at THAT size: five steps
+    from t = 999 through (i) the per-step entry points predict_scores + reverse_step fed with arreau_philox_fill's draws,
+    (ii) arreau_sample_loop eager, (iii) arreau_sample_loop replayed as a hipGraph: the state after the stretch must be
+    bit-identical in all three, and with fixed cell lengths (bench.py's d_fixed_lengths) eager and replay must agree."""
+    from arreau_amd.diffusion.diffusion_helpers import crystal_offsets
+    m, _ = full_model
+    eng = m.engine()
+    eng.set_variant(4, 3)
+    B, n, S, T, seed, steps = 256, 20, 90, 1000, 424242, 5
+    N = B * n
+    rng = np.random.RandomState(1000)
+    g = torch.Generator().manual_seed(1000)
+    angles = torch.tensor(np.stack([np.full(B, 90.0), rng.uniform(90, 180, B), np.full(B, 90.0)], 1), dtype=torch.float32)
+    lengths, frac = torch.randn(B, 3, generator=g), torch.randn(N, 3, generator=g)
+    d = lambda v: v.to(dev).contiguous()
+    off, an = crystal_offsets(torch.full((B,), n), dev), d(angles)
+
+    def fresh():
+        return d(frac.clone()), torch.full((N,), S - 1, device=dev, dtype=torch.int32), d(lengths.clone()), torch.zeros(B, 3, 3, device=dev)
+
+    f, ty, le, lat = fresh()
+    for t in range(T - 1, T - 1 - steps, -1):
+        t_c = torch.full((B,), t, device=dev, dtype=torch.int32)
+        eps, logits, len0 = eng.predict_scores(f, ty, le, an, t_c, off)
+        if t == T - 1:
+            st = eng.check_status()
+            assert st["conv_variant"] == 2 and st["edge_kernel"] == "fp16x3" and st["basis_row_bytes"] == 768, st
+        eng.reverse_step(f, ty, le, an, t_c, off, eps, logits, len0, eng.philox_fill(seed, t, 0, 3 * B).view(B, 3),
+                         eng.philox_fill(seed, t, 1, 3 * N).view(N, 3), eng.philox_fill(seed, t, 2, N * S).view(N, S), lat)
+    ref = (f, ty, le, lat)
+    assert torch.isfinite(f).all() and torch.isfinite(le).all()
+    for use_graph in (False, True):
+        out = fresh()
+        eng.sample_loop(out[0], out[1], out[2], an, off, T - 1, steps, seed, None, out[3], use_graph=use_graph)
+        assert eng.check_status()["conv_variant"] == 2
+        for name, a, b in zip(("frac", "types", "lengths", "lattice"), out, ref):
+            assert torch.equal(a, b), (use_graph, name, int((a != b).sum()))
+    fixed = d(lengths.clone())
+    res = []
+    for use_graph in (False, True):
+        out = fresh()
+        eng.sample_loop(out[0], out[1], out[2], an, off, T - 1, steps, seed, None, out[3], use_graph=use_graph, fixed_lengths=fixed)
+        assert torch.equal(out[2], fixed)
+        res.append(out)
+    for name, a, b in zip(("frac", "types", "lengths", "lattice"), res[0], res[1]):
+        assert torch.equal(a, b), ("fixed cell", name)
+    eng.check_status()
+
+
 # ------------------------------------------------------------------------------------------- reverse updates
 @pytest.mark.parametrize("t", [99, 50, 2, 1])
 def test_reverse_step_matches_oracle(dev, small_model, t):
@@ -1144,13 +1227,15 @@ def test_range_launches_of_the_basis_form(dev, full_model, monkeypatch):
     assert_scores_close(got, (eps_o, logits_o, len0_o), tag="260 receivers")
 
 
+@pytest.mark.multistream
 def test_multi_stream_experiment_report(dev, full_model):
     """The opt-in experiment (ARREAU_ALLOW_MULTISTREAM=1): the same slices forked onto their own streams, and the pipelined
     sampling loop (own stream and step graph per slice, no per-step join).  Every slice computes what the whole batch
     computes for its crystals, so the results SHOULD be bit-identical -- on MI355X, with kernels of two streams sharing CUs,
-    one crystal in a few runs was not (cause unknown; hazards, counted waits and leftover LDS /
-    register state ruled out).  This test asserts bit-equality; a mismatch is reported as an expected failure with the
-    number of crystals that differed -- the datum of this run -- instead of being tolerated."""
+    one crystal in a few runs was not.  Opt-in (tests/conftest.py: ARREAU_TEST_MULTISTREAM=1 or
+    -m multistream; skipped otherwise, because the library refuses the mode by default): it asserts bit-equality, prints
+    which crystals differed per run, and a mismatch FAILS (round 3 reported it as an expected failure, which kept a
+    recurrence green)."""
     m, _ = full_model
     eng = m.engine()
     counts, (frac, types, lengths, angles, na), d, off = _ragged_37(dev)
@@ -1194,8 +1279,7 @@ def test_multi_stream_experiment_report(dev, full_model):
     eng.check_status()
     n_bad = sum(len(v) for v in report.values())
     print(f"[multi-stream experiment] crystals that differ from the one-stream result, per run: {report}")
-    if n_bad:
-        pytest.xfail(f"multi-stream slices not bit-identical in this run: {report}")
+    assert n_bad == 0, f"multi-stream slices not bit-identical in this run: {report}"
 
 
 @pytest.mark.parametrize("case", ["small-launch forms (3 crystals)", "throughput forms (ragged 64 crystals)", "large cells (2 x 64 atoms)"])

@@ -13,6 +13,9 @@ from tests.helpers import oracle_from_module
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-5
+# every gradient tensor against oracle autograd, relative to the tensor's largest entry (round 3 allowed 2e-3; the products are
+# exact-fp32 or split-precision MFMA GEMMs and the scatter is an ordered sum: rounding level is ~1e-6)
+GRAD_TOL = 1e-4
 
 
 @pytest.fixture(scope="module")
@@ -164,7 +167,7 @@ def test_training_step_gradients_match_oracle_autograd(setup):
         g = got[name].cpu()
         scale = max(float(w.abs().max()), 1e-7)
         err = float((g - w).abs().max())
-        assert err <= 2e-3 * scale + 1e-7, (name, err, scale)
+        assert err <= GRAD_TOL * scale + 1e-7, (name, err, scale)
         checked += 1
     assert checked >= 8 + 5 * 10 + 1  # basis (4) + fiber (4) + embed + per layer 10 (incl. layer_scale) + read-outs
     assert "t_emb.gaussian_fourier_proj_w" not in got  # requires_grad = False in the reference too
@@ -272,3 +275,78 @@ def test_two_rank_training_loop_reduces_the_loss(tmp_path):
     ck = load_lightning_checkpoint(out)
     assert bool(ck["state_dict"]["model.interaction_layers.0.conv.callibrated"])
     print("two-rank training: first-epoch loss", first, "last-epoch loss", last)
+
+
+def _alexandria_like_batch(B, S, seed, T=100):
+    """B crystals with Alexandria-PBE's size statistics (mean ~8 atoms, cap 64), every random draw of the loss injected."""
+    from oracle import geometry as OG
+    rng = np.random.RandomState(seed)
+    num_atoms = np.clip(rng.geometric(1.0 / 8.0, size=B), 1, 64).tolist()
+    N = int(sum(num_atoms))
+    vol = np.array(num_atoms) / 0.055  # density of find_avg_density_of_dataset.py:40
+    edge = vol ** (1.0 / 3.0)
+    lengths = torch.tensor(edge[:, None] * rng.uniform(0.8, 1.25, size=(B, 3)), dtype=torch.float32)
+    angles = torch.tensor(np.deg2rad(rng.uniform(75, 105, size=(B, 3))), dtype=torch.float32)
+    lattice0 = OG.lattice_from_params(lengths, angles)
+    batch = SimpleNamespace(X0=torch.tensor(rng.uniform(0, 1, size=(N, 3)), dtype=torch.float32),
+                            A0=torch.tensor(rng.randint(0, S - 1, size=N)), L0=lattice0.reshape(-1, 3),
+                            num_atoms=torch.tensor(num_atoms))
+    timestep = torch.tensor(rng.randint(1, T + 1, size=B))
+    g = torch.Generator().manual_seed(seed)
+    noise = (torch.randn(N, 3, generator=g), torch.rand(N, S, generator=g), torch.randn(B, 3, generator=g))
+    return batch, lattice0, timestep, noise, N
+
+
+def test_training_step_gradients_at_the_bench_size_and_bitwise_repeatable(setup):
+    """BASELINE configs[4]'s per-GPU share -- 64 crystals, ~530 atoms -- through the library's forward + backward: every
+    gradient tensor within GRAD_TOL of oracle autograd, and the SAME bits when the step is repeated (round 4: the sender-side
+    gradient of the spatial conv is an ordered segmented sum over a reversed adjacency; it was an fp32 atomicAdd scatter,
+    reproducible only to rounding)."""
+    import copy
+    m, om, *_ = setup
+    batch, lattice0, timestep, noise, N = _alexandria_like_batch(64, 12, 21)
+    assert 350 <= N <= 800, N
+    mm = copy.deepcopy(m)
+    for layer in mm.model.interaction_layers:
+        layer.conv.callibrated.fill_(True)
+    loss = mm.training_step(batch, timestep=timestep, noise=noise)
+    first = {n: p.grad.clone() for n, p in mm.named_parameters() if p.grad is not None}
+    for p in mm.parameters():
+        p.grad = None
+    loss2 = mm.training_step(batch, timestep=timestep, noise=noise)
+    assert float(loss) == float(loss2)
+    for n, p in mm.named_parameters():
+        if p.grad is not None:
+            assert torch.equal(p.grad, first[n]), ("gradient not bitwise repeatable", n)
+    loss_o, want = _oracle_grads(om, batch, lattice0, timestep, noise)
+    assert abs(float(loss) - loss_o) <= TOL * max(1.0, abs(loss_o))
+    worst = ("", 0.0)
+    for name, w in want.items():
+        if w.numel() == 0:
+            continue
+        scale = max(float(w.abs().max()), 1e-7)
+        err = float((first[name].cpu() - w).abs().max())
+        if err / scale > worst[1]:
+            worst = (name, err / scale)
+        assert err <= GRAD_TOL * scale + 1e-7, (name, err, scale)
+    print(f"\n[gradients, 64 crystals / {N} atoms] worst relative deviation from oracle autograd: {worst[1]:.2e} ({worst[0]})")
+
+
+def test_make_train_preset_batch_fits_the_gradient_scratch():
+    """The reference's `make train` preset (Makefile:6-7: batch_size 270, hidden_dim 200; ~2,200 atoms per batch) must run:
+    round 3's batched fiber-kernel gradient put all L layers' partial sums into one scratch and failed with
+    ARREAU_ECAPACITY from ~2,100 atoms at hidden_dim 200.  Checked: the step runs (the partial sums now go
+    through the scratch in groups of layers that fit) and every gradient is finite, the fiber-kernel one non-zero."""
+    from arreau_amd.checkpoint import make_synthetic_model
+    dev = torch.device("cuda", 0)
+    m = make_synthetic_model(S=12, seed=7, num_timesteps=100, hidden_dim=200).to(dev)
+    for layer in m.model.interaction_layers:
+        layer.conv.callibrated.fill_(True)
+    batch, _lat, timestep, noise, N = _alexandria_like_batch(270, 12, 5)
+    assert N > 2100, N
+    loss = m.training_step(batch, timestep=timestep, noise=noise)
+    assert np.isfinite(float(loss))
+    grads = {n: p.grad for n, p in m.named_parameters() if p.grad is not None}
+    assert all(torch.isfinite(g).all() for g in grads.values())
+    key = [n for n in grads if n.endswith("interaction_layers.0.conv.fiber_kernel.weight")]
+    assert key and float(grads[key[0]].abs().max()) > 0
