@@ -53,6 +53,7 @@ struct arreau_model {
     const float* edge_bf16;  // w1 | w2 | wk_l as bf16x3 chunks (uint16 data), one chunk per output tile
     const float* edge_f16;   // w1 | w2 | wk_l as fp16x3 chunks (uint16 data, two planes), one chunk per output tile
     int f16_ok;              // 1 when every packed weight fits fp16 (|w| < 6e4): the fp16x3 kernels may be used
+    float edge_act_bound, node_act_bound;  // weight-derived bounds of the fp16 operands of the edge / ConvNext chains (model.hip)
     // Arithmetic / geometry variants requested for this model (defaults from ARREAU_*_VARIANT at create,
     // arreau_model_set_variant overrides) and what the last arreau_predict_scores actually launched.
     int edge_variant, mlp_variant, conv_variant, readout_variant;

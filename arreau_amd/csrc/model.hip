@@ -5,6 +5,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <vector>
 
 #include "internal.h"
@@ -269,6 +270,55 @@ extern "C" int arreau_model_create(const arreau_config* cfg, const arreau_state_
                            sd->vp_alpha_bars, sd->vp_betas, sd->q_one_step_transposed, sd->q_mats};
     for (const float* p : need) ARREAU_REQUIRE(p != nullptr, "arreau_model_create: missing state_dict entry");
 
+    // Range safety of the fp16x3 kernels (round 4): every fp16 OPERAND of the split-precision chains is bounded here from the
+    // weights alone, over everything the inputs can be --
+    //   edge chain: the 83 monomials (|pair invariants|, |cosines| <= 1, dist <= radius: R^(powers of dist)), the hidden units
+    //     GELU(W1 mono + b1) <= sum_i |W1f[j,i]| bound_i + |b1_j|, the basis GELU(W2 h + b2) * window <= the same one layer on;
+    //   node chain (per layer): the LayerNorm output (|xhat|_2 = sqrt(C)): sqrt(C - 1) |gamma_i| + |beta_i|, and the hidden units
+    //     GELU(W1 xn + b1) <= sqrt(C) |W1[j,:] * gamma|_2 + |W1[j,:] . beta| + |b1_j|  (Cauchy-Schwarz).
+    // A bound inside the fp16 range proves the kernels cannot overflow.  The L1 / L2 bounds are loose (every sign aligned), so
+    // a bound up to 64 x the range keeps the fp16x3 kernels and relies on the sticky NONFINITE flag (an overflow is loud:
+    // DiffusionLoss.sample then re-runs the batch on the full-range bf16x6 kernels); beyond that the model starts on bf16x6.
+    float edge_bound = 0.f, node_bound = 0.f;
+    {
+        std::vector<float> w1f_b;
+        fold_poly_weight(sd->basis_w1, C, w1f_b);
+        auto mons = monomials();
+        const double R = cfg->radius > 1.0f ? cfg->radius : 1.0f;
+        double mono_max = 0.0, h1_max = 0.0, basis_max = 0.0;
+        std::vector<double> mb(mons.size());
+        for (size_t mi = 0; mi < mons.size(); ++mi) {
+            double b = 1.0;
+            for (int q = 0; q < mons[mi].n; ++q) b *= mons[mi].idx[q] == 2 ? R : 1.0;
+            mb[mi] = b;
+            mono_max = std::max(mono_max, b);
+        }
+        for (int j = 0; j < C; ++j) {
+            double a = fabs((double)sd->basis_b1[j]);
+            for (size_t mi = 0; mi < mons.size(); ++mi) a += fabs((double)w1f_b[(size_t)j * ARREAU_MONO_PAD + mi]) * mb[mi];
+            h1_max = std::max(h1_max, a);
+        }
+        for (int j = 0; j < D; ++j) {
+            double a = fabs((double)sd->basis_b2[j]);
+            for (int i = 0; i < C; ++i) a += fabs((double)sd->basis_w2[(size_t)j * C + i]) * h1_max;
+            basis_max = std::max(basis_max, a);
+        }
+        edge_bound = (float)std::max(mono_max, std::max(h1_max, basis_max));
+        double nb = 0.0;
+        for (int l = 0; l < L; ++l) {
+            const float* g = sd->norm_w + (size_t)l * C;
+            const float* be = sd->norm_b + (size_t)l * C;
+            for (int i = 0; i < C; ++i) nb = std::max(nb, sqrt((double)C - 1.0) * fabs((double)g[i]) + fabs((double)be[i]));
+            for (int j = 0; j < H; ++j) {
+                const float* w = sd->linear1_w + ((size_t)l * H + j) * C;
+                double n2 = 0.0, dot = 0.0;
+                for (int i = 0; i < C; ++i) { n2 += (double)w[i] * g[i] * (double)w[i] * g[i]; dot += (double)w[i] * be[i]; }
+                nb = std::max(nb, sqrt((double)C) * sqrt(n2) + fabs(dot) + fabs((double)sd->linear1_b[(size_t)l * H + j]));
+            }
+        }
+        node_bound = (float)nb;
+    }
+
     BlobBuilder bb;
     std::vector<float> tmp;
     const size_t off_ori = bb.put(sd->ori_grid, (size_t)O * 3);
@@ -463,8 +513,13 @@ extern "C" int arreau_model_create(const arreau_config* cfg, const arreau_state_
     m->t_w1f = b + off_t_w1f; m->t_w2 = b + off_t_w2; m->t_wk = b + off_t_wk; m->t_lin1 = b + off_t_lin1;
     m->t_lin2 = b + off_t_lin2; m->t_ro_w = b + off_t_ro_w;
     auto env_int = [](const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; };
-    m->edge_variant = env_int("ARREAU_EDGE_VARIANT", 4);
-    m->mlp_variant = env_int("ARREAU_MLP_VARIANT", 3);
+    m->edge_act_bound = edge_bound;
+    m->node_act_bound = node_bound;
+    // (see the bounds above: provably in range, or within the loose bound's slack and guarded by the NONFINITE flag -> fp16x3;
+    // far outside -> the full-range bf16x6 kernels from the start.  The environment and arreau_model_set_variant override.)
+    const float f16_slack = 64.0f * 65504.0f;
+    m->edge_variant = env_int("ARREAU_EDGE_VARIANT", edge_bound <= f16_slack ? 4 : 3);
+    m->mlp_variant = env_int("ARREAU_MLP_VARIANT", node_bound <= f16_slack ? 3 : 1);
     m->conv_variant = env_int("ARREAU_CONV_VARIANT", 2);  // 2: basis form + conv_proj.hip; 1: K stash + streamed conv; 0: register conv
     m->readout_variant = env_int("ARREAU_READOUT_VARIANT", 1);
     m->ran_edge = m->ran_mlp = m->ran_conv = -1;
@@ -545,6 +600,8 @@ extern "C" int arreau_model_status(const arreau_model* model, arreau_status* out
     out->mlp_kernel = model->ran_mlp;
     out->conv_kernel = model->ran_conv;
     out->basis_row_bytes = model->ran_conv == 2 ? (arreau_basis_fp8() ? 768 : 1024) : 0;
+    out->edge_activation_bound = model->edge_act_bound;
+    out->node_activation_bound = model->node_act_bound;
     return ARREAU_OK;
 }
 

@@ -1,10 +1,22 @@
-// Exact-fp32 GEMM on the matrix pipe (v_mfma_f32_32x32x2_f32) for the shape-general / training network (train_net.hip).
+// GEMMs of the shape-general / training network (train_net.hip) on the matrix pipe: exact fp32 (v_mfma_f32_32x32x2_f32,
+// 157 TFLOP/s peak) and -- round 4 -- split precision on the 16-bit matrix instructions (sgemm_split_kernel below: fp16x3
+// for products of O(1) operands, bf16x6 where an operand is a gradient of arbitrary magnitude).
 #pragma once
+#include "f16x3.h"
 #include "internal.h"
 
 constexpr size_t ARREAU_SGEMM_PARTIAL_FLOATS = (size_t)64 * 512 * 512;  // split-K partial sums (64 slices of the largest weight)
 
 namespace arreau_sgemm_detail {
+// bf16x6 pieces (the scheme of bf16x6.h, which cannot be included next to f16x3.h: both define the kernels' GELU)
+typedef __bf16 sg_bf16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ unsigned sg_pack_hi16(float hi, float lo) {  // {hi[31:16], lo[31:16]}: two truncated bf16
+    return __builtin_amdgcn_perm(__float_as_uint(hi), __float_as_uint(lo), 0x07060302u);
+}
+__device__ __forceinline__ float sg_bf16_residual(float x) { return x - __uint_as_float(__float_as_uint(x) & 0xffff0000u); }  // exact
+__device__ __forceinline__ f32x16 sg_mfma_bf16(const u32x4& a, const u32x4& b, const f32x16& c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(sg_bf16x8, a), __builtin_bit_cast(sg_bf16x8, b), c, 0, 0, 0);
+}
 
 // C[m,n] = alpha * sum_k A(m,k) B(k,n) + beta * C[m,n];  A(m,k) = A[m*as0 + k*as1], B(k,n) = B[k*bs0 + n*bs1].
 // Exact fp32 on the matrix pipe (v_mfma_f32_32x32x2_f32): a (64 WM) x (64 WN) output tile per workgroup, four waves in a
@@ -153,6 +165,162 @@ __global__ __launch_bounds__(256) void sgemm_kernel(int M, int N, int K, const f
                 }
             }
 }
+// Split-precision form of the kernel above (round 4; BASELINE configs[4] asks for the training step on matrix-rate
+// arithmetic).  Same tiling, same operand addressing, same split-K protocol; what changes is the staging -- every fp32
+// operand element is split into 16-bit planes ON ITS WAY INTO LDS (once per element and tile, the cost amortised over the
+// 64 / 128 outputs it feeds) -- and the inner loop, which runs v_mfma_f32_32x32x16_{f16,bf16} on 16-byte fragments:
+//   MODE 1, fp16x3 (f16x3.h):  a = a1 + a2 / 2^11, two fp16 planes, a b ~= a1 b1 + (a1 b2 + a2 b1) / 2^11: three products,
+//           `main` and `cross` accumulators folded at the end.  Operand range: |v| < 65504, full 22-bit precision down to
+//           6e-5 -- forward products (activations x weights), the arithmetic the sampling kernels use.
+//   MODE 2, bf16x6 (bf16x6.h): a = a1 + a2 + a3 by exact 8-bit truncation, six products into one accumulator, the full fp32
+//           exponent range -- every product with a GRADIENT operand (magnitudes from 1e-9, e.g. behind layer_scale = 1e-6, to
+//           O(1): an fp16 plane would go subnormal there).
+// LDS image: plane-major [P][rows][BK + 8] halves, k contiguous per row (a lane's fragment = 8 consecutive k of its row:
+// one ds_read_b128; the 80-byte row stride makes those reads conflict-free); operands whose k is contiguous in memory are
+// written as 8-byte pieces, the others (a gradient read as dY^T) element by element.
+template <int MODE, int WM, int WN>
+__global__ __launch_bounds__(256) void sgemm_split_kernel(int M, int N, int K, const float* __restrict__ A, long as0, long as1,
+                                                          const float* __restrict__ B, long bs0, long bs1, float* __restrict__ C,
+                                                          int ldc, float alpha, float beta, int kchunk, float* __restrict__ partial,
+                                                          int splits, long a_bs, long b_bs, long c_bs) {
+    constexpr int BK = 32, TM = 64 * WM, TN = 64 * WN, P = MODE == 1 ? 2 : 3, LDK = BK + 8;
+    const int bi = (int)blockIdx.z / splits, zi = (int)blockIdx.z - bi * splits;
+    A += (long)bi * a_bs;
+    B += (long)bi * b_bs;
+    C += (long)bi * c_bs;
+    constexpr int KP = BK / 4;
+    constexpr int PA = WM * BK / 16, PB = WN * BK / 16;
+    __shared__ __attribute__((aligned(16))) unsigned short As[P][TM][LDK], Bs[P][TN][LDK];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int h = lane >> 5, j = lane & 31, wm = (wave >> 1) * (32 * WM), wn = (wave & 1) * (32 * WN);
+    const int m0 = blockIdx.y * TM, n0 = blockIdx.x * TN;
+    const int kbeg = zi * kchunk, kend = min(K, kbeg + kchunk);
+    constexpr int NACC = MODE == 1 ? 2 : 1;  // fp16x3: main + cross
+    f32x16 acc[NACC][WM][WN];
+#pragma unroll
+    for (int q = 0; q < NACC; ++q)
+#pragma unroll
+        for (int a = 0; a < WM; ++a)
+#pragma unroll
+            for (int b = 0; b < WN; ++b)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[q][a][b][r] = 0.f;
+    const bool a_kmajor = as1 == 1, b_nmajor = bs1 == 1;
+    f32x4 ra[PA], rb[PB];
+    auto fetch = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < PA; ++i) {
+            const int idx = tid + 256 * i;
+            const int mm = a_kmajor ? idx / KP : (idx % (TM / 4)) * 4, kk = a_kmajor ? (idx % KP) * 4 : idx / (TM / 4);
+            const int m = m0 + mm, k = k0 + kk;
+            ra[i] = (m < M && k < kend) ? *reinterpret_cast<const f32x4*>(A + (long)m * as0 + (long)k * as1) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+#pragma unroll
+        for (int i = 0; i < PB; ++i) {
+            const int idx = tid + 256 * i;
+            const int nn = b_nmajor ? (idx % (TN / 4)) * 4 : idx / KP, kk = b_nmajor ? idx / (TN / 4) : (idx % KP) * 4;
+            const int n = n0 + nn, k = k0 + kk;
+            rb[i] = (n < N && k < kend) ? *reinterpret_cast<const f32x4*>(B + (long)k * bs0 + (long)n * bs1) : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    // planes of four consecutive values as P pairs of dwords (element 0 in the low half of w[.][0])
+    auto split4 = [&](const f32x4& v, unsigned (&w)[P][2]) {
+        if constexpr (MODE == 1) {
+            split_pair2<false>(f32x2{v[0], v[1]}, w[0][0], w[1][0]);
+            split_pair2<false>(f32x2{v[2], v[3]}, w[0][1], w[1][1]);
+        } else {
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const float lo = v[2 * q], hi = v[2 * q + 1];
+                w[0][q] = sg_pack_hi16(hi, lo);
+                const float rlo = sg_bf16_residual(lo), rhi = sg_bf16_residual(hi);
+                w[1][q] = sg_pack_hi16(rhi, rlo);
+                w[2][q] = sg_pack_hi16(sg_bf16_residual(rhi), sg_bf16_residual(rlo));
+            }
+        }
+    };
+    typedef unsigned u32x2v __attribute__((ext_vector_type(2)));
+    auto put = [&](unsigned short (*img)[LDK] /* one plane */, bool kcontig, int row, int kk, const unsigned (&w)[2]) {
+        if (kcontig) {
+            *reinterpret_cast<u32x2v*>(&img[row][kk]) = u32x2v{w[0], w[1]};
+        } else {  // four rows, one k
+            img[row + 0][kk] = (unsigned short)(w[0] & 0xffffu);
+            img[row + 1][kk] = (unsigned short)(w[0] >> 16);
+            img[row + 2][kk] = (unsigned short)(w[1] & 0xffffu);
+            img[row + 3][kk] = (unsigned short)(w[1] >> 16);
+        }
+    };
+    auto stage = [&]() {
+#pragma unroll
+        for (int i = 0; i < PA; ++i) {
+            const int idx = tid + 256 * i;
+            const int mm = a_kmajor ? idx / KP : (idx % (TM / 4)) * 4, kk = a_kmajor ? (idx % KP) * 4 : idx / (TM / 4);
+            unsigned w[P][2];
+            split4(ra[i], w);
+#pragma unroll
+            for (int p = 0; p < P; ++p) put(As[p], a_kmajor, mm, kk, w[p]);
+        }
+#pragma unroll
+        for (int i = 0; i < PB; ++i) {
+            const int idx = tid + 256 * i;
+            const int nn = b_nmajor ? (idx % (TN / 4)) * 4 : idx / KP, kk = b_nmajor ? idx / (TN / 4) : (idx % KP) * 4;
+            unsigned w[P][2];
+            split4(rb[i], w);
+#pragma unroll
+            for (int p = 0; p < P; ++p) put(Bs[p], !b_nmajor, nn, kk, w[p]);
+        }
+    };
+    fetch(kbeg);
+    for (int k0 = kbeg; k0 < kend; k0 += BK) {
+        stage();
+        __syncthreads();
+        if (k0 + BK < kend) fetch(k0 + BK);
+#pragma unroll
+        for (int ks = 0; ks < BK / 16; ++ks) {
+            u32x4 fa[WM][P], fb[WN][P];
+#pragma unroll
+            for (int a = 0; a < WM; ++a)
+#pragma unroll
+                for (int p = 0; p < P; ++p) fa[a][p] = *reinterpret_cast<const u32x4*>(&As[p][wm + 32 * a + j][16 * ks + 8 * h]);
+#pragma unroll
+            for (int b = 0; b < WN; ++b)
+#pragma unroll
+                for (int p = 0; p < P; ++p) fb[b][p] = *reinterpret_cast<const u32x4*>(&Bs[p][wn + 32 * b + j][16 * ks + 8 * h]);
+#pragma unroll
+            for (int a = 0; a < WM; ++a)
+#pragma unroll
+                for (int b = 0; b < WN; ++b) {
+                    if constexpr (MODE == 1) {
+                        acc[0][a][b] = mfma_f16(fa[a][0], fb[b][0], acc[0][a][b]);
+                        acc[1][a][b] = mfma_f16(fa[a][0], fb[b][1], acc[1][a][b]);
+                        acc[1][a][b] = mfma_f16(fa[a][1], fb[b][0], acc[1][a][b]);
+                    } else {  // small terms first (bf16x6.h)
+                        acc[0][a][b] = sg_mfma_bf16(fa[a][2], fb[b][0], acc[0][a][b]);
+                        acc[0][a][b] = sg_mfma_bf16(fa[a][1], fb[b][1], acc[0][a][b]);
+                        acc[0][a][b] = sg_mfma_bf16(fa[a][0], fb[b][2], acc[0][a][b]);
+                        acc[0][a][b] = sg_mfma_bf16(fa[a][1], fb[b][0], acc[0][a][b]);
+                        acc[0][a][b] = sg_mfma_bf16(fa[a][0], fb[b][1], acc[0][a][b]);
+                        acc[0][a][b] = sg_mfma_bf16(fa[a][0], fb[b][0], acc[0][a][b]);
+                    }
+                }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int a = 0; a < WM; ++a)
+#pragma unroll
+        for (int b = 0; b < WN; ++b)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * h, n = n0 + wn + 32 * b + j;
+                float v = acc[0][a][b][r];
+                if constexpr (MODE == 1) v = fmaf(acc[1][a][b][r], F16X3_INV_SCALE, v);
+                if (m < M && n < N) {
+                    if (splits > 1) partial[((size_t)blockIdx.z * M + m) * N + n] = v;
+                    else C[(size_t)m * ldc + n] = alpha * v + (beta != 0.f ? beta * C[(size_t)m * ldc + n] : 0.f);
+                }
+            }
+}
 __global__ void splitk_reduce_kernel(const float* __restrict__ partial, int Z, int M, int N, float* __restrict__ C, int ldc,
                                      float alpha, float beta, long c_bs /* blockIdx.y = product of the batch */) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -171,7 +339,7 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ partial, int Z, i
 // (16 tiles each) and fill it together.
 inline int arreau_sgemm(hipStream_t s, float* partial, int M, int N, int K, const float* A, long as0, long as1, const float* B,
                         long bs0, long bs1, float* C, int ldc, float alpha = 1.f, float beta = 0.f, int batch = 1, long a_bs = 0,
-                        long b_bs = 0, long c_bs = 0) {
+                        long b_bs = 0, long c_bs = 0, int mode = 0 /* 0: exact fp32; 1: fp16x3; 2: bf16x6 (sgemm_split_kernel) */) {
     using namespace arreau_sgemm_detail;
     if (M == 0 || N == 0 || batch <= 0) return ARREAU_OK;
     // Tile size.  The kernel is bound by the matrix pipe of the busiest CU, so what matters is how evenly the tiles divide
@@ -193,18 +361,27 @@ inline int arreau_sgemm(hipStream_t s, float* partial, int M, int N, int K, cons
         Z = min(8, K / 1024);  // a batch of long reductions over few tiles: still about four workgroups per CU
     }
     while (Z > 1 && (size_t)batch * Z * M * N > ARREAU_SGEMM_PARTIAL_FLOATS) --Z;
-    const int BK = small ? 32 : 16;
-    const int kchunk = ((K + Z - 1) / Z + BK - 1) / BK * BK;
-    Z = (K + kchunk - 1) / kchunk;
     // 16-byte operand fetches need the contiguous dimension and the leading dimension to be multiples of four floats
     const bool a_ok = (as1 == 1 && as0 % 4 == 0 && K % 4 == 0) || (as0 == 1 && as1 % 4 == 0 && M % 4 == 0);
     const bool b_ok = (bs1 == 1 && bs0 % 4 == 0 && N % 4 == 0) || (bs0 == 1 && bs1 % 4 == 0 && K % 4 == 0);
     const bool vec = a_ok && b_ok && ((size_t)A % 16 == 0) && ((size_t)B % 16 == 0) && a_bs % 4 == 0 && b_bs % 4 == 0;
+    // The split kernel pays where it can stage 8-byte pieces -- both operands contiguous along k (Y = X W^T, the forward
+    // products) -- and the reduction is long enough to amortise the tile prologue; measured (tools/exp/sgemm_bench.hip,
+    // profiles/r04_sgemm_bench.txt): [8512,128] x [512,128]^T 20.4 -> 13.3 us, [8512,512] x [128,512]^T 27.6 -> 17.6, [68096,256] x
+    // [640,256]^T 265 -> 211, K = 2048: 74 -> 152 TFLOP/s; with an operand read across its contiguous dimension (dY W, dY^T X:
+    // 2-byte LDS writes) it is SLOWER than the exact kernel (261 -> 325 us, 282 -> 367 us), so those stay exact.
+    const bool split = mode != 0 && vec && K >= 128 && as1 == 1 && bs0 == 1;
+    const int BK = (small || split) ? 32 : 16;
+    const int kchunk = ((K + Z - 1) / Z + BK - 1) / BK * BK;
+    Z = (K + kchunk - 1) / kchunk;
     auto launch = [&](auto kernel) {
         hipLaunchKernelGGL(kernel, dim3(gn, gm, Z * batch), dim3(256), 0, s, M, N, K, A, as0, as1, B, bs0, bs1, C, ldc, alpha, beta, kchunk,
                            partial, Z, a_bs, b_bs, c_bs);
     };
-    if (small) {
+    if (split) {
+        if (small) { if (mode == 1) launch(sgemm_split_kernel<1, 1, 1>); else launch(sgemm_split_kernel<2, 1, 1>); }
+        else { if (mode == 1) launch(sgemm_split_kernel<1, 2, 2>); else launch(sgemm_split_kernel<2, 2, 2>); }
+    } else if (small) {
         if (vec) launch(sgemm_kernel<1, 1, 1, 32>); else launch(sgemm_kernel<0, 1, 1, 32>);
     } else {
         if (vec) launch(sgemm_kernel<1, 2, 2, 16>); else launch(sgemm_kernel<0, 2, 2, 16>);

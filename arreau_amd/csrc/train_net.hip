@@ -654,6 +654,11 @@ inline unsigned blocks(long n, int per = 256) { return (unsigned)((n + per - 1) 
 // ---------------------------------------------------------------------------------------------
 struct arreau_train_ctx {
     int N = 0, B = 0, capN = 0, capB = 0;
+    // arithmetic of the dense products (sgemm.h): 0 exact fp32 MFMA, 1 fp16x3, 2 bf16x6.  The training step runs its forward
+    // products on fp16x3 (activations x weights: the sampling kernels' arithmetic) and every product with a gradient operand
+    // on bf16x6 (full exponent range); the shape-general SAMPLING path stays on the exact kernel (it is the arithmetic
+    // cross-check of the fused kernels).  ARREAU_TRAIN_GEMM=exact|split|fp16 (default split).
+    int fwd_mode = 0, bwd_mode = 0;
     float* buf = nullptr;
     size_t buf_floats = 0;
     // plain row-major weights (in the model blob): [C][96], [D][C], [L][C][D], [L][H][C], [L][C][H], [L][S+4][C]
@@ -714,29 +719,29 @@ size_t layout(arreau_train_ctx& t, const arreau_model* m, int N, int B, float* b
     return c.off;
 }
 
-int gemm(hipStream_t s, arreau_train_ctx& t, int M, int N, int K, const float* A, long as0, long as1, const float* B, long bs0,
+int gemm(hipStream_t s, arreau_train_ctx& t, int mode, int M, int N, int K, const float* A, long as0, long as1, const float* B, long bs0,
          long bs1, float* C, int ldc, float alpha = 1.f, float beta = 0.f) {
-    return arreau_sgemm(s, t.partial, M, N, K, A, as0, as1, B, bs0, bs1, C, ldc, alpha, beta);
+    return arreau_sgemm(s, t.partial, M, N, K, A, as0, as1, B, bs0, bs1, C, ldc, alpha, beta, 1, 0, 0, 0, mode);
 }
 // Y[rows][out] = X[rows][in] . W[out][in]^T
 int linear(hipStream_t s, arreau_train_ctx& t, long rows, int in, int out, const float* X, const float* W, float* Y,
            float alpha = 1.f, float beta = 0.f) {
-    return gemm(s, t, (int)rows, out, in, X, in, 1, W, 1, in, Y, out, alpha, beta);
+    return gemm(s, t, t.fwd_mode, (int)rows, out, in, X, in, 1, W, 1, in, Y, out, alpha, beta);
 }
 // dX[rows][in] (+)= dY[rows][out] . W[out][in]
 int linear_dx(hipStream_t s, arreau_train_ctx& t, long rows, int in, int out, const float* dY, const float* W, float* dX,
               float alpha = 1.f, float beta = 0.f) {
-    return gemm(s, t, (int)rows, in, out, dY, out, 1, W, in, 1, dX, in, alpha, beta);
+    return gemm(s, t, t.bwd_mode, (int)rows, in, out, dY, out, 1, W, in, 1, dX, in, alpha, beta);
 }
 // the same for `batch` layers in one launch (dY / X / dW of consecutive layers dy_bs / x_bs / out * in floats apart; 0 = shared)
 int linear_dw_batched(hipStream_t s, arreau_train_ctx& t, int batch, long rows, int in, int out, const float* dY, long dy_bs,
                       const float* X, long x_bs, float* dW, float alpha = 1.f) {
-    return arreau_sgemm(s, t.partial, out, in, (int)rows, dY, 1, out, X, in, 1, dW, in, alpha, 0.f, batch, dy_bs, x_bs, (long)out * in);
+    return arreau_sgemm(s, t.partial, out, in, (int)rows, dY, 1, out, X, in, 1, dW, in, alpha, 0.f, batch, dy_bs, x_bs, (long)out * in, t.bwd_mode);
 }
 // dW[out][in] = alpha * dY[rows][out]^T . X[rows][in]
 int linear_dw(hipStream_t s, arreau_train_ctx& t, long rows, int in, int out, const float* dY, const float* X, float* dW,
               float alpha = 1.f) {
-    return gemm(s, t, out, in, (int)rows, dY, 1, out, X, in, 1, dW, in, alpha, 0.f);
+    return gemm(s, t, t.bwd_mode, out, in, (int)rows, dY, 1, out, X, in, 1, dW, in, alpha, 0.f);
 }
 // `batch` > 1: the same sums for `batch` matrices (a / b a_bs / b_bs floats apart, results out_bs / out2_bs apart) in the two
 // launches of one -- the bias gradients of the L layers (16-byte columns only).
@@ -894,7 +899,7 @@ int arreau_general_network(arreau_model* m, const arreau_graph_view& g, const in
     // kernel_l = kb . Wk_l^T for all layers in one product (conv.py:110; conv.kernel.weight stacked [L*C][D])
     TRY(linear(s, t, R, D, L * C, t.kb, t.wk, t.kern));
     // fiber kernels of all layers: fk_l = fkb . Wfk_l^T (conv.py:113-116), one batched product
-    TRY(arreau_sgemm(s, t.partial, 256, C, D, t.fkb, D, 1, m->fiber_wk, 1, D, t.fk, C, 1.f, 0.f, L, 0, (long)C * D, 256L * C));
+    TRY(arreau_sgemm(s, t.partial, 256, C, D, t.fkb, D, 1, m->fiber_wk, 1, D, t.fk, C, 1.f, 0.f, L, 0, (long)C * D, 256L * C, t.fwd_mode));
     for (int l = 0; l < L; ++l) {
         const float* xl = t.x + (size_t)l * M * C;
         float* xnext = t.x + (size_t)(l + 1) * M * C;
@@ -923,6 +928,7 @@ int arreau_general_network(arreau_model* m, const arreau_graph_view& g, const in
 
 float* arreau_general_x0(arreau_model* m, int N, int B, hipStream_t s) {
     if (ensure_ctx(m, N, B, s) != ARREAU_OK) return nullptr;
+    m->train->fwd_mode = 0;  // sampling through the shape-general path: exact fp32 products
     return m->train->x;
 }
 
@@ -938,13 +944,21 @@ extern "C" int arreau_train_forward(arreau_model* m, const float* d_frac, const 
     const int C = m->C, k = m->k, S = m->S;
     const long M = (long)N * 16;
     t.tstep = d_t; t.offsets = d_off; t.types = d_types; t.frac = d_frac; t.lengths = d_lengths; t.angles = d_angles;
+    {
+        static const int env = [] {
+            const char* e = getenv("ARREAU_TRAIN_GEMM");
+            return !e || strcmp(e, "split") == 0 ? 1 : strcmp(e, "fp16") == 0 ? 2 : 0;
+        }();
+        t.fwd_mode = env == 0 ? 0 : (m->f16_ok ? 1 : 2);
+        t.bwd_mode = env == 0 ? 0 : (env == 2 && m->f16_ok ? 1 : 2);
+    }
     // geometry and graph: the sampling path's own kernels (prep, neighbour list)
     TRY(arreau_launch_prep(m, d_frac, d_lengths, d_angles, d_t, d_off, B, N, t.lattice, t.cart, t.batch, t.cvec, s));
     TRY(arreau_launch_neighbor(t.cart, t.lattice, d_off, t.batch, B, N, m->cfg.radius, k, t.deg, t.src, t.cell, t.dir, t.dist, s));
     // embedding (ponita.py:98): x_0 = F . W_emb^T, embT = W_emb^T [S+78][C]  (F is kept for the embedder's gradient)
     LAUNCH(features_kernel, dim3((unsigned)M), dim3(64), d_frac, d_types, d_lengths, d_angles, d_t, d_off, t.batch, t.lattice,
            m->vp_betas, m->t_emb_w, m->ori, S, m->T, N, t.F);
-    TRY(gemm(s, t, (int)M, C, S + 78, t.F, S + 78, 1, m->embT, C, 1, t.x, C));
+    TRY(gemm(s, t, t.fwd_mode, (int)M, C, S + 78, t.F, S + 78, 1, m->embT, C, 1, t.x, C));
     return arreau_general_network(m, arreau_graph_view{t.batch, t.deg, t.src, t.lattice, t.dir, t.dist}, d_off, B, N, d_eps,
                                   d_logits, d_len0, s);
 }

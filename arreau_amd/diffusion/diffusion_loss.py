@@ -30,6 +30,9 @@ class SampleResult:
     lattice: Optional[np.ndarray] = None
     idx_start: Optional[np.ndarray] = None
     num_atoms: Optional[np.ndarray] = None
+    # extension (not in the reference): what the library did to produce this batch -- e.g. {"full_range_rerun": True} when an
+    # activation left the fp16 range of the default kernels and the batch was re-run on the full-range bf16x6 kernels
+    info: Optional[dict] = None
 
 
 class DiffusionLossMetric:
@@ -245,58 +248,87 @@ class DiffusionLoss(nn.Module):
         # at 256 x 20 on MI355X, but its results are not reproducible -- in about one run in four one crystal differs at the
         # 1e-5 level from the one-stream loop, cause unknown -- and parity comes first: the library
         # refuses the mode unless ARREAU_ALLOW_MULTISTREAM=1 is set (an experiment, not a product mode).
-        eng.set_batch_layout(num_atoms, groups=max(1, int(pipelined_slices)))
-        if noise == "philox":
-            if seed is None:
-                seed = int(torch.randint(0, 2 ** 62, (1,)).item())
-            if use_graph is None:
-                use_graph = n_steps >= 200  # capture + instantiation (about 2 ms) against ~4 us saved per kernel boundary
-            fixed = len_d.clone() if fixed_cell else None
-            # Frames (diffusion_loss.py:351-370): the loop is cut at the timesteps the reference visualises -- every 10th
-            # for ALL, every one for ALL_DETAILED, never the first (T - 1).  The noise is a function of (seed, timestep),
-            # so a run in segments is the same trajectory as a run in one call.
-            t_first, t_last = self.T - 1, self.T - n_steps
-            stops = [t for t in range(t_first - 1, t_last - 1, -1)
-                     if (visualization_setting == VisualizationSetting.ALL and t % 10 == 0)
-                     or visualization_setting == VisualizationSetting.ALL_DETAILED]
-            t_cur = t_first
-            for t_stop in stops + [None]:
-                n_seg = (t_cur - t_stop + 1) if t_stop is not None else (t_cur - t_last + 1)
-                if n_seg > 0:
-                    eng.sample_loop(frac_d, types_d, len_d, ang_d, off_d, t_cur, n_seg, seed, const_d, lattice_d,
-                                    use_graph=bool(use_graph), fixed_lengths=fixed)
-                    t_cur -= n_seg
-                if t_stop is not None:
-                    vis_crystal_during_sampling(z_table, types_d.cpu().numpy(), lattice_d.cpu().numpy(),
-                                                frac_d.cpu().numpy(), vis_name + f"_{t_stop}", show_bonds, num_atoms.numpy())
-        else:
-            t_d = torch.empty(B, device=dev, dtype=torch.int32)
-            done = 0
-            for timestep in reversed(range(1, self.T)):
-                if done >= n_steps:
-                    break
-                t_d.fill_(timestep)
-                eps, logits, len0 = eng.predict_scores(frac_d, types_d, len_d, ang_d, t_d, off_d)
-                if noise == "device":
-                    z_l = torch.randn((B, 3), **f32)
-                    z_f = torch.randn((N, 3), **f32)
-                    u_t = torch.rand((N, S), **f32)
-                else:
-                    z_l = torch.randn([B, 3]).to(**f32)
-                    z_f = torch.randn([N, 3], dtype=dt).to(**f32)
-                    u_t = torch.rand([N, S]).to(**f32)
-                eng.reverse_step(frac_d, types_d, len_d, ang_d, t_d, off_d, eps, logits, len0, z_l, z_f, u_t, lattice_d)
-                if const_d is not None:
-                    types_d.copy_(const_d)
-                done += 1
-                if timestep != self.T - 1 and ((visualization_setting == VisualizationSetting.ALL and timestep % 10 == 0)
-                                               or visualization_setting == VisualizationSetting.ALL_DETAILED):
-                    vis_crystal_during_sampling(z_table, types_d.cpu().numpy(), lattice_d.cpu().numpy(),
-                                                frac_d.cpu().numpy(), vis_name + f"_{timestep}", show_bonds, num_atoms.numpy())
+        # The loop as a function of the state buffers: it runs a second time, from the saved initial state, when the default
+        # fp16x3 kernels flag an overflow (see below).
+        init_state = (frac_d.clone(), types_d.clone(), len_d.clone())
+        rng_state = torch.random.get_rng_state()
+        if noise == "philox" and seed is None:
+            seed = int(torch.randint(0, 2 ** 62, (1,)).item())
+            rng_state = torch.random.get_rng_state()
+
+        def run_loop(use_graph):
+            eng.set_batch_layout(num_atoms, groups=max(1, int(pipelined_slices)))
+            if noise == "philox":
+                if use_graph is None:
+                    use_graph = n_steps >= 200  # capture + instantiation (about 2 ms) against ~4 us saved per kernel boundary
+                fixed = len_d.clone() if fixed_cell else None
+                # Frames (diffusion_loss.py:351-370): the loop is cut at the timesteps the reference visualises -- every 10th
+                # for ALL, every one for ALL_DETAILED, never the first (T - 1).  The noise is a function of (seed, timestep),
+                # so a run in segments is the same trajectory as a run in one call.
+                t_first, t_last = self.T - 1, self.T - n_steps
+                stops = [t for t in range(t_first - 1, t_last - 1, -1)
+                         if (visualization_setting == VisualizationSetting.ALL and t % 10 == 0)
+                         or visualization_setting == VisualizationSetting.ALL_DETAILED]
+                t_cur = t_first
+                for t_stop in stops + [None]:
+                    n_seg = (t_cur - t_stop + 1) if t_stop is not None else (t_cur - t_last + 1)
+                    if n_seg > 0:
+                        eng.sample_loop(frac_d, types_d, len_d, ang_d, off_d, t_cur, n_seg, seed, const_d, lattice_d,
+                                        use_graph=bool(use_graph), fixed_lengths=fixed)
+                        t_cur -= n_seg
+                    if t_stop is not None:
+                        vis_crystal_during_sampling(z_table, types_d.cpu().numpy(), lattice_d.cpu().numpy(),
+                                                    frac_d.cpu().numpy(), vis_name + f"_{t_stop}", show_bonds, num_atoms.numpy())
+            else:
+                t_d = torch.empty(B, device=dev, dtype=torch.int32)
+                done = 0
+                for timestep in reversed(range(1, self.T)):
+                    if done >= n_steps:
+                        break
+                    t_d.fill_(timestep)
+                    eps, logits, len0 = eng.predict_scores(frac_d, types_d, len_d, ang_d, t_d, off_d)
+                    if noise == "device":
+                        z_l = torch.randn((B, 3), **f32)
+                        z_f = torch.randn((N, 3), **f32)
+                        u_t = torch.rand((N, S), **f32)
+                    else:
+                        z_l = torch.randn([B, 3]).to(**f32)
+                        z_f = torch.randn([N, 3], dtype=dt).to(**f32)
+                        u_t = torch.rand([N, S]).to(**f32)
+                    eng.reverse_step(frac_d, types_d, len_d, ang_d, t_d, off_d, eps, logits, len0, z_l, z_f, u_t, lattice_d)
+                    if const_d is not None:
+                        types_d.copy_(const_d)
+                    done += 1
+                    if timestep != self.T - 1 and ((visualization_setting == VisualizationSetting.ALL and timestep % 10 == 0)
+                                                   or visualization_setting == VisualizationSetting.ALL_DETAILED):
+                        vis_crystal_during_sampling(z_table, types_d.cpu().numpy(), lattice_d.cpu().numpy(),
+                                                    frac_d.cpu().numpy(), vis_name + f"_{timestep}", show_bonds, num_atoms.numpy())
+
+        run_loop(use_graph)
+        # Range safety without an environment variable: the fp16x3 kernels never clamp -- an activation beyond 65504 reaches the
+        # outputs as NaN and sets the sticky NONFINITE flag.  When that happens on the default kernels the batch is re-run HERE,
+        # from its saved initial state and with the same draws (same Philox seed / same host generator state), on the
+        # full-range bf16x6 kernels, the engine stays on them, and the result says so (SampleResult.info).
+        info = None
+        st = eng.status(reset=False)
+        from .. import _hip as _h
+        if (st["flags"] & _h.STATUS_NONFINITE) and not (st["flags"] & ~_h.STATUS_NONFINITE) and eng.fused_shape \
+                and (st["edge_kernel"] == "fp16x3" or st["mlp_kernel"].startswith("fp16x3")):
+            import warnings
+            warnings.warn("arreau_amd: an activation left the fp16 range of the split-precision kernels (weights with activation "
+                          f"bounds edge {st['edge_activation_bound']:.3g} / node {st['node_activation_bound']:.3g}); re-running the "
+                          "batch on the full-range bf16x6 kernels, which this engine keeps from now on")
+            eng.status(reset=True)
+            eng.set_variant(3, 1)
+            frac_d.copy_(init_state[0]); types_d.copy_(init_state[1]); len_d.copy_(init_state[2])
+            torch.random.set_rng_state(rng_state)
+            run_loop(False)
+            info = {"full_range_rerun": True, "kernels": "bf16x6", "edge_activation_bound": st["edge_activation_bound"],
+                    "node_activation_bound": st["node_activation_bound"]}
         eng.check_status()  # sticky device flags (non-finite outputs, clamped indices): raise instead of returning them
         if frames:
             vis_crystal_during_sampling(z_table, types_d.cpu().numpy(), lattice_d.cpu().numpy(), frac_d.cpu().numpy(),
                                         vis_name + "_final", show_bonds, num_atoms.numpy())
         atomic_numbers = atomic_number_indexes_to_atomic_numbers(z_table, types_d.cpu().numpy())
         return SampleResult(num_atoms=num_atoms.numpy(), frac_x=frac_d.cpu().numpy().astype(np.float64),
-                            atomic_numbers=atomic_numbers, lattice=lattice_d.cpu().numpy().astype(np.float64))
+                            atomic_numbers=atomic_numbers, lattice=lattice_d.cpu().numpy().astype(np.float64), info=info)

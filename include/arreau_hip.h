@@ -132,6 +132,10 @@ typedef struct arreau_status {
     int32_t conv_kernel;
     int32_t basis_row_bytes; /* conv_kernel == 2: bytes of the stashed basis per (edge, orientation) row the kernels really used
                               * (768: fp16 plane + fp8 e4m3 residual plane; 1024: two fp16 planes); 0 otherwise */
+    float edge_activation_bound; /* bounds, from the weights alone, of every fp16 operand of the split-precision edge chain */
+    float node_activation_bound; /* (monomials, hidden units, basis) resp. ConvNext chain (LayerNorm output, hidden units): at most
+                                  * 65504 = the fp16x3 kernels provably cannot overflow; up to 64 x that the library keeps them
+                                  * and relies on NONFINITE (the host re-runs on bf16x6); beyond, the model starts on bf16x6 */
 } arreau_status;
 /* Reads (and with reset != 0 clears) the status word; synchronises `stream`. */
 int arreau_model_status(const arreau_model* model, arreau_status* out, int32_t reset, void* stream);

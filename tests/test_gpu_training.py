@@ -319,17 +319,30 @@ def test_training_step_gradients_at_the_bench_size_and_bitwise_repeatable(setup)
         if p.grad is not None:
             assert torch.equal(p.grad, first[n]), ("gradient not bitwise repeatable", n)
     loss_o, want = _oracle_grads(om, batch, lattice0, timestep, noise)
-    assert abs(float(loss) - loss_o) <= TOL * max(1.0, abs(loss_o))
-    worst = ("", 0.0)
+    # fp64 autograd through the same oracle: what both fp32 computations approximate.  A weight gradient is a sum over ~68,000
+    # (edge, orientation) rows of terms of both signs, so fp32 itself -- the oracle's autograd included -- carries a
+    # cancellation error that GRAD_TOL alone does not cover at this size; the library may be as far from fp64 as twice the
+    # fp32 oracle is, plus GRAD_TOL of the tensor's largest entry.
+    om64 = oracle_from_module(m, torch.float64)
+    b64 = SimpleNamespace(X0=batch.X0.double(), A0=batch.A0, L0=batch.L0.double(), num_atoms=batch.num_atoms)
+    _, want64 = _oracle_grads(om64, b64, lattice0.double(), timestep, tuple(x.double() for x in noise))
+    # (the loss is a mean over ~530 atoms x 12 classes + 3 x 64 lattice terms of fp32 values summed in different orders by the
+    # two sides: 5e-5 relative here, where the 17-atom test above holds 1e-5)
+    print(f"\n[loss, 64 crystals] library {float(loss):.8f} oracle {loss_o:.8f}")
+    assert abs(float(loss) - loss_o) <= 5e-5 * max(1.0, abs(loss_o))
+    worst = ("", 0.0, 0.0)
     for name, w in want.items():
         if w.numel() == 0:
             continue
-        scale = max(float(w.abs().max()), 1e-7)
-        err = float((first[name].cpu() - w).abs().max())
+        w64 = want64[name]
+        scale = max(float(w64.abs().max()), 1e-7)
+        err = float((first[name].cpu().double() - w64).abs().max())
+        err_o = float((w.double() - w64).abs().max())
         if err / scale > worst[1]:
-            worst = (name, err / scale)
-        assert err <= GRAD_TOL * scale + 1e-7, (name, err, scale)
-    print(f"\n[gradients, 64 crystals / {N} atoms] worst relative deviation from oracle autograd: {worst[1]:.2e} ({worst[0]})")
+            worst = (name, err / scale, err_o / scale)
+        assert err <= GRAD_TOL * scale + 2 * err_o + 1e-7, (name, err, err_o, scale)
+    print(f"\n[gradients, 64 crystals / {N} atoms] worst relative distance to fp64 autograd: library {worst[1]:.2e}, "
+          f"fp32 oracle autograd {worst[2]:.2e} ({worst[0]})")
 
 
 def test_make_train_preset_batch_fits_the_gradient_scratch():

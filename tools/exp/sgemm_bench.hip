@@ -63,23 +63,32 @@ int main() {
         const long as0 = sh.a_kmajor ? sh.K : 1, as1 = sh.a_kmajor ? 1 : sh.M;
         const long bs0 = sh.b_nmajor ? sh.N : 1, bs1 = sh.b_nmajor ? 1 : sh.K;
         hipLaunchKernelGGL(ref_kernel, dim3((unsigned)((nc + 255) / 256)), dim3(256), 0, s, sh.M, sh.N, sh.K, A, as0, as1, B, bs0, bs1, R);
-        if (arreau_sgemm(s, partial, sh.M, sh.N, sh.K, A, as0, as1, B, bs0, bs1, C, sh.N)) { printf("launch failed: %s\n", g_err.c_str()); return 1; }
         CK(hipDeviceSynchronize());
         std::vector<float> hc(nc), hr(nc);
-        CK(hipMemcpy(hc.data(), C, nc * 4, hipMemcpyDeviceToHost));
         CK(hipMemcpy(hr.data(), R, nc * 4, hipMemcpyDeviceToHost));
-        double maxerr = 0, maxref = 0;
-        for (size_t i = 0; i < nc; ++i) { maxerr = fmax(maxerr, fabs((double)hc[i] - hr[i])); maxref = fmax(maxref, fabs((double)hr[i])); }
-        const int reps = 20;
-        for (int i = 0; i < 3; ++i) arreau_sgemm(s, partial, sh.M, sh.N, sh.K, A, as0, as1, B, bs0, bs1, C, sh.N);
-        CK(hipEventRecord(e0, s));
-        for (int i = 0; i < reps; ++i) arreau_sgemm(s, partial, sh.M, sh.N, sh.K, A, as0, as1, B, bs0, bs1, C, sh.N);
-        CK(hipEventRecord(e1, s));
-        CK(hipEventSynchronize(e1));
-        float ms = 0;
-        CK(hipEventElapsedTime(&ms, e0, e1));
-        const double us = 1e3 * ms / reps, tf = 2.0 * sh.M * sh.N * sh.K / (us * 1e-6) / 1e12;
-        printf("%-36s M=%6d N=%4d K=%6d  %8.1f us  %6.1f TFLOP/s  rel.err %.1e\n", sh.name, sh.M, sh.N, sh.K, us, tf, maxerr / maxref);
+        double maxref = 0;
+        for (size_t i = 0; i < nc; ++i) maxref = fmax(maxref, fabs((double)hr[i]));
+        printf("%-36s M=%6d N=%4d K=%6d ", sh.name, sh.M, sh.N, sh.K);
+        for (int mode = 0; mode < 3; ++mode) {  // 0 exact fp32 MFMA, 1 fp16x3, 2 bf16x6 (round 4)
+            auto run = [&]() { return arreau_sgemm(s, partial, sh.M, sh.N, sh.K, A, as0, as1, B, bs0, bs1, C, sh.N, 1.f, 0.f, 1, 0, 0, 0, mode); };
+            CK(hipMemset(C, 0, nc * 4));
+            if (run()) { printf("launch failed: %s\n", g_err.c_str()); return 1; }
+            CK(hipDeviceSynchronize());
+            CK(hipMemcpy(hc.data(), C, nc * 4, hipMemcpyDeviceToHost));
+            double maxerr = 0;
+            for (size_t i = 0; i < nc; ++i) maxerr = fmax(maxerr, fabs((double)hc[i] - hr[i]));
+            const int reps = 20;
+            for (int i = 0; i < 3; ++i) run();
+            CK(hipEventRecord(e0, s));
+            for (int i = 0; i < reps; ++i) run();
+            CK(hipEventRecord(e1, s));
+            CK(hipEventSynchronize(e1));
+            float ms = 0;
+            CK(hipEventElapsedTime(&ms, e0, e1));
+            const double us = 1e3 * ms / reps, tf = 2.0 * sh.M * sh.N * sh.K / (us * 1e-6) / 1e12;
+            printf(" | %s %7.1f us %6.1f TF/s err %.1e", mode == 0 ? "fp32  " : mode == 1 ? "fp16x3" : "bf16x6", us, tf, maxerr / maxref);
+        }
+        printf("\n");
         CK(hipFree(A)); CK(hipFree(B)); CK(hipFree(C)); CK(hipFree(R));
     }
     return 0;
