@@ -46,7 +46,7 @@ class Config(Structure):
 
 class Status(Structure):
     _fields_ = [("flags", c_int32), ("edge_kernel", c_int32), ("mlp_kernel", c_int32), ("conv_kernel", c_int32),
-                ("basis_row_bytes", c_int32), ("edge_activation_bound", c_float), ("node_activation_bound", c_float)]
+                ("basis_row_bytes", c_int32), ("conv_cross_fp8", c_int32), ("edge_activation_bound", c_float), ("node_activation_bound", c_float)]
 
 
 _SD_FIELDS = [

@@ -22,6 +22,9 @@ contains inline asm):
     are VMEM operations in the same in-order queue); a role of waves that never counts may spill;
   * M0: in a function whose asm writes M0, every compiler instruction naming m0 is a violation (the asm does not
     restore it);
+  * LDS-DMA copies (round 4, check_lds_dma): along every path a copy meets a covering `s_waitcnt vmcnt` before the wave
+    ends -- a copy nobody waits for is published by no barrier (`--lds` prints the
+    per-kernel LDS protocol summary: reads, writes, copies, barriers, counted waits, how many barriers ahead the rings run);
   * `--all` applies the table to compiler-only pairs too: it must report nothing (self-check of the table and of the
     parser against what LLVM's own hazard recognizer pads).
 
@@ -109,6 +112,8 @@ def _mfma_passes(mn):
     if not m:
         return 16
     a, _, k = int(m.group(1)), int(m.group(2)), int(m.group(3))
+    if "f8f6f4" in mn:  # block-scaled K = 128 / 64 forms: fp8 operands take twice the passes of fp6 / fp4 (measured: 16x16x128 e4m3
+        return 16 if a == 32 else 8  # = 36 clocks against 18 for 16x16x32 f16, tools/exp/fp8_mfma_check.hip); the larger count
     if a == 32:
         return 16 if k <= 2 else 8
     if a == 16:
@@ -482,6 +487,77 @@ def check_asm_loads(name, code, succs):
     return out
 
 
+def check_lds_dma(name, code, succs, report=None):
+    """Cross-wave LDS rule (round 4), the part of it a static pass can decide.  An LDS-DMA copy (global_load_lds_*) lands in
+    LDS some time after issue; OTHER waves read the landing zone, so the protocol is: the issuing wave waits for the copy
+    (`s_waitcnt vmcnt(N)`, N <= VMEM operations it issued after the copy: vmcnt retires in order) and only then meets the
+    `s_barrier` that publishes it.  Along EVERY control-flow path from every copy this checks that such a covering wait is
+    reached before the wave ends (`ldsdma-unwaited-exit`): the hardware's implicit wait at s_endpgm would save the memory
+    safety, but a copy nobody waited for was published by no barrier, and a landing zone must not outlive its workgroup's
+    LDS allocation on the strength of an implicit rule -- every kernel that issues copies ends in an explicit vmcnt(0).
+    NOT checked, because a path search over the CFG cannot: "at most RING barriers between a copy and its covering wait".
+    The ring kernels branch on loop-invariant conditions (`has_next`: counted wait with copies following, or vmcnt(0) and
+    no more copies); a path that takes one arm at the wait and the other at the copy is infeasible, but the CFG holds it,
+    and along it the counted waits never cover anything.  (The search simply stops after RING_MAX barriers.)  Whether the
+    COUNT of a wait is right is checked on the GPU by the debug-wait twin library (every counted wait -> vmcnt(0), outputs
+    bit-identical); that each landing zone's READERS sit behind the publishing barrier needs address reasoning a lint over
+    register names cannot do and stays an argument in the source (ring protocols of edge_f16.hip / conv_proj.hip).
+    `report`, if given, receives (function, line of the copy, max barriers passed before its covering wait) per copy."""
+    out = []
+    RING_MAX, CAP = 16, 96
+    for D in code:
+        if not D.is_ldsdma:
+            continue
+        worst = 0
+        seen = set()
+        stack = [(s, 0, 0) for s in succs[D.idx]]
+        steps = 0
+        flagged = False
+        while stack and steps < 400000 and not flagged:
+            i, younger, bars = stack.pop()
+            key = (i, min(younger, CAP), bars)
+            if key in seen:
+                continue
+            seen.add(key)
+            steps += 1
+            ins = code[i]
+            if ins.vmcnt is not None and ins.vmcnt <= younger:
+                worst = max(worst, bars)
+                continue  # covered on this path
+            if ins.mn == "s_endpgm":
+                out.append((name, "ldsdma-unwaited-exit", 0, bars, D, ins, []))
+                flagged = True
+                continue
+            if ins.mn == "s_barrier":
+                bars += 1
+                if bars > RING_MAX:
+                    continue  # (stop exploring: see the docstring -- not a finding)
+            y = younger + (1 if ins.is_vmem else 0)
+            for nx in succs[i]:
+                stack.append((nx, y, bars))
+        if report is not None:
+            report.append((name, D.line, worst))
+    return out
+
+
+def lds_protocol_summary(path):
+    """Per kernel: how many LDS reads / writes / LDS-DMA copies / barriers / counted waits the ISA holds, and for the copies the
+    largest number of barriers between issue and covering wait (= how far ahead the ring runs).  Printed by `--lds`."""
+    rows = []
+    for name, code, labels in parse_functions(path):
+        succs = build_succs(code, labels)
+        rep = []
+        bad = check_lds_dma(name, code, succs, rep)
+        n_rd = sum(1 for i in code if i.is_lds and i.mn.startswith("ds_read"))
+        n_wr = sum(1 for i in code if i.is_lds and i.mn.startswith("ds_write"))
+        n_dma = sum(1 for i in code if i.is_ldsdma)
+        n_bar = sum(1 for i in code if i.mn == "s_barrier")
+        n_cnt = sum(1 for i in code if i.vmcnt is not None and i.vmcnt > 0)
+        if n_rd or n_wr or n_dma:
+            rows.append((name, n_rd, n_wr, n_dma, n_bar, n_cnt, max([w for _, _, w in rep], default=0), len(bad)))
+    return rows
+
+
 # what the rules above know how to reason about when it appears INSIDE an asm string
 _ASM_MODELLED = re.compile(r"^(s_mov_b32|s_add_u32|s_nop|s_waitcnt|landed|global_load_lds_dwordx4|global_load_dwordx4|"
                            r"global_store_dword|global_store_dwordx2|global_store_dwordx3|global_store_dwordx4|"
@@ -551,6 +627,7 @@ def lint_file(path, all_pairs=False):
         out += check_m0(name, code)
         out += check_modelled(name, code)
         out += check_scratch(name, code, succs)
+        out += check_lds_dma(name, code, succs)
     return out
 
 
@@ -574,6 +651,13 @@ def main(argv):
     all_pairs = "--all" in argv
     quiet = "--quiet" in argv
     bad = 0
+    if "--lds" in argv:
+        for f in files:
+            print(f"{f}: LDS protocol summary (kernels that touch LDS)")
+            print("  %-90s %8s %8s %8s %8s %8s %14s %6s" % ("kernel", "ds_read", "ds_write", "LDS-DMA", "barriers", "counted", "max bars ahead", "viol."))
+            for name, n_rd, n_wr, n_dma, n_bar, n_cnt, ahead, nb in lds_protocol_summary(f):
+                print("  %-90s %8d %8d %8d %8d %8d %14d %6d" % (name[:90], n_rd, n_wr, n_dma, n_bar, n_cnt, ahead, nb))
+        return 0
     for f in files:
         v = lint_file(f, all_pairs)
         nf, ni, na = summarize(f)

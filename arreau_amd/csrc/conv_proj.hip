@@ -67,10 +67,32 @@ __device__ __forceinline__ void cp_wait_but() {
 // waits for its B fragments in the open: measured 149 us per layer at 256 x 20 with PW = 4)
 // BFP8: the residual plane of the stashed basis is OCP fp8 e4m3 (edge_f16.hip): a slot block is 12 KiB -- eight 1 KiB hi
 // fragments, then eight 512 B lo fragments (8 bytes per lane), widened to fp16 in registers (exact) in front of their MFMAs.
-template <int C, int D, int PW, bool BFP8>
+// X8 (round 4, needs BFP8): the two CROSS products of the split scheme on the fp8 matrix instruction.  They sit 2^-11 below the
+// main product, so four significand bits per operand are enough (profiles/r04_cross_precision_study.txt); both cross products
+// of a PAIR of k-blocks are one v_mfma_scale_f32_16x16x128_f8f6f4 with unit scales --
+//     A = [a1_8(kb) | a2_8(kb) | a1_8(kb+1) | a2_8(kb+1)]   (packed on the host: model.hip, pack_conv_cross_fp8; 64 registers)
+//     B = [b2_8(kb) | b1_8(kb) | b2_8(kb+1) | b1_8(kb+1)]   (b2_8 = the stash's residual plane as stored, b1_8 = e4m3(8 b1))
+// -- 32 cycles for what took four fp16 instructions of 16; with the two main products a pair of k-blocks costs 64 cycles of the
+// matrix pipe instead of 96.  K = main + X / (64 * 2^11).  Measured with a timing-only build that dropped a third of the
+// matrix work: 140.6 -> 122.3 us per launch at 256 x 20 (tools/exp/sweep_libs.sh, profiles/r04a_conv_proj_sweep.txt).
+typedef int i32x8 __attribute__((ext_vector_type(8)));
+namespace {
+__device__ __forceinline__ unsigned cp_cvt4_fp8(unsigned h01, unsigned h23) {  // four fp16 -> four e4m3 of 8 x the value (the scale divides)
+    typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+    typedef short s2 __attribute__((ext_vector_type(2)));
+    s2 r = {0, 0};
+    r = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(r, __builtin_bit_cast(h2, h01), 0.125f, false);
+    r = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(r, __builtin_bit_cast(h2, h23), 0.125f, true);
+    return __builtin_bit_cast(unsigned, r);
+}
+}  // namespace
+#define CP_X8_FOLD (1.0f / (64.0f * 2048.0f))
+
+template <int C, int D, int PW, bool BFP8, bool X8 = false>
 __global__ __launch_bounds__(64 * (PW + 4), (PW + 4) / 4) void conv_proj_kernel(
     const u32x4* __restrict__ basis,     // [N*8 slots][16 fragments = (k-block, plane)][64 lanes] x 16 bytes  (BFP8: see above)
     const u32x4* __restrict__ wchunks,   // this layer's projection chunks of the packed fp16x3 stream: [C/32][32][64]
+    const u32x4* __restrict__ x8w,       // X8: this layer's fp8 cross operands [C/16 tiles][D/64 pairs][2][64 lanes] x 16 bytes
     const int32_t* __restrict__ deg, const int32_t* __restrict__ src,
     const float* __restrict__ x_in,      // [N][16][C]
     const float* __restrict__ fk,        // [16(o)][16(p)][C]
@@ -78,6 +100,7 @@ __global__ __launch_bounds__(64 * (PW + 4), (PW + 4) / 4) void conv_proj_kernel(
     float* __restrict__ x_conv)          // [N][16][C]
 {
     static_assert(C == 128 && D == 256, "roles and register budgets assume C = 128, D = 256");
+    static_assert(!X8 || BFP8, "the fp8 cross products take the stash's e4m3 residual plane as it is stored");
     constexpr int K = 8, NKB = D / 32;
     constexpr unsigned SLOT_BYTES = BFP8 ? 12288 : 16384;
     constexpr int NC = SLOT_BYTES / 4096;  // 1 KiB copies per mix wave and slot
@@ -109,8 +132,32 @@ __global__ __launch_bounds__(64 * (PW + 4), (PW + 4) / 4) void conv_proj_kernel(
     if (wave < PW) {
         // =========================================== projection role ===========================================
         const int c16 = lane & 15, g16 = lane >> 4;
-        u32x4 A1[MT][NKB], A2[MT][NKB];  // [16-channel tile][k-block]: the two fp16 planes of Wk_l rows 16 * (MT wave + mt) ..
-        {
+        u32x4 A1[MT][NKB], A2[MT][X8 ? 1 : NKB];  // [16-channel tile][k-block]: the two fp16 planes of Wk_l rows 16 * (MT wave + mt) ..
+        i32x8 A8[MT][X8 ? NKB / 2 : 1];          // X8: the fp8 cross operands instead of the residual plane
+        if constexpr (X8) {
+            const u32x4* wc = wchunks + (size_t)((MT * wave) >> 1) * 32 * 64 + lane;
+            const int t0 = (MT * wave) & 1;
+#pragma unroll
+            for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) A1[mt][kb] = wc[((kb * 2 + t0 + mt) * 2 + 0) * 64];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int kp = 0; kp < NKB / 2; ++kp) {
+                    const u32x4* a8 = x8w + ((size_t)((MT * wave + mt) * (NKB / 2) + kp) * 2) * 64 + lane;
+                    const u32x4 lo = a8[0], hi = a8[64];
+                    A8[mt][kp] = i32x8{(int)lo[0], (int)lo[1], (int)lo[2], (int)lo[3], (int)hi[0], (int)hi[1], (int)hi[2], (int)hi[3]};
+                }
+#pragma unroll
+            for (int kb = 0; kb < NKB; ++kb)
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) asm volatile("" : "+v"(A1[mt][kb]));
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int kp = 0; kp < NKB / 2; ++kp) asm volatile("" : "+v"(A8[mt][kp]));
+        } else {
             // chunk u = 32 output channels; fragment (kb, tile-in-chunk, plane) at ((kb * 2 + tile) * 2 + plane) * 64
             const u32x4* wc = wchunks + (size_t)((MT * wave) >> 1) * 32 * 64 + lane;
             const int t0 = (MT * wave) & 1;
@@ -174,7 +221,7 @@ __global__ __launch_bounds__(64 * (PW + 4), (PW + 4) / 4) void conv_proj_kernel(
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float kv = fmaf(ax[set][mt][r], F16X3_INV_SCALE, am[set][mt][r]);
+                    const float kv = fmaf(ax[set][mt][r], X8 ? CP_X8_FOLD : F16X3_INV_SCALE, am[set][mt][r]);
                     sum[mt][r] = on ? __fadd_rn(sum[mt][r], __fmul_rn(kv, xv[xbuf][mt][r])) : sum[mt][r];
                 }
         };
@@ -210,6 +257,7 @@ __global__ __launch_bounds__(64 * (PW + 4), (PW + 4) / 4) void conv_proj_kernel(
                 rb = rb == RING - 1 ? 0 : rb + 1;
                 const unsigned f_next = (unsigned)rb * SLOT_BYTES;
                 auto kstep = [&](int kb) {  // same product order per accumulator as MmaStream16 (edge_f16.hip)
+                    if constexpr (X8) return;
                     const int slot = kb % NBUF, kk = kb + DIST;
                     if (kk < NKB) frag(f, kk, kk % NBUF);
                     else frag(f_next, kk - NKB, kk % NBUF);  // first k-blocks of the next slot (published by this slot's barrier;
@@ -227,7 +275,34 @@ __global__ __launch_bounds__(64 * (PW + 4), (PW + 4) / 4) void conv_proj_kernel(
                     for (int mt = 0; mt < MT; ++mt) {
                         am[set][mt] = mfma16_f16(A1[mt][kb], b1[slot], am[set][mt]);
                         ax[set][mt] = mfma16_f16(A1[mt][kb], b2[s2], ax[set][mt]);
-                        ax[set][mt] = mfma16_f16(A2[mt][kb], b1[slot], ax[set][mt]);
+                        ax[set][mt] = mfma16_f16(A2[mt][X8 ? 0 : kb], b1[slot], ax[set][mt]);
+                    }
+                };
+                auto kpair = [&](int kp) {  // X8: two k-blocks -- two main products per tile on fp16, both cross products as one fp8 product
+                    const int kb0 = 2 * kp, kb1 = kb0 + 1, s0 = kb0 % NBUF, s1 = kb1 % NBUF;
+#pragma unroll
+                    for (int q2 = 0; q2 < 2; ++q2) {
+                        const int kk = kb0 + q2 + DIST;
+                        if (kk < NKB) frag(f, kk, kk % NBUF);
+                        else frag(f_next, kk - NKB, kk % NBUF);
+                    }
+                    if constexpr (X8) {
+                        const i32x8 B8 = {(int)b8[s0][0], (int)b8[s0][1], (int)cp_cvt4_fp8(b1[s0][0], b1[s0][1]), (int)cp_cvt4_fp8(b1[s0][2], b1[s0][3]),
+                                          (int)b8[s1][0], (int)b8[s1][1], (int)cp_cvt4_fp8(b1[s1][0], b1[s1][1]), (int)cp_cvt4_fp8(b1[s1][2], b1[s1][3])};
+#pragma unroll
+                        for (int mt = 0; mt < MT; ++mt) {
+                            am[set][mt] = mfma16_f16(A1[mt][kb0], b1[s0], am[set][mt]);
+                            am[set][mt] = mfma16_f16(A1[mt][kb1], b1[s1], am[set][mt]);
+                            ax[set][mt] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(A8[mt][kp], B8, ax[set][mt], 0, 0, 0, 0x7f7f7f7f, 0,
+                                                                                          0x7f7f7f7f);
+                        }
+                    }
+                };
+                auto pin8 = [&]() {  // one half slot of the pair form: per pair its four fragment requests, then its MFMAs
+#pragma unroll
+                    for (int i = 0; i < NKB / 4; ++i) {
+                        __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x008, 3 * MT, 0);
                     }
                 };
                 auto pin = [&]() {  // issue order of one half slot: per k-step its fragment requests, then its MFMAs (vector work floats)
@@ -237,13 +312,24 @@ __global__ __launch_bounds__(64 * (PW + 4), (PW + 4) / 4) void conv_proj_kernel(
                         __builtin_amdgcn_sched_group_barrier(0x008, 3 * MT, 0);           // MFMAs of this k-step
                     }
                 };
+                if constexpr (X8) {
+                    static_assert(!X8 || (DIST == 2 && NBUF == 4), "pair form: fragments two k-blocks ahead through four register sets");
 #pragma unroll
-                for (int kb = 0; kb < NKB / 2; ++kb) kstep(kb);
-                pin();
-                __syncthreads();  // SYNC_q
+                    for (int kp = 0; kp < NKB / 4; ++kp) kpair(kp);
+                    pin8();
+                    __syncthreads();  // SYNC_q
 #pragma unroll
-                for (int kb = NKB / 2; kb < NKB; ++kb) kstep(kb);
-                pin();
+                    for (int kp = NKB / 4; kp < NKB / 2; ++kp) kpair(kp);
+                    pin8();
+                } else {
+#pragma unroll
+                    for (int kb = 0; kb < NKB / 2; ++kb) kstep(kb);
+                    pin();
+                    __syncthreads();  // SYNC_q
+#pragma unroll
+                    for (int kb = NKB / 2; kb < NKB; ++kb) kstep(kb);
+                    pin();
+                }
                 epilogue(0, s & 3, s < nd);
             }
             write_tile();  // (the mix waves took the previous receiver's tile into registers right behind SYNC of slot 0)
@@ -349,6 +435,9 @@ __global__ __launch_bounds__(64 * (PW + 4), (PW + 4) / 4) void conv_proj_kernel(
         m = mn;
         mn = next_valid(mn + m_step);
     }
+    // (round 4, lint rule ldsdma-unwaited-exit: no LDS-DMA copy is left in flight when a wave ends -- the last copies of a ring
+    // target a chunk nobody will read; the hardware's implicit wait at s_endpgm is not relied upon)
+    cp_wait_but<0>();
     __syncthreads();  // the last receiver's tile is complete
 #pragma unroll
     for (int o = 0; o < 16; ++o) {
@@ -382,16 +471,20 @@ int arreau_launch_conv_proj(const arreau_model* m, int layer, const float* basis
     const u32x4* stream = reinterpret_cast<const u32x4*>(m->edge_f16);
     const u32x4* wchunks = stream + ((size_t)TC * NF1 + (size_t)TD * NF2 + (size_t)layer * TC * NF3) * 64;
     static const int pw_env = [] { const char* e = getenv("ARREAU_CONV_PROJ_WAVES"); return e ? atoi(e) : 4; }();
+    const u32x4* x8w = reinterpret_cast<const u32x4*>(m->conv_x8) + (size_t)layer * (m->C / 16) * (m->D / 64) * 2 * 64;
     auto launch = [&](auto kernel, int threads) {
-        ARREAU_LAUNCH(kernel, dim3(blocks), dim3(threads), 0, s, reinterpret_cast<const u32x4*>(basis), wchunks, deg, src, x_in,
+        ARREAU_LAUNCH(kernel, dim3(blocks), dim3(threads), 0, s, reinterpret_cast<const u32x4*>(basis), wchunks, x8w, deg, src, x_in,
                       m->fk + (size_t)layer * 16 * 16 * m->C, m->conv_bias + (size_t)layer * m->C, n0, Ng, x_conv);
     };
     const bool fp8 = arreau_basis_fp8();
     arreau_prof_conv(0, s);
     if (pw_env == 4) {
-        if (fp8) launch(conv_proj_kernel<128, 256, 4, true>, 512);
+        m->ran_x8 = fp8 && arreau_cross_fp8(m) ? 1 : 0;
+        if (m->ran_x8) launch(conv_proj_kernel<128, 256, 4, true, true>, 512);
+        else if (fp8) launch(conv_proj_kernel<128, 256, 4, true>, 512);
         else launch(conv_proj_kernel<128, 256, 4, false>, 512);
     } else {
+        m->ran_x8 = 0;
         if (fp8) launch(conv_proj_kernel<128, 256, 8, true>, 768);
         else launch(conv_proj_kernel<128, 256, 8, false>, 768);
     }

@@ -493,6 +493,9 @@ __global__ __launch_bounds__(64 * EH_WAVES, 2) void edge_kernel_f16x3(
         store_tile16(prev, tile_base);
         EDGE_TICK(3);
     }  // pair loop
+    // (round 4, lint rule ldsdma-unwaited-exit: no LDS-DMA copy is left in flight when a wave ends -- the last copies of a ring
+    // target a chunk nobody will read; the hardware's implicit wait at s_endpgm is not relied upon)
+    dma_wait();
     EDGE_TICK(4);
 #ifdef ARREAU_EDGE_TIMING
     tacc_[5] = clock64() - c_start_;        // whole kernel, shader-clock ticks (slot 5)

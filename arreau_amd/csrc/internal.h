@@ -53,11 +53,13 @@ struct arreau_model {
     const float* edge_bf16;  // w1 | w2 | wk_l as bf16x3 chunks (uint16 data), one chunk per output tile
     const float* edge_f16;   // w1 | w2 | wk_l as fp16x3 chunks (uint16 data, two planes), one chunk per output tile
     int f16_ok;              // 1 when every packed weight fits fp16 (|w| < 6e4): the fp16x3 kernels may be used
+    const float* conv_x8;    // [L] fp8 e4m3 cross-product operands of conv.kernel.weight (conv_proj.hip, round 4; uint8 data)
+    int x8_ok;               // 1 when 64 |w| <= 448 for every kernel weight: the fp8 cross products may be used
     float edge_act_bound, node_act_bound;  // weight-derived bounds of the fp16 operands of the edge / ConvNext chains (model.hip)
     // Arithmetic / geometry variants requested for this model (defaults from ARREAU_*_VARIANT at create,
     // arreau_model_set_variant overrides) and what the last arreau_predict_scores actually launched.
     int edge_variant, mlp_variant, conv_variant, readout_variant;
-    mutable int ran_edge, ran_mlp, ran_conv;
+    mutable int ran_edge, ran_mlp, ran_conv, ran_x8;
     // training (train_net.hip): plain row-major fp32 copies of the weights the sampling kernels hold only in packed
     // form, and the step's activation buffers (created on first use)
     const float *t_w1f, *t_w2, *t_wk, *t_lin1, *t_lin2, *t_ro_w;
@@ -314,6 +316,10 @@ bool arreau_basis_form(const arreau_model* m, int receivers);
 // significand bits; default) -- what the basis form stores (3 bytes per value), applied by every fp16x3 edge kernel so that all
 // launch sizes evaluate the same numbers.  ARREAU_BASIS_FP8=0: both planes fp16 everywhere (the round-2 arithmetic).
 bool arreau_basis_fp8();
+// Round 4: the two cross products of the per-layer kernel projection (conv_proj.hip) on the fp8 matrix instruction (twice the fp16
+// rate; operands e4m3: model.hip, pack_conv_cross_fp8).  Applies to the basis form with the fp8 residual plane; ARREAU_CROSS_FP8=0
+// keeps three fp16 products (bit-identical to the K pair of the small launches).  Read per call (tests toggle it).
+bool arreau_cross_fp8(const arreau_model* m);
 void arreau_prof_conv(int end, hipStream_t s);  // api.hip: hipEvents around the message kernel while bench.py profiles
 int arreau_launch_conv_proj(const arreau_model* m, int layer, const float* basis, const int32_t* deg, const int32_t* src,
                             const float* x_in, float* x_conv, int N, hipStream_t s, NodeRange r = NodeRange());

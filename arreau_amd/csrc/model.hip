@@ -175,6 +175,53 @@ static float pack_linear_f16x3_m16(const float* W, int out_dim, int in_dim, int 
     return wmax;
 }
 
+// OCP fp8 e4m3fn, round to nearest even, saturating at +-448 (what v_cvt_scalef32_pk_fp8_f16 produces: tools/exp/fp8_cvt_check.hip)
+static inline uint8_t f32_to_e4m3_rne_sat(float x) {
+    const uint8_t sign = signbit(x) ? 0x80 : 0;
+    const float a = fabsf(x);
+    if (!(a == a)) return 0x7f;
+    if (a >= 448.0f) return sign | 0x7e;
+    int e;
+    const float f = frexpf(a, &e);  // a = f 2^e, f in [0.5, 1)
+    const int E = e - 1;            // a = (2 f) 2^E
+    if (a == 0.0f) return sign;
+    if (E < -6) return sign | (uint8_t)nearbyintf(ldexpf(a, 9));  // subnormal steps of 2^-9 (8 = the smallest normal: same code)
+    int mant = (int)nearbyintf((2.0f * f - 1.0f) * 8.0f), ex = E + 7;
+    if (mant == 8) { mant = 0; ++ex; }
+    const int code = (ex << 3) | mant;
+    return sign | (uint8_t)(code > 0x7e ? 0x7e : code);
+}
+
+// Cross-product operands of conv_proj.hip's fp8 form (round 4).  The two cross products of the split scheme sit 2^-11 below
+// the main one, so their operands need a handful of bits: both run as ONE v_mfma_scale_f32_16x16x128_f8f6f4 per pair of
+// 32-wide k-blocks (twice the fp16 rate),  X = sum_k a1_8 b2_8 + a2_8 b1_8  with
+//     a1_8 = e4m3(64 a1),  a2_8 = e4m3(8 a2),  b1_8 = e4m3(8 b1),  b2_8 = e4m3(b2) (the stash's residual plane as stored),
+// i.e. X = 64 (a1 b2 + a2 b1) and K = a1 b1 + X / (64 * 2^11).  (profiles/r04_cross_precision_study.txt: outputs move by
+// less than the fp32 oracle's own distance to fp64.)  Layout, per layer: [16-channel tile T = 0..7][k-block pair kp][half h][lane]
+// x 16 bytes: bytes 0-7 = a1_8, bytes 8-15 = a2_8 of output row 16 T + (lane & 15), k-block 2 kp + h, in the k order of the
+// stashed basis fragments (pack_linear_f16x3_m16, native).  Returns the largest |64 a1| (beyond 448 the operand would saturate:
+// the caller then keeps the fp16 cross products).
+static float pack_conv_cross_fp8(const float* W /*[C][D]*/, int C, int D, uint8_t* Q) {
+    float amax = 0.f;
+    for (int T = 0; T < C / 16; ++T)
+        for (int kp = 0; kp < D / 64; ++kp)
+            for (int h = 0; h < 2; ++h)
+                for (int lane = 0; lane < 64; ++lane)
+                    for (int e = 0; e < 8; ++e) {
+                        const int g = lane >> 4, kb = 2 * kp + h;
+                        const int out = 16 * T + (lane & 15);
+                        const int in = 32 * kb + 16 * (e >> 2) + 4 * g + (e & 3);
+                        const float w = W[(size_t)out * D + in];
+                        const float a1 = f16_to_f32(f32_to_f16_rne(w));
+                        const float a2 = f16_to_f32(f32_to_f16_rne((w - a1) * 2048.0f));
+                        amax = fmaxf(amax, fabsf(64.0f * a1));
+                        const size_t base = ((((size_t)T * (D / 64) + kp) * 2 + h) * 64 + lane) * 16;
+                        Q[base + e] = f32_to_e4m3_rne_sat(64.0f * a1);
+                        Q[base + 8 + e] = f32_to_e4m3_rne_sat(8.0f * a2);
+                    }
+    return amax;
+}
+
 // Monomial table: distinct monomials of degree 1..3 in 6 variables in the canonical order
 // (i), (i<=j), (i<=j<=k), each lexicographic.  The device code (edge.hip) generates them in the
 // same order.
@@ -369,6 +416,14 @@ extern "C" int arreau_model_create(const arreau_config* cfg, const arreau_state_
             wmax16 = fmaxf(wmax16, pack_linear_f16x3_m16(sd->conv_kernel_w + (size_t)l * C * D, C, D, D,
                                                          q + f_w1 + f_w2 + l * f_wk, true));  // K = basis, native order
     }
+    // fp8 cross-product operands of the per-layer projection (conv_proj.hip): 64 KiB per layer
+    const size_t x8_layer_floats = (size_t)(C / 16) * (D / 64) * 2 * 64 * 16 / 4;
+    const size_t off_x8 = bb.reserve(fused ? x8_layer_floats * L : 0);
+    float x8_amax = 0.f;
+    if (fused)
+        for (int l = 0; l < L; ++l)
+            x8_amax = fmaxf(x8_amax, pack_conv_cross_fp8(sd->conv_kernel_w + (size_t)l * C * D, C, D,
+                                                         reinterpret_cast<uint8_t*>(bb.data.data() + off_x8 + l * x8_layer_floats)));
     const size_t off_fk = bb.reserve((size_t)L * O * O * C);
     const size_t off_conv_bias = bb.put(sd->conv_bias, (size_t)L * C);
     const size_t off_ln_w = bb.put(sd->norm_w, (size_t)L * C);
@@ -490,7 +545,7 @@ extern "C" int arreau_model_create(const arreau_config* cfg, const arreau_state_
     }
     float* b = m->blob;
     m->ori = b + off_ori; m->w1p = b + off_w1p; m->b1 = b + off_b1; m->w2p = b + off_w2p; m->b2 = b + off_b2;
-    m->wkp = b + off_wkp; m->edge_bf16 = b + off_es16; m->edge_f16 = b + off_ef16; m->f16_ok = fused && wmax16 < 60000.0f ? 1 : 0; m->fk = b + off_fk; m->conv_bias = b + off_conv_bias; m->ln_w = b + off_ln_w;
+    m->wkp = b + off_wkp; m->edge_bf16 = b + off_es16; m->edge_f16 = b + off_ef16; m->f16_ok = fused && wmax16 < 60000.0f ? 1 : 0; m->conv_x8 = b + off_x8; m->x8_ok = fused && x8_amax <= 448.0f ? 1 : 0; m->fk = b + off_fk; m->conv_bias = b + off_conv_bias; m->ln_w = b + off_ln_w;
     m->ln_b = b + off_ln_b; m->mlp = b + off_mlp; m->mlp_bf16 = b + off_mlp16; m->mlp_f16 = b + off_mlpf16; m->mlp_f16m = b + off_mlpf16m; m->mb1 = b + off_mb1; m->mb2 = b + off_mb2;
     m->ls = b + off_ls; m->embT = b + off_embT; m->ro_wT = b + off_ro_wT; m->ro_b = b + off_ro_b; m->ro_pack = b + off_ro_pack; m->ro_wv = b + off_ro_wv;
     for (int l = 0; l < L; ++l) m->ro_bv_host[l] = sd->readout_b[(size_t)l * RO + S];
@@ -523,6 +578,7 @@ extern "C" int arreau_model_create(const arreau_config* cfg, const arreau_state_
     m->conv_variant = env_int("ARREAU_CONV_VARIANT", 2);  // 2: basis form + conv_proj.hip; 1: K stash + streamed conv; 0: register conv
     m->readout_variant = env_int("ARREAU_READOUT_VARIANT", 1);
     m->ran_edge = m->ran_mlp = m->ran_conv = -1;
+    m->ran_x8 = 0;
     m->fused = fused ? 1 : 0;
     // ARREAU_GENERAL_PATH=1 (or edge variant 5): run the shape-general fp32 kernels also for the fused shape (cross-check)
     if (!fused || getenv("ARREAU_GENERAL_PATH")) m->edge_variant = ARREAU_VARIANT_GENERAL;
@@ -600,6 +656,7 @@ extern "C" int arreau_model_status(const arreau_model* model, arreau_status* out
     out->mlp_kernel = model->ran_mlp;
     out->conv_kernel = model->ran_conv;
     out->basis_row_bytes = model->ran_conv == 2 ? (arreau_basis_fp8() ? 768 : 1024) : 0;
+    out->conv_cross_fp8 = model->ran_conv == 2 ? model->ran_x8 : 0;
     out->edge_activation_bound = model->edge_act_bound;
     out->node_activation_bound = model->node_act_bound;
     return ARREAU_OK;

@@ -431,6 +431,9 @@ __global__ __launch_bounds__(512, 2) void conv_kernel_streamed(
         if (m >= n_iter) break;
         receiver(P1{});
     }
+    // (round 4, lint rule ldsdma-unwaited-exit: no LDS-DMA copy is left in flight when a wave ends -- the last copies of a ring
+    // target a chunk nobody will read; the hardware's implicit wait at s_endpgm is not relied upon)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -917,6 +920,11 @@ bool arreau_basis_form(const arreau_model* m, int receivers) {
 bool arreau_basis_fp8() {
     static const int env = [] { const char* e = getenv("ARREAU_BASIS_FP8"); return e ? atoi(e) : 1; }();
     return env != 0;
+}
+
+bool arreau_cross_fp8(const arreau_model* m) {
+    const char* e = getenv("ARREAU_CROSS_FP8");
+    return (e == nullptr || atoi(e) != 0) && m->x8_ok && arreau_basis_fp8();
 }
 
 bool arreau_range_launches_supported(const arreau_model* m) {

@@ -236,6 +236,9 @@ __global__ __launch_bounds__(64 * NW, 2) void mlp_kernel_f16x3_m16(
             sl = sl == NSLOT - 1 ? 0 : sl + 1;
         }
     }
+    // (round 4, lint rule ldsdma-unwaited-exit: no LDS-DMA copy is left in flight when a wave ends -- the last copies of a ring
+    // target a chunk nobody will read; the hardware's implicit wait at s_endpgm is not relied upon)
+    dma_wait();
     if (!active) return;
 
     // ---- bias, layer scale, residual; write x_out; read-out partials (all in registers) ------------------

@@ -101,7 +101,7 @@ class HipEngine:
         return {"flags": int(st.flags), "edge_kernel": _hip.EDGE_KERNELS.get(st.edge_kernel, "none"),
                 "mlp_kernel": _hip.MLP_KERNELS.get(st.mlp_kernel, "none"), "edge_variant": int(st.edge_kernel),
                 "mlp_variant": int(st.mlp_kernel), "conv_variant": int(st.conv_kernel),
-                "basis_row_bytes": int(st.basis_row_bytes), "edge_activation_bound": float(st.edge_activation_bound),
+                "basis_row_bytes": int(st.basis_row_bytes), "conv_cross_fp8": int(st.conv_cross_fp8), "edge_activation_bound": float(st.edge_activation_bound),
                 "node_activation_bound": float(st.node_activation_bound)}
 
     def check_status(self, reset=True):

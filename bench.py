@@ -569,6 +569,12 @@ def run_rank(args, rank, local_rank, world):
             # design adds: reported beside the PMC figure, never as achieved work.
             rows = e_mean * 16 / launches_per_step
             row_bytes = int(status.get("basis_row_bytes") or 768)
+            # the roof of the arithmetic this kernel runs: three fp16 products per fp32 product (2500 / 3), or -- round 4 default --
+            # one fp16 product + the two cross products as ONE fp8 product at twice the fp16 rate = two fp16-equivalents (2500 / 2)
+            x8 = bool(status.get("conv_cross_fp8"))
+            proj_peak = MFMA_BF16_PEAK_TFLOPS / 2.0 if x8 else edge_peak
+            proj_peak_note = ("fp32-equivalent roof of the projection's scheme: main product on fp16 MFMAs + both cross products as one fp8 "
+                              "(e4m3) MFMA product at twice the fp16 rate = 2 fp16-equivalents: 2500 TFLOP/s / 2" if x8 else edge_peak_note)
             cbytes = conv_pass_bytes(Nl)
             cflops = rows * conv_proj_flops_per_row()
             t = conv_ms.value * 1e-3
@@ -583,9 +589,10 @@ def run_rank(args, rank, local_rank, world):
             roofline = {
                 "kernel": "conv_proj_kernel<128,256> x L per step (kernel projection of the layer on fp16x3 MFMAs from the stashed "
                           "basis + message passing + spherical convolution; conv.py:110-127)",
-                "bound": "mfma", "achieved": cflops / t / 1e12, "peak": edge_peak, "unit": "TFLOP/s",
-                "frac": cflops / t / 1e12 / edge_peak, "traffic": pmc,
-                "peak_note": edge_peak_note, "frac_of_fp32_mfma_peak": cflops / t / 1e12 / MFMA_F32_PEAK_TFLOPS,
+                "bound": "mfma", "achieved": cflops / t / 1e12, "peak": proj_peak, "unit": "TFLOP/s",
+                "frac": cflops / t / 1e12 / proj_peak, "traffic": pmc,
+                "peak_note": proj_peak_note, "frac_of_fp32_mfma_peak": cflops / t / 1e12 / MFMA_F32_PEAK_TFLOPS,
+                "frac_of_f16x3_roof": cflops / t / 1e12 / F16X3_EQUIV_PEAK_TFLOPS, "cross_products": "fp8 e4m3" if x8 else "fp16",
                 "avg_launch_ms": conv_ms.value, "launches_timed": int(conv_launches.value),
                 "launches_per_step": int(round(conv_launches.value / args.steps)),
                 "algorithmic_flops_per_launch": cflops,
@@ -632,9 +639,10 @@ def run_rank(args, rank, local_rank, world):
                           f"message path (conv kernel variant {status.get('conv_variant')}): 2 = no K stash -- the edge kernel "
                           "stores the windowed basis once (fp16 plane + residual plane rounded to fp8 e4m3: 3 bytes per value, "
                           "11 + 4 significand bits; ARREAU_BASIS_FP8=0: both planes fp16) and every layer's message kernel "
-                          "projects it; 1 = the round-2 pair with a K stash of 3-byte floats; environment: "
+                          f"projects it, its two cross products as one fp8 (e4m3) MFMA product: conv_cross_fp8={status.get('conv_cross_fp8')} "
+                          "(round 4; ARREAU_CROSS_FP8=0: three fp16 products); 1 = the round-2 pair with a K stash of 3-byte floats; environment: "
                           f"ARREAU_BASIS_FP8={os.environ.get('ARREAU_BASIS_FP8', '1')} ARREAU_CONV_VARIANT={os.environ.get('ARREAU_CONV_VARIANT', '2')}; "
-                          "measured deviations from the fp32 / fp64 CPU oracle: profiles/parity_r03.json; "
+                          "measured deviations from the fp32 / fp64 CPU oracle: profiles/parity_r04.json; "
                           "roofline.fp32_mfma_variant = the same step on the plain fp32-MFMA kernels",
             "data": "synthetic",
             "config": {

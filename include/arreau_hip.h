@@ -132,6 +132,8 @@ typedef struct arreau_status {
     int32_t conv_kernel;
     int32_t basis_row_bytes; /* conv_kernel == 2: bytes of the stashed basis per (edge, orientation) row the kernels really used
                               * (768: fp16 plane + fp8 e4m3 residual plane; 1024: two fp16 planes); 0 otherwise */
+    int32_t conv_cross_fp8;  /* conv_kernel == 2: 1 when the layer projections ran their two cross products on the fp8 matrix instruction
+                              * (round 4 default; e4m3 operands, twice the fp16 rate), 0 for three fp16 products (ARREAU_CROSS_FP8=0) */
     float edge_activation_bound; /* bounds, from the weights alone, of every fp16 operand of the split-precision edge chain */
     float node_activation_bound; /* (monomials, hidden units, basis) resp. ConvNext chain (LayerNorm output, hidden units): at most
                                   * 65504 = the fp16x3 kernels provably cannot overflow; up to 64 x that the library keeps them

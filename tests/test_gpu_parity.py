@@ -285,7 +285,8 @@ def test_status_flags_overflow_and_bad_indices(dev):
     assert 0 < healthy["edge_activation_bound"] < 65504 and 0 < healthy["node_activation_bound"] < 65504, healthy
     m = make_synthetic_model(S=12, seed=7, num_timesteps=100)
     with torch.no_grad():  # blow up the hidden units of the first ConvNext MLP: |linear_1 output| >> 65504
-        m.model.interaction_layers[0].linear_1.weight.mul_(1.5e5)
+        m.model.interaction_layers[0].linear_1.weight.mul_(1.5e5)  # (every weight still fits fp16: the kernels exist for it)
+        m.model.interaction_layers[0].norm.weight.mul_(4.0)
     m = m.to(dev)
     eng = m.engine()
     state = random_state(12, [8, 8], 3)
@@ -324,7 +325,7 @@ def test_status_flags_overflow_and_bad_indices(dev):
 
 def test_sampler_reruns_an_overflowing_batch_on_the_full_range_kernels(dev):
     """Range safety without an environment variable, the dynamic half.  This model's hidden units exceed 65504 (first
-    ConvNext layer's linear_1 scaled by 2e4) while its weight-derived bound stays inside the slack the library grants the
+    ConvNext layer's linear_1 scaled by 1e5) while its weight-derived bound stays inside the slack the library grants the
     loose bound (<= 64 x the range), so it starts on the fp16x3 kernels; the overflow raises the sticky NONFINITE flag inside
     `model.sample`, which re-runs the batch from its saved initial state -- same draws -- on the bf16x6 kernels, says so in
     SampleResult.info, and the result follows the oracle's sampler like any other model's (same bounds as
@@ -334,8 +335,8 @@ def test_sampler_reruns_an_overflowing_batch_on_the_full_range_kernels(dev):
     from arreau_amd.diffusion.inference.visualize_crystal import VisualizationSetting
     m = make_synthetic_model(S=12, seed=7, num_timesteps=100)
     with torch.no_grad():
-        m.model.interaction_layers[0].linear_1.weight.mul_(2.0e4)
-        m.model.interaction_layers[0].linear_2.weight.mul_(1.0 / 2.0e4)  # (keeps the layer's output, and the trajectory, tame)
+        m.model.interaction_layers[0].linear_1.weight.mul_(1.0e5)
+        m.model.interaction_layers[0].linear_2.weight.mul_(1.0e-5)  # (keeps the layer's output, and the trajectory, tame)
     m = m.to(dev)
     st = m.engine().status()
     assert 65504 < st["node_activation_bound"] <= 64 * 65504, st
@@ -354,10 +355,21 @@ def test_sampler_reruns_an_overflowing_batch_on_the_full_range_kernels(dev):
     assert np.isfinite(res.frac_x).all() and np.isfinite(res.lattice).all()
     st = m.engine().status()
     assert st["flags"] == 0 and st["mlp_kernel"] == "bf16x6", st
+    # the free-running trajectory follows the oracle's (hidden units of 1e5 x weights of 1e-5: the fp32 rounding of this
+    # model is coarser than a healthy one's, so ten times the other sampler test's 1e-5 on nine coordinates in ten) ...
     df = np.abs(res.frac_x - f_o.numpy().astype(np.float64))
     df = np.minimum(df, 1 - df)
-    assert np.quantile(df, 0.9) <= 1e-5 and df.max() <= 1e-2, (np.quantile(df, 0.9), df.max())
+    assert np.quantile(df, 0.9) <= 1e-4 and df.max() <= 1e-2, (np.quantile(df, 0.9), df.max())
     np.testing.assert_allclose(res.lattice, lat_o.numpy(), atol=1e-3 * max(1.0, float(lat_o.abs().max())), rtol=0)
+    # ... and per step, teacher-forced, the kernels the engine is now on meet the 1e-5 bound against the oracle
+    state = random_state(12, [8, 5, 3], 4, sampler_like=True)
+    eps_o, logits_o, len0_o, (ei, dists, direction, _c, _l) = _oracle_scores(om32, *state, 60)
+    deg, src, sdir, sdist = slots_from_edges(ei, dists, direction, 16, 8)
+    f, ty, le, an, off = _to_dev(dev, *state)
+    got = m.engine().predict_scores(f, ty, le, an, torch.full((3,), 60, device=dev, dtype=torch.int32), off,
+                                    edges=tuple(x.to(dev).contiguous() for x in (deg, src, sdir, sdist)))
+    assert_scores_close(got, (eps_o, logits_o, len0_o), "full-range kernels after the re-run")
+    assert m.engine().check_status()["mlp_kernel"] == "bf16x6"
     # the engine stays on the full-range kernels: the next batch needs no second run, philox loop included
     res2 = m.sample(n_per, B, VisualizationSetting.NONE, False, max_steps=steps, seed=5)
     assert res2.info is None and np.isfinite(res2.frac_x).all()
@@ -817,14 +829,17 @@ def test_large_cell_regime_vs_oracle(dev, small_model):
 
 
 @pytest.mark.parametrize("B,n", [(256, 20), (64, 64), (1024, 20), (1024, 64)])
-def test_full_size_batch_independence_and_determinism(dev, full_model, B, n):
+def test_full_size_batch_independence_and_determinism(dev, full_model, B, n, monkeypatch):
     """At the benchmark sizes (config 2: 256 x 20; config 4 regime: 64 atoms per crystal; config 3's per-GPU share:
     1024 x 20 = 8192 crystals over 8 GPUs; BASELINE configs[3] at FULL size: 1024 x 64 = 65,536 atoms, a 16 GB K stash
     whose per-layer blocks lie beyond 2^32 bytes, the two-pass neighbour list and the XCD-aware receiver order all at
     once) the oracle is too slow,
     so use size-independent properties: (1) two evaluations are bitwise identical (no atomics, fixed summation
-    order); (2) crystals are independent -- a crystal evaluated inside the big batch gives bitwise the same
-    scores as the same crystal evaluated alone; (3) that lone crystal matches the oracle to 1e-5."""
+    order); (2) crystals are independent -- a crystal evaluated inside the big batch gives the same scores as the same
+    crystal evaluated alone: BITWISE when both run the same arithmetic (ARREAU_CROSS_FP8=0: three fp16 products in the
+    batch's basis form and in the lone crystal's K pair alike), and within the bound of the fp8 cross products (round 4:
+    the default of the basis form, i.e. of batches above 2,000 atoms; see test_launch_geometry_switches...) otherwise;
+    (3) that lone crystal matches the oracle to 1e-5."""
     m, om32 = full_model
     # physical cells (no exactly tied periodic images: the oracle's unstable sort would pick different ones)
     state = random_state(90, [n] * B, 100 + B, cell=(4.0, 8.0) if n <= 20 else (6.0, 9.0))
@@ -835,11 +850,22 @@ def test_full_size_batch_independence_and_determinism(dev, full_model, B, n):
     for x, y in zip(a, b):
         assert torch.equal(x, y)
     assert all(torch.isfinite(x).all() for x in a)
+    assert m.engine().check_status()["conv_variant"] == 2
+    monkeypatch.setenv("ARREAU_CROSS_FP8", "0")  # (read per launch)
+    a16 = _engine_scores(m, dev, state, t)
+    monkeypatch.delenv("ARREAU_CROSS_FP8")
+    worst = [0.0, 0.0, 0.0]
     for ci in (0, B // 2, B - 1):
         sl = slice(ci * n, (ci + 1) * n)
         one = (frac[sl], types[sl], lengths[ci:ci + 1], angles[ci:ci + 1], na[ci:ci + 1])
         eps1, logits1, len01 = _engine_scores(m, dev, one, t)
-        assert torch.equal(eps1, a[0][sl]) and torch.equal(logits1, a[1][sl]) and torch.equal(len01, a[2][ci:ci + 1])
+        assert torch.equal(eps1, a16[0][sl]) and torch.equal(logits1, a16[1][sl]) and torch.equal(len01, a16[2][ci:ci + 1])
+        for i, (x, y) in enumerate(((eps1, a[0][sl]), (logits1, a[1][sl]), (len01, a[2][ci:ci + 1]))):
+            worst[i] = max(worst[i], float((x - y).abs().max()))
+    lmax, gmax = float(a[1].abs().max()), float(a[2].abs().max())
+    print(f"\n[lone crystal vs batch of {B} x {n}, fp8 cross products in the batch] eps {worst[0]:.2e} logits {worst[1]:.2e} "
+          f"(|logits| {lmax:.1f}) len0 {worst[2]:.2e} (|len0| {gmax:.1f})")
+    assert worst[0] <= 3e-7 and worst[1] <= 4e-7 * max(1.0, lmax) and worst[2] <= 6 * (n / 20.0) ** 0.5 * ulp32(gmax)
     eps_o, logits_o, len0_o, _ = _oracle_scores(om32, *one, t)
     assert_scores_close((eps1, logits1, len01), (eps_o, logits_o, len0_o), atoms_per_crystal=n)
     m.engine().check_status()
@@ -985,7 +1011,7 @@ def test_launch_geometry_switches_and_counted_waits_are_bitwise_neutral(dev):
     outs = {}
     with tempfile.TemporaryDirectory() as d:
         for tag, env in (("default", {}), ("k3off", {"ARREAU_CONV_VARIANT": "1", "ARREAU_K3": "0"}), ("conv0", {"ARREAU_CONV_VARIANT": "0"}),
-                         ("pair", {"ARREAU_CONV_VARIANT": "1"}), ("basis16", {"ARREAU_BASIS_FP8": "0"}),
+                         ("pair", {"ARREAU_CONV_VARIANT": "1"}), ("basis16", {"ARREAU_BASIS_FP8": "0"}), ("x16", {"ARREAU_CROSS_FP8": "0"}),
                          ("wgs", {"ARREAU_EDGE_WGS": "100000"}),
                          ("dbgwait", {"ARREAU_HIP_LIB": LIB_DEBUG_WAIT}), ("nb1", {"ARREAU_MLP_NB": "1"}),
                          ("nb2", {"ARREAU_MLP_NB": "2"}), ("slots4", {"ARREAU_MLP_SLOTS": "4"}),
@@ -1011,14 +1037,25 @@ def test_launch_geometry_switches_and_counted_waits_are_bitwise_neutral(dev):
     # Same products in the same order: the basis form (default) is bit-identical to the round-2 pair on an fp32 K stash and
     # to the register form of the conv kernel -- every fp16x3 edge kernel rounds the basis' residual plane to fp8 e4m3, the
     # form the stash holds (3 bytes per value).
+    # (Round 4: with three fp16 products -- ARREAU_CROSS_FP8=0, "x16"; the default now runs the two cross products of the
+    # projection on the fp8 matrix instruction, bounded below.)
     for tag in ("k3off", "conv0"):
-        for x, y in zip(outs["default"], outs[tag]):
+        for x, y in zip(outs["x16"], outs[tag]):
             assert torch.equal(x, y), tag
+    # What the fp8 cross products cost.  The cross products sit 2^-11 below the main product; with e4m3 operands (four
+    # significand bits) their error is 2^-15 .. 2^-16 of a term.  In the fp32 oracle (tools/exp/cross_precision_study.py,
+    # profiles/r04_cross_precision_study.txt) the outputs move by eps 9e-8 / logits 6-7e-7 at |logits| = 2, len0 one to two ulps
+    # -- inside the fp32 oracle's own distance to fp64.  Bounded here like the other operand formats.
+    x_eps, x_logits, x_len0 = (float((a - b).abs().max()) for a, b in zip(outs["default"], outs["x16"]))
+    print(f"[fp8 cross products] |fp8 cross - fp16 cross| : eps {x_eps:.2e}  logits {x_logits:.2e} (|logits| {float(outs['x16'][1].abs().max()):.1f})"
+          f"  len0 {x_len0:.2e} (|len0| {float(outs['x16'][2].abs().max()):.1f})")
+    assert x_eps <= 3e-7 and x_logits <= 4e-7 * max(1.0, float(outs["x16"][1].abs().max()))
+    assert x_len0 <= 6 * ulp32(float(outs["x16"][2].abs().max()))
     # What that rounding costs (11 + 4 significand bits of the basis; ARREAU_BASIS_FP8=0 keeps both planes in fp16 = the
     # round-2 arithmetic).  In the fp32 oracle it is invisible (tools/exp/basis_precision_study.py: both forms at the
     # rounding floor, eps 7e-8 / logits 3.6e-7 at |logits| = 2); measured here: eps 1.3e-7, logits 1.9e-6 at |logits| = 6.8
     # (2.8e-7 relative), len0 4 ulps.  Bounded so that a coarser format cannot eat the parity margin silently.
-    b_eps, b_logits, b_len0 = (float((a - b).abs().max()) for a, b in zip(outs["default"], outs["basis16"]))
+    b_eps, b_logits, b_len0 = (float((a - b).abs().max()) for a, b in zip(outs["x16"], outs["basis16"]))
     print(f"[basis stash] |fp16 + fp8 - fp16 + fp16| : eps {b_eps:.2e}  logits {b_logits:.2e} (|logits| {float(outs['basis16'][1].abs().max()):.1f})"
           f"  len0 {b_len0:.2e} (|len0| {float(outs['basis16'][2].abs().max()):.1f})")
     assert b_eps <= 3e-7 and b_logits <= 4e-7 * max(1.0, float(outs["basis16"][1].abs().max()))

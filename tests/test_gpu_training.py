@@ -325,7 +325,11 @@ def test_training_step_gradients_at_the_bench_size_and_bitwise_repeatable(setup)
     # fp32 oracle is, plus GRAD_TOL of the tensor's largest entry.
     om64 = oracle_from_module(m, torch.float64)
     b64 = SimpleNamespace(X0=batch.X0.double(), A0=batch.A0, L0=batch.L0.double(), num_atoms=batch.num_atoms)
-    _, want64 = _oracle_grads(om64, b64, lattice0.double(), timestep, tuple(x.double() for x in noise))
+    torch.set_default_dtype(torch.float64)  # (the oracle, like the reference, builds its constant tables in the default dtype)
+    try:
+        _, want64 = _oracle_grads(om64, b64, lattice0.double(), timestep, tuple(x.double() for x in noise))
+    finally:
+        torch.set_default_dtype(torch.float32)
     # (the loss is a mean over ~530 atoms x 12 classes + 3 x 64 lattice terms of fp32 values summed in different orders by the
     # two sides: 5e-5 relative here, where the 17-atom test above holds 1e-5)
     print(f"\n[loss, 64 crystals] library {float(loss):.8f} oracle {loss_o:.8f}")

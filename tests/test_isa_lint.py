@@ -47,17 +47,19 @@ def test_hazard_is_found_along_a_branch(lint, tmp_path):
 
 
 def test_valu_written_sgpr_read_by_asm_vmem(lint, tmp_path):
-    body = "\tv_readfirstlane_b32 s20, v0\n" + ASM % "\ts_add_u32 m0, s22, 0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 v221, s[20:21]"
+    wait = "\ts_waitcnt vmcnt(0)\n"  # (every copy is waited for: the LDS-DMA rule of round 4 is not what these snippets test)
+    body = "\tv_readfirstlane_b32 s20, v0\n" + ASM % "\ts_add_u32 m0, s22, 0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 v221, s[20:21]" + wait
     assert run(lint, tmp_path, body) == ["valu-sgpr-vmem"]  # 2 states, needs 5
-    ok = "\tv_readfirstlane_b32 s20, v0\n\ts_nop 2\n" + ASM % "\ts_add_u32 m0, s22, 0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 v221, s[20:21]"
+    ok = "\tv_readfirstlane_b32 s20, v0\n\ts_nop 2\n" + ASM % "\ts_add_u32 m0, s22, 0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 v221, s[20:21]" + wait
     assert run(lint, tmp_path, ok) == []
     # an SALU-written base needs nothing
-    assert run(lint, tmp_path, "\ts_add_u32 s20, s20, 0x2000\n" + ASM % "\ts_add_u32 m0, s22, 0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 v221, s[20:21]") == []
+    assert run(lint, tmp_path, "\ts_add_u32 s20, s20, 0x2000\n" + ASM % "\ts_add_u32 m0, s22, 0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 v221, s[20:21]" + wait) == []
 
 
 def test_m0_write_before_lds_dma(lint, tmp_path):
-    assert run(lint, tmp_path, ASM % "\ts_mov_b32 m0, s12\n\tglobal_load_lds_dwordx4 v[6:7], off") == ["salu-m0-ldsdma"]
-    assert run(lint, tmp_path, ASM % "\ts_mov_b32 m0, s12\n\ts_nop 0\n\tglobal_load_lds_dwordx4 v[6:7], off") == []
+    wait = "\ts_waitcnt vmcnt(0)\n"
+    assert run(lint, tmp_path, ASM % "\ts_mov_b32 m0, s12\n\tglobal_load_lds_dwordx4 v[6:7], off" + wait) == ["salu-m0-ldsdma"]
+    assert run(lint, tmp_path, ASM % "\ts_mov_b32 m0, s12\n\ts_nop 0\n\tglobal_load_lds_dwordx4 v[6:7], off" + wait) == []
 
 
 def test_compiler_use_of_m0_next_to_asm_that_overwrites_it(lint, tmp_path):
@@ -126,3 +128,23 @@ def test_product_sources_are_lint_clean_and_the_build_runs_the_lint():
             with_asm.add(src)
     assert with_asm <= set(b.ASM_LINT), with_asm - set(b.ASM_LINT)
     assert callable(b._isa_lint().lint_file)
+
+
+def test_lds_dma_copy_needs_a_covering_wait(lint, tmp_path):
+    """Round 4: an LDS-DMA copy must meet a covering vmcnt wait on every path -- before the wave ends; a counted wait that leaves the copy among the N youngest does not cover it."""
+    dma = ASM % "\ts_mov_b32 m0, s4\n\ts_nop 0\n\tglobal_load_lds_dwordx4 v1, s[2:3]"
+    # waited, then published by the barrier: clean
+    assert run(lint, tmp_path, dma + "\ts_waitcnt vmcnt(0)\n\ts_barrier\n") == []
+    # the wave ends without ever waiting for its copy
+    assert "ldsdma-unwaited-exit" in run(lint, tmp_path, dma + "\ts_barrier\n")
+    # a counted wait: vmcnt(1) with ONE younger VMEM operation covers the copy, with none it does not
+    younger = "\tglobal_load_dword v9, v[10:11], off\n"
+    assert run(lint, tmp_path, dma + younger + (ASM % "\ts_waitcnt vmcnt(1)") + "\ts_barrier\n\ts_waitcnt vmcnt(0)\n") == []
+    assert "ldsdma-unwaited-exit" in run(lint, tmp_path, dma + (ASM % "\ts_waitcnt vmcnt(1)") + "\ts_barrier\n")
+    # a path around the wait (conditional branch) is found
+    body = dma + "\ts_cbranch_scc1 .LBB0_2\n\ts_waitcnt vmcnt(0)\n.LBB0_2:\n\ts_barrier\n"
+    assert "ldsdma-unwaited-exit" in run(lint, tmp_path, body)
+    # a wait many barriers later is fine (deep rings; the depth is reported by --lds, not judged)
+    assert run(lint, tmp_path, dma + "\ts_barrier\n" * 9 + "\ts_waitcnt vmcnt(0)\n") == []
+    rows = lint.lds_protocol_summary(str(tmp_path / "k-hip-amdgcn-amd-amdhsa-gfx950.s"))
+    assert rows and rows[0][3] == 1  # one LDS-DMA copy in the last snippet

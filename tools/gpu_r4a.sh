@@ -10,6 +10,7 @@ grep -h "^\[plain 1e-5\]\|^\[gradients" gpurun_out/${tag}_pytest.log
 [ $rc -eq 0 ] || { grep -n "Error\|assert\|FAILED" gpurun_out/${tag}_pytest.log | tail -n 30; exit $rc; }
 ARREAU_TEST_MULTISTREAM=1 timeout -k 10 300 python3 -m pytest tests/test_gpu_parity.py -m gpu -q -s -k multi_stream_experiment > gpurun_out/${tag}_multistream.log 2>&1
 echo "multistream rc=$?"; grep -h "multi-stream experiment\|passed\|failed" gpurun_out/${tag}_multistream.log | tail -n 3
+timeout -k 10 60 tools/exp/_bin/fp8_mfma_check 2>&1 | tee gpurun_out/${tag}_fp8_mfma_check.txt
 timeout -k 10 300 python3 -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -n 1 || exit 1
 timeout -k 10 500 python3 bench.py > gpurun_out/${tag}_bench_c2.json 2> gpurun_out/${tag}_bench_c2.err || { tail -n 30 gpurun_out/${tag}_bench_c2.err; exit 1; }
 python3 - <<PY
