@@ -70,20 +70,25 @@ __device__ __forceinline__ void cp_wait_but() {
 // X8 (round 4, needs BFP8): the two CROSS products of the split scheme on the fp8 matrix instruction.  They sit 2^-11 below the
 // main product, so four significand bits per operand are enough (profiles/r04_cross_precision_study.txt); both cross products
 // of a PAIR of k-blocks are one v_mfma_scale_f32_16x16x128_f8f6f4 with unit scales --
-//     A = [a1_8(kb) | a2_8(kb) | a1_8(kb+1) | a2_8(kb+1)]   (packed on the host: model.hip, pack_conv_cross_fp8; 64 registers)
-//     B = [b2_8(kb) | b1_8(kb) | b2_8(kb+1) | b1_8(kb+1)]   (b2_8 = the stash's residual plane as stored, b1_8 = e4m3(8 b1))
-// -- 32 cycles for what took four fp16 instructions of 16; with the two main products a pair of k-blocks costs 64 cycles of the
-// matrix pipe instead of 96.  K = main + X / (64 * 2^11).  Measured with a timing-only build that dropped a third of the
-// matrix work: 140.6 -> 122.3 us per launch at 256 x 20 (tools/exp/sweep_libs.sh, profiles/r04a_conv_proj_sweep.txt).
+//     A = [a1_8(kb) | a1_8(kb+1) | a2_8(kb) | a2_8(kb+1)]   (packed on the host: model.hip, pack_conv_cross_fp8; 64 registers)
+//     B = [b2_8(kb) | b2_8(kb+1) | b1_8(kb) | b1_8(kb+1)]   (b2_8 = the stash's residual planes as stored -- the two 8-byte LDS reads
+//                                                            land in place --, b1_8 = e4m3(b1), converted here)
+// -- 36 cycles for what took four fp16 instructions of 18 (tools/exp/fp8_mfma_check.hip); with the two main products a pair of
+// k-blocks costs 72 cycles of the matrix pipe instead of 108.  a1_8 = e4m3(64 a1), a2_8 = e4m3(64 a2): K = main + X / (64 * 2^11).
+// A timing-only build that dropped a third of the matrix work measured 140.6 -> 122.3 us per launch at 256 x 20
+// (profiles/r04a_conv_proj_sweep.txt); the real kernel, all products kept: 133.8 -> 125.1 us, step 1.414 -> 1.360 ms (same box).
 typedef int i32x8 __attribute__((ext_vector_type(8)));
 namespace {
-__device__ __forceinline__ unsigned cp_cvt4_fp8(unsigned h01, unsigned h23) {  // four fp16 -> four e4m3 of 8 x the value (the scale divides)
+// four fp16 -> four e4m3 (round to nearest even, saturating) INTO `into`: each conversion writes one 16-bit word of its
+// destination and keeps the other, so the destination is an input too -- converting into the register that already is the MFMA
+// operand's slot (its old content is dead) costs no move
+__device__ __forceinline__ int cp_cvt4_fp8(int into, unsigned h01, unsigned h23) {
     typedef _Float16 h2 __attribute__((ext_vector_type(2)));
     typedef short s2 __attribute__((ext_vector_type(2)));
-    s2 r = {0, 0};
-    r = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(r, __builtin_bit_cast(h2, h01), 0.125f, false);
-    r = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(r, __builtin_bit_cast(h2, h23), 0.125f, true);
-    return __builtin_bit_cast(unsigned, r);
+    s2 r = __builtin_bit_cast(s2, into);
+    r = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(r, __builtin_bit_cast(h2, h01), 1.0f, false);
+    r = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(r, __builtin_bit_cast(h2, h23), 1.0f, true);
+    return __builtin_bit_cast(int, r);
 }
 }  // namespace
 #define CP_X8_FOLD (1.0f / (64.0f * 2048.0f))
@@ -97,7 +102,8 @@ __global__ __launch_bounds__(64 * (PW + 4), (PW + 4) / 4) void conv_proj_kernel(
     const float* __restrict__ x_in,      // [N][16][C]
     const float* __restrict__ fk,        // [16(o)][16(p)][C]
     const float* __restrict__ conv_bias, int n0, int N /* receivers n0 .. n0 + N - 1 (absolute indices into whole-batch arrays) */,
-    float* __restrict__ x_conv)          // [N][16][C]
+    float* __restrict__ x_conv,          // [N][16][C]
+    int reverse)  // walk the receivers from the last to the first (see the launcher: the Infinity Cache holds the END of the last pass)
 {
     static_assert(C == 128 && D == 256, "roles and register budgets assume C = 128, D = 256");
     static_assert(!X8 || BFP8, "the fp8 cross products take the stash's e4m3 residual plane as it is stored");
@@ -119,9 +125,10 @@ __global__ __launch_bounds__(64 * (PW + 4), (PW + 4) / 4) void conv_proj_kernel(
     const int xcd = blockIdx.x & 7, wg_in_xcd = blockIdx.x >> 3, wgs_per_xcd = gridDim.x >> 3;
     const int n_iter = xcd_order ? ((N + 8 * GROUP - 1) / (8 * GROUP)) * GROUP : N;
     const int m_step = xcd_order ? wgs_per_xcd : (int)gridDim.x;
-    auto local_of = [&](int m) { return xcd_order ? ((m / GROUP) * 8 + xcd) * GROUP + (m % GROUP) : m; };
+    auto fwd_of = [&](int m) { return xcd_order ? ((m / GROUP) * 8 + xcd) * GROUP + (m % GROUP) : m; };
+    auto local_of = [&](int m) { return reverse ? N - 1 - fwd_of(m) : fwd_of(m); };  // (only called for valid m)
     auto next_valid = [&](int m) {
-        while (m < n_iter && local_of(m) >= N) m += m_step;
+        while (m < n_iter && fwd_of(m) >= N) m += m_step;
         return m;
     };
     int m = next_valid(xcd_order ? wg_in_xcd : (int)blockIdx.x);
@@ -201,10 +208,18 @@ __global__ __launch_bounds__(64 * (PW + 4), (PW + 4) / 4) void conv_proj_kernel(
         typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
         u32x4 b1[NBUF], b2[NBUF];
         u32x2_t b8[NBUF];  // BFP8: the lo fragment as stored (8 fp8 per lane)
+        // X8: the fp8 operand of a pair of k-blocks, [b2_8(kb) | b2_8(kb + 1) | b1_8(kb) | b1_8(kb + 1)]: two blocks alternate (the
+        // residual fragments of the next pair arrive from LDS while this pair's block is the MFMA's operand)
+        i32x8 B8[2] = {i32x8{0, 0, 0, 0, 0, 0, 0, 0}, i32x8{0, 0, 0, 0, 0, 0, 0, 0}};
         const char* ring_b = reinterpret_cast<const char*>(&ring[0][0]);
         const unsigned hi_off = 16u * lane, lo_off = 8192u + 8u * lane;
         auto frag = [&](unsigned base /* byte offset of the slot buffer: wave-uniform */, int kb, int sl_) {
-            if constexpr (BFP8) {
+            if constexpr (X8) {
+                b1[sl_] = *reinterpret_cast<const u32x4*>(ring_b + base + hi_off + 1024 * kb);
+                const u32x2_t t = *reinterpret_cast<const u32x2_t*>(ring_b + base + lo_off + 512 * kb);
+                B8[(kb >> 1) & 1][2 * (kb & 1)] = (int)t[0];
+                B8[(kb >> 1) & 1][2 * (kb & 1) + 1] = (int)t[1];
+            } else if constexpr (BFP8) {
                 b1[sl_] = *reinterpret_cast<const u32x4*>(ring_b + base + hi_off + 1024 * kb);
                 b8[sl_] = *reinterpret_cast<const u32x2_t*>(ring_b + base + lo_off + 512 * kb);
             } else {
@@ -287,13 +302,16 @@ __global__ __launch_bounds__(64 * (PW + 4), (PW + 4) / 4) void conv_proj_kernel(
                         else frag(f_next, kk - NKB, kk % NBUF);
                     }
                     if constexpr (X8) {
-                        const i32x8 B8 = {(int)b8[s0][0], (int)b8[s0][1], (int)cp_cvt4_fp8(b1[s0][0], b1[s0][1]), (int)cp_cvt4_fp8(b1[s0][2], b1[s0][3]),
-                                          (int)b8[s1][0], (int)b8[s1][1], (int)cp_cvt4_fp8(b1[s1][0], b1[s1][1]), (int)cp_cvt4_fp8(b1[s1][2], b1[s1][3])};
+                        i32x8& Bp = B8[kp & 1];  // (its residual halves were loaded two k-blocks ago)
+                        Bp[4] = cp_cvt4_fp8(Bp[4], b1[s0][0], b1[s0][1]);
+                        Bp[5] = cp_cvt4_fp8(Bp[5], b1[s0][2], b1[s0][3]);
+                        Bp[6] = cp_cvt4_fp8(Bp[6], b1[s1][0], b1[s1][1]);
+                        Bp[7] = cp_cvt4_fp8(Bp[7], b1[s1][2], b1[s1][3]);
 #pragma unroll
                         for (int mt = 0; mt < MT; ++mt) {
                             am[set][mt] = mfma16_f16(A1[mt][kb0], b1[s0], am[set][mt]);
                             am[set][mt] = mfma16_f16(A1[mt][kb1], b1[s1], am[set][mt]);
-                            ax[set][mt] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(A8[mt][kp], B8, ax[set][mt], 0, 0, 0, 0x7f7f7f7f, 0,
+                            ax[set][mt] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(A8[mt][kp], Bp, ax[set][mt], 0, 0, 0, 0x7f7f7f7f, 0,
                                                                                           0x7f7f7f7f);
                         }
                     }
@@ -471,10 +489,17 @@ int arreau_launch_conv_proj(const arreau_model* m, int layer, const float* basis
     const u32x4* stream = reinterpret_cast<const u32x4*>(m->edge_f16);
     const u32x4* wchunks = stream + ((size_t)TC * NF1 + (size_t)TD * NF2 + (size_t)layer * TC * NF3) * 64;
     static const int pw_env = [] { const char* e = getenv("ARREAU_CONV_PROJ_WAVES"); return e ? atoi(e) : 4; }();
+    // Boustrophedon over the layers (round 4).  The stash (503 MB at 256 x 20) is larger than the 256 MiB Infinity Cache, so a pass
+    // that starts where the previous one started finds nothing of it on the die; a pass that starts where the previous one ENDED
+    // finds the last ~100-250 MB (MI355X_MICROARCH.md: a line stays while the bytes touched since its last use fit the cache).
+    // The edge kernel wrote the stash front to back, so layer 0 reads it back to front, layer 1 front to back, ...  Each receiver
+    // is computed exactly as before: bit-identical.  ARREAU_CONV_PROJ_BOUSTROPHEDON=0: every pass front to back (A/B).
+    static const int bous_env = [] { const char* e = getenv("ARREAU_CONV_PROJ_BOUSTROPHEDON"); return e ? atoi(e) : 1; }();
+    const int reverse = bous_env != 0 && (layer & 1) == 0 ? 1 : 0;
     const u32x4* x8w = reinterpret_cast<const u32x4*>(m->conv_x8) + (size_t)layer * (m->C / 16) * (m->D / 64) * 2 * 64;
     auto launch = [&](auto kernel, int threads) {
         ARREAU_LAUNCH(kernel, dim3(blocks), dim3(threads), 0, s, reinterpret_cast<const u32x4*>(basis), wchunks, x8w, deg, src, x_in,
-                      m->fk + (size_t)layer * 16 * 16 * m->C, m->conv_bias + (size_t)layer * m->C, n0, Ng, x_conv);
+                      m->fk + (size_t)layer * 16 * 16 * m->C, m->conv_bias + (size_t)layer * m->C, n0, Ng, x_conv, reverse);
     };
     const bool fp8 = arreau_basis_fp8();
     arreau_prof_conv(0, s);

@@ -195,17 +195,19 @@ static inline uint8_t f32_to_e4m3_rne_sat(float x) {
 // Cross-product operands of conv_proj.hip's fp8 form (round 4).  The two cross products of the split scheme sit 2^-11 below
 // the main one, so their operands need a handful of bits: both run as ONE v_mfma_scale_f32_16x16x128_f8f6f4 per pair of
 // 32-wide k-blocks (twice the fp16 rate),  X = sum_k a1_8 b2_8 + a2_8 b1_8  with
-//     a1_8 = e4m3(64 a1),  a2_8 = e4m3(8 a2),  b1_8 = e4m3(8 b1),  b2_8 = e4m3(b2) (the stash's residual plane as stored),
-// i.e. X = 64 (a1 b2 + a2 b1) and K = a1 b1 + X / (64 * 2^11).  (profiles/r04_cross_precision_study.txt: outputs move by
-// less than the fp32 oracle's own distance to fp64.)  Layout, per layer: [16-channel tile T = 0..7][k-block pair kp][half h][lane]
-// x 16 bytes: bytes 0-7 = a1_8, bytes 8-15 = a2_8 of output row 16 T + (lane & 15), k-block 2 kp + h, in the k order of the
-// stashed basis fragments (pack_linear_f16x3_m16, native).  Returns the largest |64 a1| (beyond 448 the operand would saturate:
-// the caller then keeps the fp16 cross products).
+//     a1_8 = e4m3(64 a1),  a2_8 = e4m3(64 a2),  b1_8 = e4m3(b1),  b2_8 = e4m3(b2) (the stash's residual plane as stored),
+// i.e. X = 64 (a1 b2 + a2 b1) and K = a1 b1 + X / (64 * 2^11).  (The weights are scaled into the format's normal range; the basis
+// is taken as it is -- |b1| up to 448 before the CORRECTION term saturates, values below 2^-9 drop out of it: their share of
+// a product 2^-11 below the main one is beneath fp32 rounding.  profiles/r04_cross_precision_study.txt: outputs move by less than
+// the fp32 oracle's own distance to fp64.)  Layout, per layer: [16-channel tile T = 0..7][k-block pair kp][plane h][lane] x 16
+// bytes: plane 0 = a1_8 of k-blocks 2 kp (bytes 0-7) and 2 kp + 1 (bytes 8-15), plane 1 = a2_8 likewise, of output row
+// 16 T + (lane & 15), in the k order of the stashed basis fragments (pack_linear_f16x3_m16, native).  Returns the largest |64 a1|
+// (beyond 448 the operand would saturate: the caller then keeps the fp16 cross products).
 static float pack_conv_cross_fp8(const float* W /*[C][D]*/, int C, int D, uint8_t* Q) {
     float amax = 0.f;
     for (int T = 0; T < C / 16; ++T)
         for (int kp = 0; kp < D / 64; ++kp)
-            for (int h = 0; h < 2; ++h)
+            for (int h = 0; h < 2; ++h)  // k-block 2 kp + h
                 for (int lane = 0; lane < 64; ++lane)
                     for (int e = 0; e < 8; ++e) {
                         const int g = lane >> 4, kb = 2 * kp + h;
@@ -215,9 +217,9 @@ static float pack_conv_cross_fp8(const float* W /*[C][D]*/, int C, int D, uint8_
                         const float a1 = f16_to_f32(f32_to_f16_rne(w));
                         const float a2 = f16_to_f32(f32_to_f16_rne((w - a1) * 2048.0f));
                         amax = fmaxf(amax, fabsf(64.0f * a1));
-                        const size_t base = ((((size_t)T * (D / 64) + kp) * 2 + h) * 64 + lane) * 16;
-                        Q[base + e] = f32_to_e4m3_rne_sat(64.0f * a1);
-                        Q[base + 8 + e] = f32_to_e4m3_rne_sat(8.0f * a2);
+                        const size_t plane0 = ((((size_t)T * (D / 64) + kp) * 2 + 0) * 64 + lane) * 16, plane1 = plane0 + 64 * 16;
+                        Q[plane0 + 8 * h + e] = f32_to_e4m3_rne_sat(64.0f * a1);
+                        Q[plane1 + 8 * h + e] = f32_to_e4m3_rne_sat(64.0f * a2);
                     }
     return amax;
 }

@@ -82,6 +82,9 @@ def project(basis, W):
         cross = q_e4m3(b2).double() @ q_e4m3(a1).double().T + q_e4m3(b1).double() @ q_e4m3(a2).double().T
     elif m == "e4m3s":   # e4m3 with the weight planes scaled into the format's range (x 64: power of two, exact)
         cross = (q_e4m3(b2).double() @ q_e4m3(a1 * 64).double().T + q_e4m3(b1).double() @ q_e4m3(a2 * 64).double().T) / 64
+    elif m == "e4m3hw":  # what conv_proj.hip's X8 form computes: ONE fp8 product per pair of k-blocks, so the four operand scales
+        # are tied -- a1_8 = e4m3(64 a1), b2_8 = e4m3(b2) (as stashed), a2_8 = e4m3(64 a2), b1_8 = e4m3(b1): X = 64 (a1 b2 + a2 b1)
+        cross = (q_e4m3(b2).double() @ q_e4m3(a1 * 64).double().T + q_e4m3(b1).double() @ q_e4m3(a2 * 64).double().T) / 64
     elif m == "e2m3blk":  # fp6, data-dependent scale per lane block on both sides
         cross = cross_fp6(b1, b2, a1, a2)
     elif m == "e2m3fixB":  # fp6, weights block-scaled (host), basis with ONE fixed scale (no maximum to find in the kernel)
@@ -128,7 +131,7 @@ def main():
         print(name, ": max |eps|, |logits|, |len0| =", " ".join("%.3g" % float(a.abs().max()) for a in base[:3]))
         d64 = lambda q: " / ".join("%.2e" % float((a.double() - b).abs().max()) for a, b in zip(q[:3], ref64[:3]))
         print("   %-12s: distance to the fp64 oracle (eps / logits / len0) = %s" % ("fp32 oracle", d64(base)))
-        modes = ["f16x3", "e4m3", "e4m3s", "e2m3blk", "e2m3fixB:1", "e2m3fixB:0.5", "e2m3fixB:0.25", "nocross_b2", "nocross"]
+        modes = ["f16x3", "e4m3hw", "e4m3", "e4m3s", "e2m3blk", "e2m3fixB:1", "e2m3fixB:0.5", "e2m3fixB:0.25", "nocross_b2", "nocross"]
         for mode in modes:
             if ":" in mode:
                 MODE[0], FIXED_B[0] = mode.split(":")[0], float(mode.split(":")[1])
