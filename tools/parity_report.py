@@ -30,7 +30,7 @@ import torch.nn.functional as F
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "parity_r02.json"))
+    ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "parity_r04.json"))
     ap.add_argument("--quick", action="store_true", help="only the [20]x8 case")
     args = ap.parse_args()
     from arreau_amd.checkpoint import make_synthetic_model
@@ -46,11 +46,17 @@ def main():
     rng = np.random.RandomState(5)
     cases = [("20x8_sampler_like", [20] * 8, dict(sampler_like=True), 4)]
     if not args.quick:
-        cases += [("64x2_dense", [64, 64], dict(cell=(6.0, 9.0)), 41),
+        cases += [("20x40_sampler_like", [20] * 40, dict(sampler_like=True), 6), ("64x2_dense", [64, 64], dict(cell=(6.0, 9.0)), 41),
                   ("ragged_420", [int(v) for v in rng.randint(1, 7, size=420)], dict(cell=(3.5, 9.0)), 91)]
     # (edge variant, mlp variant): the default kernels, the exact fp32-MFMA kernels, the small-batch ConvNext kernel
     # (hidden dimension split over eight waves) and the shape-general fp32 GEMM network
-    variants = [("default_fp16x3", 4, 3), ("fp32_mfma", 0, 0), ("small_launch_mlp_form", 4, 4), ("general_fp32_gemm", 5, 3)]
+    # Round 4: "basis_form_*" = the message path of launches above 2,000 receivers (what bench.py's `value` runs: stashed basis,
+    # per-layer projection in conv_proj.hip), forced at these oracle-sized batches with ARREAU_BASIS_MIN_RECEIVERS=240 (read per
+    # launch; batches of at most 240 atoms keep the K pair and report it) -- with the two cross products on the fp8 matrix
+    # instruction (the default) and with three fp16 products (ARREAU_CROSS_FP8=0).
+    variants = [("default_fp16x3", 4, 3, {}), ("fp32_mfma", 0, 0, {}), ("small_launch_mlp_form", 4, 4, {}), ("general_fp32_gemm", 5, 3, {}),
+                ("basis_form_fp8_cross", 4, 3, {"ARREAU_BASIS_MIN_RECEIVERS": "240"}),
+                ("basis_form_fp16_cross", 4, 3, {"ARREAU_BASIS_MIN_RECEIVERS": "240", "ARREAU_CROSS_FP8": "0"})]
     report = {"model": "synthetic S=90 T=1000 C=128 D=256 L=5 (make_synthetic_model seed 1234, trained_like)",
               "edges": "oracle's radius_graph_pbc, teacher-forced", "device": torch.cuda.get_device_name(0),
               "cases": {}}
@@ -80,12 +86,17 @@ def main():
                    "oracle_f32_vs_f64": {"eps": float((eps32.double() - eps64).abs().max()),
                                          "logits": float((log32.double() - log64).abs().max()),
                                          "len0": float((len32.double() - len64).abs().max())}}
-            for vname, ev, mv in variants:
+            for vname, ev, mv, env in variants:
                 eng.set_variant(ev, mv)
-                eps, logits, len0 = eng.predict_scores(f, ty, le, an, t_c, off, edges=edges)
-                st = eng.check_status()
+                os.environ.update(env)
+                try:
+                    eps, logits, len0 = eng.predict_scores(f, ty, le, an, t_c, off, edges=edges)
+                    st = eng.check_status()
+                finally:
+                    for k in env:
+                        del os.environ[k]
                 e, l, g = eps.cpu(), logits.cpu(), len0.cpu()
-                r = {"kernels": [st["edge_kernel"], st["mlp_kernel"]],
+                r = {"kernels": [st["edge_kernel"], st["mlp_kernel"]], "message_path": st["conv_variant"], "fp8_cross": st["conv_cross_fp8"],
                      "eps": float((e - eps32).abs().max()), "logits": float((l - log32).abs().max()),
                      "len0": float((g - len32).abs().max()),
                      "eps_vs_f64": float((e.double() - eps64).abs().max()),
@@ -104,6 +115,9 @@ def main():
     report["worst"] = worst
     report["ratio_fp16x3_over_fp32mfma_vs_f64"] = {
         k: worst["default_fp16x3"][k + "_vs_f64"] / max(worst["fp32_mfma"][k + "_vs_f64"], 1e-30)
+        for k in ("eps", "logits", "len0")}
+    report["ratio_basis_form_fp8_cross_over_fp32mfma_vs_f64"] = {
+        k: worst["basis_form_fp8_cross"][k + "_vs_f64"] / max(worst["fp32_mfma"][k + "_vs_f64"], 1e-30)
         for k in ("eps", "logits", "len0")}
     os.makedirs(os.path.dirname(args.out), exist_ok=True)
     with open(args.out, "w") as fh:
