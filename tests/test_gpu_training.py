@@ -367,3 +367,53 @@ def test_make_train_preset_batch_fits_the_gradient_scratch():
     assert all(torch.isfinite(g).all() for g in grads.values())
     key = [n for n in grads if n.endswith("interaction_layers.0.conv.fiber_kernel.weight")]
     assert key and float(grads[key[0]].abs().max()) > 0
+
+
+def test_reversed_adjacency_of_a_crystal_above_256_atoms(setup):
+    """The ordered sender-side gradient walks a reversed adjacency that one workgroup builds per crystal, senders in passes of
+    256: a 300-atom crystal (two passes, a carried base between them) next to small ones -- every gradient against oracle
+    autograd, referenced to fp64 like the 64-crystal test, and bitwise repeatable."""
+    import copy
+    from oracle import geometry as OG
+    m, om, *_ = setup
+    rng = np.random.RandomState(33)
+    num_atoms = [3, 300, 7]
+    B, N, S = len(num_atoms), sum(num_atoms), 12
+    edge = (np.array(num_atoms) / 0.055) ** (1.0 / 3.0)
+    lengths = torch.tensor(edge[:, None] * rng.uniform(0.9, 1.1, size=(B, 3)), dtype=torch.float32)
+    angles = torch.tensor(np.deg2rad(rng.uniform(80, 100, size=(B, 3))), dtype=torch.float32)
+    lattice0 = OG.lattice_from_params(lengths, angles)
+    batch = SimpleNamespace(X0=torch.tensor(rng.uniform(0, 1, size=(N, 3)), dtype=torch.float32),
+                            A0=torch.tensor(rng.randint(0, S - 1, size=N)), L0=lattice0.reshape(-1, 3),
+                            num_atoms=torch.tensor(num_atoms))
+    timestep = torch.tensor([5, 60, 100])
+    g = torch.Generator().manual_seed(2)
+    noise = (torch.randn(N, 3, generator=g), torch.rand(N, S, generator=g), torch.randn(B, 3, generator=g))
+    mm = copy.deepcopy(m)
+    for layer in mm.model.interaction_layers:
+        layer.conv.callibrated.fill_(True)
+    loss = mm.training_step(batch, timestep=timestep, noise=noise)
+    first = {n: p.grad.clone() for n, p in mm.named_parameters() if p.grad is not None}
+    for p in mm.parameters():
+        p.grad = None
+    mm.training_step(batch, timestep=timestep, noise=noise)
+    for n, p in mm.named_parameters():
+        if p.grad is not None:
+            assert torch.equal(p.grad, first[n]), ("gradient not bitwise repeatable", n)
+    loss_o, want = _oracle_grads(om, batch, lattice0, timestep, noise)
+    assert abs(float(loss) - loss_o) <= 5e-5 * max(1.0, abs(loss_o))
+    om64 = oracle_from_module(m, torch.float64)
+    b64 = SimpleNamespace(X0=batch.X0.double(), A0=batch.A0, L0=batch.L0.double(), num_atoms=batch.num_atoms)
+    torch.set_default_dtype(torch.float64)
+    try:
+        _, want64 = _oracle_grads(om64, b64, lattice0.double(), timestep, tuple(x.double() for x in noise))
+    finally:
+        torch.set_default_dtype(torch.float32)
+    for name, w in want.items():
+        if w.numel() == 0:
+            continue
+        w64 = want64[name]
+        scale = max(float(w64.abs().max()), 1e-7)
+        err = float((first[name].cpu().double() - w64).abs().max())
+        err_o = float((w.double() - w64).abs().max())
+        assert err <= GRAD_TOL * scale + 2 * err_o + 1e-7, (name, err, err_o, scale)
