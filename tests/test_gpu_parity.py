@@ -1074,6 +1074,32 @@ def test_launch_geometry_switches_and_counted_waits_are_bitwise_neutral(dev):
     assert d_len0 <= 3 * ulp32(float(outs["k3off"][2].abs().max()))
 
 
+def test_fp8_cross_products_fall_back_when_a_weight_would_saturate(dev, monkeypatch):
+    """The fp8 cross operands hold 64 x the weight's fp16 plane (model.hip, pack_conv_cross_fp8): a kernel weight beyond 7 would
+    saturate at 448, so such a model keeps three fp16 products (arreau_status.conv_cross_fp8 == 0) -- and matches the oracle like
+    any other; the same model with the weight back in range takes the fp8 form."""
+    from arreau_amd.checkpoint import make_synthetic_model
+    monkeypatch.setenv("ARREAU_BASIS_MIN_RECEIVERS", "240")
+    state = random_state(12, [20] * 16, 23, cell=(4.0, 8.0))
+    f, ty, le, an, off = _to_dev(dev, *state)
+    t_c = torch.full((16,), 40, device=dev, dtype=torch.int32)
+    for big, want in ((True, 0), (False, 1)):
+        m = make_synthetic_model(S=12, seed=1234, num_timesteps=100)
+        if big:
+            with torch.no_grad():
+                m.model.interaction_layers[2].conv.kernel.weight[5, 17] = 9.0
+        m = m.to(dev)
+        om32 = oracle_from_module(m, torch.float32)
+        eps_o, logits_o, len0_o, (ei, dists, direction, _c, _l) = _oracle_scores(om32, *state, 40)
+        deg, src, sdir, sdist = slots_from_edges(ei, dists, direction, 320, 8)
+        eng = m.engine()
+        got = eng.predict_scores(f, ty, le, an, t_c, off, edges=tuple(x.to(dev).contiguous() for x in (deg, src, sdir, sdist)))
+        st = eng.check_status()
+        assert st["conv_variant"] == 2 and st["conv_cross_fp8"] == want, st
+        assert_scores_close(got, (eps_o, logits_o, len0_o), f"kernel weight {'9.0' if big else 'in range'}")
+        eng.close()
+
+
 def test_basis_stash_holds_fp16_and_e4m3_planes(dev, full_model):
     """The stash the edge kernel writes in the basis form, read back from the workspace: per edge slot a 12 KiB block of
     eight 1 KiB hi fragments (fp16, [k-block][lane][8 halves]) and eight 512 B lo fragments (OCP fp8 e4m3).  Against the
