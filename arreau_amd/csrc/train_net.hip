@@ -955,6 +955,9 @@ extern "C" int arreau_train_forward(arreau_model* m, const float* d_frac, const 
     // geometry and graph: the sampling path's own kernels (prep, neighbour list)
     TRY(arreau_launch_prep(m, d_frac, d_lengths, d_angles, d_t, d_off, B, N, t.lattice, t.cart, t.batch, t.cvec, s));
     TRY(arreau_launch_neighbor(t.cart, t.lattice, d_off, t.batch, B, N, m->cfg.radius, k, t.deg, t.src, t.cell, t.dir, t.dist, s));
+    // sender-side adjacency of this step's graph, for the ordered, atomic-free d(x_l) of the spatial conv in the backward pass
+    // (built here, while the caller's offsets are certainly alive: the backward pass reads only the context's own arrays)
+    LAUNCH(reverse_adjacency_kernel, dim3((unsigned)B), dim3(256), d_off, t.deg, t.src, k, t.rev_start, t.rev_cnt, t.rev_idx);
     // embedding (ponita.py:98): x_0 = F . W_emb^T, embT = W_emb^T [S+78][C]  (F is kept for the embedder's gradient)
     LAUNCH(features_kernel, dim3((unsigned)M), dim3(64), d_frac, d_types, d_lengths, d_angles, d_t, d_off, t.batch, t.lattice,
            m->vp_betas, m->t_emb_w, m->ori, S, m->T, N, t.F);
@@ -981,8 +984,6 @@ extern "C" int arreau_train_backward(arreau_model* m, const float* d_g_eps, cons
     ARREAU_CHECK_HIP(hipMemsetAsync(t.dx, 0, (size_t)M * C * sizeof(float), s));
     ARREAU_CHECK_HIP(hipMemsetAsync(t.dfkb, 0, (size_t)256 * D * sizeof(float), s));
     const float invL = 1.0f / (float)L;
-    // sender-side adjacency of this step's graph (for the ordered, atomic-free d(x_l) of the spatial conv)
-    LAUNCH(reverse_adjacency_kernel, dim3((unsigned)t.B), dim3(256), t.offsets, t.deg, t.src, k, t.rev_start, t.rev_cnt, t.rev_idx);
     for (int l = L - 1; l >= 0; --l) {
         const float* xl = t.x + (size_t)l * M * C;
         const float* xnext = t.x + (size_t)(l + 1) * M * C;
