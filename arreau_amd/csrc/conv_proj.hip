@@ -91,7 +91,10 @@ __device__ __forceinline__ int cp_cvt4_fp8(int into, unsigned h01, unsigned h23)
     return __builtin_bit_cast(int, r);
 }
 }  // namespace
-#define CP_X8_FOLD (1.0f / (64.0f * 2048.0f))
+// X8: the instruction's block scales fold the cross products in -- operand A carries 2^-17 = 1 / (64 * 2^11) (E8M0 byte 127 - 17 in
+// every lane), so each fp8 product adds X / (64 * 2^11) straight into the MAIN accumulator: no second accumulator, no fold
+#define CP_X8_SCALE_A 0x6e6e6e6e
+#define CP_X8_SCALE_B 0x7f7f7f7f
 
 template <int C, int D, int PW, bool BFP8, bool X8 = false>
 __global__ __launch_bounds__(64 * (PW + 4), (PW + 4) / 4) void conv_proj_kernel(
@@ -227,7 +230,11 @@ __global__ __launch_bounds__(64 * (PW + 4), (PW + 4) / 4) void conv_proj_kernel(
                 b2[sl_] = *reinterpret_cast<const u32x4*>(ring_b + base + hi_off + 2048 * kb + 1024);
             }
         };
-        f32x4v am[1][MT], ax[1][MT];
+        // X8: two accumulator sets alternate between consecutive slots -- slot q's epilogue (fold, multiply by the sender rows, ordered
+        // add) runs INSIDE slot q + 1's MFMA stream, behind its first pair of k-blocks, instead of holding the matrix pipe up between
+        // two slots (round 4: a timing-only build without the epilogue arithmetic ran 131 -> 99 us per launch)
+        constexpr int NSET = X8 ? 2 : 1;
+        f32x4v am[NSET][MT], ax[X8 ? 1 : NSET][MT];  // (X8: the cross products accumulate into am, scaled by the instruction)
         f32x4v sum[MT];
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) sum[mt] = f32x4v{0.f, 0.f, 0.f, 0.f};
@@ -236,9 +243,18 @@ __global__ __launch_bounds__(64 * (PW + 4), (PW + 4) / 4) void conv_proj_kernel(
             for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
-                    const float kv = fmaf(ax[set][mt][r], X8 ? CP_X8_FOLD : F16X3_INV_SCALE, am[set][mt][r]);
+                    float kv = am[set][mt][r];
+                    if constexpr (!X8) kv = fmaf(ax[set][mt][r], F16X3_INV_SCALE, kv);
                     sum[mt][r] = on ? __fadd_rn(sum[mt][r], __fmul_rn(kv, xv[xbuf][mt][r])) : sum[mt][r];
                 }
+        };
+        auto epilogue_piece = [&](int set, int xbuf, bool on, int v) {  // value v = 4 mt + r of the same arithmetic
+            const int mt = v >> 2, r = v & 3;
+            if (mt < MT) {
+                float kv = am[set][mt][r];
+                if constexpr (!X8) kv = fmaf(ax[set][mt][r], F16X3_INV_SCALE, kv);
+                sum[mt][r] = on ? __fadd_rn(sum[mt][r], __fmul_rn(kv, xv[xbuf][mt][r])) : sum[mt][r];
+            }
         };
         auto write_tile = [&]() {
             // (address re-derived from an opaque copy of the lane index right here: kept across the whole slot sequence it
@@ -263,9 +279,12 @@ __global__ __launch_bounds__(64 * (PW + 4), (PW + 4) / 4) void conv_proj_kernel(
             const int32_t* srow_next = src + (size_t)(has_next ? n0 + local_of(mn) : n) * K;
 #pragma unroll
             for (int s = 0; s < K; ++s) {
-                constexpr int set = 0;
+                const int set = X8 ? (s & 1) : 0;
 #pragma unroll
-                for (int mt = 0; mt < MT; ++mt) { am[set][mt] = f32x4v{0.f, 0.f, 0.f, 0.f}; ax[set][mt] = f32x4v{0.f, 0.f, 0.f, 0.f}; }
+                for (int mt = 0; mt < MT; ++mt) {
+                    am[set][mt] = f32x4v{0.f, 0.f, 0.f, 0.f};
+                    if constexpr (!X8) ax[set][mt] = f32x4v{0.f, 0.f, 0.f, 0.f};
+                }
                 if (s + 2 < K) load_x(srow, s + 2, (s + 2) & 3);
                 else load_x(srow_next, s + 2 - K, (s + 2) & 3);  // (the last receiver re-reads its own rows: never used)
                 const unsigned f = (unsigned)rb * SLOT_BYTES;
@@ -307,12 +326,56 @@ __global__ __launch_bounds__(64 * (PW + 4), (PW + 4) / 4) void conv_proj_kernel(
                         Bp[5] = cp_cvt4_fp8(Bp[5], b1[s0][2], b1[s0][3]);
                         Bp[6] = cp_cvt4_fp8(Bp[6], b1[s1][0], b1[s1][1]);
                         Bp[7] = cp_cvt4_fp8(Bp[7], b1[s1][2], b1[s1][3]);
+                        // (one accumulator per tile now carries all three products of a pair: the tiles alternate, so that no MFMA waits for
+                        // the one issued just before it)
+#pragma unroll
+                        for (int mt = 0; mt < MT; ++mt) am[set][mt] = mfma16_f16(A1[mt][kb0], b1[s0], am[set][mt]);
+#pragma unroll
+                        for (int mt = 0; mt < MT; ++mt) am[set][mt] = mfma16_f16(A1[mt][kb1], b1[s1], am[set][mt]);
+#pragma unroll
+                        for (int mt = 0; mt < MT; ++mt)
+                            am[set][mt] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(A8[mt][kp], Bp, am[set][mt], 0, 0, 0, CP_X8_SCALE_A, 0,
+                                                                                          CP_X8_SCALE_B);
+                    }
+                };
+                // pair kp with the PREVIOUS slot's epilogue dealt between its six MFMAs (sched_barrier keeps every piece behind its MFMA:
+                // the vector instructions issue while the matrix pipe works; left to itself hipcc emits the epilogue as one block)
+                auto kpair_with_epilogue = [&](int kp, int pset, int pxbuf, bool pon) {
+                    const int kb0 = 2 * kp, kb1 = kb0 + 1, s0 = kb0 % NBUF, s1 = kb1 % NBUF;
+#pragma unroll
+                    for (int q2 = 0; q2 < 2; ++q2) {
+                        const int kk = kb0 + q2 + DIST;
+                        if (kk < NKB) frag(f, kk, kk % NBUF);
+                        else frag(f_next, kk - NKB, kk % NBUF);
+                    }
+                    if constexpr (X8) {
+                        i32x8& Bp = B8[kp & 1];
+                        Bp[4] = cp_cvt4_fp8(Bp[4], b1[s0][0], b1[s0][1]);
+                        Bp[5] = cp_cvt4_fp8(Bp[5], b1[s0][2], b1[s0][3]);
+                        Bp[6] = cp_cvt4_fp8(Bp[6], b1[s1][0], b1[s1][1]);
+                        Bp[7] = cp_cvt4_fp8(Bp[7], b1[s1][2], b1[s1][3]);
+                        __builtin_amdgcn_sched_barrier(0);
+                        int v = 0;
 #pragma unroll
                         for (int mt = 0; mt < MT; ++mt) {
                             am[set][mt] = mfma16_f16(A1[mt][kb0], b1[s0], am[set][mt]);
+                            epilogue_piece(pset, pxbuf, pon, v++);
+                            if (mt == 0) epilogue_piece(pset, pxbuf, pon, v++);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+#pragma unroll
+                        for (int mt = 0; mt < MT; ++mt) {
                             am[set][mt] = mfma16_f16(A1[mt][kb1], b1[s1], am[set][mt]);
-                            ax[set][mt] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(A8[mt][kp], Bp, ax[set][mt], 0, 0, 0, 0x7f7f7f7f, 0,
-                                                                                          0x7f7f7f7f);
+                            epilogue_piece(pset, pxbuf, pon, v++);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+#pragma unroll
+                        for (int mt = 0; mt < MT; ++mt) {
+                            am[set][mt] = __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(A8[mt][kp], Bp, am[set][mt], 0, 0, 0, CP_X8_SCALE_A, 0,
+                                                                                          CP_X8_SCALE_B);
+                            epilogue_piece(pset, pxbuf, pon, v++);
+                            if (mt == 0) epilogue_piece(pset, pxbuf, pon, v++);
+                            __builtin_amdgcn_sched_barrier(0);
                         }
                     }
                 };
@@ -332,9 +395,20 @@ __global__ __launch_bounds__(64 * (PW + 4), (PW + 4) / 4) void conv_proj_kernel(
                 };
                 if constexpr (X8) {
                     static_assert(!X8 || (DIST == 2 && NBUF == 4), "pair form: fragments two k-blocks ahead through four register sets");
-#pragma unroll
-                    for (int kp = 0; kp < NKB / 4; ++kp) kpair(kp);
-                    pin8();
+                    kpair(0);
+                    __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x008, 3 * MT, 0);
+                    // the previous slot's epilogue (the other accumulator set: its MFMAs retired a pair of k-blocks ago).  The LAST slot of
+                    // a receiver keeps its epilogue at its own end: carried into the next receiver it would make both accumulator sets
+                    // and a set of sender rows live across the receiver loop, and hipcc then spills the weight registers (round 3 met the
+                    // same wall with a deferred epilogue behind the loop)
+                    if (s > 0) {
+                        kpair_with_epilogue(1, set ^ 1, (s - 1) & 3, s - 1 < nd);
+                    } else {
+                        kpair(1);
+                        __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x008, 3 * MT, 0);
+                    }
                     __syncthreads();  // SYNC_q
 #pragma unroll
                     for (int kp = NKB / 4; kp < NKB / 2; ++kp) kpair(kp);
@@ -348,7 +422,7 @@ __global__ __launch_bounds__(64 * (PW + 4), (PW + 4) / 4) void conv_proj_kernel(
                     for (int kb = NKB / 2; kb < NKB; ++kb) kstep(kb);
                     pin();
                 }
-                epilogue(0, s & 3, s < nd);
+                if (!X8 || s == K - 1) epilogue(set, s & 3, s < nd);
             }
             write_tile();  // (the mix waves took the previous receiver's tile into registers right behind SYNC of slot 0)
             if (!has_next) break;
