@@ -207,7 +207,7 @@ __global__ __launch_bounds__(64 * (PW + 4), (PW + 4) / 4) void conv_proj_kernel(
         // slot has been published by the barrier in the middle of the previous slot).  hipcc, left alone, sinks every
         // ds_read to within one or two MFMAs of its use -- measured: the LDS latency exposed at each of the 64 k-steps of a
         // receiver, a matrix pipe busy 45 % of the time -- so the issue order is pinned with sched_group_barrier below.
-        constexpr int DIST = PW == 4 ? 2 : 1, NBUF = PW == 4 ? 4 : 2;
+        constexpr int DIST = (PW == 4 || X8) ? 2 : 1, NBUF = (PW == 4 || X8) ? 4 : 2;
         typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
         u32x4 b1[NBUF], b2[NBUF];
         u32x2_t b8[NBUF];  // BFP8: the lo fragment as stored (8 fp8 per lane)
@@ -583,8 +583,9 @@ int arreau_launch_conv_proj(const arreau_model* m, int layer, const float* basis
         else if (fp8) launch(conv_proj_kernel<128, 256, 4, true>, 512);
         else launch(conv_proj_kernel<128, 256, 4, false>, 512);
     } else {
-        m->ran_x8 = 0;
-        if (fp8) launch(conv_proj_kernel<128, 256, 8, true>, 768);
+        m->ran_x8 = fp8 && arreau_cross_fp8(m) ? 1 : 0;
+        if (m->ran_x8) launch(conv_proj_kernel<128, 256, 8, true, true>, 768);
+        else if (fp8) launch(conv_proj_kernel<128, 256, 8, true>, 768);
         else launch(conv_proj_kernel<128, 256, 8, false>, 768);
     }
     arreau_prof_conv(1, s);
