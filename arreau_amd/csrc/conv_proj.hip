@@ -111,13 +111,19 @@ __global__ __launch_bounds__(64 * (PW + 4), (PW + 4) / 4) void conv_proj_kernel(
     static_assert(C == 128 && D == 256, "roles and register budgets assume C = 128, D = 256");
     static_assert(!X8 || BFP8, "the fp8 cross products take the stash's e4m3 residual plane as it is stored");
     constexpr int K = 8, NKB = D / 32;
-    constexpr unsigned SLOT_BYTES = BFP8 ? 12288 : 16384;
+    constexpr unsigned SLOT_BYTES = BFP8 ? 12288 : 16384;   // a slot block of the stash in HBM
+    // X8: in LDS a slot takes 16 KiB -- behind the two stashed planes a third one, b1_8 = e4m3(b1), 8 bytes per lane and k-block like
+    // the residual plane.  It is written by the MIX wave that copied the fp16 fragments it converts (its own copies, behind its own
+    // counted wait, before the barrier that publishes the slot): the projection wave, alone on its SIMD, pays ~7.5 cycles for every
+    // vector instruction it issues (a timing-only build without its 32 conversions per slot ran 120 -> 109 us per launch), the mix
+    // wave has the time.
+    constexpr unsigned SLOT_LDS = X8 ? 16384 : SLOT_BYTES;
     constexpr int NC = SLOT_BYTES / 4096;  // 1 KiB copies per mix wave and slot
     // NINE slot buffers (slot q of the workgroup's sequence lives in buffer q mod 9) + one tile = 152 KiB of the CU's 160:
     // the stream's rate is bytes in flight over the loaded HBM latency (about 4.3 us: 80-96 KiB in flight per CU gave
     // 4.7 TB/s with eight buffers), and an LDS-DMA byte in flight needs its landing place for the whole flight.
     constexpr int RING = 9;
-    __shared__ u32x4 ring[RING][SLOT_BYTES / 16];
+    __shared__ u32x4 ring[RING][SLOT_LDS / 16];
     __shared__ __attribute__((aligned(16))) float tile[16 * CP_STR];      // x1 of the receiver just finished
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
@@ -220,8 +226,11 @@ __global__ __launch_bounds__(64 * (PW + 4), (PW + 4) / 4) void conv_proj_kernel(
             if constexpr (X8) {
                 b1[sl_] = *reinterpret_cast<const u32x4*>(ring_b + base + hi_off + 1024 * kb);
                 const u32x2_t t = *reinterpret_cast<const u32x2_t*>(ring_b + base + lo_off + 512 * kb);
+                const u32x2_t t8 = *reinterpret_cast<const u32x2_t*>(ring_b + base + lo_off + 4096 + 512 * kb);  // b1_8 (mix waves)
                 B8[(kb >> 1) & 1][2 * (kb & 1)] = (int)t[0];
                 B8[(kb >> 1) & 1][2 * (kb & 1) + 1] = (int)t[1];
+                B8[(kb >> 1) & 1][4 + 2 * (kb & 1)] = (int)t8[0];
+                B8[(kb >> 1) & 1][4 + 2 * (kb & 1) + 1] = (int)t8[1];
             } else if constexpr (BFP8) {
                 b1[sl_] = *reinterpret_cast<const u32x4*>(ring_b + base + hi_off + 1024 * kb);
                 b8[sl_] = *reinterpret_cast<const u32x2_t*>(ring_b + base + lo_off + 512 * kb);
@@ -287,9 +296,9 @@ __global__ __launch_bounds__(64 * (PW + 4), (PW + 4) / 4) void conv_proj_kernel(
                 }
                 if (s + 2 < K) load_x(srow, s + 2, (s + 2) & 3);
                 else load_x(srow_next, s + 2 - K, (s + 2) & 3);  // (the last receiver re-reads its own rows: never used)
-                const unsigned f = (unsigned)rb * SLOT_BYTES;
+                const unsigned f = (unsigned)rb * SLOT_LDS;
                 rb = rb == RING - 1 ? 0 : rb + 1;
-                const unsigned f_next = (unsigned)rb * SLOT_BYTES;
+                const unsigned f_next = (unsigned)rb * SLOT_LDS;
                 auto kstep = [&](int kb) {  // same product order per accumulator as MmaStream16 (edge_f16.hip)
                     if constexpr (X8) return;
                     const int slot = kb % NBUF, kk = kb + DIST;
@@ -321,11 +330,7 @@ __global__ __launch_bounds__(64 * (PW + 4), (PW + 4) / 4) void conv_proj_kernel(
                         else frag(f_next, kk - NKB, kk % NBUF);
                     }
                     if constexpr (X8) {
-                        i32x8& Bp = B8[kp & 1];  // (its residual halves were loaded two k-blocks ago)
-                        Bp[4] = cp_cvt4_fp8(Bp[4], b1[s0][0], b1[s0][1]);
-                        Bp[5] = cp_cvt4_fp8(Bp[5], b1[s0][2], b1[s0][3]);
-                        Bp[6] = cp_cvt4_fp8(Bp[6], b1[s1][0], b1[s1][1]);
-                        Bp[7] = cp_cvt4_fp8(Bp[7], b1[s1][2], b1[s1][3]);
+                        i32x8& Bp = B8[kp & 1];  // (residual and fp8 halves of both k-blocks were loaded two k-blocks ago)
                         // (one accumulator per tile now carries all three products of a pair: the tiles alternate, so that no MFMA waits for
                         // the one issued just before it)
 #pragma unroll
@@ -350,10 +355,6 @@ __global__ __launch_bounds__(64 * (PW + 4), (PW + 4) / 4) void conv_proj_kernel(
                     }
                     if constexpr (X8) {
                         i32x8& Bp = B8[kp & 1];
-                        Bp[4] = cp_cvt4_fp8(Bp[4], b1[s0][0], b1[s0][1]);
-                        Bp[5] = cp_cvt4_fp8(Bp[5], b1[s0][2], b1[s0][3]);
-                        Bp[6] = cp_cvt4_fp8(Bp[6], b1[s1][0], b1[s1][1]);
-                        Bp[7] = cp_cvt4_fp8(Bp[7], b1[s1][2], b1[s1][3]);
                         __builtin_amdgcn_sched_barrier(0);
                         int v = 0;
 #pragma unroll
@@ -384,7 +385,7 @@ __global__ __launch_bounds__(64 * (PW + 4), (PW + 4) / 4) void conv_proj_kernel(
                     for (int i = 0; i < NKB / 4; ++i) {
                         __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
                         __builtin_amdgcn_sched_group_barrier(0x008, 3 * MT, 0);
-                    }
+                    }  // (the two 8-byte planes of a k-block pair arrive as one ds_read2st64_b64 each)
                 };
                 auto pin = [&]() {  // issue order of one half slot: per k-step its fragment requests, then its MFMAs (vector work floats)
 #pragma unroll
@@ -454,13 +455,42 @@ __global__ __launch_bounds__(64 * (PW + 4), (PW + 4) / 4) void conv_proj_kernel(
     }
     asm volatile("" : "+v"(bias));
     const unsigned lane16 = 16u * lane;
-    const unsigned ring0 = __builtin_amdgcn_readfirstlane((unsigned)(size_t)&ring[0][0]) + 1024u * NC * w4;
+    const unsigned ring_base = __builtin_amdgcn_readfirstlane((unsigned)(size_t)&ring[0][0]);
+    const unsigned ring0 = ring_base + 1024u * NC * w4;
     int wb = 0;  // ring buffer the next copy goes to (copies are issued in slot order)
     auto copy_slot = [&](int n, int s) {  // this wave's quarter of slot s of receiver n -> the next ring buffer
-        const char* g = reinterpret_cast<const char*>(basis) + ((size_t)n * K + s) * SLOT_BYTES + 1024u * NC * w4;
+        if constexpr (X8) {
+            // the fp16 fragments of k-blocks 2 w4, 2 w4 + 1 and the KiB that holds their two residual fragments: the wave converts
+            // exactly what it copied
+            const char* g = reinterpret_cast<const char*>(basis) + ((size_t)n * K + s) * SLOT_BYTES;
+            const unsigned l = ring_base + wb * SLOT_LDS;
+            cp_glds16(lane16, g + 2048 * w4, l + 2048u * w4);
+            cp_glds16(lane16, g + 2048 * w4 + 1024, l + 2048u * w4 + 1024u);
+            cp_glds16(lane16, g + 8192 + 1024 * w4, l + 8192u + 1024u * w4);
+        } else {
+            const char* g = reinterpret_cast<const char*>(basis) + ((size_t)n * K + s) * SLOT_BYTES + 1024u * NC * w4;
 #pragma unroll
-        for (int j = 0; j < NC; ++j) cp_glds16(lane16, g + 1024 * j, ring0 + wb * SLOT_BYTES + 1024u * j);
+            for (int j = 0; j < NC; ++j) cp_glds16(lane16, g + 1024 * j, ring0 + wb * SLOT_BYTES + 1024u * j);
+        }
         wb = wb == RING - 1 ? 0 : wb + 1;
+    };
+    // X8: b1_8 of the two k-blocks this wave copied, for the slot in ring buffer `cb` (its copies have landed: called behind the
+    // counted wait that covers them, in front of the barrier that publishes the slot)
+    int cb = 0;
+    auto convert_slot = [&]() {
+        if constexpr (X8) {
+            char* slot = reinterpret_cast<char*>(&ring[0][0]) + (unsigned)cb * SLOT_LDS;
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                const u32x4 h = *reinterpret_cast<const u32x4*>(slot + 1024 * (2 * w4 + j) + 16 * lane);
+                typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+                u32x2_t o;
+                o[0] = (unsigned)cp_cvt4_fp8(0, h[0], h[1]);
+                o[1] = (unsigned)cp_cvt4_fp8(0, h[2], h[3]);
+                *reinterpret_cast<u32x2_t*>(slot + 12288 + 512 * (2 * w4 + j) + 8 * lane) = o;
+            }
+            cb = cb == RING - 1 ? 0 : cb + 1;
+        }
     };
     const unsigned st_off = 4u * ((8 * ph) * C + c);
     auto store_out = [&](int n, float (&out)[8]) {
@@ -480,6 +510,7 @@ __global__ __launch_bounds__(64 * (PW + 4), (PW + 4) / 4) void conv_proj_kernel(
 #pragma unroll
         for (int s = 0; s < K; ++s) copy_slot(n, s);
         cp_wait_but<7 * NC>();
+        convert_slot();   // slot 0
         __syncthreads();  // SYNC_-1
     }
     int i = 0, n_prev = 0;
@@ -498,6 +529,7 @@ __global__ __launch_bounds__(64 * (PW + 4), (PW + 4) / 4) void conv_proj_kernel(
             if (!has_next) cp_wait_but<0>();
             else if (s <= 6 && i >= 2) cp_wait_but<6 * NC + 8>();
             else cp_wait_but<6 * NC>();
+            convert_slot();   // slot q + 1 (at the very end of the sequence: a buffer nobody reads any more)
             __syncthreads();  // SYNC_q: slot q - 1's buffer is free
             if (has_next) copy_slot(n_next, s);  // slot q + 8 = slot s of the next receiver
             if (i > 0) {  // orientation mix of the previous receiver, two input orientations per step (o ascending)
