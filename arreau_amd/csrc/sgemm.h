@@ -2,6 +2,8 @@
 // 157 TFLOP/s peak) and -- round 4 -- split precision on the 16-bit matrix instructions (sgemm_split_kernel below: fp16x3
 // for products of O(1) operands, bf16x6 where an operand is a gradient of arbitrary magnitude).
 #pragma once
+#include <type_traits>
+
 #include "f16x3.h"
 #include "internal.h"
 
@@ -176,20 +178,30 @@ __global__ __launch_bounds__(256) void sgemm_kernel(int M, int N, int K, const f
 //           exponent range -- every product with a GRADIENT operand (magnitudes from 1e-9, e.g. behind layer_scale = 1e-6, to
 //           O(1): an fp16 plane would go subnormal there).
 // LDS image: plane-major [P][rows][BK + 8] halves, k contiguous per row (a lane's fragment = 8 consecutive k of its row:
-// one ds_read_b128; the 80-byte row stride makes those reads conflict-free); operands whose k is contiguous in memory are
-// written as 8-byte pieces, the others (a gradient read as dY^T) element by element.
-template <int MODE, int WM, int WN>
-__global__ __launch_bounds__(256) void sgemm_split_kernel(int M, int N, int K, const float* __restrict__ A, long as0, long as1,
-                                                          const float* __restrict__ B, long bs0, long bs1, float* __restrict__ C,
-                                                          int ldc, float alpha, float beta, int kchunk, float* __restrict__ partial,
-                                                          int splits, long a_bs, long b_bs, long c_bs) {
+// one ds_read_b128; the 80-byte row stride makes those reads conflict-free).
+// Staging by operand layout (AK / BKC: the operand is contiguous along k in memory):
+//   k-contiguous (X W^T: activations, weights as stored): 16-byte pieces along k, written as 8-byte pieces per plane;
+//   row-contiguous (dY W: the weight read across its rows; dY^T X: both operands of a weight gradient): a LANE owns a
+//           ROW of the tile and the wave a run of k -- KPT = 8 (64-row tiles) or 16 (128-row tiles) dword loads per thread,
+//           each wave-instruction 256 contiguous bytes of one k-row -- so the planes of its KPT consecutive k leave as one or
+//           two ds_write_b128 per plane (rows 80 bytes apart: conflict-free) and no transposing store exists.  The first
+//           form of this kernel wrote such operands as 2-byte stores and was slower than the exact kernel (261 -> 325 us).
+// Two workgroups per CU (launch bound: 256 registers): the kernel keeps ONE LDS buffer and two barriers per k-step, so a
+// workgroup alone on its CU never overlaps staging with matrix work -- the fp16x3 128 x 128 form took 268 registers, ran
+// one wave per SIMD and reached 110 TFLOP/s (effective) on [64768, 256] x [640, 256]^T, 15 % of its matrix time.
+template <int MODE, int WM, int WN, bool AK, bool BKC, int PD>
+__global__ __launch_bounds__(256, 2) void sgemm_split_kernel(int M, int N, int K, const float* __restrict__ A, long as0, long as1,
+                                                             const float* __restrict__ B, long bs0, long bs1, float* __restrict__ C,
+                                                             int ldc, float alpha, float beta, int kchunk, float* __restrict__ partial,
+                                                             int splits, long a_bs, long b_bs, long c_bs) {
     constexpr int BK = 32, TM = 64 * WM, TN = 64 * WN, P = MODE == 1 ? 2 : 3, LDK = BK + 8;
     const int bi = (int)blockIdx.z / splits, zi = (int)blockIdx.z - bi * splits;
     A += (long)bi * a_bs;
     B += (long)bi * b_bs;
     C += (long)bi * c_bs;
     constexpr int KP = BK / 4;
-    constexpr int PA = WM * BK / 16, PB = WN * BK / 16;
+    constexpr int PA = WM * BK / 16, PB = WN * BK / 16;   // k-contiguous: 16-byte pieces per thread
+    constexpr int EA = 4 * PA, EB = 4 * PB;               // row-contiguous: elements (consecutive k of one row) per thread
     __shared__ __attribute__((aligned(16))) unsigned short As[P][TM][LDK], Bs[P][TN][LDK];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int h = lane >> 5, j = lane & 31, wm = (wave >> 1) * (32 * WM), wn = (wave & 1) * (32 * WN);
@@ -205,121 +217,177 @@ __global__ __launch_bounds__(256) void sgemm_split_kernel(int M, int N, int K, c
             for (int b = 0; b < WN; ++b)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[q][a][b][r] = 0.f;
-    const bool a_kmajor = as1 == 1, b_nmajor = bs1 == 1;
-    f32x4 ra[PA], rb[PB];
-    auto fetch = [&](int k0) {
+    // PD register sets: the tile PD k-steps ahead is in flight while this one is multiplied (PD = 1 left the global latency
+    // exposed -- a timing-only build without the loads ran 204 -> 128 us on [68096, 640] x [640, 256] and 244 -> 123 us on
+    // the matching weight gradient, while one without the matrix instructions still took 132 us)
+    f32x4 ra[PD][AK ? PA : 1], rb[PD][BKC ? PB : 1];
+    float ea[PD][AK ? 1 : EA], eb[PD][BKC ? 1 : EB];
+    // row-contiguous operands: this thread's row of the tile and its first k inside the tile
+    const int a_row = 64 * (wave % WM) + lane, a_k = (wave / WM) * EA;
+    const int b_row = 64 * (wave % WN) + lane, b_k = (wave / WN) * EB;
+    // Every load is UNCONDITIONAL (round 4: as predicated loads each sat in its own basic block behind two branches, and hipcc,
+    // unable to count them, waited with vmcnt(0) at the top of the loop -- for the tile just requested as well).  Rows beyond M / N
+    // are clamped to the last row: their products land in accumulator rows that are never stored.  Beyond K (the last k-step of a
+    // ragged K; k-slices are multiples of the k-step) the A operand is zeroed by a select -- in stage(), behind the matrix work:
+    // written next to the load, hipcc waits for the load right there -- and B re-reads its last k, an element that takes part
+    // in the same outputs anyway (so a non-finite value there reaches nothing it would not reach already).
+    const int a_m = min(m0 + (AK ? tid / KP : a_row), M - 1), b_n = min(n0 + (BKC ? tid / KP : b_row), N - 1);
+    auto fetch = [&](int k0, int u) {
+        if constexpr (AK) {
+            const float* src = A + min(k0 + (tid % KP) * 4, K - 4);
 #pragma unroll
-        for (int i = 0; i < PA; ++i) {
-            const int idx = tid + 256 * i;
-            const int mm = a_kmajor ? idx / KP : (idx % (TM / 4)) * 4, kk = a_kmajor ? (idx % KP) * 4 : idx / (TM / 4);
-            const int m = m0 + mm, k = k0 + kk;
-            ra[i] = (m < M && k < kend) ? *reinterpret_cast<const f32x4*>(A + (long)m * as0 + (long)k * as1) : f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int i = 0; i < PA; ++i) {  // piece i: row + 256 i / KP of the tile
+                ra[u][i] = *reinterpret_cast<const f32x4*>(src + (long)min(a_m + (256 / KP) * i, M - 1) * as0);
+            }
+        } else {
+            const float* src = A + a_m;  // (as0 == 1)
+#pragma unroll
+            for (int i = 0; i < EA; ++i) {
+                ea[u][i] = src[(long)min(k0 + a_k + i, K - 1) * as1];
+            }
         }
+        if constexpr (BKC) {
+            const float* src = B + min(k0 + (tid % KP) * 4, K - 4);
 #pragma unroll
-        for (int i = 0; i < PB; ++i) {
-            const int idx = tid + 256 * i;
-            const int nn = b_nmajor ? (idx % (TN / 4)) * 4 : idx / KP, kk = b_nmajor ? idx / (TN / 4) : (idx % KP) * 4;
-            const int n = n0 + nn, k = k0 + kk;
-            rb[i] = (n < N && k < kend) ? *reinterpret_cast<const f32x4*>(B + (long)k * bs0 + (long)n * bs1) : f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int i = 0; i < PB; ++i) rb[u][i] = *reinterpret_cast<const f32x4*>(src + (long)min(b_n + (256 / KP) * i, N - 1) * bs1);
+        } else {
+            const float* src = B + b_n;  // (bs1 == 1)
+#pragma unroll
+            for (int i = 0; i < EB; ++i) eb[u][i] = src[(long)min(k0 + b_k + i, K - 1) * bs0];
         }
     };
-    // planes of four consecutive values as P pairs of dwords (element 0 in the low half of w[.][0])
-    auto split4 = [&](const f32x4& v, unsigned (&w)[P][2]) {
+    // planes of two consecutive values as one dword per plane (element 0 in the low half)
+    auto split2 = [&](float v0, float v1, unsigned (&w)[P]) {
         if constexpr (MODE == 1) {
-            split_pair2<false>(f32x2{v[0], v[1]}, w[0][0], w[1][0]);
-            split_pair2<false>(f32x2{v[2], v[3]}, w[0][1], w[1][1]);
+            split_pair2<false>(f32x2{v0, v1}, w[0], w[1]);
         } else {
-#pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                const float lo = v[2 * q], hi = v[2 * q + 1];
-                w[0][q] = sg_pack_hi16(hi, lo);
-                const float rlo = sg_bf16_residual(lo), rhi = sg_bf16_residual(hi);
-                w[1][q] = sg_pack_hi16(rhi, rlo);
-                w[2][q] = sg_pack_hi16(sg_bf16_residual(rhi), sg_bf16_residual(rlo));
-            }
+            w[0] = sg_pack_hi16(v1, v0);
+            const float r0 = sg_bf16_residual(v0), r1 = sg_bf16_residual(v1);
+            w[1] = sg_pack_hi16(r1, r0);
+            w[2] = sg_pack_hi16(sg_bf16_residual(r1), sg_bf16_residual(r0));
         }
     };
     typedef unsigned u32x2v __attribute__((ext_vector_type(2)));
-    auto put = [&](unsigned short (*img)[LDK] /* one plane */, bool kcontig, int row, int kk, const unsigned (&w)[2]) {
-        if (kcontig) {
-            *reinterpret_cast<u32x2v*>(&img[row][kk]) = u32x2v{w[0], w[1]};
-        } else {  // four rows, one k
-            img[row + 0][kk] = (unsigned short)(w[0] & 0xffffu);
-            img[row + 1][kk] = (unsigned short)(w[0] >> 16);
-            img[row + 2][kk] = (unsigned short)(w[1] & 0xffffu);
-            img[row + 3][kk] = (unsigned short)(w[1] >> 16);
+    auto stage = [&](int u, int k0) {
+        if constexpr (AK) {
+            const bool live = k0 + (tid % KP) * 4 < kend;
+#pragma unroll
+            for (int i = 0; i < PA; ++i) {
+                const int idx = tid + 256 * i;
+                const int row = idx / KP, kk = (idx % KP) * 4;
+                asm volatile("" : "+v"(ra[u][i]));  // (the select stays here)
+                if (!live) ra[u][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+                unsigned w0[P], w1[P];
+                split2(ra[u][i][0], ra[u][i][1], w0);
+                split2(ra[u][i][2], ra[u][i][3], w1);
+#pragma unroll
+                for (int p = 0; p < P; ++p) *reinterpret_cast<u32x2v*>(&As[p][row][kk]) = u32x2v{w0[p], w1[p]};
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < EA / 8; ++q) {  // eight consecutive k = 16 bytes per plane
+                unsigned w[4][P];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    asm volatile("" : "+v"(ea[u][8 * q + e]));
+                    if (k0 + a_k + 8 * q + e >= kend) ea[u][8 * q + e] = 0.f;
+                }
+#pragma unroll
+                for (int e = 0; e < 4; ++e) split2(ea[u][8 * q + 2 * e], ea[u][8 * q + 2 * e + 1], w[e]);
+#pragma unroll
+                for (int p = 0; p < P; ++p) *reinterpret_cast<u32x4*>(&As[p][a_row][a_k + 8 * q]) = u32x4{w[0][p], w[1][p], w[2][p], w[3][p]};
+            }
+        }
+        if constexpr (BKC) {
+#pragma unroll
+            for (int i = 0; i < PB; ++i) {
+                const int idx = tid + 256 * i;
+                const int row = idx / KP, kk = (idx % KP) * 4;
+                unsigned w0[P], w1[P];
+                split2(rb[u][i][0], rb[u][i][1], w0);
+                split2(rb[u][i][2], rb[u][i][3], w1);
+#pragma unroll
+                for (int p = 0; p < P; ++p) *reinterpret_cast<u32x2v*>(&Bs[p][row][kk]) = u32x2v{w0[p], w1[p]};
+            }
+        } else {
+#pragma unroll
+            for (int q = 0; q < EB / 8; ++q) {
+                unsigned w[4][P];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) split2(eb[u][8 * q + 2 * e], eb[u][8 * q + 2 * e + 1], w[e]);
+#pragma unroll
+                for (int p = 0; p < P; ++p) *reinterpret_cast<u32x4*>(&Bs[p][b_row][b_k + 8 * q]) = u32x4{w[0][p], w[1][p], w[2][p], w[3][p]};
+            }
         }
     };
-    auto stage = [&]() {
 #pragma unroll
-        for (int i = 0; i < PA; ++i) {
-            const int idx = tid + 256 * i;
-            const int mm = a_kmajor ? idx / KP : (idx % (TM / 4)) * 4, kk = a_kmajor ? (idx % KP) * 4 : idx / (TM / 4);
-            unsigned w[P][2];
-            split4(ra[i], w);
+    for (int u = 0; u < PD; ++u) fetch(kbeg + u * BK, u);  // (beyond kend: zeros, no access)
+    for (int kb = kbeg; kb < kend; kb += PD * BK) {
 #pragma unroll
-            for (int p = 0; p < P; ++p) put(As[p], a_kmajor, mm, kk, w[p]);
+        for (int u = 0; u < PD; ++u) {
+            const int k0 = kb + u * BK;
+            if (u > 0 && k0 >= kend) break;  // (workgroup-uniform)
+            stage(u, k0);
+            __syncthreads();
+            if (k0 + PD * BK < kend) fetch(k0 + PD * BK, u);
+#pragma unroll
+            for (int ks = 0; ks < BK / 16; ++ks) {
+                u32x4 fa[WM][P], fb[WN][P];
+#pragma unroll
+                for (int a = 0; a < WM; ++a)
+#pragma unroll
+                    for (int p = 0; p < P; ++p) fa[a][p] = *reinterpret_cast<const u32x4*>(&As[p][wm + 32 * a + j][16 * ks + 8 * h]);
+#pragma unroll
+                for (int b = 0; b < WN; ++b)
+#pragma unroll
+                    for (int p = 0; p < P; ++p) fb[b][p] = *reinterpret_cast<const u32x4*>(&Bs[p][wn + 32 * b + j][16 * ks + 8 * h]);
+#pragma unroll
+                for (int a = 0; a < WM; ++a)
+#pragma unroll
+                    for (int b = 0; b < WN; ++b) {
+                        if constexpr (MODE == 1) {
+                            acc[0][a][b] = mfma_f16(fa[a][0], fb[b][0], acc[0][a][b]);
+                            acc[1][a][b] = mfma_f16(fa[a][0], fb[b][1], acc[1][a][b]);
+                            acc[1][a][b] = mfma_f16(fa[a][1], fb[b][0], acc[1][a][b]);
+                        } else {  // small terms first (bf16x6.h)
+                            acc[0][a][b] = sg_mfma_bf16(fa[a][2], fb[b][0], acc[0][a][b]);
+                            acc[0][a][b] = sg_mfma_bf16(fa[a][1], fb[b][1], acc[0][a][b]);
+                            acc[0][a][b] = sg_mfma_bf16(fa[a][0], fb[b][2], acc[0][a][b]);
+                            acc[0][a][b] = sg_mfma_bf16(fa[a][1], fb[b][0], acc[0][a][b]);
+                            acc[0][a][b] = sg_mfma_bf16(fa[a][0], fb[b][1], acc[0][a][b]);
+                            acc[0][a][b] = sg_mfma_bf16(fa[a][0], fb[b][0], acc[0][a][b]);
+                        }
+                    }
+            }
+            __syncthreads();
         }
+    }
+    // epilogue: the split-K / beta == 0 forms never read C (a per-element `beta != 0 ? C : 0` made every store a branch + load block)
+    float* outp = splits > 1 ? partial + (size_t)blockIdx.z * M * N : C;
+    const int ldo = splits > 1 ? N : ldc;
+    const float oa = splits > 1 ? 1.f : alpha;
+    auto store_tiles = [&](auto read_c) {
 #pragma unroll
-        for (int i = 0; i < PB; ++i) {
-            const int idx = tid + 256 * i;
-            const int nn = b_nmajor ? (idx % (TN / 4)) * 4 : idx / KP, kk = b_nmajor ? idx / (TN / 4) : (idx % KP) * 4;
-            unsigned w[P][2];
-            split4(rb[i], w);
+        for (int a = 0; a < WM; ++a)
 #pragma unroll
-            for (int p = 0; p < P; ++p) put(Bs[p], !b_nmajor, nn, kk, w[p]);
-        }
-    };
-    fetch(kbeg);
-    for (int k0 = kbeg; k0 < kend; k0 += BK) {
-        stage();
-        __syncthreads();
-        if (k0 + BK < kend) fetch(k0 + BK);
+            for (int b = 0; b < WN; ++b) {
+                const int n = n0 + wn + 32 * b + j;
+                if (n >= N) continue;
 #pragma unroll
-        for (int ks = 0; ks < BK / 16; ++ks) {
-            u32x4 fa[WM][P], fb[WN][P];
-#pragma unroll
-            for (int a = 0; a < WM; ++a)
-#pragma unroll
-                for (int p = 0; p < P; ++p) fa[a][p] = *reinterpret_cast<const u32x4*>(&As[p][wm + 32 * a + j][16 * ks + 8 * h]);
-#pragma unroll
-            for (int b = 0; b < WN; ++b)
-#pragma unroll
-                for (int p = 0; p < P; ++p) fb[b][p] = *reinterpret_cast<const u32x4*>(&Bs[p][wn + 32 * b + j][16 * ks + 8 * h]);
-#pragma unroll
-            for (int a = 0; a < WM; ++a)
-#pragma unroll
-                for (int b = 0; b < WN; ++b) {
-                    if constexpr (MODE == 1) {
-                        acc[0][a][b] = mfma_f16(fa[a][0], fb[b][0], acc[0][a][b]);
-                        acc[1][a][b] = mfma_f16(fa[a][0], fb[b][1], acc[1][a][b]);
-                        acc[1][a][b] = mfma_f16(fa[a][1], fb[b][0], acc[1][a][b]);
-                    } else {  // small terms first (bf16x6.h)
-                        acc[0][a][b] = sg_mfma_bf16(fa[a][2], fb[b][0], acc[0][a][b]);
-                        acc[0][a][b] = sg_mfma_bf16(fa[a][1], fb[b][1], acc[0][a][b]);
-                        acc[0][a][b] = sg_mfma_bf16(fa[a][0], fb[b][2], acc[0][a][b]);
-                        acc[0][a][b] = sg_mfma_bf16(fa[a][1], fb[b][0], acc[0][a][b]);
-                        acc[0][a][b] = sg_mfma_bf16(fa[a][0], fb[b][1], acc[0][a][b]);
-                        acc[0][a][b] = sg_mfma_bf16(fa[a][0], fb[b][0], acc[0][a][b]);
+                for (int r = 0; r < 16; ++r) {
+                    const int m = m0 + wm + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    float v = acc[0][a][b][r];
+                    if constexpr (MODE == 1) v = fmaf(acc[1][a][b][r], F16X3_INV_SCALE, v);
+                    if (m < M) {
+                        float* o = outp + (size_t)m * ldo + n;
+                        if constexpr (decltype(read_c)::value) *o = fmaf(beta, *o, oa * v);
+                        else *o = oa * v;
                     }
                 }
-        }
-        __syncthreads();
-    }
-#pragma unroll
-    for (int a = 0; a < WM; ++a)
-#pragma unroll
-        for (int b = 0; b < WN; ++b)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wm + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * h, n = n0 + wn + 32 * b + j;
-                float v = acc[0][a][b][r];
-                if constexpr (MODE == 1) v = fmaf(acc[1][a][b][r], F16X3_INV_SCALE, v);
-                if (m < M && n < N) {
-                    if (splits > 1) partial[((size_t)blockIdx.z * M + m) * N + n] = v;
-                    else C[(size_t)m * ldc + n] = alpha * v + (beta != 0.f ? beta * C[(size_t)m * ldc + n] : 0.f);
-                }
             }
+    };
+    if (splits == 1 && beta != 0.f) store_tiles(std::true_type{});
+    else store_tiles(std::false_type{});
 }
 __global__ void splitk_reduce_kernel(const float* __restrict__ partial, int Z, int M, int N, float* __restrict__ C, int ldc,
                                      float alpha, float beta, long c_bs /* blockIdx.y = product of the batch */) {
@@ -348,13 +416,20 @@ inline int arreau_sgemm(hipStream_t s, float* partial, int M, int N, int K, cons
     // workgroups, 4.2 per CU.  So 128 x 128 only when there are at least two of them per CU.  If even those are too few (weight gradients: a handful of
     // tiles under a reduction over all rows), split K as well: enough slices for about one workgroup per CU, at least two k-steps
     // each, more slices for very long reductions.
-    const int tiles128 = ((M + 127) / 128) * ((N + 127) / 128);
-    const bool small = tiles128 < 512;
+    const int tiles128 = ((M + 127) / 128) * ((N + 127) / 128) * batch;
+    // A long reduction over a handful of output tiles (the weight gradients: K = all rows) keeps the 128 x 128 tile when K slices
+    // of at least eight k-steps can fill the chip with them: a 64 x 64 tile reads each operand twice as often, and those launches
+    // are bound by their loads (round 4: [640, 68096] x [68096, 256] without its loads 244 -> 123 us).
+    const int z128 = min(64, K / 256);
+    const bool long_k = mode != 0 && tiles128 < 512 && K >= 2048 && (long)tiles128 * z128 >= 256;
+    const bool small = tiles128 < 512 && !long_k;
     const int T = small ? 64 : 128;
     const int gm = (M + T - 1) / T, gn = (N + T - 1) / T;
     int Z = 1;
     const int tiles = gm * gn * batch;
-    if (tiles < 128 && K >= 256) {
+    if (long_k) {
+        Z = min(z128, (384 + tiles128 - 1) / tiles128);
+    } else if (tiles < 128 && K >= 256) {
         const int fill = (256 + tiles - 1) / tiles;
         Z = min(64, min(max(fill, K / 1024), K / 128));
     } else if (batch > 1 && tiles < 512 && K >= 2048) {
@@ -365,12 +440,13 @@ inline int arreau_sgemm(hipStream_t s, float* partial, int M, int N, int K, cons
     const bool a_ok = (as1 == 1 && as0 % 4 == 0 && K % 4 == 0) || (as0 == 1 && as1 % 4 == 0 && M % 4 == 0);
     const bool b_ok = (bs1 == 1 && bs0 % 4 == 0 && N % 4 == 0) || (bs0 == 1 && bs1 % 4 == 0 && K % 4 == 0);
     const bool vec = a_ok && b_ok && ((size_t)A % 16 == 0) && ((size_t)B % 16 == 0) && a_bs % 4 == 0 && b_bs % 4 == 0;
-    // The split kernel pays where it can stage 8-byte pieces -- both operands contiguous along k (Y = X W^T, the forward
-    // products) -- and the reduction is long enough to amortise the tile prologue; measured (tools/exp/sgemm_bench.hip,
-    // profiles/r04_sgemm_bench.txt): [8512,128] x [512,128]^T 20.4 -> 13.3 us, [8512,512] x [128,512]^T 27.6 -> 17.6, [68096,256] x
-    // [640,256]^T 265 -> 211, K = 2048: 74 -> 152 TFLOP/s; with an operand read across its contiguous dimension (dY W, dY^T X:
-    // 2-byte LDS writes) it is SLOWER than the exact kernel (261 -> 325 us, 282 -> 367 us), so those stay exact.
-    const bool split = mode != 0 && vec && K >= 128 && as1 == 1 && bs0 == 1;
+    // The split kernel takes every 16-byte-fetchable layout with a reduction long enough to amortise the tile prologue (measured,
+    // tools/exp/sgemm_bench.hip, profiles/r04_sgemm_bench.txt).  An operand that is not contiguous along k is fetched as dwords (no
+    // alignment needed), so only its k-contiguous operands must pass the 16-byte test.
+    const bool ak = as1 == 1, bk = bs0 == 1;
+    const bool a_split_ok = ak ? (as0 % 4 == 0 && K % 4 == 0 && (size_t)A % 16 == 0 && a_bs % 4 == 0) : as0 == 1;
+    const bool b_split_ok = bk ? (bs1 % 4 == 0 && K % 4 == 0 && (size_t)B % 16 == 0 && b_bs % 4 == 0) : bs1 == 1;
+    const bool split = mode != 0 && a_split_ok && b_split_ok && K >= 128;
     const int BK = (small || split) ? 32 : 16;
     const int kchunk = ((K + Z - 1) / Z + BK - 1) / BK * BK;
     Z = (K + kchunk - 1) / kchunk;
@@ -379,8 +455,18 @@ inline int arreau_sgemm(hipStream_t s, float* partial, int M, int N, int K, cons
                            partial, Z, a_bs, b_bs, c_bs);
     };
     if (split) {
-        if (small) { if (mode == 1) launch(sgemm_split_kernel<1, 1, 1>); else launch(sgemm_split_kernel<2, 1, 1>); }
-        else { if (mode == 1) launch(sgemm_split_kernel<1, 2, 2>); else launch(sgemm_split_kernel<2, 2, 2>); }
+        auto pick = [&](auto mode_c, auto w_c) {
+            constexpr int MD = decltype(mode_c)::value, W = decltype(w_c)::value;
+            // two tiles in flight wherever the registers allow it at two workgroups per CU (fp16x3 at 128 x 128 holds 128 accumulators)
+            constexpr int PD = (MD == 1 && W == 2) ? 1 : 2;
+            if (ak && bk) launch(sgemm_split_kernel<MD, W, W, true, true, PD>);
+            else if (ak) launch(sgemm_split_kernel<MD, W, W, true, false, PD>);
+            else if (bk) launch(sgemm_split_kernel<MD, W, W, false, true, PD>);
+            else launch(sgemm_split_kernel<MD, W, W, false, false, PD>);
+        };
+        using std::integral_constant;
+        if (small) { if (mode == 1) pick(integral_constant<int, 1>{}, integral_constant<int, 1>{}); else pick(integral_constant<int, 2>{}, integral_constant<int, 1>{}); }
+        else { if (mode == 1) pick(integral_constant<int, 1>{}, integral_constant<int, 2>{}); else pick(integral_constant<int, 2>{}, integral_constant<int, 2>{}); }
     } else if (small) {
         if (vec) launch(sgemm_kernel<1, 1, 1, 32>); else launch(sgemm_kernel<0, 1, 1, 32>);
     } else {

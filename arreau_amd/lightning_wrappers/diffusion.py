@@ -2,6 +2,7 @@
 (constructor arguments, attributes, state_dict keys, `load_from_checkpoint`, `forward`, `sample`)
 with the per-step work running in libarreau_hip.so.  pytorch_lightning is not required; the class
 is a plain nn.Module that reads and writes Lightning-format checkpoint dicts."""
+import collections
 import os
 import pathlib
 from types import SimpleNamespace
@@ -59,6 +60,7 @@ class PONITA_DIFFUSION(nn.Module):
         is not -- the copy packs its own on first use."""
         import copy
         eng, self._engine = self._engine, None
+        saved = self._drop_transient()  # (device events cannot be copied; the caches name THIS module's parameters)
         try:
             new = self.__class__.__new__(self.__class__)
             memo[id(self)] = new
@@ -66,12 +68,21 @@ class PONITA_DIFFUSION(nn.Module):
                 new.__dict__[k] = copy.deepcopy(v, memo)
         finally:
             self._engine = eng
+            self.__dict__.update(saved)
         return new
+
+    _TRANSIENT = ("_steps_in_flight", "_named_parameter_cache", "_trainable_parameter_cache", "_grad_flat")
+
+    def _drop_transient(self):
+        """per-step state of the training loop (parameter maps, the flat gradient buffer, events of steps in flight): rebuilt
+        on next use"""
+        return {k: self.__dict__.pop(k) for k in self._TRANSIENT if k in self.__dict__}
 
     # ---- device / engine management --------------------------------------------------------------
     def _apply(self, fn, *a, **kw):
         out = super()._apply(fn, *a, **kw)
         self._engine = None  # parameters moved or changed dtype: repack on next use
+        self._drop_transient()
         self._device = self.z_table_zs.device
         return out
 
@@ -116,21 +127,42 @@ class PONITA_DIFFUSION(nn.Module):
         `self.model` (what loss.backward() does in the reference) and returns the loss as a 0-d CUDA tensor.
         On the first training forward the conv weights are rescaled by the activation std ratios
         (FiberBundleConv.callibrate, ponita/nn/conv.py:121-123,140-146) -- after this step's gradients were taken."""
+        # The step never waits for the device (inputs cross in asynchronous copies), so the host could run many steps ahead:
+        # it is held to TWO steps in flight -- on the MI355X box an unbounded run-ahead stalled the launch queue for 80 ms at a
+        # time (round 4, kernel trace: a gap of that length in the middle of a forward pass; 3.2 -> 20 ms per step).
+        inflight = self.__dict__.setdefault("_steps_in_flight", collections.deque())
+        if len(inflight) >= 2:
+            inflight.popleft().synchronize()
         loss, parts = self.diffusion_loss(self, graph, self.t_emb, timestep=timestep, noise=noise, return_parts=True,
                                           training=True)
         eng = self.engine(for_training=True)
         grads = eng.train_backward(parts["grad_eps"], parts["grad_logits"], parts["grad_lengths"])
-        params = dict(self.named_parameters())
+        params = self.__dict__.get("_named_parameter_cache")
+        if params is None:  # (walking the module tree every step was 0.2 ms of host time; the Parameter objects are stable)
+            params = self.__dict__["_named_parameter_cache"] = dict(self.named_parameters())
+        covered = True
         for name, g in grads.items():
             p = params.get(name)
             if p is not None and p.requires_grad:
-                p.grad = g.to(device=p.device, dtype=p.dtype).reshape(p.shape)
+                if g.dtype is p.dtype and g.device == p.device:
+                    p.grad = g if g.shape == p.shape else g.reshape(p.shape)  # a view of the engine's flat gradient buffer
+                else:
+                    p.grad = g.to(device=p.device, dtype=p.dtype).reshape(p.shape)
+                    covered = False
+            else:
+                covered = False
+        # every gradient of the step is a view of ONE buffer: the optimizer driver (arreau_amd.train.optimizer_step) may then
+        # all-reduce / measure / clip that buffer instead of 70 tensors
+        self._grad_flat = eng.last_grad_flat if covered else None
         self._callibrate_if_needed(eng)
         # the device status word is sticky: checking it every few steps loses nothing and keeps the step free of host
         # synchronisation (a check is a device-to-host read)
         self._train_steps = getattr(self, "_train_steps", 0) + 1
         if self._train_steps % self.STATUS_CHECK_EVERY == 1:
             eng.check_status()
+        done = torch.cuda.Event()
+        done.record(torch.cuda.current_stream(eng.device))
+        inflight.append(done)
         return loss
 
     @torch.no_grad()

@@ -39,12 +39,37 @@ def all_reduce_gradients(parameters: Iterable[torch.nn.Parameter], world_size: i
     return off
 
 
+def _trainable_parameters(model):
+    cache = model.__dict__.get("_trainable_parameter_cache")
+    if cache is None:
+        cache = model.__dict__["_trainable_parameter_cache"] = [p for p in model.parameters()]
+    return cache
+
+
 def optimizer_step(model, optimizer, world_size: int = 1, clip: Optional[float] = GRAD_CLIP):
-    """all-reduce -> clip -> Adam step -> invalidate the engine's packed weights.  Returns the gradient norm."""
-    all_reduce_gradients(model.parameters(), world_size)
-    norm = torch.nn.utils.clip_grad_norm_([p for p in model.parameters() if p.grad is not None], clip) if clip else None
+    """all-reduce -> clip -> Adam step -> invalidate the engine's packed weights.  Returns the gradient norm.
+
+    When PONITA_DIFFUSION.training_step left every gradient as a view of the engine's flat buffer (`model._grad_flat`), the
+    collective, the norm and the clip run on that ONE buffer: no gather into a bucket and no scatter back, one norm instead of a
+    multi-tensor norm over 70 tensors (torch.nn.utils.clip_grad_norm_'s arithmetic: total 2-norm, coefficient
+    max_norm / (norm + 1e-6) clamped to 1)."""
+    flat = getattr(model, "_grad_flat", None)
+    params = _trainable_parameters(model)
+    if flat is not None and all(p.grad is None or p.grad.untyped_storage().data_ptr() == flat.untyped_storage().data_ptr() for p in params):
+        if world_size > 1:
+            import torch.distributed as dist
+            dist.all_reduce(flat, op=dist.ReduceOp.SUM)
+            flat /= world_size
+        norm = None
+        if clip:
+            norm = torch.linalg.vector_norm(flat, 2)
+            flat.mul_(torch.clamp(clip / (norm + 1e-6), max=1.0))
+    else:
+        all_reduce_gradients(params, world_size)
+        norm = torch.nn.utils.clip_grad_norm_([p for p in params if p.grad is not None], clip) if clip else None
     optimizer.step()
     optimizer.zero_grad(set_to_none=True)
+    model._grad_flat = None
     model.notify_parameters_changed()
     return norm
 

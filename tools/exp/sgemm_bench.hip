@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 #include <string>
 #include <vector>
 
@@ -23,7 +24,9 @@ __global__ void ref_kernel(int M, int N, int K, const float* A, long as0, long a
 
 struct Shape { const char* name; int M, N, K; int a_kmajor, b_nmajor; };
 
-int main() {
+int main(int argc, char** argv) {
+    const char* filter = argc > 1 ? argv[1] : nullptr;   // substring of the shape name
+    const int mode_mask = argc > 2 ? atoi(argv[2]) : 7;  // bit m: run mode m
     const Shape shapes[] = {
         {"edge W2 fwd  [R,128]x[256,128]^T", 68096, 256, 128, 1, 0},
         {"kern fwd     [R,256]x[640,256]^T", 68096, 640, 256, 1, 0},
@@ -36,6 +39,12 @@ int main() {
         {"lin1 dW      [M,512]^Tx[M,128]  ", 512, 128, 8512, 0, 1},
         {"readout dW   [M,94]^Tx[M,128]   ", 94, 128, 8512, 0, 1},
         {"fiber        [256,256]x[128,256]^T", 256, 128, 256, 1, 0},
+        {"edge W2 dx   [R,256]x[256,128]  ", 68096, 128, 256, 1, 1},
+        {"edge W2 dW   [R,256]^Tx[R,128]  ", 256, 128, 68096, 0, 1},
+        {"lin2 dx      [M,128]x[128,512]  ", 8512, 512, 128, 1, 1},
+        {"lin2 dW      [M,128]^Tx[M,512]  ", 128, 512, 8512, 0, 1},
+        {"ragged dW    [8501,500]^Tx[8501,132]", 500, 132, 8501, 0, 1},
+        {"ragged dx    [8501,260]x[260,132]", 8501, 132, 260, 1, 1},
         {"sweep 128x128 tiles K=32", 8512, 512, 32, 1, 0},
         {"sweep 128x128 tiles K=128", 8512, 512, 128, 1, 0},
         {"sweep 128x128 tiles K=512", 8512, 512, 512, 1, 0},
@@ -51,6 +60,7 @@ int main() {
     hipEvent_t e0, e1;
     CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
     for (const Shape& sh : shapes) {
+        if (filter && !strstr(sh.name, filter)) continue;
         const size_t na = (size_t)sh.M * sh.K, nb = (size_t)sh.K * sh.N, nc = (size_t)sh.M * sh.N;
         std::vector<float> ha(na), hb(nb);
         srand(1);
@@ -70,6 +80,7 @@ int main() {
         for (size_t i = 0; i < nc; ++i) maxref = fmax(maxref, fabs((double)hr[i]));
         printf("%-36s M=%6d N=%4d K=%6d ", sh.name, sh.M, sh.N, sh.K);
         for (int mode = 0; mode < 3; ++mode) {  // 0 exact fp32 MFMA, 1 fp16x3, 2 bf16x6 (round 4)
+            if (!((mode_mask >> mode) & 1)) continue;
             auto run = [&]() { return arreau_sgemm(s, partial, sh.M, sh.N, sh.K, A, as0, as1, B, bs0, bs1, C, sh.N, 1.f, 0.f, 1, 0, 0, 0, mode); };
             CK(hipMemset(C, 0, nc * 4));
             if (run()) { printf("launch failed: %s\n", g_err.c_str()); return 1; }
