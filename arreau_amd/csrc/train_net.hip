@@ -441,6 +441,99 @@ __global__ void conv_backward_dx_kernel(const float* __restrict__ kern, int ldk,
     dx[i] += acc;
 }
 // x2[n,p,c] = sum_o x1[n,o,c] fk[o,p,c] / 16 + bias[c]   (conv.py:113-127)
+// float4 forms of the five kernels around the spatial / spherical convolution (C and the kernel pitch multiples of four; the
+// same sums in the same order per element, so the results are bit-identical to the scalar forms): a thread owns four channels,
+// a quarter of the address arithmetic and of the load instructions, 16 bytes per lane and request.
+__global__ void conv_forward_kernel4(const f32x4* __restrict__ kern, int ldk4, const f32x4* __restrict__ x,
+                                     const int32_t* __restrict__ deg, const int32_t* __restrict__ src, int N, int k, int C4,
+                                     f32x4* __restrict__ x1) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)N * 16 * C4) return;
+    const int c = (int)(i % C4);
+    const long row = i / C4;
+    const int o = (int)(row & 15), n = (int)(row >> 4);
+    const int nd = min(deg[n], k);
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+    for (int s = 0; s < nd; ++s) {
+        const int j = src[(size_t)n * k + s];
+        const f32x4 kv = kern[(((size_t)n * k + s) * 16 + o) * ldk4 + c], xv = x[((size_t)j * 16 + o) * C4 + c];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[q] += kv[q] * xv[q];
+    }
+    x1[i] = acc;
+}
+__global__ void conv_backward_kern_kernel4(const f32x4* __restrict__ x, const f32x4* __restrict__ dx1, const int32_t* __restrict__ deg,
+                                           const int32_t* __restrict__ src, int N, int k, int C4, int ldk4, f32x4* __restrict__ dkern) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)N * k * 16 * C4) return;
+    const int c = (int)(i % C4);
+    const long row = i / C4;
+    const int o = (int)(row & 15);
+    const long e = row >> 4;
+    const int n = (int)(e / k), s = (int)(e % k);
+    const size_t ik = (size_t)row * ldk4 + c;
+    if (s >= min(deg[n], k)) { dkern[ik] = f32x4{0.f, 0.f, 0.f, 0.f}; return; }
+    const int j = src[e];
+    const f32x4 a = dx1[((size_t)n * 16 + o) * C4 + c], b = x[((size_t)j * 16 + o) * C4 + c];
+    dkern[ik] = f32x4{a[0] * b[0], a[1] * b[1], a[2] * b[2], a[3] * b[3]};
+}
+__global__ void conv_backward_dx_kernel4(const f32x4* __restrict__ kern, int ldk4, const f32x4* __restrict__ dx1,
+                                         const int32_t* __restrict__ rev_start, const int32_t* __restrict__ rev_cnt,
+                                         const int32_t* __restrict__ rev_idx, int N, int k, int C4, f32x4* __restrict__ dx) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)N * 16 * C4) return;
+    const int c = (int)(i % C4);
+    const long row = i / C4;
+    const int o = (int)(row & 15), j = (int)(row >> 4);
+    const int st = rev_start[j], cnt = rev_cnt[j];
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+    for (int q = 0; q < cnt; ++q) {
+        const int e = rev_idx[st + q], n = e / k;
+        const f32x4 kv = kern[((size_t)e * 16 + o) * ldk4 + c], dv = dx1[((size_t)n * 16 + o) * C4 + c];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[r] += kv[r] * dv[r];
+    }
+    f32x4 d = dx[i];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) d[r] += acc[r];
+    dx[i] = d;
+}
+__global__ void mix_forward_kernel4(const f32x4* __restrict__ x1, const f32x4* __restrict__ fk, const f32x4* __restrict__ bias,
+                                    int N, int C4, f32x4* __restrict__ x2) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)N * 16 * C4) return;
+    const int c = (int)(i % C4);
+    const long row = i / C4;
+    const int p = (int)(row & 15), n = (int)(row >> 4);
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int o = 0; o < 16; ++o) {
+        const f32x4 a = x1[((size_t)n * 16 + o) * C4 + c], b = fk[((size_t)o * 16 + p) * C4 + c];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[r] += a[r] * b[r];
+    }
+    const f32x4 bv = bias[c];
+    x2[i] = f32x4{acc[0] * (1.0f / 16.0f) + bv[0], acc[1] * (1.0f / 16.0f) + bv[1], acc[2] * (1.0f / 16.0f) + bv[2],
+                  acc[3] * (1.0f / 16.0f) + bv[3]};
+}
+__global__ void mix_backward_x_kernel4(const f32x4* __restrict__ dx2, const f32x4* __restrict__ fk, int N, int C4,
+                                       f32x4* __restrict__ dx1) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= (long)N * 16 * C4) return;
+    const int c = (int)(i % C4);
+    const long row = i / C4;
+    const int o = (int)(row & 15), n = (int)(row >> 4);
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int p = 0; p < 16; ++p) {
+        const f32x4 a = dx2[((size_t)n * 16 + p) * C4 + c], b = fk[((size_t)o * 16 + p) * C4 + c];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) acc[r] += a[r] * b[r];
+    }
+    dx1[i] = f32x4{acc[0] * (1.0f / 16.0f), acc[1] * (1.0f / 16.0f), acc[2] * (1.0f / 16.0f), acc[3] * (1.0f / 16.0f)};
+}
 __global__ void mix_forward_kernel(const float* __restrict__ x1, const float* __restrict__ fk, const float* __restrict__ bias,
                                    int N, int C, float* __restrict__ x2) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -656,6 +749,19 @@ __global__ void fold_poly_weight_kernel(const float* __restrict__ w1, int C, flo
             if (mono_of[col] == mi) acc += w1[c * ARREAU_POLY_COLS + col];
     w1f[i] = acc;
 }
+// Weight refresh after an optimizer step: up to 24 device-to-device copies as ONE launch (they were 19 hipMemcpyAsync = 19
+// blit-kernel launches, 85 us of the step's 330 us optimizer tail; blockIdx.y = segment).
+struct CopySegments {
+    float* dst[24];
+    const float* src[24];
+    unsigned n[24];
+};
+__global__ void copy_segments_kernel(CopySegments seg) {
+    float* __restrict__ d = seg.dst[blockIdx.y];
+    const float* __restrict__ s = seg.src[blockIdx.y];
+    const unsigned n = seg.n[blockIdx.y];
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) d[i] = s[i];
+}
 __global__ void transpose_kernel(const float* __restrict__ in, int rows, int cols, float* __restrict__ out) {  // out[c][r]
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < rows * cols) out[(size_t)(i % cols) * rows + i / cols] = in[i];
@@ -838,6 +944,8 @@ int launch_gelu_backward(hipStream_t s, float* g, const float* pre, const float*
     ARREAU_CHECK_HIP(hipGetLastError());
     return ARREAU_OK;
 }
+#define V4(p) reinterpret_cast<const f32x4*>(p)
+#define V4W(p) reinterpret_cast<f32x4*>(p)
 #define TRY(expr) do { int rc_ = (expr); if (rc_) return rc_; } while (0)
 #define LAUNCH(kernel, grid, block, ...)                                  \
     do {                                                                  \
@@ -920,8 +1028,14 @@ int arreau_general_network(arreau_model* m, const arreau_graph_view& g, const in
         float* xnext = t.x + (size_t)(l + 1) * M * C;
         float* x1 = t.x1 + (size_t)l * M * C;
         float* fk = t.fk + (size_t)l * 256 * C;
-        LAUNCH(conv_forward_kernel, dim3(blocks(M * C)), dim3(256), t.kern + (size_t)l * C, L * C, xl, g.deg, g.src, N, k, C, x1);
-        LAUNCH(mix_forward_kernel, dim3(blocks(M * C)), dim3(256), x1, fk, m->conv_bias + (size_t)l * C, N, C, t.dtmp);
+        if (C % 4 == 0) {
+            LAUNCH(conv_forward_kernel4, dim3(blocks(M * C / 4)), dim3(256), V4(t.kern + (size_t)l * C), L * C / 4, V4(xl), g.deg, g.src, N, k,
+                   C / 4, V4W(x1));
+            LAUNCH(mix_forward_kernel4, dim3(blocks(M * C / 4)), dim3(256), V4(x1), V4(fk), V4(m->conv_bias + (size_t)l * C), N, C / 4, V4W(t.dtmp));
+        } else {
+            LAUNCH(conv_forward_kernel, dim3(blocks(M * C)), dim3(256), t.kern + (size_t)l * C, L * C, xl, g.deg, g.src, N, k, C, x1);
+            LAUNCH(mix_forward_kernel, dim3(blocks(M * C)), dim3(256), x1, fk, m->conv_bias + (size_t)l * C, N, C, t.dtmp);
+        }
         LAUNCH(ln_forward_kernel, dim3(blocks(M, 4)), dim3(256), t.dtmp, m->ln_w + (size_t)l * C, m->ln_b + (size_t)l * C, M, C,
                t.xhat + (size_t)l * M * C, t.rstd + (size_t)l * M, t.xn_all + (size_t)l * M * C);
         float* hpre = t.hpre + (size_t)l * M * H;
@@ -1031,11 +1145,19 @@ extern "C" int arreau_train_backward(arreau_model* m, const float* d_g_eps, cons
         TRY(linear_dx(s, t, M, C, H, dh, t.lin1 + (size_t)l * H * C, dxn));                                          // dxn
         LAUNCH(ln_backward_kernel, dim3(blocks(M, 4)), dim3(256), dxn, xhat, t.rstd + (size_t)l * M, m->ln_w + (size_t)l * C, M, C, dx2);
         // spherical conv: x2 = mix(x1, fk) / 16 + bias
-        LAUNCH(mix_backward_x_kernel, dim3(blocks(M * C)), dim3(256), dx2, fk, N, C, t.dx1);
         // spatial conv: x1 = sum_s kern * x_l[src]; the residual path already sits in dx (= d x_l so far)
-        LAUNCH(conv_backward_kern_kernel, dim3(blocks(R * C)), dim3(256), xl, t.dx1, t.deg, t.src, N, k, C, L * C, t.dkern + (size_t)l * C);
-        LAUNCH(conv_backward_dx_kernel, dim3(blocks(M * C)), dim3(256), t.kern + (size_t)l * C, L * C, t.dx1, t.rev_start, t.rev_cnt,
-               t.rev_idx, N, k, C, t.dx);
+        if (C % 4 == 0) {
+            LAUNCH(mix_backward_x_kernel4, dim3(blocks(M * C / 4)), dim3(256), V4(dx2), V4(fk), N, C / 4, V4W(t.dx1));
+            LAUNCH(conv_backward_kern_kernel4, dim3(blocks(R * C / 4)), dim3(256), V4(xl), V4(t.dx1), t.deg, t.src, N, k, C / 4, L * C / 4,
+                   V4W(t.dkern + (size_t)l * C));
+            LAUNCH(conv_backward_dx_kernel4, dim3(blocks(M * C / 4)), dim3(256), V4(t.kern + (size_t)l * C), L * C / 4, V4(t.dx1), t.rev_start,
+                   t.rev_cnt, t.rev_idx, N, k, C / 4, V4W(t.dx));
+        } else {
+            LAUNCH(mix_backward_x_kernel, dim3(blocks(M * C)), dim3(256), dx2, fk, N, C, t.dx1);
+            LAUNCH(conv_backward_kern_kernel, dim3(blocks(R * C)), dim3(256), xl, t.dx1, t.deg, t.src, N, k, C, L * C, t.dkern + (size_t)l * C);
+            LAUNCH(conv_backward_dx_kernel, dim3(blocks(M * C)), dim3(256), t.kern + (size_t)l * C, L * C, t.dx1, t.rev_start, t.rev_cnt,
+                   t.rev_idx, N, k, C, t.dx);
+        }
     }
     // d(fiber kernel) of every layer = sum over nodes of x1 (x) dx2 / 16: one batched pair of launches (both operands were kept
     // per layer), then its two uses
@@ -1144,30 +1266,34 @@ extern "C" int arreau_model_update_train_weights(arreau_model* m, const arreau_s
     hipStream_t s = (hipStream_t)stream;
     const size_t C = m->C, D = m->D, L = m->L, H = m->H, S = m->S, RO = S + 4;
     auto W = [](const float* p) { return const_cast<float*>(p); };
+    CopySegments seg;
+    int nseg = 0;
     auto cp = [&](const float* dst, const float* src, size_t n) {
-        return hipMemcpyAsync(W(dst), src, n * sizeof(float), hipMemcpyDeviceToDevice, s);
+        seg.dst[nseg] = W(dst); seg.src[nseg] = src; seg.n[nseg] = (unsigned)n;
+        ++nseg;
     };
     m->packed_stale = 1;
     LAUNCH(fold_poly_weight_kernel, dim3(blocks((long)C * ARREAU_MONO_PAD)), dim3(256), d->basis_w1, (int)C, W(m->t_w1f));
-    ARREAU_CHECK_HIP(cp(m->b1, d->basis_b1, C));
-    ARREAU_CHECK_HIP(cp(m->t_w2, d->basis_w2, D * C));
-    ARREAU_CHECK_HIP(cp(m->b2, d->basis_b2, D));
-    ARREAU_CHECK_HIP(cp(m->fiber_w1, d->fiber_w1, C * 3));
-    ARREAU_CHECK_HIP(cp(m->fiber_b1, d->fiber_b1, C));
-    ARREAU_CHECK_HIP(cp(m->fiber_w2, d->fiber_w2, D * C));
-    ARREAU_CHECK_HIP(cp(m->fiber_b2, d->fiber_b2, D));
     LAUNCH(transpose_kernel, dim3(blocks((long)C * (S + 78))), dim3(256), d->x_embedder_w, (int)C, (int)(S + 78), W(m->embT));
-    ARREAU_CHECK_HIP(cp(m->t_wk, d->conv_kernel_w, L * C * D));
-    ARREAU_CHECK_HIP(cp(m->fiber_wk, d->conv_fiber_w, L * C * D));
-    ARREAU_CHECK_HIP(cp(m->conv_bias, d->conv_bias, L * C));
-    ARREAU_CHECK_HIP(cp(m->ln_w, d->norm_w, L * C));
-    ARREAU_CHECK_HIP(cp(m->ln_b, d->norm_b, L * C));
-    ARREAU_CHECK_HIP(cp(m->t_lin1, d->linear1_w, L * H * C));
-    ARREAU_CHECK_HIP(cp(m->mb1, d->linear1_b, L * H));
-    ARREAU_CHECK_HIP(cp(m->t_lin2, d->linear2_w, L * C * H));
-    ARREAU_CHECK_HIP(cp(m->mb2, d->linear2_b, L * C));
-    if (m->cfg.has_layer_scale && d->layer_scale) ARREAU_CHECK_HIP(cp(m->ls, d->layer_scale, L * C));
-    ARREAU_CHECK_HIP(cp(m->t_ro_w, d->readout_w, L * RO * C));
-    ARREAU_CHECK_HIP(cp(m->ro_b, d->readout_b, L * RO));
+    cp(m->b1, d->basis_b1, C);
+    cp(m->t_w2, d->basis_w2, D * C);
+    cp(m->b2, d->basis_b2, D);
+    cp(m->fiber_w1, d->fiber_w1, C * 3);
+    cp(m->fiber_b1, d->fiber_b1, C);
+    cp(m->fiber_w2, d->fiber_w2, D * C);
+    cp(m->fiber_b2, d->fiber_b2, D);
+    cp(m->t_wk, d->conv_kernel_w, L * C * D);
+    cp(m->fiber_wk, d->conv_fiber_w, L * C * D);
+    cp(m->conv_bias, d->conv_bias, L * C);
+    cp(m->ln_w, d->norm_w, L * C);
+    cp(m->ln_b, d->norm_b, L * C);
+    cp(m->t_lin1, d->linear1_w, L * H * C);
+    cp(m->mb1, d->linear1_b, L * H);
+    cp(m->t_lin2, d->linear2_w, L * C * H);
+    cp(m->mb2, d->linear2_b, L * C);
+    if (m->cfg.has_layer_scale && d->layer_scale) cp(m->ls, d->layer_scale, L * C);
+    cp(m->t_ro_w, d->readout_w, L * RO * C);
+    cp(m->ro_b, d->readout_b, L * RO);
+    LAUNCH(copy_segments_kernel, dim3(64, nseg), dim3(256), seg);
     return ARREAU_OK;
 }

