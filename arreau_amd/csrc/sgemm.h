@@ -167,6 +167,24 @@ __global__ __launch_bounds__(256) void sgemm_kernel(int M, int N, int K, const f
                 }
             }
 }
+// Element-wise work fused into the split kernel's epilogue (round 4; never with split-K, whose partial sums pass through
+// splitk_reduce_kernel).  All operands share C's shape and pitch; the arithmetic is the element-wise kernels' of train_net.hip
+// (same expressions, so a fused and an unfused product agree to the bit):
+//   1  bias + GELU:            v += vec[n];  C = v;  out = gelu(v) * (row ? row[m] : 1)        (ponita.py:65: basis MLPs; convnext.py: linear_1)
+//   2  GELU backward:          C = v * gelu'(mat[m][n]) * (row ? row[m] : 1)                     (mat = the pre-activation)
+//   3  bias, scale, residual:  v += vec[n];  C = v;  out = v * vec2[n] + mat[m][n]               (convnext.py: x + layer_scale * linear_2(...))
+struct SgemmEpilogue {
+    int kind = 0;
+    const float* vec = nullptr;
+    const float* vec2 = nullptr;
+    const float* row = nullptr;
+    const float* mat = nullptr;
+    float* out = nullptr;
+};
+__device__ __forceinline__ float sg_gelu_exact(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+__device__ __forceinline__ float sg_gelu_grad(float x) {
+    return 0.5f * (1.0f + erff(x * 0.70710678118654752440f)) + x * 0.39894228040143267794f * expf(-0.5f * x * x);
+}
 // Split-precision form of the kernel above (round 4; BASELINE configs[4] asks for the training step on matrix-rate
 // arithmetic).  Same tiling, same operand addressing, same split-K protocol; what changes is the staging -- every fp32
 // operand element is split into 16-bit planes ON ITS WAY INTO LDS (once per element and tile, the cost amortised over the
@@ -189,12 +207,12 @@ __global__ __launch_bounds__(256) void sgemm_kernel(int M, int N, int K, const f
 // Two workgroups per CU (launch bound: 256 registers): the kernel keeps ONE LDS buffer and two barriers per k-step, so a
 // workgroup alone on its CU never overlaps staging with matrix work -- the fp16x3 128 x 128 form took 268 registers, ran
 // one wave per SIMD and reached 110 TFLOP/s (effective) on [64768, 256] x [640, 256]^T, 15 % of its matrix time.
-template <int MODE, int WM, int WN, bool AK, bool BKC, int PD>
+template <int MODE, int WM, int WN, bool AK, bool BKC, int PD, int BK>
 __global__ __launch_bounds__(256, 2) void sgemm_split_kernel(int M, int N, int K, const float* __restrict__ A, long as0, long as1,
                                                              const float* __restrict__ B, long bs0, long bs1, float* __restrict__ C,
                                                              int ldc, float alpha, float beta, int kchunk, float* __restrict__ partial,
-                                                             int splits, long a_bs, long b_bs, long c_bs) {
-    constexpr int BK = 32, TM = 64 * WM, TN = 64 * WN, P = MODE == 1 ? 2 : 3, LDK = BK + 8;
+                                                             int splits, long a_bs, long b_bs, long c_bs, SgemmEpilogue epi) {
+    constexpr int TM = 64 * WM, TN = 64 * WN, P = MODE == 1 ? 2 : 3, LDK = BK + 8;  // (row pitch 80 / 144 bytes: conflict-free b128 reads)
     const int bi = (int)blockIdx.z / splits, zi = (int)blockIdx.z - bi * splits;
     A += (long)bi * a_bs;
     B += (long)bi * b_bs;
@@ -203,7 +221,7 @@ __global__ __launch_bounds__(256, 2) void sgemm_split_kernel(int M, int N, int K
     constexpr int PA = WM * BK / 16, PB = WN * BK / 16;   // k-contiguous: 16-byte pieces per thread
     constexpr int EA = 4 * PA, EB = 4 * PB;               // row-contiguous: elements (consecutive k of one row) per thread
     __shared__ __attribute__((aligned(16))) unsigned short As[P][TM][LDK], Bs[P][TN][LDK];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int h = lane >> 5, j = lane & 31, wm = (wave >> 1) * (32 * WM), wn = (wave & 1) * (32 * WN);
     const int m0 = blockIdx.y * TM, n0 = blockIdx.x * TN;
     const int kbeg = zi * kchunk, kend = min(K, kbeg + kchunk);
@@ -231,29 +249,65 @@ __global__ __launch_bounds__(256, 2) void sgemm_split_kernel(int M, int N, int K
     // ragged K; k-slices are multiples of the k-step) the A operand is zeroed by a select -- in stage(), behind the matrix work:
     // written next to the load, hipcc waits for the load right there -- and B re-reads its last k, an element that takes part
     // in the same outputs anyway (so a non-finite value there reaches nothing it would not reach already).
-    const int a_m = min(m0 + (AK ? tid / KP : a_row), M - 1), b_n = min(n0 + (BKC ? tid / KP : b_row), N - 1);
-    auto fetch = [&](int k0, int u) {
-        if constexpr (AK) {
-            const float* src = A + min(k0 + (tid % KP) * 4, K - 4);
+    // Addresses: a uniform tile base (scalar registers, advanced by the k-step) + per-thread 32-bit element offsets computed ONCE
+    // (row clamp folded in).  Computed per load they were ~130 vector instructions per k-step -- 64-bit multiplies and clamps -- and a
+    // timing-only build without the loads ran 195 -> 134 us on [68096, 640] x [640, 256] although the loads themselves were prefetched.
+    const float* a_tile = A + (AK ? (long)m0 * as0 : (long)m0);
+    const float* b_tile = B + (BKC ? (long)n0 * bs1 : (long)n0);
+    unsigned a_off[AK ? PA : 1], b_off[BKC ? PB : 1];
+    if constexpr (AK) {
 #pragma unroll
-            for (int i = 0; i < PA; ++i) {  // piece i: row + 256 i / KP of the tile
-                ra[u][i] = *reinterpret_cast<const f32x4*>(src + (long)min(a_m + (256 / KP) * i, M - 1) * as0);
+        for (int i = 0; i < PA; ++i) a_off[i] = (unsigned)(min(tid / KP + (256 / KP) * i, M - 1 - m0) * (int)as0 + (tid % KP) * 4);
+    } else {
+        a_off[0] = (unsigned)min(a_row, M - 1 - m0);
+    }
+    if constexpr (BKC) {
+#pragma unroll
+        for (int i = 0; i < PB; ++i) b_off[i] = (unsigned)(min(tid / KP + (256 / KP) * i, N - 1 - n0) * (int)bs1 + (tid % KP) * 4);
+    } else {
+        b_off[0] = (unsigned)min(b_row, N - 1 - n0);
+    }
+    auto fetch = [&](int k0, int u) {
+        const bool inside = k0 + BK <= K;  // (uniform) the whole k-step lies inside the matrix: no clamp
+        if constexpr (AK) {
+            if (inside) {
+                const float* src = a_tile + k0;
+#pragma unroll
+                for (int i = 0; i < PA; ++i) ra[u][i] = *reinterpret_cast<const f32x4*>(src + a_off[i]);
+            } else {
+                const int shift = min(k0 + (tid % KP) * 4, K - 4) - (tid % KP) * 4;
+#pragma unroll
+                for (int i = 0; i < PA; ++i) ra[u][i] = *reinterpret_cast<const f32x4*>(a_tile + shift + a_off[i]);
             }
         } else {
-            const float* src = A + a_m;  // (as0 == 1)
+            if (inside) {
+                const float* src = a_tile + (long)(k0 + a_k) * as1;  // (uniform per wave: a scalar pointer stepped by the pitch)
 #pragma unroll
-            for (int i = 0; i < EA; ++i) {
-                ea[u][i] = src[(long)min(k0 + a_k + i, K - 1) * as1];
+                for (int i = 0; i < EA; ++i, src += as1) ea[u][i] = src[a_off[0]];
+            } else {
+#pragma unroll
+                for (int i = 0; i < EA; ++i) ea[u][i] = (a_tile + (long)min(k0 + a_k + i, K - 1) * as1)[a_off[0]];
             }
         }
         if constexpr (BKC) {
-            const float* src = B + min(k0 + (tid % KP) * 4, K - 4);
+            if (inside) {
+                const float* src = b_tile + k0;
 #pragma unroll
-            for (int i = 0; i < PB; ++i) rb[u][i] = *reinterpret_cast<const f32x4*>(src + (long)min(b_n + (256 / KP) * i, N - 1) * bs1);
+                for (int i = 0; i < PB; ++i) rb[u][i] = *reinterpret_cast<const f32x4*>(src + b_off[i]);
+            } else {
+                const int shift = min(k0 + (tid % KP) * 4, K - 4) - (tid % KP) * 4;
+#pragma unroll
+                for (int i = 0; i < PB; ++i) rb[u][i] = *reinterpret_cast<const f32x4*>(b_tile + shift + b_off[i]);
+            }
         } else {
-            const float* src = B + b_n;  // (bs1 == 1)
+            if (inside) {
+                const float* src = b_tile + (long)(k0 + b_k) * bs0;
 #pragma unroll
-            for (int i = 0; i < EB; ++i) eb[u][i] = src[(long)min(k0 + b_k + i, K - 1) * bs0];
+                for (int i = 0; i < EB; ++i, src += bs0) eb[u][i] = src[b_off[0]];
+            } else {
+#pragma unroll
+                for (int i = 0; i < EB; ++i) eb[u][i] = (b_tile + (long)min(k0 + b_k + i, K - 1) * bs0)[b_off[0]];
+            }
         }
     };
     // planes of two consecutive values as one dword per plane (element 0 in the low half)
@@ -366,28 +420,62 @@ __global__ __launch_bounds__(256, 2) void sgemm_split_kernel(int M, int N, int K
     float* outp = splits > 1 ? partial + (size_t)blockIdx.z * M * N : C;
     const int ldo = splits > 1 ? N : ldc;
     const float oa = splits > 1 ? 1.f : alpha;
-    auto store_tiles = [&](auto read_c) {
+    auto store_tiles = [&](auto read_c, auto fused) {
 #pragma unroll
         for (int a = 0; a < WM; ++a)
 #pragma unroll
             for (int b = 0; b < WN; ++b) {
                 const int n = n0 + wn + 32 * b + j;
                 if (n >= N) continue;
+                const int mb = m0 + wm + 32 * a + 4 * h;  // register r holds row mb + (r & 3) + 8 (r >> 2)
+                float v[16];
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int m = m0 + wm + 32 * a + (r & 3) + 8 * (r >> 2) + 4 * h;
-                    float v = acc[0][a][b][r];
-                    if constexpr (MODE == 1) v = fmaf(acc[1][a][b][r], F16X3_INV_SCALE, v);
-                    if (m < M) {
-                        float* o = outp + (size_t)m * ldo + n;
-                        if constexpr (decltype(read_c)::value) *o = fmaf(beta, *o, oa * v);
-                        else *o = oa * v;
+                    v[r] = acc[0][a][b][r];
+                    if constexpr (MODE == 1) v[r] = fmaf(acc[1][a][b][r], F16X3_INV_SCALE, v[r]);
+                    v[r] *= oa;
+                }
+                if constexpr (decltype(fused)::value) {
+                    // the tile's operands first (16 independent loads), then the arithmetic, then the stores: written load - compute -
+                    // store per element, every load waited behind the previous store (the pointers may alias for all hipcc knows)
+                    float mv[16], rv[16];
+                    const float cv = epi.kind == 2 ? 0.f : epi.vec[n], c2 = epi.kind == 3 ? epi.vec2[n] : 0.f;
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int m = min(mb + (r & 3) + 8 * (r >> 2), M - 1);
+                        mv[r] = epi.kind == 1 ? 0.f : epi.mat[(size_t)m * ldo + n];
+                        rv[r] = epi.row ? epi.row[m] : 1.0f;
+                    }
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        if (epi.kind == 1) { v[r] += cv; mv[r] = sg_gelu_exact(v[r]) * rv[r]; }
+                        else if (epi.kind == 2) v[r] = v[r] * sg_gelu_grad(mv[r]) * rv[r];
+                        else { v[r] += cv; mv[r] = v[r] * c2 + mv[r]; }
+                    }
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int m = mb + (r & 3) + 8 * (r >> 2);
+                        if (m < M) {
+                            outp[(size_t)m * ldo + n] = v[r];
+                            if (epi.kind != 2) epi.out[(size_t)m * ldo + n] = mv[r];
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int m = mb + (r & 3) + 8 * (r >> 2);
+                        if (m < M) {
+                            float* o = outp + (size_t)m * ldo + n;
+                            if constexpr (decltype(read_c)::value) *o = fmaf(beta, *o, v[r]);
+                            else *o = v[r];
+                        }
                     }
                 }
             }
     };
-    if (splits == 1 && beta != 0.f) store_tiles(std::true_type{});
-    else store_tiles(std::false_type{});
+    if (splits == 1 && beta != 0.f) store_tiles(std::true_type{}, std::false_type{});
+    else if (splits == 1 && epi.kind != 0) store_tiles(std::false_type{}, std::true_type{});
+    else store_tiles(std::false_type{}, std::false_type{});
 }
 __global__ void splitk_reduce_kernel(const float* __restrict__ partial, int Z, int M, int N, float* __restrict__ C, int ldc,
                                      float alpha, float beta, long c_bs /* blockIdx.y = product of the batch */) {
@@ -407,7 +495,8 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ partial, int Z, i
 // (16 tiles each) and fill it together.
 inline int arreau_sgemm(hipStream_t s, float* partial, int M, int N, int K, const float* A, long as0, long as1, const float* B,
                         long bs0, long bs1, float* C, int ldc, float alpha = 1.f, float beta = 0.f, int batch = 1, long a_bs = 0,
-                        long b_bs = 0, long c_bs = 0, int mode = 0 /* 0: exact fp32; 1: fp16x3; 2: bf16x6 (sgemm_split_kernel) */) {
+                        long b_bs = 0, long c_bs = 0, int mode = 0 /* 0: exact fp32; 1: fp16x3; 2: bf16x6 (sgemm_split_kernel) */,
+                        const arreau_sgemm_detail::SgemmEpilogue* epi = nullptr, bool* fused = nullptr /* out: the epilogue ran inside the product */) {
     using namespace arreau_sgemm_detail;
     if (M == 0 || N == 0 || batch <= 0) return ARREAU_OK;
     // Tile size.  The kernel is bound by the matrix pipe of the busiest CU, so what matters is how evenly the tiles divide
@@ -454,15 +543,28 @@ inline int arreau_sgemm(hipStream_t s, float* partial, int M, int N, int K, cons
         hipLaunchKernelGGL(kernel, dim3(gn, gm, Z * batch), dim3(256), 0, s, M, N, K, A, as0, as1, B, bs0, bs1, C, ldc, alpha, beta, kchunk,
                            partial, Z, a_bs, b_bs, c_bs);
     };
+    // the element-wise epilogue runs inside the product where the split kernel takes it whole (no k-slices, no accumulation into C)
+    // ... and only on the 64 x 64 tiles: at 128 x 128 (two workgroups per CU, 64 outputs per thread) the erf / exp arithmetic of the GELU
+    // epilogues is not hidden behind anything and the fused product ran slower than product + element-wise launch (round 4: 133 + 31 us
+    // -> 256 us for the kernel-projection gradient with the GELU derivative)
+    const bool fuse = epi && epi->kind != 0 && split && small && Z == 1 && beta == 0.f && batch == 1;
+    if (fused) *fused = fuse;
+    SgemmEpilogue ep = fuse ? *epi : SgemmEpilogue{};
+    auto launch_split = [&](auto kernel) {
+        hipLaunchKernelGGL(kernel, dim3(gn, gm, Z * batch), dim3(256), 0, s, M, N, K, A, as0, as1, B, bs0, bs1, C, ldc, alpha, beta, kchunk,
+                           partial, Z, a_bs, b_bs, c_bs, ep);
+    };
     if (split) {
         auto pick = [&](auto mode_c, auto w_c) {
             constexpr int MD = decltype(mode_c)::value, W = decltype(w_c)::value;
             // two tiles in flight wherever the registers allow it at two workgroups per CU (fp16x3 at 128 x 128 holds 128 accumulators)
             constexpr int PD = (MD == 1 && W == 2) ? 1 : 2;
-            if (ak && bk) launch(sgemm_split_kernel<MD, W, W, true, true, PD>);
-            else if (ak) launch(sgemm_split_kernel<MD, W, W, true, false, PD>);
-            else if (bk) launch(sgemm_split_kernel<MD, W, W, false, true, PD>);
-            else launch(sgemm_split_kernel<MD, W, W, false, false, PD>);
+            // (k-steps of 64 for the 64 x 64 tiles -- half the barriers of the node-level products -- measured the same to 6 % slower)
+            constexpr int BKS = 32;
+            if (ak && bk) launch_split(sgemm_split_kernel<MD, W, W, true, true, PD, BKS>);
+            else if (ak) launch_split(sgemm_split_kernel<MD, W, W, true, false, PD, BKS>);
+            else if (bk) launch_split(sgemm_split_kernel<MD, W, W, false, true, PD, BKS>);
+            else launch_split(sgemm_split_kernel<MD, W, W, false, false, PD, BKS>);
         };
         using std::integral_constant;
         if (small) { if (mode == 1) pick(integral_constant<int, 1>{}, integral_constant<int, 1>{}); else pick(integral_constant<int, 2>{}, integral_constant<int, 1>{}); }

@@ -559,19 +559,46 @@ __global__ void mix_backward_x_kernel(const float* __restrict__ dx2, const float
 }
 // dfk[o,p,c] = sum_n x1[n,o,c] dx2[n,p,c] / 16: chunks of 32 atoms summed by separate workgroups, then the chunks in
 // order (deterministic)
-constexpr int MIX_CHUNK = 32;
-__global__ void mix_backward_fk_partial_kernel(const float* __restrict__ x1, const float* __restrict__ dx2, int N, int C,
-                                               float* __restrict__ part /*[chunks][256][C]*/, int chunk = MIX_CHUNK) {
-    const int op = blockIdx.x, o = op >> 4, p = op & 15;
-    const int n0 = blockIdx.y * chunk, n1 = min(N, n0 + chunk);
-    // blockIdx.z = layer (the layers' x1 / dx2 / partial sums lie N * 16 * C, resp. chunks * 256 * C floats apart)
-    x1 += (size_t)blockIdx.z * N * 16 * C;
-    dx2 += (size_t)blockIdx.z * N * 16 * C;
-    part += (size_t)blockIdx.z * gridDim.y * 256 * C;
+constexpr int MIX_CHUNK = 16;
+// d(fiber kernel)[o][p][c] = sum_n x1[n][o][c] dx2[n][p][c]: ONE block per (chunk of atoms, layer), a thread per channel holding all
+// 16 x 16 sums (round 4; the first form ran a block per (o, p) pair and read both operands 16 times: 81 us at 64 crystals, most of
+// it L2 traffic).  Atoms in ascending order inside a chunk, chunks added in order by the final kernel: the same sums as before.
+__global__ __launch_bounds__(128) void mix_backward_fk_partial_kernel(const float* __restrict__ x1, const float* __restrict__ dx2, int N, int C,
+                                                                      float* __restrict__ part /*[chunks][256][C]*/, int chunk = MIX_CHUNK) {
+    const int n0 = blockIdx.x * chunk, n1 = min(N, n0 + chunk);
+    // blockIdx.y = layer (the layers' x1 / dx2 / partial sums lie N * 16 * C, resp. chunks * 256 * C floats apart)
+    x1 += (size_t)blockIdx.y * N * 16 * C;
+    dx2 += (size_t)blockIdx.y * N * 16 * C;
+    part += ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 256 * C;
     for (int c = threadIdx.x; c < C; c += blockDim.x) {
-        float acc = 0.f;
-        for (int n = n0; n < n1; ++n) acc += x1[((size_t)n * 16 + o) * C + c] * dx2[((size_t)n * 16 + p) * C + c];
-        part[((size_t)blockIdx.y * 256 + op) * C + c] = acc;
+        float acc[16][16];
+#pragma unroll
+        for (int o = 0; o < 16; ++o)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[o][q] = 0.f;
+        float xn[16], dn[16];  // the next atom's rows travel while this atom's 256 products run
+        auto load = [&](int n) {
+#pragma unroll
+            for (int o = 0; o < 16; ++o) {
+                xn[o] = x1[((size_t)n * 16 + o) * C + c];
+                dn[o] = dx2[((size_t)n * 16 + o) * C + c];
+            }
+        };
+        if (n0 < n1) load(n0);
+        for (int n = n0; n < n1; ++n) {
+            float xv[16], dv[16];
+#pragma unroll
+            for (int o = 0; o < 16; ++o) { xv[o] = xn[o]; dv[o] = dn[o]; }
+            if (n + 1 < n1) load(n + 1);
+#pragma unroll
+            for (int o = 0; o < 16; ++o)
+#pragma unroll
+                for (int q = 0; q < 16; ++q) acc[o][q] += xv[o] * dv[q];
+        }
+#pragma unroll
+        for (int o = 0; o < 16; ++o)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) part[(size_t)(o * 16 + q) * C + c] = acc[o][q];
     }
 }
 __global__ void mix_backward_fk_final_kernel(const float* __restrict__ part, int chunks, int C, float* __restrict__ dfk) {
@@ -736,18 +763,24 @@ __global__ void unfold_poly_grad_kernel(const float* __restrict__ dw1f, int C, f
 }
 // the forward direction: fold basis_fn.1.weight [C][258] onto the 83 monomials (columns of one monomial summed in
 // column order), padding columns zero -- the device twin of fold_poly_weight in model.hip
+// one block per channel: the row of 258 polynomial weights and the column -> monomial map sit in LDS (round 4: a thread per
+// output element read its row uncoalesced, 34 us of the optimizer tail); columns are added in ascending order as before
 __global__ void fold_poly_weight_kernel(const float* __restrict__ w1, int C, float* __restrict__ w1f) {
     __shared__ int mono_of[ARREAU_POLY_COLS];
-    for (int col = threadIdx.x; col < ARREAU_POLY_COLS; col += blockDim.x) mono_of[col] = mono_of_poly_column(col);
+    __shared__ float row[ARREAU_POLY_COLS];
+    const int c = blockIdx.x;
+    for (int col = threadIdx.x; col < ARREAU_POLY_COLS; col += blockDim.x) {
+        mono_of[col] = mono_of_poly_column(col);
+        row[col] = w1[c * ARREAU_POLY_COLS + col];
+    }
     __syncthreads();
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= C * ARREAU_MONO_PAD) return;
-    const int c = i / ARREAU_MONO_PAD, mi = i % ARREAU_MONO_PAD;
-    float acc = 0.f;
-    if (mi < ARREAU_NUM_MONO)
-        for (int col = 0; col < ARREAU_POLY_COLS; ++col)
-            if (mono_of[col] == mi) acc += w1[c * ARREAU_POLY_COLS + col];
-    w1f[i] = acc;
+    for (int mi = threadIdx.x; mi < ARREAU_MONO_PAD; mi += blockDim.x) {
+        float acc = 0.f;
+        if (mi < ARREAU_NUM_MONO)
+            for (int col = 0; col < ARREAU_POLY_COLS; ++col)
+                if (mono_of[col] == mi) acc += row[col];
+        w1f[c * ARREAU_MONO_PAD + mi] = acc;
+    }
 }
 // Weight refresh after an optimizer step: up to 24 device-to-device copies as ONE launch (they were 19 hipMemcpyAsync = 19
 // blit-kernel launches, 85 us of the step's 330 us optimizer tail; blockIdx.y = segment).
@@ -840,19 +873,20 @@ size_t layout(arreau_train_ctx& t, const arreau_model* m, int N, int B, float* b
     return c.off;
 }
 
+typedef arreau_sgemm_detail::SgemmEpilogue Epi;
 int gemm(hipStream_t s, arreau_train_ctx& t, int mode, int M, int N, int K, const float* A, long as0, long as1, const float* B, long bs0,
-         long bs1, float* C, int ldc, float alpha = 1.f, float beta = 0.f) {
-    return arreau_sgemm(s, t.partial, M, N, K, A, as0, as1, B, bs0, bs1, C, ldc, alpha, beta, 1, 0, 0, 0, mode);
+         long bs1, float* C, int ldc, float alpha = 1.f, float beta = 0.f, const Epi* epi = nullptr, bool* fused = nullptr) {
+    return arreau_sgemm(s, t.partial, M, N, K, A, as0, as1, B, bs0, bs1, C, ldc, alpha, beta, 1, 0, 0, 0, mode, epi, fused);
 }
 // Y[rows][out] = X[rows][in] . W[out][in]^T
 int linear(hipStream_t s, arreau_train_ctx& t, long rows, int in, int out, const float* X, const float* W, float* Y,
-           float alpha = 1.f, float beta = 0.f) {
-    return gemm(s, t, t.fwd_mode, (int)rows, out, in, X, in, 1, W, 1, in, Y, out, alpha, beta);
+           float alpha = 1.f, float beta = 0.f, const Epi* epi = nullptr, bool* fused = nullptr) {
+    return gemm(s, t, t.fwd_mode, (int)rows, out, in, X, in, 1, W, 1, in, Y, out, alpha, beta, epi, fused);
 }
 // dX[rows][in] (+)= dY[rows][out] . W[out][in]
 int linear_dx(hipStream_t s, arreau_train_ctx& t, long rows, int in, int out, const float* dY, const float* W, float* dX,
-              float alpha = 1.f, float beta = 0.f) {
-    return gemm(s, t, t.bwd_mode, (int)rows, in, out, dY, out, 1, W, in, 1, dX, in, alpha, beta);
+              float alpha = 1.f, float beta = 0.f, const Epi* epi = nullptr, bool* fused = nullptr) {
+    return gemm(s, t, t.bwd_mode, (int)rows, in, out, dY, out, 1, W, in, 1, dX, in, alpha, beta, epi, fused);
 }
 // the same for `batch` layers in one launch (dY / X / dW of consecutive layers dy_bs / x_bs / out * in floats apart; 0 = shared)
 int linear_dw_batched(hipStream_t s, arreau_train_ctx& t, int batch, long rows, int in, int out, const float* dY, long dy_bs,
@@ -944,6 +978,26 @@ int launch_gelu_backward(hipStream_t s, float* g, const float* pre, const float*
     ARREAU_CHECK_HIP(hipGetLastError());
     return ARREAU_OK;
 }
+// pre = X W^T + bias, act = gelu(pre) * rowscale: inside the product where the split kernel takes it, else as the element-wise launch
+int linear_bias_gelu(hipStream_t s, arreau_train_ctx& t, long rows, int in, int out, const float* X, const float* W, const float* bias,
+                     const float* rowscale, float* pre, float* act) {
+    Epi e;
+    e.kind = 1; e.vec = bias; e.row = rowscale; e.out = act;
+    bool fused = false;
+    int rc = linear(s, t, rows, in, out, X, W, pre, 1.f, 0.f, &e, &fused);
+    if (rc || fused) return rc;
+    return launch_bias_gelu(s, pre, bias, rowscale, rows, out, act);
+}
+// dX = (dY W) * gelu'(pre) * rowscale
+int linear_dx_gelu_backward(hipStream_t s, arreau_train_ctx& t, long rows, int in, int out, const float* dY, const float* W, const float* pre,
+                            const float* rowscale, float* dX) {
+    Epi e;
+    e.kind = 2; e.mat = pre; e.row = rowscale;
+    bool fused = false;
+    int rc = linear_dx(s, t, rows, in, out, dY, W, dX, 1.f, 0.f, &e, &fused);
+    if (rc || fused) return rc;
+    return launch_gelu_backward(s, dX, pre, rowscale, rows, in);
+}
 #define V4(p) reinterpret_cast<const f32x4*>(p)
 #define V4W(p) reinterpret_cast<f32x4*>(p)
 #define TRY(expr) do { int rc_ = (expr); if (rc_) return rc_; } while (0)
@@ -1010,14 +1064,12 @@ int arreau_general_network(arreau_model* m, const arreau_graph_view& g, const in
            t.mono, t.window);
     TRY(linear(s, t, R, ARREAU_MONO_PAD, C, t.mono, t.w1f, t.h1pre));
     TRY(launch_bias_gelu(s, t.h1pre, m->b1, (const float*)nullptr, R, C, t.h1));
-    TRY(linear(s, t, R, C, D, t.h1, t.w2, t.h2pre));
-    TRY(launch_bias_gelu(s, t.h2pre, m->b2, (const float*)t.window, R, D, t.kb));
+    TRY(linear_bias_gelu(s, t, R, C, D, t.h1, t.w2, m->b2, (const float*)t.window, t.h2pre, t.kb));
     // fiber basis (ponita.py:66,95)
     LAUNCH(fiber_poly_kernel, dim3(1), dim3(256), m->ori, t.fpoly);
     TRY(linear(s, t, 256, 3, C, t.fpoly, m->fiber_w1, t.fh1pre));
     TRY(launch_bias_gelu(s, t.fh1pre, m->fiber_b1, (const float*)nullptr, 256L, C, t.fh1));
-    TRY(linear(s, t, 256, C, D, t.fh1, m->fiber_w2, t.fh2pre));
-    TRY(launch_bias_gelu(s, t.fh2pre, m->fiber_b2, (const float*)nullptr, 256L, D, t.fkb));
+    TRY(linear_bias_gelu(s, t, 256, C, D, t.fh1, m->fiber_w2, m->fiber_b2, (const float*)nullptr, t.fh2pre, t.fkb));
     ARREAU_CHECK_HIP(hipMemsetAsync(t.rbar, 0, (size_t)M * RO * sizeof(float), s));
     // kernel_l = kb . Wk_l^T for all layers in one product (conv.py:110; conv.kernel.weight stacked [L*C][D])
     TRY(linear(s, t, R, D, L * C, t.kb, t.wk, t.kern));
@@ -1041,10 +1093,16 @@ int arreau_general_network(arreau_model* m, const arreau_graph_view& g, const in
         float* hpre = t.hpre + (size_t)l * M * H;
         float* h = t.h + (size_t)l * M * H;
         float* out = t.out + (size_t)l * M * C;
-        TRY(linear(s, t, M, C, H, t.xn_all + (size_t)l * M * C, t.lin1 + (size_t)l * H * C, hpre));
-        TRY(launch_bias_gelu(s, hpre, m->mb1 + (size_t)l * H, (const float*)nullptr, M, H, h));
-        TRY(linear(s, t, M, H, C, h, t.lin2 + (size_t)l * C * H, out));
-        LAUNCH(bias_scale_residual_kernel, dim3(blocks(M * C)), dim3(256), out, m->mb2 + (size_t)l * C, m->ls + (size_t)l * C, xl, M, C, xnext);
+        TRY(linear_bias_gelu(s, t, M, C, H, t.xn_all + (size_t)l * M * C, t.lin1 + (size_t)l * H * C, m->mb1 + (size_t)l * H, (const float*)nullptr,
+                             hpre, h));
+        {   // out = h W2^T + b2;  x_{l+1} = out * layer_scale + x_l  (in the product's epilogue where the split kernel runs it)
+            Epi e;
+            e.kind = 3; e.vec = m->mb2 + (size_t)l * C; e.vec2 = m->ls + (size_t)l * C; e.mat = xl; e.out = xnext;
+            bool fused = false;
+            TRY(linear(s, t, M, H, C, h, t.lin2 + (size_t)l * C * H, out, 1.f, 0.f, &e, &fused));
+            if (!fused)
+                LAUNCH(bias_scale_residual_kernel, dim3(blocks(M * C)), dim3(256), out, m->mb2 + (size_t)l * C, m->ls + (size_t)l * C, xl, M, C, xnext);
+        }
         // read-out of this layer, averaged over layers (ponita.py:105,108); biases are added in train_outputs_kernel
         TRY(linear(s, t, M, C, RO, xnext, t.ro_w + (size_t)l * RO * C, t.rbar, 1.0f / (float)L, 1.0f));
     }
@@ -1138,8 +1196,7 @@ extern "C" int arreau_train_backward(arreau_model* m, const float* d_g_eps, cons
         float* dh = t.dh + (size_t)l * M * H;
         LAUNCH(scale_cols_kernel, dim3(blocks(M * C)), dim3(256), t.dx, m->ls + (size_t)l * C, M, C, dout);   // dout
         if (!m->cfg.has_layer_scale) TRY(colsum(s, t, dout, nullptr, M, C, 1.0f, W(g->linear2_b) + (size_t)l * C));
-        TRY(linear_dx(s, t, M, H, C, dout, t.lin2 + (size_t)l * C * H, dh));
-        TRY(launch_gelu_backward(s, dh, hpre, (const float*)nullptr, M, H));      // dhpre
+        TRY(linear_dx_gelu_backward(s, t, M, H, C, dout, t.lin2 + (size_t)l * C * H, hpre, (const float*)nullptr, dh));   // dhpre
         float* dxn = t.dxn_all + (size_t)l * M * C;
         float* dx2 = t.dx2_all + (size_t)l * M * C;
         TRY(linear_dx(s, t, M, C, H, dh, t.lin1 + (size_t)l * H * C, dxn));                                          // dxn
@@ -1171,7 +1228,7 @@ extern "C" int arreau_train_backward(arreau_model* m, const float* d_g_eps, cons
         const int Lg = (int)std::min<size_t>((size_t)L, PARTIAL_FLOATS / ((size_t)chunks * 256 * C));
         for (int l0 = 0; l0 < L; l0 += Lg) {
             const int nl = std::min(Lg, L - l0);
-            LAUNCH(mix_backward_fk_partial_kernel, dim3(256, chunks, nl), dim3(128), t.x1 + (size_t)l0 * N * 16 * C,
+            LAUNCH(mix_backward_fk_partial_kernel, dim3(chunks, nl), dim3(128), t.x1 + (size_t)l0 * N * 16 * C,
                    t.dx2_all + (size_t)l0 * N * 16 * C, N, C, t.partial, chunk);
             LAUNCH(mix_backward_fk_final_kernel, dim3(blocks(256L * C), nl), dim3(256), t.partial, chunks, C, t.dfk_all + (size_t)l0 * 256 * C);
         }
@@ -1190,15 +1247,13 @@ extern "C" int arreau_train_backward(arreau_model* m, const float* d_g_eps, cons
     TRY(colsum(s, t, t.dx2_all, nullptr, M, C, 1.0f, W(g->conv_bias), 0, nullptr, nullptr, L, (long)M * C, 0, C, 0));
     // kernel projections of all layers at once: dWk [L*C][D] = dkern^T . kb,  dkb = dkern . Wk
     TRY(linear_dw(s, t, R, D, L * C, t.dkern, t.kb, W(g->conv_kernel_w)));
-    TRY(linear_dx(s, t, R, D, L * C, t.dkern, t.wk, t.dkb));
+    TRY(linear_dx_gelu_backward(s, t, R, D, L * C, t.dkern, t.wk, t.h2pre, (const float*)t.window, t.dkb));   // dh2pre
     // embedding: x_0 = F . W_emb^T  -> dW_emb[c][i] = sum_rows dx[row][c] F[row][i]
     TRY(linear_dw(s, t, M, S + 78, C, t.dx, t.F, W(g->x_embedder_w)));
     // edge basis MLP
-    TRY(launch_gelu_backward(s, t.dkb, t.h2pre, (const float*)t.window, R, D));      // dh2pre
     TRY(linear_dw(s, t, R, C, D, t.dkb, t.h1, W(g->basis_w2)));
     TRY(colsum(s, t, t.dkb, nullptr, R, D, 1.0f, W(g->basis_b2)));
-    TRY(linear_dx(s, t, R, C, D, t.dkb, t.w2, t.dh1));
-    TRY(launch_gelu_backward(s, t.dh1, t.h1pre, (const float*)nullptr, R, C));       // dh1pre
+    TRY(linear_dx_gelu_backward(s, t, R, C, D, t.dkb, t.w2, t.h1pre, (const float*)nullptr, t.dh1));   // dh1pre
     TRY(linear_dw(s, t, R, ARREAU_MONO_PAD, C, t.dh1, t.mono, t.dw1f));
     LAUNCH(unfold_poly_grad_kernel, dim3(blocks((long)C * ARREAU_POLY_COLS)), dim3(256), t.dw1f, C, W(g->basis_w1));
     TRY(colsum(s, t, t.dh1, nullptr, R, C, 1.0f, W(g->basis_b1)));
@@ -1206,8 +1261,7 @@ extern "C" int arreau_train_backward(arreau_model* m, const float* d_g_eps, cons
     TRY(launch_gelu_backward(s, t.dfkb, t.fh2pre, (const float*)nullptr, 256L, D));
     TRY(linear_dw(s, t, 256, C, D, t.dfkb, t.fh1, W(g->fiber_w2)));
     TRY(colsum(s, t, t.dfkb, nullptr, 256, D, 1.0f, W(g->fiber_b2)));
-    TRY(linear_dx(s, t, 256, C, D, t.dfkb, m->fiber_w2, t.dfh1));
-    TRY(launch_gelu_backward(s, t.dfh1, t.fh1pre, (const float*)nullptr, 256L, C));
+    TRY(linear_dx_gelu_backward(s, t, 256, C, D, t.dfkb, m->fiber_w2, t.fh1pre, (const float*)nullptr, t.dfh1));
     TRY(linear_dw(s, t, 256, 3, C, t.dfh1, t.fpoly, W(g->fiber_w1)));
     TRY(colsum(s, t, t.dfh1, nullptr, 256, C, 1.0f, W(g->fiber_b1)));
     return ARREAU_OK;
@@ -1273,7 +1327,7 @@ extern "C" int arreau_model_update_train_weights(arreau_model* m, const arreau_s
         ++nseg;
     };
     m->packed_stale = 1;
-    LAUNCH(fold_poly_weight_kernel, dim3(blocks((long)C * ARREAU_MONO_PAD)), dim3(256), d->basis_w1, (int)C, W(m->t_w1f));
+    LAUNCH(fold_poly_weight_kernel, dim3((unsigned)C), dim3(128), d->basis_w1, (int)C, W(m->t_w1f));
     LAUNCH(transpose_kernel, dim3(blocks((long)C * (S + 78))), dim3(256), d->x_embedder_w, (int)C, (int)(S + 78), W(m->embT));
     cp(m->b1, d->basis_b1, C);
     cp(m->t_w2, d->basis_w2, D * C);
