@@ -535,7 +535,7 @@ inline int arreau_sgemm(hipStream_t s, float* partial, int M, int N, int K, cons
     const bool ak = as1 == 1, bk = bs0 == 1;
     const bool a_split_ok = ak ? (as0 % 4 == 0 && K % 4 == 0 && (size_t)A % 16 == 0 && a_bs % 4 == 0) : as0 == 1;
     const bool b_split_ok = bk ? (bs1 % 4 == 0 && K % 4 == 0 && (size_t)B % 16 == 0 && b_bs % 4 == 0) : bs1 == 1;
-    const bool split = mode != 0 && a_split_ok && b_split_ok && K >= 128;
+    const bool split = mode != 0 && a_split_ok && b_split_ok && K >= 64;
     const int BK = (small || split) ? 32 : 16;
     const int kchunk = ((K + Z - 1) / Z + BK - 1) / BK * BK;
     Z = (K + kchunk - 1) / kchunk;

@@ -1181,10 +1181,8 @@ extern "C" int arreau_train_backward(arreau_model* m, const float* d_g_eps, cons
         const float* h = t.h + (size_t)l * M * H;
         const float* out = t.out + (size_t)l * M * C;
         // read-out (ponita.py:105,108); its weight gradient: one batched product over the layers, below the loop
+        // (every layer's read-out sees the same d(rbar): the bias gradients are equal -- copied to the other layers in one launch below)
         if (l == L - 1) TRY(colsum(s, t, t.drbar, nullptr, M, RO, invL, W(g->readout_b) + (size_t)l * RO));
-        else  // every layer's read-out sees the same d(rbar): the bias gradients are equal
-            ARREAU_CHECK_HIP(hipMemcpyAsync(W(g->readout_b) + (size_t)l * RO, g->readout_b + (size_t)(L - 1) * RO, RO * sizeof(float),
-                                            hipMemcpyDeviceToDevice, s));
         TRY(linear_dx(s, t, M, C, RO, t.drbar, t.ro_w + (size_t)l * RO * C, t.dx, invL, 1.0f));   // dx = d x_{l+1}
         // ConvNext tail: x_{l+1} = out * ls + x_l
         // d(layer_scale) = sum_rows dx * out and d(linear_2.bias) = sum_rows dout = ls * sum_rows dx, in one pass over dx
@@ -1215,6 +1213,17 @@ extern "C" int arreau_train_backward(arreau_model* m, const float* d_g_eps, cons
             LAUNCH(conv_backward_dx_kernel, dim3(blocks(M * C)), dim3(256), t.kern + (size_t)l * C, L * C, t.dx1, t.rev_start, t.rev_cnt,
                    t.rev_idx, N, k, C, t.dx);
         }
+    }
+    if (L > 1) {
+        CopySegments seg;
+        const int nseg = std::min(L - 1, 24);
+        for (int l = 0; l < nseg; ++l) {
+            seg.dst[l] = W(g->readout_b) + (size_t)l * RO; seg.src[l] = g->readout_b + (size_t)(L - 1) * RO; seg.n[l] = (unsigned)RO;
+        }
+        LAUNCH(copy_segments_kernel, dim3(1, nseg), dim3(128), seg);
+        for (int l = nseg; l < L - 1; ++l)  // (more than 25 layers: the rest one by one)
+            ARREAU_CHECK_HIP(hipMemcpyAsync(W(g->readout_b) + (size_t)l * RO, g->readout_b + (size_t)(L - 1) * RO, RO * sizeof(float),
+                                            hipMemcpyDeviceToDevice, s));
     }
     // d(fiber kernel) of every layer = sum over nodes of x1 (x) dx2 / 16: one batched pair of launches (both operands were kept
     // per layer), then its two uses

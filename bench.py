@@ -776,11 +776,7 @@ def run_rank_c5(args, rank, local_rank, world):
             "last_loss": float(loss),
             "ranks": ranks_info,
             "forward_backward_ms": fb_ms,
-            "roofline": {"kernel": "training step, forward + backward (sgemm_kernel + elementwise kernels of train_net.hip)",
-                         "bound": "mfma", "achieved": flops / (fb_ms * 1e-3) / 1e12, "peak": MFMA_F32_PEAK_TFLOPS,
-                         "unit": "TFLOP/s", "frac": flops / (fb_ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TFLOPS, "traffic": None,
-                         "peak_note": "dense fp32-MFMA peak; the training kernels are one exact-fp32 MFMA GEMM per Linear "
-                                      "(v_mfma_f32_32x32x2_f32) + element-wise kernels, every intermediate in HBM"},
+            "roofline": training_roofline(flops, fb_ms),
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline_training(model, batches[0], args.cpu_steps)
@@ -788,6 +784,26 @@ def run_rank_c5(args, rank, local_rank, world):
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def training_roofline(flops, fb_ms):
+    """The training step's matrix work against the roof of the arithmetic it runs in.  ARREAU_TRAIN_GEMM (train_net.hip) selects it:
+    default `split` = forward products as fp16x3 (3 fp16 MFMA products per fp32 product: 2500 / 3 TFLOP/s), products with a gradient
+    operand as bf16x6 (2500 / 6); one third of the algorithmic FLOPs are forward, two thirds backward, so the step's roof is the
+    harmonic mix 1 / (1/3 / 833 + 2/3 / 417) = 500 TFLOP/s.  `exact`: every product on v_mfma_f32_32x32x2_f32 (157.3)."""
+    mode = os.environ.get("ARREAU_TRAIN_GEMM", "split")
+    if mode == "exact":
+        peak, note = MFMA_F32_PEAK_TFLOPS, "exact fp32 MFMA products (ARREAU_TRAIN_GEMM=exact): dense fp32-input MFMA peak"
+    elif mode == "fp16":
+        peak, note = F16X3_EQUIV_PEAK_TFLOPS, "every product as fp16x3 (ARREAU_TRAIN_GEMM=fp16): 2500 / 3"
+    else:
+        peak = 1.0 / ((1.0 / 3.0) / F16X3_EQUIV_PEAK_TFLOPS + (2.0 / 3.0) / BF16X6_EQUIV_PEAK_TFLOPS)
+        note = ("split-precision products on the 16-bit matrix pipe (sgemm_split_kernel): forward fp16x3 (2500 / 3 TFLOP/s of fp32-equivalent "
+                "work), gradient products bf16x6 (2500 / 6); harmonic mix over 1/3 forward + 2/3 backward FLOPs")
+    ach = flops / (fb_ms * 1e-3) / 1e12
+    return {"kernel": "training step, forward + backward (sgemm_split_kernel products + element-wise / gather kernels of train_net.hip)",
+            "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": None, "peak_note": note,
+            "frac_of_fp32_mfma_peak": ach / MFMA_F32_PEAK_TFLOPS, "gemm_mode": mode}
 
 
 def cpu_baseline_training(model, batch, steps):

@@ -108,6 +108,55 @@ def test_gradient_all_reduce_averages_one_flat_bucket():
         assert torch.equal(g1, torch.arange(5.0) * 0.5)            # (1 * arange + 0) / 2
 
 
+class _ToyModule(torch.nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.a = torch.nn.Parameter(torch.zeros(4, 3))
+        self.b = torch.nn.Parameter(torch.zeros(5))
+
+    def notify_parameters_changed(self):
+        self.notified = True
+
+
+def _flat_worker(rank, world, port, outfile):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from arreau_amd.train import optimizer_step
+    m = _ToyModule()
+    opt = torch.optim.SGD(m.parameters(), lr=1.0)
+    flat = torch.zeros(20)  # what HipEngine.train_backward leaves: every gradient a view of one buffer (16-byte aligned segments)
+    m.a.grad = flat[0:12].view(4, 3)
+    m.b.grad = flat[12:17]
+    m.a.grad.fill_(float(rank + 1))
+    m.b.grad.copy_(torch.arange(5.0) * (rank + 1))
+    m._grad_flat = flat
+    norm = optimizer_step(m, opt, world, clip=0.5)
+    assert m.notified and m._grad_flat is None
+    if rank == 0:
+        torch.save([m.a.detach().clone(), m.b.detach().clone(), norm], outfile)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_optimizer_step_reduces_and_clips_the_flat_gradient_buffer():
+    """The training step's gradients are views of ONE buffer (PONITA_DIFFUSION.training_step sets `_grad_flat`): optimizer_step
+    averages that buffer over the ranks with one collective, takes its 2-norm and clips it (torch.nn.utils.clip_grad_norm_'s
+    arithmetic), then steps.  world_size 2 over gloo."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    with tempfile.TemporaryDirectory() as d:
+        out = os.path.join(d, "p.pt")
+        mp.spawn(_flat_worker, args=(2, port, out), nprocs=2, join=True)
+        a, b, norm = torch.load(out)
+        ga, gb = torch.full((4, 3), 1.5), torch.arange(5.0) * 1.5   # mean over the two ranks
+        total = torch.sqrt((ga ** 2).sum() + (gb ** 2).sum())
+        coef = min(1.0, 0.5 / (float(total) + 1e-6))
+        assert abs(float(norm) - float(total)) < 1e-5
+        assert torch.allclose(a, -coef * ga, atol=1e-6) and torch.allclose(b, -coef * gb, atol=1e-6)   # SGD, lr = 1
+
+
 def _metric_worker(rank, world, port, outfile):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
