@@ -32,6 +32,10 @@ PY
 fi
 [ $part = benches ] && exit 0
 tools/prof_bench.sh ${tag}_c2 --no-fp32-variant || exit 1
+tools/gpu_prof_c5.sh ${tag}_c5 > gpurun_out/${tag}_c5_prof_tail.txt 2>&1 || { tail -n 20 gpurun_out/${tag}_c5_prof_tail.txt; exit 1; }
+tail -n 12 gpurun_out/${tag}_c5_prof_tail.txt
+tools/gpu_c5_trace.sh ${tag}_c5 > gpurun_out/${tag}_c5_trace_tail.txt 2>&1 || { tail -n 20 gpurun_out/${tag}_c5_trace_tail.txt; exit 1; }
+head -n 1 gpurun_out/${tag}_c5_step.txt gpurun_out/${tag}_c5_step_full.txt
 for c in c2 c4; do
   tools/hbm_traffic.sh $c > gpurun_out/${tag}_hbm_$c.txt 2>&1 || { tail -n 20 gpurun_out/${tag}_hbm_$c.txt; exit 1; }
   cat gpurun_out/${tag}_hbm_$c.txt
