@@ -21,6 +21,7 @@ EXPORTS = [
     "arreau_model_status", "arreau_model_set_variant", "arreau_ponita_forward",
     "arreau_diffusion_noise", "arreau_diffusion_losses", "arreau_sample_loop", "arreau_philox_fill",
     "arreau_train_forward", "arreau_train_backward", "arreau_train_conv_stats", "arreau_model_update_train_weights",
+    "arreau_debug_sgemm",
     "arreau_model_set_batch_layout", "arreau_debug_set_pollution", "arreau_debug_leftover_fraction",
 ]
 
@@ -103,6 +104,8 @@ def lib():
     L.arreau_train_forward.argtypes = [c_void_p] * 7 + [c_int32, c_int32] + [c_void_p] * 4
     L.arreau_train_backward.argtypes = [c_void_p] * 4 + [POINTER(StateDict), c_void_p]
     L.arreau_train_conv_stats.argtypes = [c_void_p, c_void_p, c_void_p]
+    L.arreau_debug_sgemm.argtypes = [c_int32, c_int32, c_int32, c_int32, c_void_p, c_int64, c_int64, c_void_p, c_int64, c_int64, c_void_p, c_int32,
+                                     c_float, c_float, c_void_p]
     L.arreau_model_update_train_weights.argtypes = [c_void_p, POINTER(StateDict), c_void_p]
     L.arreau_model_set_batch_layout.argtypes = [c_void_p, c_void_p, c_int32, c_int32]
     L.arreau_debug_set_pollution.argtypes = [ctypes.c_uint32]

@@ -1360,3 +1360,21 @@ extern "C" int arreau_model_update_train_weights(arreau_model* m, const arreau_s
     LAUNCH(copy_segments_kernel, dim3(64, nseg), dim3(256), seg);
     return ARREAU_OK;
 }
+
+extern "C" int arreau_debug_sgemm(int32_t mode, int32_t M, int32_t N, int32_t K, const float* d_A, int64_t as0, int64_t as1, const float* d_B,
+                                  int64_t bs0, int64_t bs1, float* d_C, int32_t ldc, float alpha, float beta, void* stream) {
+    ARREAU_REQUIRE(d_A && d_B && d_C, "arreau_debug_sgemm: null pointer");
+    ARREAU_REQUIRE(M >= 0 && N >= 0 && K >= 1 && ldc >= N && mode >= 0 && mode <= 2, "arreau_debug_sgemm: bad size or mode");
+    ARREAU_REQUIRE((as0 == 1 || as1 == 1) && (bs0 == 1 || bs1 == 1), "arreau_debug_sgemm: one stride of each operand must be 1");
+    hipStream_t s = (hipStream_t)stream;
+    float* partial = nullptr;
+    ARREAU_CHECK_HIP(hipMalloc((void**)&partial, ARREAU_SGEMM_PARTIAL_FLOATS * sizeof(float)));
+    int rc = arreau_sgemm(s, partial, M, N, K, d_A, (long)as0, (long)as1, d_B, (long)bs0, (long)bs1, d_C, ldc, alpha, beta, 1, 0, 0, 0, mode);
+    const hipError_t e = hipStreamSynchronize(s);
+    (void)hipFree(partial);
+    if (rc == ARREAU_OK && e != hipSuccess) {
+        arreau_set_error(std::string("arreau_debug_sgemm: ") + hipGetErrorString(e));
+        rc = ARREAU_EHIP;
+    }
+    return rc;
+}

@@ -342,6 +342,15 @@ int arreau_model_update_train_weights(arreau_model* model, const arreau_state_di
  * d_stats[L][3] = unbiased std of x (layer input), x_1 (after the spatial conv), x_2 (after the spherical conv). */
 int arreau_train_conv_stats(arreau_model* model, float* d_stats, void* stream);
 
+/* The dense product every Linear of the training step runs through (no counterpart in the reference: torch.nn.functional.linear and
+ * autograd's matmuls, ponita.py:65-66, conv.py:110-116, convnext.py:24-30), exposed so that the parity tests can call it directly:
+ *   C[m][n] = alpha * sum_k A(m, k) B(k, n) + beta * C[m][n],   A(m, k) = d_A[m * as0 + k * as1],  B(k, n) = d_B[k * bs0 + n * bs1]
+ * (strides in elements; one of each operand's strides must be 1).  `mode`: 0 = exact fp32 products (v_mfma_f32_32x32x2_f32),
+ * 1 = fp16x3, 2 = bf16x6 (three / six 16-bit MFMA products per fp32 product; shapes the split kernel does not take run exact).
+ * Device pointers; the split-K scratch is allocated and freed inside (a test hook, not a production entry point). */
+int arreau_debug_sgemm(int32_t mode, int32_t M, int32_t N, int32_t K, const float* d_A, int64_t as0, int64_t as1, const float* d_B,
+                       int64_t bs0, int64_t bs1, float* d_C, int32_t ldc, float alpha, float beta, void* stream);
+
 /* Timing hook used by bench.py: records hipEvents around the dominant kernel of
  * arreau_predict_scores (the edge kernel) on the stream it is launched on.
  * enable=1 starts collecting; arreau_edge_kernel_time_ms returns the mean over the launches
