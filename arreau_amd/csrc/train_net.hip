@@ -426,7 +426,10 @@ __global__ void conv_backward_kern_kernel(const float* __restrict__ x, const flo
 // (sender side: one thread owns one element of dx -- a segmented sum in a fixed order, no atomics)
 __global__ void conv_backward_dx_kernel(const float* __restrict__ kern, int ldk, const float* __restrict__ dx1,
                                         const int32_t* __restrict__ rev_start, const int32_t* __restrict__ rev_cnt,
-                                        const int32_t* __restrict__ rev_idx, int N, int k, int C, float* __restrict__ dx) {
+                                        const int32_t* __restrict__ rev_idx, int N, int k, int C, const float* dx_in,
+                                        const float* __restrict__ add2, float* dx) {
+    // dx = dx_in + (sender-side sum) + add2: dx_in / dx may be the same array (element-wise); add2 = the read-out's contribution to the
+    // NEXT layer down (null at layer 0): d x_l is complete when this launch ends
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (long)N * 16 * C) return;
     const int c = (int)(i % C);
@@ -438,7 +441,9 @@ __global__ void conv_backward_dx_kernel(const float* __restrict__ kern, int ldk,
         const int e = rev_idx[st + q], n = e / k;
         acc += kern[((size_t)e * 16 + o) * ldk + c] * dx1[((size_t)n * 16 + o) * C + c];
     }
-    dx[i] += acc;
+    float v = dx_in[i] + acc;
+    if (add2) v += add2[i];
+    dx[i] = v;
 }
 // x2[n,p,c] = sum_o x1[n,o,c] fk[o,p,c] / 16 + bias[c]   (conv.py:113-127)
 // float4 forms of the five kernels around the spatial / spherical convolution (C and the kernel pitch multiples of four; the
@@ -480,7 +485,8 @@ __global__ void conv_backward_kern_kernel4(const f32x4* __restrict__ x, const f3
 }
 __global__ void conv_backward_dx_kernel4(const f32x4* __restrict__ kern, int ldk4, const f32x4* __restrict__ dx1,
                                          const int32_t* __restrict__ rev_start, const int32_t* __restrict__ rev_cnt,
-                                         const int32_t* __restrict__ rev_idx, int N, int k, int C4, f32x4* __restrict__ dx) {
+                                         const int32_t* __restrict__ rev_idx, int N, int k, int C4, const f32x4* dx_in,
+                                         const f32x4* __restrict__ add2, f32x4* dx) {
     const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= (long)N * 16 * C4) return;
     const int c = (int)(i % C4);
@@ -495,9 +501,14 @@ __global__ void conv_backward_dx_kernel4(const f32x4* __restrict__ kern, int ldk
 #pragma unroll
         for (int r = 0; r < 4; ++r) acc[r] += kv[r] * dv[r];
     }
-    f32x4 d = dx[i];
+    f32x4 d = dx_in[i];
 #pragma unroll
     for (int r = 0; r < 4; ++r) d[r] += acc[r];
+    if (add2) {
+        const f32x4 a2 = add2[i];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) d[r] += a2[r];
+    }
     dx[i] = d;
 }
 __global__ void mix_forward_kernel4(const f32x4* __restrict__ x1, const f32x4* __restrict__ fk, const f32x4* __restrict__ bias,
@@ -763,24 +774,29 @@ __global__ void unfold_poly_grad_kernel(const float* __restrict__ dw1f, int C, f
 }
 // the forward direction: fold basis_fn.1.weight [C][258] onto the 83 monomials (columns of one monomial summed in
 // column order), padding columns zero -- the device twin of fold_poly_weight in model.hip
-// one block per channel: the row of 258 polynomial weights and the column -> monomial map sit in LDS (round 4: a thread per
-// output element read its row uncoalesced, 34 us of the optimizer tail); columns are added in ascending order as before
-__global__ void fold_poly_weight_kernel(const float* __restrict__ w1, int C, float* __restrict__ w1f) {
-    __shared__ int mono_of[ARREAU_POLY_COLS];
-    __shared__ float row[ARREAU_POLY_COLS];
-    const int c = blockIdx.x;
-    for (int col = threadIdx.x; col < ARREAU_POLY_COLS; col += blockDim.x) {
-        mono_of[col] = mono_of_poly_column(col);
-        row[col] = w1[c * ARREAU_POLY_COLS + col];
+// The columns of every monomial, ascending, -1 terminated (at most 3! = 6 permutations): built once per training context.
+__global__ void mono_columns_kernel(int32_t* __restrict__ tab /*[ARREAU_MONO_PAD][8]*/) {
+    const int mi = blockIdx.x * blockDim.x + threadIdx.x;
+    if (mi >= ARREAU_MONO_PAD) return;
+    int n = 0;
+    if (mi < ARREAU_NUM_MONO)
+        for (int col = 0; col < ARREAU_POLY_COLS; ++col)
+            if (mono_of_poly_column(col) == mi && n < 8) tab[mi * 8 + n++] = col;
+    for (; n < 8; ++n) tab[mi * 8 + n] = -1;
+}
+// a thread per (channel, monomial): its columns from the table, added in ascending order as before (round 4: scanning all 258 columns
+// per output element was 28-34 us of the optimizer tail)
+__global__ void fold_poly_weight_kernel(const float* __restrict__ w1, int C, const int32_t* __restrict__ tab, float* __restrict__ w1f) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= C * ARREAU_MONO_PAD) return;
+    const int c = i / ARREAU_MONO_PAD, mi = i % ARREAU_MONO_PAD;
+    float acc = 0.f;
+    for (int q = 0; q < 8; ++q) {
+        const int col = tab[mi * 8 + q];
+        if (col < 0) break;
+        acc += w1[c * ARREAU_POLY_COLS + col];
     }
-    __syncthreads();
-    for (int mi = threadIdx.x; mi < ARREAU_MONO_PAD; mi += blockDim.x) {
-        float acc = 0.f;
-        if (mi < ARREAU_NUM_MONO)
-            for (int col = 0; col < ARREAU_POLY_COLS; ++col)
-                if (mono_of[col] == mi) acc += row[col];
-        w1f[c * ARREAU_MONO_PAD + mi] = acc;
-    }
+    w1f[i] = acc;
 }
 // Weight refresh after an optimizer step: up to 24 device-to-device copies as ONE launch (they were 19 hipMemcpyAsync = 19
 // blit-kernel launches, 85 us of the step's 330 us optimizer tail; blockIdx.y = segment).
@@ -818,12 +834,12 @@ struct arreau_train_ctx {
     // plain row-major weights (in the model blob): [C][96], [D][C], [L][C][D], [L][H][C], [L][C][H], [L][S+4][C]
     const float *w1f, *w2, *wk, *lin1, *lin2, *ro_w;
     // forward state
-    int32_t *batch, *deg, *src, *cell, *rev_start, *rev_cnt, *rev_idx;
+    int32_t *batch, *deg, *src, *cell, *rev_start, *rev_cnt, *rev_idx, *mono_cols;
     float *lattice, *cart, *cvec, *dir, *dist;
     float *mono, *window, *h1pre, *h1, *h2pre, *kb, *fpoly, *fh1pre, *fh1, *fh2pre, *fkb, *F;
     float *x, *x1, *xhat, *rstd, *xn, *hpre, *h, *out, *fk, *rbar, *gs, *kern;
     // backward temporaries
-    float *dx, *dtmp, *dh, *drbar, *dx1, *dkern, *dkb, *dh1, *dfk, *dfkb, *dfh1, *dw1f, *partial, *scratch_cols, *colpart;
+    float *dx, *dxro, *dtmp, *dh, *drbar, *dx1, *dkern, *dkb, *dh1, *dfk, *dfkb, *dfh1, *dw1f, *partial, *scratch_cols, *colpart;
     float *dxn_all, *dx2_all;  // [L][M][C]: d(LayerNorm output) and d(spherical conv output), for the batched bias / norm gradients
     float *xn_all, *dout_all, *dfk_all;  // [L][...]: LayerNorm outputs (forward), d(out) and d(fiber kernel) (backward), for the batched weight gradients
     int32_t* colcount;  // colsum_kernel's arrival counters (one per 64-column group; zero between launches)
@@ -852,6 +868,7 @@ size_t layout(arreau_train_ctx& t, const arreau_model* m, int N, int B, float* b
     t.w1f = m->t_w1f; t.w2 = m->t_w2; t.wk = m->t_wk; t.lin1 = m->t_lin1; t.lin2 = m->t_lin2; t.ro_w = m->t_ro_w;
     t.batch = c.take<int32_t>(N); t.deg = c.take<int32_t>(N); t.src = c.take<int32_t>(N * k); t.cell = c.take<int32_t>(N * k);
     t.rev_start = c.take<int32_t>(N); t.rev_cnt = c.take<int32_t>(N); t.rev_idx = c.take<int32_t>(N * k);
+    t.mono_cols = c.take<int32_t>(ARREAU_MONO_PAD * 8);
     t.lattice = c.take<float>(B * 9); t.cart = c.take<float>(N * 3); t.cvec = c.take<float>(B * C);
     t.dir = c.take<float>(N * k * 3); t.dist = c.take<float>(N * k);
     t.mono = c.take<float>(R * ARREAU_MONO_PAD); t.window = c.take<float>(R);
@@ -862,7 +879,7 @@ size_t layout(arreau_train_ctx& t, const arreau_model* m, int N, int B, float* b
     t.rstd = c.take<float>(L * M); t.xn = c.take<float>(M * C); t.hpre = c.take<float>(L * M * H); t.h = c.take<float>(L * M * H);
     t.out = c.take<float>(L * M * C); t.fk = c.take<float>(L * 256 * C); t.rbar = c.take<float>(M * RO); t.gs = c.take<float>(N * 3);
     t.kern = c.take<float>(R * L * C);   // all layers' spatial kernels, [R][L*C] (one GEMM: the basis is layer-independent)
-    t.dx = c.take<float>(M * C); t.dtmp = c.take<float>(M * C); t.dh = c.take<float>(L * M * H); t.drbar = c.take<float>(M * RO);
+    t.dx = c.take<float>(M * C); t.dxro = c.take<float>(L * M * C); t.dtmp = c.take<float>(M * C); t.dh = c.take<float>(L * M * H); t.drbar = c.take<float>(M * RO);
     t.xn_all = c.take<float>(L * M * C); t.dout_all = c.take<float>(L * M * C); t.dfk_all = c.take<float>(L * 256 * C);
     t.dxn_all = c.take<float>(L * M * C); t.dx2_all = c.take<float>(L * M * C);  // kept per layer for the batched weight gradients
     t.dx1 = c.take<float>(M * C); t.dkern = c.take<float>(R * L * C); t.dkb = c.take<float>(R * D); t.dh1 = c.take<float>(R * C);
@@ -1048,6 +1065,8 @@ static int ensure_ctx(arreau_model* m, int N, int B, hipStream_t s) {
     m->train = t;
     ARREAU_CHECK_HIP(hipMemsetAsync(t->scratch_cols, 0, 1024 * sizeof(float), s));
     ARREAU_CHECK_HIP(hipMemsetAsync(t->colcount, 0, COLCOUNT_INTS * sizeof(int32_t), s));
+    hipLaunchKernelGGL(mono_columns_kernel, dim3(1), dim3(128), 0, s, t->mono_cols);
+    ARREAU_CHECK_HIP(hipGetLastError());
     return ARREAU_OK;
 }
 
@@ -1168,7 +1187,11 @@ extern "C" int arreau_train_backward(arreau_model* m, const float* d_g_eps, cons
     const long R = (long)N * k * 16, M = (long)N * 16;
     auto W = [](const float* p) { return const_cast<float*>(p); };  // the gradient struct reuses the const state_dict type
     LAUNCH(train_outputs_backward_kernel, dim3((unsigned)M), dim3(128), d_g_eps, d_g_logits, d_g_len0, t.batch, m->ori, S, N, t.drbar);
-    ARREAU_CHECK_HIP(hipMemsetAsync(t.dx, 0, (size_t)M * C * sizeof(float), s));
+    // The read-outs' contributions to d x_{l+1} = d(rbar) . W_ro,l / L depend on nothing inside the layer loop: ONE batched product for all
+    // layers up front (they were L launches of the element-wise-fetch kernel -- 94 read-out columns are no multiple of four -- 13.6 us
+    // each inside the chain); layer L - 1 starts from its slice, the others are added by the launch that completes d x_{l+1}.
+    TRY(arreau_sgemm(s, t.partial, (int)M, C, RO, t.drbar, RO, 1, t.ro_w, C, 1, t.dxro, C, 1.0f / (float)L, 0.f, L, 0, (long)RO * C, (long)M * C,
+                     t.bwd_mode));
     ARREAU_CHECK_HIP(hipMemsetAsync(t.dfkb, 0, (size_t)256 * D * sizeof(float), s));
     const float invL = 1.0f / (float)L;
     for (int l = L - 1; l >= 0; --l) {
@@ -1183,16 +1206,17 @@ extern "C" int arreau_train_backward(arreau_model* m, const float* d_g_eps, cons
         // read-out (ponita.py:105,108); its weight gradient: one batched product over the layers, below the loop
         // (every layer's read-out sees the same d(rbar): the bias gradients are equal -- copied to the other layers in one launch below)
         if (l == L - 1) TRY(colsum(s, t, t.drbar, nullptr, M, RO, invL, W(g->readout_b) + (size_t)l * RO));
-        TRY(linear_dx(s, t, M, C, RO, t.drbar, t.ro_w + (size_t)l * RO * C, t.dx, invL, 1.0f));   // dx = d x_{l+1}
+        const float* dxl = l == L - 1 ? t.dxro + (size_t)l * M * C : t.dx;   // d x_{l+1}
+        const float* dx_add = l > 0 ? t.dxro + (size_t)(l - 1) * M * C : nullptr;
         // ConvNext tail: x_{l+1} = out * ls + x_l
         // d(layer_scale) = sum_rows dx * out and d(linear_2.bias) = sum_rows dout = ls * sum_rows dx, in one pass over dx
         if (m->cfg.has_layer_scale)
-            TRY(colsum(s, t, t.dx, out, M, C, 1.0f, W(g->layer_scale) + (size_t)l * C, 0, W(g->linear2_b) + (size_t)l * C, m->ls + (size_t)l * C));
+            TRY(colsum(s, t, dxl, out, M, C, 1.0f, W(g->layer_scale) + (size_t)l * C, 0, W(g->linear2_b) + (size_t)l * C, m->ls + (size_t)l * C));
         // (the weight gradients of linear_2, linear_1, the read-out and the fiber kernel are products nothing below waits for:
         // their operands are kept per layer and each kind runs as ONE batched product after the loop)
         float* dout = t.dout_all + (size_t)l * M * C;
         float* dh = t.dh + (size_t)l * M * H;
-        LAUNCH(scale_cols_kernel, dim3(blocks(M * C)), dim3(256), t.dx, m->ls + (size_t)l * C, M, C, dout);   // dout
+        LAUNCH(scale_cols_kernel, dim3(blocks(M * C)), dim3(256), dxl, m->ls + (size_t)l * C, M, C, dout);   // dout
         if (!m->cfg.has_layer_scale) TRY(colsum(s, t, dout, nullptr, M, C, 1.0f, W(g->linear2_b) + (size_t)l * C));
         TRY(linear_dx_gelu_backward(s, t, M, H, C, dout, t.lin2 + (size_t)l * C * H, hpre, (const float*)nullptr, dh));   // dhpre
         float* dxn = t.dxn_all + (size_t)l * M * C;
@@ -1206,12 +1230,12 @@ extern "C" int arreau_train_backward(arreau_model* m, const float* d_g_eps, cons
             LAUNCH(conv_backward_kern_kernel4, dim3(blocks(R * C / 4)), dim3(256), V4(xl), V4(t.dx1), t.deg, t.src, N, k, C / 4, L * C / 4,
                    V4W(t.dkern + (size_t)l * C));
             LAUNCH(conv_backward_dx_kernel4, dim3(blocks(M * C / 4)), dim3(256), V4(t.kern + (size_t)l * C), L * C / 4, V4(t.dx1), t.rev_start,
-                   t.rev_cnt, t.rev_idx, N, k, C / 4, V4W(t.dx));
+                   t.rev_cnt, t.rev_idx, N, k, C / 4, V4(dxl), dx_add ? V4(dx_add) : (const f32x4*)nullptr, V4W(t.dx));
         } else {
             LAUNCH(mix_backward_x_kernel, dim3(blocks(M * C)), dim3(256), dx2, fk, N, C, t.dx1);
             LAUNCH(conv_backward_kern_kernel, dim3(blocks(R * C)), dim3(256), xl, t.dx1, t.deg, t.src, N, k, C, L * C, t.dkern + (size_t)l * C);
             LAUNCH(conv_backward_dx_kernel, dim3(blocks(M * C)), dim3(256), t.kern + (size_t)l * C, L * C, t.dx1, t.rev_start, t.rev_cnt,
-                   t.rev_idx, N, k, C, t.dx);
+                   t.rev_idx, N, k, C, dxl, dx_add, t.dx);
         }
     }
     if (L > 1) {
@@ -1336,7 +1360,8 @@ extern "C" int arreau_model_update_train_weights(arreau_model* m, const arreau_s
         ++nseg;
     };
     m->packed_stale = 1;
-    LAUNCH(fold_poly_weight_kernel, dim3((unsigned)C), dim3(128), d->basis_w1, (int)C, W(m->t_w1f));
+    if (!m->train) TRY(ensure_ctx(m, 1, 1, s));  // (the monomial column table lives in the training context)
+    LAUNCH(fold_poly_weight_kernel, dim3(blocks((long)C * ARREAU_MONO_PAD)), dim3(256), d->basis_w1, (int)C, m->train->mono_cols, W(m->t_w1f));
     LAUNCH(transpose_kernel, dim3(blocks((long)C * (S + 78))), dim3(256), d->x_embedder_w, (int)C, (int)(S + 78), W(m->embT));
     cp(m->b1, d->basis_b1, C);
     cp(m->t_w2, d->basis_w2, D * C);
