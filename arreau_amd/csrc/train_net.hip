@@ -99,7 +99,9 @@ __global__ __launch_bounds__(256) void colsum4_partial_kernel(const f32x4* __res
                                                               int cols4, long rows_per_chunk,
                                                               f32x4* __restrict__ part,   // [batch][chunks][cols4]
                                                               f32x4* __restrict__ part2,  // plain sums of a (or null)
-                                                              long a_bs4, long b_bs4)     // blockIdx.y = matrix of the batch (strides in float4)
+                                                              long a_bs4, long b_bs4,     // blockIdx.y = matrix of the batch (strides in float4)
+                                                              f32x4* __restrict__ scaled_out = nullptr,      // also a * colscale (or null):
+                                                              const f32x4* __restrict__ colscale = nullptr)  // d(out) = d(x) * layer_scale in the same pass
 {
     __shared__ f32x4 sh[256];
     a += (long)blockIdx.y * a_bs4;
@@ -114,6 +116,7 @@ __global__ __launch_bounds__(256) void colsum4_partial_kernel(const f32x4* __res
     f32x4 acc[4] = {zero, zero, zero, zero};  // four 16-byte loads (per operand) in flight; combined in a fixed order
     f32x4 plain[4] = {zero, zero, zero, zero};
     const bool dual = part2 != nullptr;
+    const f32x4 cs = scaled_out && act ? colscale[c4] : zero;
     if (act) {
         long r = r0 + ph;
         for (; r + 3 * P < r1; r += 4 * P) {
@@ -123,6 +126,7 @@ __global__ __launch_bounds__(256) void colsum4_partial_kernel(const f32x4* __res
                 const f32x4 av = a[i];
                 acc[u] += b ? av * b[i] : av;
                 if (dual) plain[u] += av;
+                if (scaled_out) scaled_out[i] = av * cs;
             }
         }
         for (; r < r1; r += P) {
@@ -130,6 +134,7 @@ __global__ __launch_bounds__(256) void colsum4_partial_kernel(const f32x4* __res
             const f32x4 av = a[i];
             acc[0] += b ? av * b[i] : av;
             if (dual) plain[0] += av;
+            if (scaled_out) scaled_out[i] = av * cs;
         }
     }
     auto block_sum = [&](f32x4 v, f32x4* dst) {  // phases added in order by the phase-0 thread of each column
@@ -919,7 +924,9 @@ int linear_dw(hipStream_t s, arreau_train_ctx& t, long rows, int in, int out, co
 // launches of one -- the bias gradients of the L layers (16-byte columns only).
 int colsum(hipStream_t s, arreau_train_ctx& t, const float* a, const float* b, long rows, int cols, float scale, float* out,
            int accumulate = 0, float* out2 = nullptr, const float* colscale2 = nullptr, int batch = 1, long a_bs = 0, long b_bs = 0,
-           long out_bs = 0, long out2_bs = 0) {
+           long out_bs = 0, long out2_bs = 0, float* scaled_out = nullptr /* also a * colscale_out (16-byte path, one matrix) */,
+           const float* colscale_out = nullptr, bool* wrote_scaled = nullptr) {
+    if (wrote_scaled) *wrote_scaled = false;
     if (cols > 1024) {
         arreau_set_error("colsum: more than 1024 columns");
         return ARREAU_EINVAL;
@@ -934,7 +941,9 @@ int colsum(hipStream_t s, arreau_train_ctx& t, const float* a, const float* b, l
         f32x4* part = reinterpret_cast<f32x4*>(t.colpart);
         f32x4* part2 = b && out2 ? part + (size_t)COLSUM4_MAX_BATCH * COLSUM4_MAX_CHUNKS * 256 : nullptr;
         hipLaunchKernelGGL(colsum4_partial_kernel, dim3(chunks, batch), dim3(256), 0, s, reinterpret_cast<const f32x4*>(a),
-                           reinterpret_cast<const f32x4*>(b), rows, cols / 4, rpc, part, part2, a_bs / 4, b_bs / 4);
+                           reinterpret_cast<const f32x4*>(b), rows, cols / 4, rpc, part, part2, a_bs / 4, b_bs / 4,
+                           batch == 1 ? reinterpret_cast<f32x4*>(scaled_out) : (f32x4*)nullptr, reinterpret_cast<const f32x4*>(colscale_out));
+        if (wrote_scaled) *wrote_scaled = batch == 1 && scaled_out != nullptr;
         ARREAU_CHECK_HIP(hipGetLastError());
         hipLaunchKernelGGL(colsum4_final_kernel, dim3((cols / 4 + 7) / 8, batch), dim3(256), 0, s, part, part2, chunks, cols / 4, scale,
                            accumulate, out, part2 ? out2 : nullptr, colscale2, out_bs, out2_bs);
@@ -1210,13 +1219,15 @@ extern "C" int arreau_train_backward(arreau_model* m, const float* d_g_eps, cons
         const float* dx_add = l > 0 ? t.dxro + (size_t)(l - 1) * M * C : nullptr;
         // ConvNext tail: x_{l+1} = out * ls + x_l
         // d(layer_scale) = sum_rows dx * out and d(linear_2.bias) = sum_rows dout = ls * sum_rows dx, in one pass over dx
+        float* dout = t.dout_all + (size_t)l * M * C;
+        bool have_dout = false;  // (d(out) = d(x) * layer_scale rides in the column-sum pass over d(x) where that pass takes 16-byte columns)
         if (m->cfg.has_layer_scale)
-            TRY(colsum(s, t, dxl, out, M, C, 1.0f, W(g->layer_scale) + (size_t)l * C, 0, W(g->linear2_b) + (size_t)l * C, m->ls + (size_t)l * C));
+            TRY(colsum(s, t, dxl, out, M, C, 1.0f, W(g->layer_scale) + (size_t)l * C, 0, W(g->linear2_b) + (size_t)l * C, m->ls + (size_t)l * C, 1, 0, 0,
+                       0, 0, dout, m->ls + (size_t)l * C, &have_dout));
         // (the weight gradients of linear_2, linear_1, the read-out and the fiber kernel are products nothing below waits for:
         // their operands are kept per layer and each kind runs as ONE batched product after the loop)
-        float* dout = t.dout_all + (size_t)l * M * C;
         float* dh = t.dh + (size_t)l * M * H;
-        LAUNCH(scale_cols_kernel, dim3(blocks(M * C)), dim3(256), dxl, m->ls + (size_t)l * C, M, C, dout);   // dout
+        if (!have_dout) LAUNCH(scale_cols_kernel, dim3(blocks(M * C)), dim3(256), dxl, m->ls + (size_t)l * C, M, C, dout);   // dout
         if (!m->cfg.has_layer_scale) TRY(colsum(s, t, dout, nullptr, M, C, 1.0f, W(g->linear2_b) + (size_t)l * C));
         TRY(linear_dx_gelu_backward(s, t, M, H, C, dout, t.lin2 + (size_t)l * C * H, hpre, (const float*)nullptr, dh));   // dhpre
         float* dxn = t.dxn_all + (size_t)l * M * C;
