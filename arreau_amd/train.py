@@ -46,7 +46,7 @@ def _trainable_parameters(model):
     return cache
 
 
-def optimizer_step(model, optimizer, world_size: int = 1, clip: Optional[float] = GRAD_CLIP):
+def optimizer_step(model, optimizer, world_size: int = 1, clip: Optional[float] = GRAD_CLIP, always_reduce: bool = False):
     """all-reduce -> clip -> Adam step -> invalidate the engine's packed weights.  Returns the gradient norm.
 
     When PONITA_DIFFUSION.training_step left every gradient as a view of the engine's flat buffer (`model._grad_flat`), the
@@ -56,7 +56,7 @@ def optimizer_step(model, optimizer, world_size: int = 1, clip: Optional[float] 
     flat = getattr(model, "_grad_flat", None)
     params = _trainable_parameters(model)
     if flat is not None and all(p.grad is None or p.grad.untyped_storage().data_ptr() == flat.untyped_storage().data_ptr() for p in params):
-        if world_size > 1:
+        if world_size > 1 or always_reduce:  # (always_reduce: a one-rank group still runs the collective -- bench.py's RCCL rehearsal)
             import torch.distributed as dist
             dist.all_reduce(flat, op=dist.ReduceOp.SUM)
             flat /= world_size

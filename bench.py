@@ -345,9 +345,17 @@ def run_rank(args, rank, local_rank, world):
     dev = torch.device("cuda", 0 if one_device else local_rank)
     torch.cuda.set_device(dev)
     dist = None
-    if world > 1:
+    # ARREAU_BENCH_FORCE_DIST=1: a ONE-rank run also creates the process group and goes through every collective of the N-rank path
+    # (barriers, the timing all-gather, the rank records; c5: the gradient all-reduce) -- the only way to execute the RCCL branch on
+    # a one-GPU box (two ranks cannot share a device under RCCL)
+    force_dist = world == 1 and os.environ.get("ARREAU_BENCH_FORCE_DIST", "0") == "1"
+    if world > 1 or force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if force_dist:
+            os.environ.setdefault("MASTER_PORT", "29533")
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
@@ -689,9 +697,17 @@ def run_rank_c5(args, rank, local_rank, world):
     dev = torch.device("cuda", 0 if one_device else local_rank)
     torch.cuda.set_device(dev)
     dist = None
-    if world > 1:
+    # ARREAU_BENCH_FORCE_DIST=1: a ONE-rank run also creates the process group and goes through every collective of the N-rank path
+    # (barriers, the timing all-gather, the rank records; c5: the gradient all-reduce) -- the only way to execute the RCCL branch on
+    # a one-GPU box (two ranks cannot share a device under RCCL)
+    force_dist = world == 1 and os.environ.get("ARREAU_BENCH_FORCE_DIST", "0") == "1"
+    if world > 1 or force_dist:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        if force_dist:
+            os.environ.setdefault("MASTER_PORT", "29533")
+            os.environ.setdefault("RANK", "0")
+            os.environ.setdefault("WORLD_SIZE", "1")
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
         else:
@@ -716,7 +732,7 @@ def run_rank_c5(args, rank, local_rank, world):
 
     def one_step(i):
         loss = model.training_step(batches[i % len(batches)])
-        optimizer_step(model, optimizer, world)
+        optimizer_step(model, optimizer, world, always_reduce=force_dist)
         return loss
 
     def sync():
@@ -755,7 +771,7 @@ def run_rank_c5(args, rank, local_rank, world):
     fb_ms = 1e3 * (time.perf_counter() - t1) / args.steps
     ranks_info = {"backend": (dist.get_backend() if dist is not None else None),
                   "world_size": (dist.get_world_size() if dist is not None else 1),
-                  "data_path_collectives": 1 if world > 1 else 0,
+                  "data_path_collectives": 1 if (world > 1 or force_dist) else 0,
                   "note": "one all-reduce of the flat fp32 gradient bucket per step (arreau_amd.train.optimizer_step); RCCL when the backend is nccl",
                   "per_rank": gather_json(dist, dev if backend == "nccl" else "cpu", world,
                                           dict(device_identity(torch, dev), rank=rank, local_rank=local_rank, pid=os.getpid(),
