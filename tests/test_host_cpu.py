@@ -160,3 +160,28 @@ def test_diffusion_loss_metric_sums_and_counts():
     m.update(torch.tensor([1.0, 2.0]), SimpleNamespace(batch=torch.tensor([0, 0, 1, 1, 1])))
     assert m.total_samples == 5 and abs(float(m.compute()) - 6.0 / 5.0) < 1e-7
     assert m.sync() is m and m.total_samples == 5  # no process group: nothing to reduce
+
+
+def test_host_inputs_are_packed_into_one_staging_buffer_on_the_calling_thread():
+    """diffusion_loss._pack: the training step's host tensors (mixed dtypes and shapes, non-contiguous views included) land in
+    16-byte aligned segments of ONE staging buffer, cast to its element type -- through numpy on the calling thread (torch's
+    copy_ goes parallel above 32,768 elements: under a container CPU quota that throttled the whole training loop)."""
+    import torch
+    from arreau_amd.diffusion.diffusion_loss import _pack
+    g = torch.Generator().manual_seed(0)
+    a = torch.rand((7, 3), generator=g, dtype=torch.float64)
+    b = torch.rand((500, 90), generator=g)                      # 45,000 elements: above torch's parallel-copy grain
+    c = torch.rand((4, 6), generator=g).t()                     # a non-contiguous view
+    host = [(0, a), (1, b), (2, c)]
+    offs, total = [], 0
+    for _, v in host:
+        offs.append(total)
+        total += -(-v.numel() // 4) * 4
+    assert all(o % 4 == 0 for o in offs)
+    stage = torch.full((total,), -1.0, dtype=torch.float32)
+    _pack(stage, host, offs)
+    for (_, v), o in zip(host, offs):
+        assert torch.equal(stage[o:o + v.numel()], v.reshape(-1).to(torch.float32))
+    ints = torch.full((12,), -1, dtype=torch.int32)
+    _pack(ints, [(0, torch.arange(5, dtype=torch.int64)), (1, torch.tensor([7, 8, 9], dtype=torch.int16))], [0, 8])
+    assert ints.tolist() == [0, 1, 2, 3, 4, -1, -1, -1, 7, 8, 9, -1]
