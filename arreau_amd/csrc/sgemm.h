@@ -2,6 +2,8 @@
 // 157 TFLOP/s peak) and -- round 4 -- split precision on the 16-bit matrix instructions (sgemm_split_kernel below: fp16x3
 // for products of O(1) operands, bf16x6 where an operand is a gradient of arbitrary magnitude).
 #pragma once
+#include <stdlib.h>
+
 #include <type_traits>
 
 #include "f16x3.h"
@@ -211,9 +213,26 @@ template <int MODE, int WM, int WN, bool AK, bool BKC, int PD, int BK>
 __global__ __launch_bounds__(256, 2) void sgemm_split_kernel(int M, int N, int K, const float* __restrict__ A, long as0, long as1,
                                                              const float* __restrict__ B, long bs0, long bs1, float* __restrict__ C,
                                                              int ldc, float alpha, float beta, int kchunk, float* __restrict__ partial,
-                                                             int splits, long a_bs, long b_bs, long c_bs, SgemmEpilogue epi) {
+                                                             int splits, long a_bs, long b_bs, long c_bs, SgemmEpilogue epi, int swz, int gm, int gn, int zb) {
     constexpr int TM = 64 * WM, TN = 64 * WN, P = MODE == 1 ? 2 : 3, LDK = BK + 8;  // (row pitch 80 / 144 bytes: conflict-free b128 reads)
-    const int bi = (int)blockIdx.z / splits, zi = (int)blockIdx.z - bi * splits;
+    // Tile of this workgroup.  swz != 0: a 1-D grid dealt so that the workgroups which read the same operand panel run on ONE XCD, one
+    // after the other (consecutive workgroups go to the 8 XCDs in turn, each with its own L2): swz = 1 -- all column tiles of a row
+    // tile (the panel of A: activations / gradients, 66-166 MB at 64 crystals, which five column tiles otherwise pull into five L2s);
+    // swz = 2 -- all tiles of a k-slice of a split-K product (both slice panels).  Round 4, PMC: the training step moved 6.3 GB per
+    // step through the L2s, 4 GB of it in these products -- [64768, 256] x [640, 256]^T 500 MB against 232 MB of operands + output.
+    int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+    if (swz != 0) {
+        const int xcd = (int)blockIdx.x & 7, sl = (int)blockIdx.x >> 3;
+        if (swz == 1) {
+            by = (sl / gn) * 8 + xcd; bx = sl % gn; bz = 0;
+            if (by >= gm) return;  // (workgroup-uniform, before any barrier)
+        } else {
+            const int per = gm * gn, tl = sl % per;
+            bz = (sl / per) * 8 + xcd; by = tl / gn; bx = tl % gn;
+            if (bz >= zb) return;
+        }
+    }
+    const int bi = bz / splits, zi = bz - bi * splits;
     A += (long)bi * a_bs;
     B += (long)bi * b_bs;
     C += (long)bi * c_bs;
@@ -223,7 +242,7 @@ __global__ __launch_bounds__(256, 2) void sgemm_split_kernel(int M, int N, int K
     __shared__ __attribute__((aligned(16))) unsigned short As[P][TM][LDK], Bs[P][TN][LDK];
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int h = lane >> 5, j = lane & 31, wm = (wave >> 1) * (32 * WM), wn = (wave & 1) * (32 * WN);
-    const int m0 = blockIdx.y * TM, n0 = blockIdx.x * TN;
+    const int m0 = by * TM, n0 = bx * TN;
     const int kbeg = zi * kchunk, kend = min(K, kbeg + kchunk);
     constexpr int NACC = MODE == 1 ? 2 : 1;  // fp16x3: main + cross
     f32x16 acc[NACC][WM][WN];
@@ -417,7 +436,7 @@ __global__ __launch_bounds__(256, 2) void sgemm_split_kernel(int M, int N, int K
         }
     }
     // epilogue: the split-K / beta == 0 forms never read C (a per-element `beta != 0 ? C : 0` made every store a branch + load block)
-    float* outp = splits > 1 ? partial + (size_t)blockIdx.z * M * N : C;
+    float* outp = splits > 1 ? partial + (size_t)bz * M * N : C;
     const int ldo = splits > 1 ? N : ldc;
     const float oa = splits > 1 ? 1.f : alpha;
     auto store_tiles = [&](auto read_c, auto fused) {
@@ -550,9 +569,14 @@ inline int arreau_sgemm(hipStream_t s, float* partial, int M, int N, int K, cons
     const bool fuse = epi && epi->kind != 0 && split && small && Z == 1 && beta == 0.f && batch == 1;
     if (fused) *fused = fuse;
     SgemmEpilogue ep = fuse ? *epi : SgemmEpilogue{};
+    // XCD-aware tile order (see the kernel): slices of a split-K product together; else, for one product, the column tiles of a row tile
+    static const bool swz_on = [] { const char* e = getenv("ARREAU_SGEMM_SWIZZLE"); return !e || atoi(e) != 0; }();
+    const int swz = !swz_on ? 0 : (Z > 1 ? 2 : (batch == 1 && gn > 1 ? 1 : 0));
+    const int zb = Z * batch;
+    const dim3 grid = swz == 1 ? dim3(8u * gn * ((gm + 7) / 8)) : swz == 2 ? dim3(8u * gm * gn * ((zb + 7) / 8)) : dim3(gn, gm, zb);
     auto launch_split = [&](auto kernel) {
-        hipLaunchKernelGGL(kernel, dim3(gn, gm, Z * batch), dim3(256), 0, s, M, N, K, A, as0, as1, B, bs0, bs1, C, ldc, alpha, beta, kchunk,
-                           partial, Z, a_bs, b_bs, c_bs, ep);
+        hipLaunchKernelGGL(kernel, grid, dim3(256), 0, s, M, N, K, A, as0, as1, B, bs0, bs1, C, ldc, alpha, beta, kchunk,
+                           partial, Z, a_bs, b_bs, c_bs, ep, swz, gm, gn, zb);
     };
     if (split) {
         auto pick = [&](auto mode_c, auto w_c) {
