@@ -792,7 +792,7 @@ def run_rank_c5(args, rank, local_rank, world):
             "last_loss": float(loss),
             "ranks": ranks_info,
             "forward_backward_ms": fb_ms,
-            "roofline": training_roofline(flops, fb_ms),
+            "roofline": training_roofline(flops, fb_ms, args.hidden_dim, B),
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline_training(model, batches[0], args.cpu_steps)
@@ -802,7 +802,7 @@ def run_rank_c5(args, rank, local_rank, world):
         dist.destroy_process_group()
 
 
-def training_roofline(flops, fb_ms):
+def training_roofline(flops, fb_ms, hidden_dim=128, crystals=64):
     """The training step's matrix work against the roof of the arithmetic it runs in.  ARREAU_TRAIN_GEMM (train_net.hip) selects it:
     default `split` = forward products as fp16x3 (3 fp16 MFMA products per fp32 product: 2500 / 3 TFLOP/s), products with a gradient
     operand as bf16x6 (2500 / 6); one third of the algorithmic FLOPs are forward, two thirds backward, so the step's roof is the
@@ -817,9 +817,16 @@ def training_roofline(flops, fb_ms):
         note = ("split-precision products on the 16-bit matrix pipe (sgemm_split_kernel): forward fp16x3 (2500 / 3 TFLOP/s of fp32-equivalent "
                 "work), gradient products bf16x6 (2500 / 6); harmonic mix over 1/3 forward + 2/3 backward FLOPs")
     ach = flops / (fb_ms * 1e-3) / 1e12
-    return {"kernel": "training step, forward + backward (sgemm_split_kernel products + element-wise / gather kernels of train_net.hip)",
-            "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": None, "peak_note": note,
-            "frac_of_fp32_mfma_peak": ach / MFMA_F32_PEAK_TFLOPS, "gemm_mode": mode}
+    # bytes through the L2s per forward + backward step from the committed PMC passes (tools/hbm_traffic_c5.sh): valid for the default
+    # workload only (64 crystals per GPU, hidden_dim 128, split-precision products)
+    traffic = measured_traffic(64, 0, "hbm_bytes_per_step_forward_backward") if (mode == "split" and hidden_dim == 128 and crystals == 64) else None
+    out = {"kernel": "training step, forward + backward (sgemm_split_kernel products + element-wise / gather kernels of train_net.hip)",
+           "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": traffic, "peak_note": note,
+           "frac_of_fp32_mfma_peak": ach / MFMA_F32_PEAK_TFLOPS, "gemm_mode": mode}
+    if traffic:
+        out["hbm"] = {"achieved": traffic / (fb_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": traffic / (fb_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                      "note": "PMC bytes per step (every intermediate of the step is materialised) over the forward + backward time"}
+    return out
 
 
 def cpu_baseline_training(model, batch, steps):

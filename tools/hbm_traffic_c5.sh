@@ -9,7 +9,7 @@ for c in FETCH_SIZE WRITE_SIZE; do
   timeout -k 10 400 rocprofv3 --kernel-trace --pmc $c --output-format csv -d gpurun_out/pmc_traffic_c5_$c -- python3 bench.py --config c5 --steps 4 --warmup 2 --no-cpu-baseline > gpurun_out/pmc_traffic_c5_$c.json 2> gpurun_out/pmc_traffic_c5_$c.err || { tail -n 5 gpurun_out/pmc_traffic_c5_$c.err; exit 1; }
 done
 python3 - <<'PY'
-import csv, glob, json, collections
+import csv, glob, json, collections, re
 tot = {}
 top = collections.defaultdict(lambda: [0.0, 0.0])
 for ci, c in enumerate(("FETCH_SIZE", "WRITE_SIZE")):
@@ -21,7 +21,7 @@ for ci, c in enumerate(("FETCH_SIZE", "WRITE_SIZE")):
         tot[(tag, c)] = sum(float(r["Counter_Value"]) for r in rows[a:b])
         tot[(tag, "launches")] = b - a
     for r in rows[marks[-3]:marks[-2]]:
-        top[r["Kernel_Name"].split("(")[0][:70]][ci] += float(r["Counter_Value"])
+        top[re.sub(r"\(anonymous namespace\)::|arreau_sgemm_detail::|void ", "", r["Kernel_Name"]).split("(")[0][:70]][ci] += float(r["Counter_Value"])
 out = {"note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, tools/hbm_traffic_c5.sh) over `python bench.py --config c5 --steps 4 "
                "--warmup 2 --no-cpu-baseline`; the dispatches of one step cut out by their prep_kernel launches; KB summed over the step; "
                "gfx950 correction (MI355X_MICROARCH.md, HBM): FETCH_SIZE counts wide coalesced reads at 1/2 -> doubled",
@@ -29,10 +29,10 @@ out = {"note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes, tools/
 for tag in ("forward_backward", "with_optimizer"):
     out["hbm_bytes_per_step_" + tag] = (2 * tot[(tag, "FETCH_SIZE")] + tot[(tag, "WRITE_SIZE")]) * 1024
     out["launches_" + tag] = tot[(tag, "launches")]
-out["largest_kernels_forward_backward_bytes"] = {k: (2 * v[0] + v[1]) * 1024 for k, v in sorted(top.items(), key=lambda kv: -(2 * kv[1][0] + kv[1][1]))[:12]}
+out["largest_kernels_forward_backward_bytes"] = {k: (2 * v[0] + v[1]) * 1024 for k, v in sorted(top.items(), key=lambda kv: -(2 * kv[1][0] + kv[1][1]))[:24]}
 json.dump(out, open("gpurun_out/hbm_traffic_pmc_c5.json", "w"), indent=1)
 print("training step: %.3f GB forward + backward (%d launches), %.3f GB with the optimizer part" % (
     out["hbm_bytes_per_step_forward_backward"] / 1e9, out["launches_forward_backward"], out["hbm_bytes_per_step_with_optimizer"] / 1e9))
-for k, v in list(out["largest_kernels_forward_backward_bytes"].items())[:8]:
+for k, v in list(out["largest_kernels_forward_backward_bytes"].items())[:24]:
     print("  %-70s %8.1f MB" % (k, v / 1e6))
 PY
