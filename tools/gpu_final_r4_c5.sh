@@ -23,3 +23,9 @@ head -n 1 gpurun_out/${tag}_c5_step.txt gpurun_out/${tag}_c5_step_full.txt
 grep "kernel time" gpurun_out/${tag}_c5_step.txt gpurun_out/${tag}_c5_step_full.txt
 timeout -k 10 300 tools/exp/_bin/sgemm_bench > gpurun_out/${tag}_sgemm_bench.txt 2>&1 || { tail -n 5 gpurun_out/${tag}_sgemm_bench.txt; exit 1; }
 cut -c1-37,62-260 gpurun_out/${tag}_sgemm_bench.txt | head -n 12
+tools/hbm_traffic_c5.sh > gpurun_out/${tag}_hbm_c5.txt 2>&1 || { tail -n 5 gpurun_out/${tag}_hbm_c5.txt; exit 1; }
+head -n 8 gpurun_out/${tag}_hbm_c5.txt
+cp gpurun_out/hbm_traffic_pmc_c5.json gpurun_out/${tag}_hbm_traffic_pmc_c5.json
+timeout -k 10 500 python3 bench.py > gpurun_out/${tag}_bench_c2.json 2> gpurun_out/${tag}_bench_c2.err || { tail -n 30 gpurun_out/${tag}_bench_c2.err; exit 1; }
+python3 -c "
+import json; d=json.load(open('gpurun_out/${tag}_bench_c2.json')); print('c2', round(d['value'],1), round(d['ms_per_step'],4), d['roofline'].get('avg_launch_ms'), (d.get('full_sampler_measured') or {}).get('crystals_per_min'))"
