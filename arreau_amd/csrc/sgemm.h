@@ -496,14 +496,31 @@ __global__ __launch_bounds__(256, 2) void sgemm_split_kernel(int M, int N, int K
     else if (splits == 1 && epi.kind != 0) store_tiles(std::false_type{}, std::true_type{});
     else store_tiles(std::false_type{}, std::false_type{});
 }
-__global__ void splitk_reduce_kernel(const float* __restrict__ partial, int Z, int M, int N, float* __restrict__ C, int ldc,
-                                     float alpha, float beta, long c_bs /* blockIdx.y = product of the batch */) {
-    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= (long)M * N) return;
-    partial += (size_t)blockIdx.y * Z * M * N;
+// Sum of the k-slices' partial tiles.  A block covers 256 / ZP output elements; ZP threads share an element, each adding every ZP-th
+// slice in ascending order, and the ZP sums are added in ascending order by the first of them: a fixed association, so the result is
+// reproducible bit for bit (the order differs from a single running sum; nothing depends on that).  With one thread per element a product
+// of 256 slices over 12 K outputs was 48 workgroups of 256 dependent loads each (66 us for 12 MB).
+template <int ZP>
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ partial, int Z, int M, int N, float* __restrict__ C, int ldc,
+                                                            float alpha, float beta, long c_bs /* blockIdx.y = product of the batch */) {
+    constexpr int EPB = 256 / ZP;
+    __shared__ float sh[ZP][EPB];
+    const int el = threadIdx.x % EPB, zl = threadIdx.x / EPB;
+    const long i = (long)blockIdx.x * EPB + el;
+    const long MN = (long)M * N;
+    partial += (size_t)blockIdx.y * Z * MN;
     C += (long)blockIdx.y * c_bs;
     float s = 0.f;
-    for (int z = 0; z < Z; ++z) s += partial[(size_t)z * M * N + i];
+    if (i < MN)
+        for (int z = zl; z < Z; z += ZP) s += partial[(size_t)z * MN + i];
+    if constexpr (ZP > 1) {
+        sh[zl][el] = s;
+        __syncthreads();
+        if (zl != 0) return;
+#pragma unroll
+        for (int q = 1; q < ZP; ++q) s += sh[q][el];
+    }
+    if (i >= MN) return;
     const int m = (int)(i / N), n = (int)(i % N);
     C[(size_t)m * ldc + n] = alpha * s + (beta != 0.f ? beta * C[(size_t)m * ldc + n] : 0.f);
 }
@@ -537,6 +554,11 @@ inline int arreau_sgemm(hipStream_t s, float* partial, int M, int N, int K, cons
     const int tiles = gm * gn * batch;
     if (long_k) {
         Z = min(z128, (384 + tiles128 - 1) / tiles128);
+    } else if (mode != 0 && tiles < 512 && K >= 1024) {
+        // split kernel, few 64 x 64 tiles under a long reduction (the weight gradients of the small Linears): slices of at least four
+        // k-steps until about a thousand workgroups are in flight -- at five workgroups per CU the chip holds 1,280, and [94, 128] from
+        // 8,096 rows x 5 layers ran as 140 workgroups of 36 k-steps each (24.8 us; the partial sums stay within a few MB)
+        Z = min(min(256, K / 128), (1024 + tiles - 1) / tiles);
     } else if (tiles < 128 && K >= 256) {
         const int fill = (256 + tiles - 1) / tiles;
         Z = min(64, min(max(fill, K / 1024), K / 128));
@@ -600,8 +622,13 @@ inline int arreau_sgemm(hipStream_t s, float* partial, int M, int N, int K, cons
     }
     ARREAU_CHECK_HIP(hipGetLastError());
     if (Z > 1) {
-        hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)(((long)M * N + 255) / 256), batch), dim3(256), 0, s, partial, Z, M, N, C, ldc,
-                           alpha, beta, c_bs);
+        const long mn = (long)M * N;
+        if (Z <= 8)
+            hipLaunchKernelGGL(splitk_reduce_kernel<1>, dim3((unsigned)((mn + 255) / 256), batch), dim3(256), 0, s, partial, Z, M, N, C, ldc, alpha, beta, c_bs);
+        else if (Z <= 32)
+            hipLaunchKernelGGL(splitk_reduce_kernel<4>, dim3((unsigned)((mn + 63) / 64), batch), dim3(256), 0, s, partial, Z, M, N, C, ldc, alpha, beta, c_bs);
+        else
+            hipLaunchKernelGGL(splitk_reduce_kernel<8>, dim3((unsigned)((mn + 31) / 32), batch), dim3(256), 0, s, partial, Z, M, N, C, ldc, alpha, beta, c_bs);
         ARREAU_CHECK_HIP(hipGetLastError());
     }
     return ARREAU_OK;
