@@ -844,7 +844,7 @@ struct arreau_train_ctx {
     float *mono, *window, *h1pre, *h1, *h2pre, *kb, *fpoly, *fh1pre, *fh1, *fh2pre, *fkb, *F;
     float *x, *x1, *xhat, *rstd, *xn, *hpre, *h, *out, *fk, *rbar, *gs, *kern;
     // backward temporaries
-    float *dx, *dxro, *dtmp, *dh, *drbar, *dx1, *dkern, *dkb, *dh1, *dfk, *dfkb, *dfh1, *dw1f, *partial, *scratch_cols, *colpart;
+    float *dx, *dxro, *rbar_all, *dfkb_all, *dtmp, *dh, *drbar, *dx1, *dkern, *dkb, *dh1, *dfk, *dfkb, *dfh1, *dw1f, *partial, *scratch_cols, *colpart;
     float *dxn_all, *dx2_all;  // [L][M][C]: d(LayerNorm output) and d(spherical conv output), for the batched bias / norm gradients
     float *xn_all, *dout_all, *dfk_all;  // [L][...]: LayerNorm outputs (forward), d(out) and d(fiber kernel) (backward), for the batched weight gradients
     int32_t* colcount;  // colsum_kernel's arrival counters (one per 64-column group; zero between launches)
@@ -882,13 +882,13 @@ size_t layout(arreau_train_ctx& t, const arreau_model* m, int N, int B, float* b
     t.fh2pre = c.take<float>(256 * D); t.fkb = c.take<float>(256 * D); t.F = c.take<float>(M * (S + 78));
     t.x = c.take<float>((L + 1) * M * C); t.x1 = c.take<float>(L * M * C); t.xhat = c.take<float>(L * M * C);
     t.rstd = c.take<float>(L * M); t.xn = c.take<float>(M * C); t.hpre = c.take<float>(L * M * H); t.h = c.take<float>(L * M * H);
-    t.out = c.take<float>(L * M * C); t.fk = c.take<float>(L * 256 * C); t.rbar = c.take<float>(M * RO); t.gs = c.take<float>(N * 3);
+    t.out = c.take<float>(L * M * C); t.fk = c.take<float>(L * 256 * C); t.rbar = c.take<float>(M * RO); t.rbar_all = c.take<float>(L * M * RO); t.gs = c.take<float>(N * 3);
     t.kern = c.take<float>(R * L * C);   // all layers' spatial kernels, [R][L*C] (one GEMM: the basis is layer-independent)
     t.dx = c.take<float>(M * C); t.dxro = c.take<float>(L * M * C); t.dtmp = c.take<float>(M * C); t.dh = c.take<float>(L * M * H); t.drbar = c.take<float>(M * RO);
     t.xn_all = c.take<float>(L * M * C); t.dout_all = c.take<float>(L * M * C); t.dfk_all = c.take<float>(L * 256 * C);
     t.dxn_all = c.take<float>(L * M * C); t.dx2_all = c.take<float>(L * M * C);  // kept per layer for the batched weight gradients
     t.dx1 = c.take<float>(M * C); t.dkern = c.take<float>(R * L * C); t.dkb = c.take<float>(R * D); t.dh1 = c.take<float>(R * C);
-    t.dfk = c.take<float>(256 * C); t.dfkb = c.take<float>(256 * D); t.dfh1 = c.take<float>(256 * C);
+    t.dfk = c.take<float>(256 * C); t.dfkb = c.take<float>(256 * D); t.dfkb_all = c.take<float>(L * 256 * D); t.dfh1 = c.take<float>(256 * C);
     t.dw1f = c.take<float>(C * ARREAU_MONO_PAD); t.partial = c.take<float>(PARTIAL_FLOATS); t.scratch_cols = c.take<float>(1024);
     t.colpart = c.take<float>((size_t)2 * COLSUM4_MAX_BATCH * COLSUM4_MAX_CHUNKS * 1024);  // (two results per pass, up to eight matrices per call)
     t.colcount = c.take<int32_t>(COLCOUNT_INTS);
@@ -1024,6 +1024,13 @@ int linear_dx_gelu_backward(hipStream_t s, arreau_train_ctx& t, long rows, int i
     if (rc || fused) return rc;
     return launch_gelu_backward(s, dX, pre, rowscale, rows, in);
 }
+// out[m][n] = sum over z = 0 .. Z - 1, in that order, of part[z][m][n] (a running sum from zero: the association of Z accumulating launches)
+int ordered_sum(hipStream_t s, const float* part, int Z, int M, int N, float* out) {
+    hipLaunchKernelGGL(arreau_sgemm_detail::splitk_reduce_kernel<1>, dim3((unsigned)(((long)M * N + 255) / 256), 1), dim3(256), 0, s, part, Z, M, N, out, N,
+                       1.0f, 0.0f, 0L);
+    ARREAU_CHECK_HIP(hipGetLastError());
+    return ARREAU_OK;
+}
 #define V4(p) reinterpret_cast<const f32x4*>(p)
 #define V4W(p) reinterpret_cast<f32x4*>(p)
 #define TRY(expr) do { int rc_ = (expr); if (rc_) return rc_; } while (0)
@@ -1098,7 +1105,6 @@ int arreau_general_network(arreau_model* m, const arreau_graph_view& g, const in
     TRY(linear(s, t, 256, 3, C, t.fpoly, m->fiber_w1, t.fh1pre));
     TRY(launch_bias_gelu(s, t.fh1pre, m->fiber_b1, (const float*)nullptr, 256L, C, t.fh1));
     TRY(linear_bias_gelu(s, t, 256, C, D, t.fh1, m->fiber_w2, m->fiber_b2, (const float*)nullptr, t.fh2pre, t.fkb));
-    ARREAU_CHECK_HIP(hipMemsetAsync(t.rbar, 0, (size_t)M * RO * sizeof(float), s));
     // kernel_l = kb . Wk_l^T for all layers in one product (conv.py:110; conv.kernel.weight stacked [L*C][D])
     TRY(linear(s, t, R, D, L * C, t.kb, t.wk, t.kern));
     // fiber kernels of all layers: fk_l = fkb . Wfk_l^T (conv.py:113-116), one batched product
@@ -1131,9 +1137,12 @@ int arreau_general_network(arreau_model* m, const arreau_graph_view& g, const in
             if (!fused)
                 LAUNCH(bias_scale_residual_kernel, dim3(blocks(M * C)), dim3(256), out, m->mb2 + (size_t)l * C, m->ls + (size_t)l * C, xl, M, C, xnext);
         }
-        // read-out of this layer, averaged over layers (ponita.py:105,108); biases are added in train_outputs_kernel
-        TRY(linear(s, t, M, C, RO, xnext, t.ro_w + (size_t)l * RO * C, t.rbar, 1.0f / (float)L, 1.0f));
     }
+    // read-outs of all layers, averaged (ponita.py:105,108; biases are added in train_outputs_kernel): ONE batched product over the kept
+    // x_1 .. x_L and a sum in layer order -- the same products and the same association as L accumulating launches inside the loop
+    TRY(arreau_sgemm(s, t.partial, (int)M, RO, C, t.x + (size_t)M * C, C, 1, t.ro_w, 1, C, t.rbar_all, RO, 1.0f / (float)L, 0.f, L, (long)M * C,
+                     (long)RO * C, (long)M * RO, t.fwd_mode));
+    TRY(ordered_sum(s, t.rbar_all, L, (int)M, RO, t.rbar));
     LAUNCH(train_outputs_kernel, dim3(N), dim3(128), t.rbar, m->ro_b, m->ori, S, L, N, d_eps, d_logits, t.gs);
     LAUNCH(pool_crystals_kernel, dim3(blocks(3 * B, 128)), dim3(128), t.gs, d_off, B, d_len0);
     m->ran_edge = m->ran_mlp = ARREAU_VARIANT_GENERAL;
@@ -1201,7 +1210,6 @@ extern "C" int arreau_train_backward(arreau_model* m, const float* d_g_eps, cons
     // each inside the chain); layer L - 1 starts from its slice, the others are added by the launch that completes d x_{l+1}.
     TRY(arreau_sgemm(s, t.partial, (int)M, C, RO, t.drbar, RO, 1, t.ro_w, C, 1, t.dxro, C, 1.0f / (float)L, 0.f, L, 0, (long)RO * C, (long)M * C,
                      t.bwd_mode));
-    ARREAU_CHECK_HIP(hipMemsetAsync(t.dfkb, 0, (size_t)256 * D * sizeof(float), s));
     const float invL = 1.0f / (float)L;
     for (int l = L - 1; l >= 0; --l) {
         const float* xl = t.x + (size_t)l * M * C;
@@ -1276,8 +1284,11 @@ extern "C" int arreau_train_backward(arreau_model* m, const float* d_g_eps, cons
                    t.dx2_all + (size_t)l0 * N * 16 * C, N, C, t.partial, chunk);
             LAUNCH(mix_backward_fk_final_kernel, dim3(blocks(256L * C), nl), dim3(256), t.partial, chunks, C, t.dfk_all + (size_t)l0 * 256 * C);
         }
-        for (int l = L - 1; l >= 0; --l)  // (accumulated in the order of the layer loop)
-            TRY(linear_dx(s, t, 256, D, C, t.dfk_all + (size_t)l * 256 * C, m->fiber_wk + (size_t)l * C * D, t.dfkb, 1.0f, 1.0f));
+        // d(fiber basis) = sum over layers of d(fk_l) . Wfk_l: one batched product, summed in the order of the layer loop (L - 1 first:
+        // slot z of the scratch holds layer L - 1 - z)
+        TRY(arreau_sgemm(s, t.partial, 256, D, C, t.dfk_all + (size_t)(L - 1) * 256 * C, C, 1, m->fiber_wk + (size_t)(L - 1) * C * D, D, 1, t.dfkb_all, D,
+                         1.0f, 0.f, L, -256L * C, -(long)C * D, 256L * D, t.bwd_mode));
+        TRY(ordered_sum(s, t.dfkb_all, L, 256, D, t.dfkb));
     }
     // the layers' weight gradients, one batched product per kind (operands kept per layer above / by the forward pass)
     TRY(linear_dw_batched(s, t, L, M, C, RO, t.drbar, 0, t.x + (size_t)M * C, (long)M * C, W(g->readout_w), invL));         // x_{l+1}
