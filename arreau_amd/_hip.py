@@ -25,7 +25,7 @@ EXPORTS = [
     "arreau_model_set_batch_layout", "arreau_debug_set_pollution", "arreau_debug_leftover_fraction",
 ]
 
-STATUS_NONFINITE, STATUS_BAD_TIMESTEP, STATUS_BAD_TYPE = 1, 2, 4
+STATUS_NONFINITE, STATUS_BAD_TIMESTEP, STATUS_BAD_TYPE, STATUS_BASIS_RANGE = 1, 2, 4, 8
 EDGE_KERNELS = {0: "fp32-mfma", 1: "fp32-mfma", 2: "fp32-mfma", 3: "bf16x6", 4: "fp16x3", 5: "general-fp32-gemm"}
 MLP_KERNELS = {0: "fp32-mfma", 1: "bf16x6", 2: "fp16x3-32x32x16", 3: "fp16x3-16x16x32",
                5: "general-fp32-gemm"}
@@ -47,7 +47,8 @@ class Config(Structure):
 
 class Status(Structure):
     _fields_ = [("flags", c_int32), ("edge_kernel", c_int32), ("mlp_kernel", c_int32), ("conv_kernel", c_int32),
-                ("basis_row_bytes", c_int32), ("conv_cross_fp8", c_int32), ("edge_activation_bound", c_float), ("node_activation_bound", c_float)]
+                ("basis_row_bytes", c_int32), ("conv_cross_fp8", c_int32), ("edge_activation_bound", c_float), ("node_activation_bound", c_float),
+                ("basis_q16_share", c_float), ("cross_fp8_share", c_float)]
 
 
 _SD_FIELDS = [

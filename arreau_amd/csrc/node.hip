@@ -914,17 +914,18 @@ bool arreau_basis_form(const arreau_model* m, int receivers) {
     const int min_receivers = e ? atoi(e) : 2000;
     // (L >= 2: the stash -- 96 or 128 KiB per atom -- lives in the workspace region sized for L per-layer K buffers of 64 KiB per atom)
     return m->conv_variant == 2 && m->edge_variant == 4 && m->f16_ok && m->k == 8 && m->C == 128 && m->D == 256 && m->L >= 2 &&
-           receivers > (min_receivers > 240 ? min_receivers : 240);
+           receivers > (min_receivers > 240 && !m->calibrating ? min_receivers : 240);
 }
 
-bool arreau_basis_fp8() {
-    static const int env = [] { const char* e = getenv("ARREAU_BASIS_FP8"); return e ? atoi(e) : 1; }();
-    return env != 0;
+bool arreau_basis_q16(const arreau_model* m) {
+    static const int env = [] { const char* e = getenv("ARREAU_BASIS_Q16"); return e ? atoi(e) : -1; }();
+    // (the environment overrides the model's calibration either way -- A/B, tests -- except while that calibration runs)
+    return env >= 0 && !m->calibrating ? env != 0 : m->q16_ok != 0;
 }
 
 bool arreau_cross_fp8(const arreau_model* m) {
     const char* e = getenv("ARREAU_CROSS_FP8");
-    return (e == nullptr || atoi(e) != 0) && m->x8_ok && arreau_basis_fp8();
+    return (e == nullptr || atoi(e) != 0 || m->calibrating) && m->x8_ok && arreau_basis_q16(m);
 }
 
 bool arreau_range_launches_supported(const arreau_model* m) {

@@ -212,13 +212,13 @@ class DiffusionLoss(nn.Module):
         t_d, types0, off = stage_to_device(dev, torch.int32, [t.reshape(B), batch.A0, off_host])
         nz = eng.diffusion_noise(frac_d, types0, cell_d, t_d, off, z_frac_d, u_types_d, z_len_d)
         evaluate = eng.train_forward if training else eng.predict_scores
-        eps, logits, len0 = evaluate(nz["noisy_frac"], nz["noisy_types"], nz["noisy_lengths"], nz["angles"], t_d, off)
+        run = lambda: evaluate(nz["noisy_frac"], nz["noisy_types"], nz["noisy_lengths"], nz["angles"], t_d, off)
+        # (validation: sticky device flags -> raise, a BASIS_RANGE flag -> repeated on three fp16 products: HipEngine.checked.
+        # Reading the flags synchronises the stream, so the training step -- whose host work overlaps the device's, and whose
+        # forward runs no fp8 product -- leaves that to PONITA_DIFFUSION.training_step, every STATUS_CHECK_EVERY steps.)
+        eps, logits, len0 = run() if training else eng.checked(run)
         losses, grads = eng.diffusion_losses(eps, nz["target_eps"], logits, types0, nz["noisy_types"], t_d, len0,
                                              nz["lengths"], off, with_grads=True)
-        if not training:
-            # sticky device flags -> raise.  Reading them synchronises the stream, so the training step (whose host work
-            # overlaps the device's) leaves that to PONITA_DIFFUSION.training_step, every STATUS_CHECK_EVERY steps.
-            eng.check_status()
         if return_parts:
             return losses[0], dict(error_frac_x=losses[1], error_atomic_type=losses[2], error_lattice=losses[3],
                                    vb=losses[4], ce=losses[5], pred_eps=eps, logits=logits, pred_lengths=len0,
@@ -324,6 +324,7 @@ class DiffusionLoss(nn.Module):
         # fp16x3 kernels flag an overflow (see below).
         init_state = (frac_d.clone(), types_d.clone(), len_d.clone())
         rng_state = torch.random.get_rng_state()
+        cuda_rng_state = torch.cuda.get_rng_state(dev) if noise == "device" else None  # (the draws of noise='device')
         if noise == "philox" and seed is None:
             seed = int(torch.randint(0, 2 ** 62, (1,)).item())
             rng_state = torch.random.get_rng_state()
@@ -379,24 +380,41 @@ class DiffusionLoss(nn.Module):
         run_loop(use_graph)
         # Range safety without an environment variable: the fp16x3 kernels never clamp -- an activation beyond 65504 reaches the
         # outputs as NaN and sets the sticky NONFINITE flag.  When that happens on the default kernels the batch is re-run HERE,
-        # from its saved initial state and with the same draws (same Philox seed / same host generator state), on the
-        # full-range bf16x6 kernels, the engine stays on them, and the result says so (SampleResult.info).
+        # from its saved initial state and with the same draws (same Philox seed / same host and device generator states), on
+        # the full-range bf16x6 kernels; the engine stays on them if that run came out finite, and the result says so
+        # (SampleResult.info).  The same for BASIS_RANGE (a basis value beyond e4m3's range met the fp8 cross products of the
+        # layer projections): reading the flag has switched the library to three fp16 products, the batch is re-run with them.
         info = None
         st = eng.status(reset=False)
         from .. import _hip as _h
-        if (st["flags"] & _h.STATUS_NONFINITE) and not (st["flags"] & ~_h.STATUS_NONFINITE) and eng.fused_shape \
-                and (st["edge_kernel"] == "fp16x3" or st["mlp_kernel"].startswith("fp16x3")):
+        overflow = (st["flags"] & _h.STATUS_NONFINITE) and not (st["flags"] & ~(_h.STATUS_NONFINITE | _h.STATUS_BASIS_RANGE)) \
+            and eng.fused_shape and (st["edge_kernel"] == "fp16x3" or st["mlp_kernel"].startswith("fp16x3"))
+        basis_range = st["flags"] == _h.STATUS_BASIS_RANGE
+        if overflow or basis_range:
             import warnings
-            warnings.warn("arreau_amd: an activation left the fp16 range of the split-precision kernels (weights with activation "
-                          f"bounds edge {st['edge_activation_bound']:.3g} / node {st['node_activation_bound']:.3g}); re-running the "
-                          "batch on the full-range bf16x6 kernels, which this engine keeps from now on")
+            if overflow:
+                warnings.warn("arreau_amd: an activation left the fp16 range of the split-precision kernels (weights with activation "
+                              f"bounds edge {st['edge_activation_bound']:.3g} / node {st['node_activation_bound']:.3g}); re-running the "
+                              "batch on the full-range bf16x6 kernels, which this engine keeps if they come out finite")
+            else:
+                warnings.warn("arreau_amd: a basis value above 448 reached the e4m3 planes of the block-quantised basis stash; "
+                              "re-running the batch with two fp16 planes and three fp16 products, which this engine keeps from now on")
             eng.status(reset=True)
-            eng.set_variant(3, 1)
+            previous = (st["edge_variant"], st["mlp_variant"])
+            if overflow:
+                eng.set_variant(3, 1)
             frac_d.copy_(init_state[0]); types_d.copy_(init_state[1]); len_d.copy_(init_state[2])
             torch.random.set_rng_state(rng_state)
+            if cuda_rng_state is not None:
+                torch.cuda.set_rng_state(cuda_rng_state, dev)
             run_loop(False)
-            info = {"full_range_rerun": True, "kernels": "bf16x6", "edge_activation_bound": st["edge_activation_bound"],
-                    "node_activation_bound": st["node_activation_bound"]}
+            if overflow:
+                if eng.status(reset=False)["flags"] & _h.STATUS_NONFINITE:
+                    eng.set_variant(*previous)  # not a range problem (e.g. a degenerate cell): keep the faster kernels, raise below
+                info = {"full_range_rerun": True, "kernels": "bf16x6", "edge_activation_bound": st["edge_activation_bound"],
+                        "node_activation_bound": st["node_activation_bound"]}
+            else:
+                info = {"fp16_planes_rerun": True}
         eng.check_status()  # sticky device flags (non-finite outputs, clamped indices): raise instead of returning them
         if frames:
             vis_crystal_during_sampling(z_table, types_d.cpu().numpy(), lattice_d.cpu().numpy(), frac_d.cpu().numpy(),

@@ -16,55 +16,62 @@ def _f32(t):
     return t.detach().to("cpu", torch.float32).contiguous()
 
 
+def pack_state(module):
+    """(Config, host tensors, StateDict of their pointers) of a PONITA_DIFFUSION in the reference's state_dict layout: what
+    arreau_model_create and arreau_calibrate_formats take.  Host side only; the tensors must outlive every use of the struct."""
+    net = module.model
+    sd = module.state_dict()
+    L = net.num_layers
+    S = module.num_atomic_states
+    cfg = _hip.Config(
+        num_atomic_states=S, hidden_dim=net.hidden_dim, basis_dim=net.basis_dim, num_layers=L,
+        num_ori=net.num_ori, widening_factor=net.widening_factor, degree=net.degree,
+        max_neighbors=int(module.diffusion_loss.max_neighbors), num_timesteps=int(module.diffusion_loss.T),
+        radius=float(module.diffusion_loss.cutoff),
+        has_layer_scale=int(f"model.interaction_layers.0.layer_scale" in sd and
+                            sd["model.interaction_layers.0.layer_scale"] is not None))
+    il = "model.interaction_layers.{}."
+    stack = lambda fmt: torch.stack([_f32(sd[fmt.format(i)]) for i in range(L)], 0).contiguous()
+    host = {
+        "basis_w1": _f32(sd["model.basis_fn.1.weight"]), "basis_b1": _f32(sd["model.basis_fn.1.bias"]),
+        "basis_w2": _f32(sd["model.basis_fn.3.weight"]), "basis_b2": _f32(sd["model.basis_fn.3.bias"]),
+        "fiber_w1": _f32(sd["model.fiber_basis_fn.1.weight"]), "fiber_b1": _f32(sd["model.fiber_basis_fn.1.bias"]),
+        "fiber_w2": _f32(sd["model.fiber_basis_fn.3.weight"]), "fiber_b2": _f32(sd["model.fiber_basis_fn.3.bias"]),
+        "x_embedder_w": _f32(sd["model.x_embedder.weight"]),
+        "conv_kernel_w": stack(il + "conv.kernel.weight"), "conv_fiber_w": stack(il + "conv.fiber_kernel.weight"),
+        "conv_bias": stack(il + "conv.bias"), "norm_w": stack(il + "norm.weight"), "norm_b": stack(il + "norm.bias"),
+        "linear1_w": stack(il + "linear_1.weight"), "linear1_b": stack(il + "linear_1.bias"),
+        "linear2_w": stack(il + "linear_2.weight"), "linear2_b": stack(il + "linear_2.bias"),
+        "readout_w": stack("model.read_out_layers.{}.weight"), "readout_b": stack("model.read_out_layers.{}.bias"),
+        "ori_grid": _f32(net.ori_grid), "t_emb_w": _f32(sd["t_emb.gaussian_fourier_proj_w"]),
+        "ve_sigmas": _f32(sd["diffusion_loss.pos_diffusion.sigmas"]),
+        "vp_alpha_bars": _f32(sd["diffusion_loss.lattice_diffusion.alpha_bars"]),
+        "vp_betas": _f32(sd["diffusion_loss.lattice_diffusion.betas"]),
+        "q_one_step_transposed": _f32(sd["diffusion_loss.d3pm.q_one_step_transposed"]),
+        "q_mats": _f32(sd["diffusion_loss.d3pm.q_mats"]),
+    }
+    if cfg.has_layer_scale:
+        host["layer_scale"] = stack(il + "layer_scale")
+    expect = {"basis_w1": (net.hidden_dim, 258), "x_embedder_w": (net.hidden_dim, S + 78),
+              "readout_w": (L, S + 4, net.hidden_dim), "ori_grid": (net.num_ori, 3),
+              "q_mats": (cfg.num_timesteps, S, S), "ve_sigmas": (cfg.num_timesteps + 1,)}
+    for k, shp in expect.items():
+        if tuple(host[k].shape) != shp:
+            raise ValueError(f"state_dict entry for {k} has shape {tuple(host[k].shape)}, expected {shp}")
+    csd = _hip.StateDict()
+    for name in _hip._SD_FIELDS:
+        t = host.get(name)
+        setattr(csd, name, t.data_ptr() if t is not None else None)
+    return cfg, host, csd, S, L
+
+
 class HipEngine:
     def __init__(self, module, device):
         """module: a PONITA_DIFFUSION (state_dict layout of the reference); device: cuda device."""
         _hip.require_gpu()
         self.device = torch.device(device)
-        net = module.model
-        sd = module.state_dict()
-        L = net.num_layers
-        S = module.num_atomic_states
-        cfg = _hip.Config(
-            num_atomic_states=S, hidden_dim=net.hidden_dim, basis_dim=net.basis_dim, num_layers=L,
-            num_ori=net.num_ori, widening_factor=net.widening_factor, degree=net.degree,
-            max_neighbors=int(module.diffusion_loss.max_neighbors), num_timesteps=int(module.diffusion_loss.T),
-            radius=float(module.diffusion_loss.cutoff),
-            has_layer_scale=int(f"model.interaction_layers.0.layer_scale" in sd and
-                                sd["model.interaction_layers.0.layer_scale"] is not None))
+        cfg, host, csd, S, L = pack_state(module)
         self.cfg = cfg
-        il = "model.interaction_layers.{}."
-        stack = lambda fmt: torch.stack([_f32(sd[fmt.format(i)]) for i in range(L)], 0).contiguous()
-        host = {
-            "basis_w1": _f32(sd["model.basis_fn.1.weight"]), "basis_b1": _f32(sd["model.basis_fn.1.bias"]),
-            "basis_w2": _f32(sd["model.basis_fn.3.weight"]), "basis_b2": _f32(sd["model.basis_fn.3.bias"]),
-            "fiber_w1": _f32(sd["model.fiber_basis_fn.1.weight"]), "fiber_b1": _f32(sd["model.fiber_basis_fn.1.bias"]),
-            "fiber_w2": _f32(sd["model.fiber_basis_fn.3.weight"]), "fiber_b2": _f32(sd["model.fiber_basis_fn.3.bias"]),
-            "x_embedder_w": _f32(sd["model.x_embedder.weight"]),
-            "conv_kernel_w": stack(il + "conv.kernel.weight"), "conv_fiber_w": stack(il + "conv.fiber_kernel.weight"),
-            "conv_bias": stack(il + "conv.bias"), "norm_w": stack(il + "norm.weight"), "norm_b": stack(il + "norm.bias"),
-            "linear1_w": stack(il + "linear_1.weight"), "linear1_b": stack(il + "linear_1.bias"),
-            "linear2_w": stack(il + "linear_2.weight"), "linear2_b": stack(il + "linear_2.bias"),
-            "readout_w": stack("model.read_out_layers.{}.weight"), "readout_b": stack("model.read_out_layers.{}.bias"),
-            "ori_grid": _f32(net.ori_grid), "t_emb_w": _f32(sd["t_emb.gaussian_fourier_proj_w"]),
-            "ve_sigmas": _f32(sd["diffusion_loss.pos_diffusion.sigmas"]),
-            "vp_alpha_bars": _f32(sd["diffusion_loss.lattice_diffusion.alpha_bars"]),
-            "vp_betas": _f32(sd["diffusion_loss.lattice_diffusion.betas"]),
-            "q_one_step_transposed": _f32(sd["diffusion_loss.d3pm.q_one_step_transposed"]),
-            "q_mats": _f32(sd["diffusion_loss.d3pm.q_mats"]),
-        }
-        if cfg.has_layer_scale:
-            host["layer_scale"] = stack(il + "layer_scale")
-        expect = {"basis_w1": (net.hidden_dim, 258), "x_embedder_w": (net.hidden_dim, S + 78),
-                  "readout_w": (L, S + 4, net.hidden_dim), "ori_grid": (net.num_ori, 3),
-                  "q_mats": (cfg.num_timesteps, S, S), "ve_sigmas": (cfg.num_timesteps + 1,)}
-        for k, shp in expect.items():
-            if tuple(host[k].shape) != shp:
-                raise ValueError(f"state_dict entry for {k} has shape {tuple(host[k].shape)}, expected {shp}")
-        csd = _hip.StateDict()
-        for name in _hip._SD_FIELDS:
-            t = host.get(name)
-            setattr(csd, name, t.data_ptr() if t is not None else None)
         self._handle = ctypes.c_void_p()
         with torch.cuda.device(self.device):
             _hip.check(_hip.lib().arreau_model_create(ctypes.byref(cfg), ctypes.byref(csd),
@@ -102,7 +109,8 @@ class HipEngine:
                 "mlp_kernel": _hip.MLP_KERNELS.get(st.mlp_kernel, "none"), "edge_variant": int(st.edge_kernel),
                 "mlp_variant": int(st.mlp_kernel), "conv_variant": int(st.conv_kernel),
                 "basis_row_bytes": int(st.basis_row_bytes), "conv_cross_fp8": int(st.conv_cross_fp8), "edge_activation_bound": float(st.edge_activation_bound),
-                "node_activation_bound": float(st.node_activation_bound)}
+                "node_activation_bound": float(st.node_activation_bound),
+                "basis_q16_share": float(st.basis_q16_share), "cross_fp8_share": float(st.cross_fp8_share)}
 
     def check_status(self, reset=True):
         """Raise if a kernel flagged a condition under which its results must not be trusted."""
@@ -118,8 +126,27 @@ class HipEngine:
                 why.append("a timestep index was outside the schedule")
             if f & _hip.STATUS_BAD_TYPE:
                 why.append("an atom-type index was outside [0, num_atomic_states)")
+            if f & _hip.STATUS_BASIS_RANGE:
+                why.append("a basis value above 448 reached the e4m3 planes of the block-quantised basis stash (they saturate); "
+                           "the library has switched this model to two fp16 planes and three fp16 products -- evaluate again")
             raise _hip.ArreauHipError("arreau_hip status flags %d: %s" % (f, "; ".join(why)))
         return st
+
+    def checked(self, fn):
+        """Run `fn()` (one evaluation through this engine), then read the sticky flags.  If the only flag is BASIS_RANGE -- a
+        basis value beyond e4m3's range met the block-quantised stash's e4m3 planes, whose result is then less accurate than
+        the parity target -- the library has already switched the model to two fp16 planes and three fp16 products: `fn()` runs once more and its result
+        is the one returned.  Any other flag raises (check_status)."""
+        out = fn()
+        st = self.status(reset=False)
+        if st["flags"] == _hip.STATUS_BASIS_RANGE:
+            import warnings
+            warnings.warn("arreau_amd: a basis value above 448 reached the e4m3 planes of the block-quantised basis stash; this "
+                          "engine keeps two fp16 planes and three fp16 products from now on and the evaluation is repeated with them")
+            self.status(reset=True)
+            out = fn()
+        self.check_status()
+        return out
 
     def set_batch_layout(self, num_atoms, groups=0):
         """Tell the library the (host-side) atom count of every crystal of the batches that follow, so that it may run

@@ -283,9 +283,8 @@ class PONITA_DIFFUSION(nn.Module):
                 raise ValueError("graph.batch must list the atoms of each crystal contiguously, crystals in order")
         f32 = lambda t: torch.as_tensor(t).to(dev, torch.float32).contiguous()
         edges = eng.edges_to_slots(graph.edge_index, graph.dists, graph.inter_atom_direction, N)
-        logits, vec_out, gscalar = eng.ponita_forward(f32(x), f32(graph.vec), f32(graph.lattice),
-                                                      crystal_offsets(n_cpu, dev), edges)
-        eng.check_status()
+        xd, vd, ld, od = f32(x), f32(graph.vec), f32(graph.lattice), crystal_offsets(n_cpu, dev)
+        logits, vec_out, gscalar = eng.checked(lambda: eng.ponita_forward(xd, vd, ld, od, edges))
         return logits, vec_out, gscalar, None, [None] * self.model.num_layers
 
     @torch.no_grad()

@@ -576,7 +576,7 @@ def run_rank(args, rank, local_rank, world):
             # its ALGORITHMIC bytes are those of 8(d)'s conv pass (read x, write x_1).  The basis stash it streams is traffic the
             # design adds: reported beside the PMC figure, never as achieved work.
             rows = e_mean * 16 / launches_per_step
-            row_bytes = int(status.get("basis_row_bytes") or 768)
+            row_bytes = int(status.get("basis_row_bytes") or 544)
             # the roof of the arithmetic this kernel runs: three fp16 products per fp32 product (2500 / 3), or -- round 4 default --
             # one fp16 product + the two cross products as ONE fp8 product at twice the fp16 rate = two fp16-equivalents (2500 / 2)
             x8 = bool(status.get("conv_cross_fp8"))
@@ -645,12 +645,12 @@ def run_rank(args, rank, local_rank, world):
                           f"arreau_model_status): edge={status['edge_kernel']}, mlp={status['mlp_kernel']}.  fp16x3 = each "
                           "fp32 product of the dense layers as 3 fp16 MFMA products (two 11-bit operand planes, f16x3.h); "
                           f"message path (conv kernel variant {status.get('conv_variant')}): 2 = no K stash -- the edge kernel "
-                          "stores the windowed basis once (fp16 plane + residual plane rounded to fp8 e4m3: 3 bytes per value, "
-                          "11 + 4 significand bits; ARREAU_BASIS_FP8=0: both planes fp16) and every layer's message kernel "
+                          "stores the windowed basis once (block-quantised: 16-bit mantissas + one exponent per 8 values, 2.125 bytes "
+                          f"per value, basis_row_bytes={status.get('basis_row_bytes')}; ARREAU_BASIS_Q16=0: two fp16 planes) and every layer's message kernel "
                           f"projects it, its two cross products as one fp8 (e4m3) MFMA product: conv_cross_fp8={status.get('conv_cross_fp8')} "
                           "(round 4; ARREAU_CROSS_FP8=0: three fp16 products); 1 = the round-2 pair with a K stash of 3-byte floats; environment: "
-                          f"ARREAU_BASIS_FP8={os.environ.get('ARREAU_BASIS_FP8', '1')} ARREAU_CONV_VARIANT={os.environ.get('ARREAU_CONV_VARIANT', '2')}; "
-                          "measured deviations from the fp32 / fp64 CPU oracle: profiles/parity_r04.json; "
+                          f"ARREAU_BASIS_Q16={os.environ.get('ARREAU_BASIS_Q16', '1')} ARREAU_CONV_VARIANT={os.environ.get('ARREAU_CONV_VARIANT', '2')}; "
+                          "measured deviations from the fp32 / fp64 CPU oracle: profiles/parity_r05.json; "
                           "roofline.fp32_mfma_variant = the same step on the plain fp32-MFMA kernels",
             "data": "synthetic",
             "config": {

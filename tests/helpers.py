@@ -51,3 +51,36 @@ def slots_from_edges(edge_index, dists, direction, N, k):
         sdist[r, s] = dists[e].float()
         deg[r] += 1
     return deg, src, sdir, sdist
+
+
+def make_heavy_tailed(module, seed=5, df=3.0, boost=50.0, boosted_rows=3):
+    """Replace the weights the low-precision operands of the message path are built from -- every layer's
+    `conv.kernel.weight` and the two Linears of `basis_fn` -- by heavy-tailed draws (Student-t with `df` degrees of freedom,
+    scaled to the standard deviation of the tensor they replace) and multiply a few output rows of every kernel by `boost`:
+    the regime in which a 4-significand-bit operand (the e4m3 cross products, conv_proj.hip) or a shared block exponent
+    (the Q16 stash) hurts first, which Gaussian / uniform initialisers never visit.  In place; returns the module.
+    (|kernel weight| stays below 7, so the fp8 cross products remain selected: arreau_model.x8_ok.)"""
+    g = torch.Generator().manual_seed(seed)
+    t_dist = torch.distributions.StudentT(df)
+
+    def redraw(w):
+        std = float(w.std())
+        torch.manual_seed(int(torch.randint(0, 2 ** 31, (1,), generator=g)))
+        z = t_dist.sample(w.shape)
+        return (z * (std / float(z.std()))).to(w.dtype)
+
+    state = torch.random.get_rng_state()
+    try:
+        with torch.no_grad():
+            net = module.model
+            for lin in (net.basis_fn[1], net.basis_fn[3]):
+                lin.weight.copy_(redraw(lin.weight))
+            for layer in net.interaction_layers:
+                w = redraw(layer.conv.kernel.weight)
+                rows = torch.randperm(w.shape[0], generator=g)[:boosted_rows]
+                w[rows] *= boost
+                w.clamp_(-6.5, 6.5)
+                layer.conv.kernel.weight.copy_(w)
+    finally:
+        torch.random.set_rng_state(state)
+    return module

@@ -1,11 +1,14 @@
 #!/bin/bash
-# usage (GPU box): tools/gpu_round.sh <tag>   -- GPU test suite, parity report, default bench; everything logged under gpurun_out/
-tag=${1:-r02}
-cd $GRAFT_REPO_ROOT
-timeout -k 10 900 python -m pytest tests -m gpu -x -q > gpurun_out/${tag}_pytest.log 2>&1; rc=$?
-tail -n 15 gpurun_out/${tag}_pytest.log
-[ $rc -eq 0 ] || exit $rc
-timeout -k 10 600 python tools/parity_report.py --out gpurun_out/${tag}_parity.json > gpurun_out/${tag}_parity.log 2>&1 || { tail -n 30 gpurun_out/${tag}_parity.log; exit 1; }
-tail -n 16 gpurun_out/${tag}_parity.log
-timeout -k 10 600 python bench.py > gpurun_out/${tag}_bench_c2.json 2> gpurun_out/${tag}_bench_c2.err || { tail -n 30 gpurun_out/${tag}_bench_c2.err; exit 1; }
-cat gpurun_out/${tag}_bench_c2.json
+# usage (GPU box): tools/gpu_round.sh <tag> [prev-lib tag]  -- the whole GPU suite, then (optionally) an A/B at 256 x 20 of the in-tree library
+# against tools/exp/ab/lib_<prev>.so (alternating on this box: graph replay ms per step + the message kernel's launch time)
+tag=$1; prev=$2
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+timeout -k 10 1000 python3 -m pytest tests -m gpu -x -q -s > gpurun_out/${tag}_pytest.log 2>&1; rc=$?
+grep -n "passed\|failed" gpurun_out/${tag}_pytest.log | tail -n 2
+[ $rc -eq 0 ] || { grep -n "Error\|assert \|FAILED" gpurun_out/${tag}_pytest.log | tail -n 20; exit $rc; }
+[ -n "$prev" ] || exit 0
+for i in 1 2; do for v in $prev cur; do
+  if [ $v = cur ]; then unset ARREAU_HIP_LIB; else export ARREAU_HIP_LIB=$GRAFT_REPO_ROOT/tools/exp/ab/lib_$v.so; fi
+  timeout -k 10 300 python3 bench.py --no-cpu-baseline --no-fp32-variant --no-full-sampler --steps 60 > gpurun_out/${tag}_ab_${v}_$i.json 2>gpurun_out/${tag}_ab_${v}_$i.err || { tail -n 20 gpurun_out/${tag}_ab_${v}_$i.err; exit 1; }
+  python3 -c "import json; d=json.load(open('gpurun_out/${tag}_ab_${v}_$i.json')); print('$v', $i, 'ms_per_step', round(d['ms_per_step'],4), 'eager', round(d['eager_loop']['ms_per_step'],4), 'conv_proj us', round(1e3*d['roofline']['avg_launch_ms'],1), 'edge us', round(1e3*d['roofline']['edge_kernel'].get('avg_launch_ms', 0),1) if 'edge_kernel' in d['roofline'] else '')"
+done; done

@@ -30,8 +30,9 @@ import torch.nn.functional as F
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "parity_r04.json"))
+    ap.add_argument("--out", default=os.path.join(ROOT, "profiles", "parity_r05.json"))
     ap.add_argument("--quick", action="store_true", help="only the [20]x8 case")
+    ap.add_argument("--heavy-tailed", action="store_true", help="Student-t kernel / basis weights (tests/helpers.py: make_heavy_tailed)")
     args = ap.parse_args()
     from arreau_amd.checkpoint import make_synthetic_model
     from arreau_amd.diffusion.diffusion_helpers import crystal_offsets
@@ -40,24 +41,33 @@ def main():
 
     dev = torch.device("cuda", 0)
     S = 90
-    m = make_synthetic_model(S=S, seed=1234).to(dev)
+    m = make_synthetic_model(S=S, seed=1234)
+    if args.heavy_tailed:
+        from tests.helpers import make_heavy_tailed
+        make_heavy_tailed(m, seed=5)
+    m = m.to(dev)
     om32, om64 = oracle_from_module(m, torch.float32), oracle_from_module(m, torch.float64)
     eng = m.engine()
     rng = np.random.RandomState(5)
     cases = [("20x8_sampler_like", [20] * 8, dict(sampler_like=True), 4)]
     if not args.quick:
         cases += [("20x40_sampler_like", [20] * 40, dict(sampler_like=True), 6), ("64x2_dense", [64, 64], dict(cell=(6.0, 9.0)), 41),
-                  ("ragged_420", [int(v) for v in rng.randint(1, 7, size=420)], dict(cell=(3.5, 9.0)), 91)]
+                  ("ragged_420", [int(v) for v in rng.randint(1, 7, size=420)], dict(cell=(3.5, 9.0)), 91),
+                  ("20x256_bench_size", [20] * 256, dict(cell=(4.0, 8.0)), 17)]
     # (edge variant, mlp variant): the default kernels, the exact fp32-MFMA kernels, the small-batch ConvNext kernel
     # (hidden dimension split over eight waves) and the shape-general fp32 GEMM network
     # Round 4: "basis_form_*" = the message path of launches above 2,000 receivers (what bench.py's `value` runs: stashed basis,
     # per-layer projection in conv_proj.hip), forced at these oracle-sized batches with ARREAU_BASIS_MIN_RECEIVERS=240 (read per
-    # launch; batches of at most 240 atoms keep the K pair and report it) -- with the two cross products on the fp8 matrix
-    # instruction (the default) and with three fp16 products (ARREAU_CROSS_FP8=0).
+    # launch) -- with the two cross products on the fp8 matrix instruction (the default), with three fp16 products
+    # (ARREAU_CROSS_FP8=0); ARREAU_BASIS_Q16=0 in the environment of the whole run gives the same rows on two fp16 planes in the stash instead of
+    # the block-quantised values (that switch is read once per process).  Batches of at most 240 atoms
+    # cannot take the basis form at all: their "basis_form_*" rows are SKIPPED (round 4 recorded them under a name they did not
+    # run).
     variants = [("default_fp16x3", 4, 3, {}), ("fp32_mfma", 0, 0, {}), ("small_launch_mlp_form", 4, 4, {}), ("general_fp32_gemm", 5, 3, {}),
                 ("basis_form_fp8_cross", 4, 3, {"ARREAU_BASIS_MIN_RECEIVERS": "240"}),
                 ("basis_form_fp16_cross", 4, 3, {"ARREAU_BASIS_MIN_RECEIVERS": "240", "ARREAU_CROSS_FP8": "0"})]
-    report = {"model": "synthetic S=90 T=1000 C=128 D=256 L=5 (make_synthetic_model seed 1234, trained_like)",
+    report = {"model": "synthetic S=90 T=1000 C=128 D=256 L=5 (make_synthetic_model seed 1234, trained_like)" +
+                       (" with heavy-tailed kernel / basis weights (make_heavy_tailed seed 5)" if args.heavy_tailed else ""),
               "edges": "oracle's radius_graph_pbc, teacher-forced", "device": torch.cuda.get_device_name(0),
               "cases": {}}
     worst = {v[0]: {"eps": 0.0, "logits": 0.0, "len0": 0.0, "eps_vs_f64": 0.0, "logits_vs_f64": 0.0,
@@ -95,8 +105,11 @@ def main():
                 finally:
                     for k in env:
                         del os.environ[k]
+                if vname.startswith("basis_form") and (st["conv_variant"] != 2 or st["conv_cross_fp8"] != (1 if "fp8" in vname else 0)):
+                    rec[vname] = {"skipped": f"this batch ran message path {st['conv_variant']} with conv_cross_fp8 = {st['conv_cross_fp8']}"}
+                    continue
                 e, l, g = eps.cpu(), logits.cpu(), len0.cpu()
-                r = {"kernels": [st["edge_kernel"], st["mlp_kernel"]], "message_path": st["conv_variant"], "fp8_cross": st["conv_cross_fp8"],
+                r = {"kernels": [st["edge_kernel"], st["mlp_kernel"]], "message_path": st["conv_variant"], "fp8_cross": st["conv_cross_fp8"], "basis_row_bytes": st["basis_row_bytes"],
                      "eps": float((e - eps32).abs().max()), "logits": float((l - log32).abs().max()),
                      "len0": float((g - len32).abs().max()),
                      "eps_vs_f64": float((e.double() - eps64).abs().max()),
