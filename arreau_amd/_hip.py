@@ -22,10 +22,10 @@ EXPORTS = [
     "arreau_diffusion_noise", "arreau_diffusion_losses", "arreau_sample_loop", "arreau_philox_fill",
     "arreau_train_forward", "arreau_train_backward", "arreau_train_conv_stats", "arreau_model_update_train_weights",
     "arreau_debug_sgemm",
-    "arreau_model_set_batch_layout", "arreau_debug_set_pollution", "arreau_debug_leftover_fraction",
+    "arreau_model_set_batch_layout", "arreau_model_set_formats", "arreau_debug_set_pollution", "arreau_debug_leftover_fraction",
 ]
 
-STATUS_NONFINITE, STATUS_BAD_TIMESTEP, STATUS_BAD_TYPE, STATUS_BASIS_RANGE = 1, 2, 4, 8
+STATUS_NONFINITE, STATUS_BAD_TIMESTEP, STATUS_BAD_TYPE = 1, 2, 4
 EDGE_KERNELS = {0: "fp32-mfma", 1: "fp32-mfma", 2: "fp32-mfma", 3: "bf16x6", 4: "fp16x3", 5: "general-fp32-gemm"}
 MLP_KERNELS = {0: "fp32-mfma", 1: "bf16x6", 2: "fp16x3-32x32x16", 3: "fp16x3-16x16x32",
                5: "general-fp32-gemm"}
@@ -48,7 +48,7 @@ class Config(Structure):
 class Status(Structure):
     _fields_ = [("flags", c_int32), ("edge_kernel", c_int32), ("mlp_kernel", c_int32), ("conv_kernel", c_int32),
                 ("basis_row_bytes", c_int32), ("conv_cross_fp8", c_int32), ("edge_activation_bound", c_float), ("node_activation_bound", c_float),
-                ("basis_q16_share", c_float), ("cross_fp8_share", c_float)]
+                ("basis_fp8_share", c_float), ("cross_fp8_share", c_float)]
 
 
 _SD_FIELDS = [
@@ -109,12 +109,16 @@ def lib():
                                      c_float, c_float, c_void_p]
     L.arreau_model_update_train_weights.argtypes = [c_void_p, POINTER(StateDict), c_void_p]
     L.arreau_model_set_batch_layout.argtypes = [c_void_p, c_void_p, c_int32, c_int32]
+    if hasattr(L, "arreau_model_set_formats") or not os.environ.get("ARREAU_HIP_LIB"):  # (an older build under test: tools/ab.sh)
+        L.arreau_model_set_formats.argtypes = [c_void_p, c_int32, c_int32]
     L.arreau_debug_set_pollution.argtypes = [ctypes.c_uint32]
     L.arreau_debug_leftover_fraction.argtypes = [ctypes.c_uint32, POINTER(c_double), POINTER(c_double), c_void_p]
     L.arreau_profile_edge_kernel.argtypes = [c_int32]
     L.arreau_edge_kernel_time_ms.argtypes = [POINTER(c_double), POINTER(c_int64)]
     L.arreau_conv_kernel_time_ms.argtypes = [POINTER(c_double), POINTER(c_int64)]
     for name in EXPORTS:
+        if os.environ.get("ARREAU_HIP_LIB") and not hasattr(L, name):
+            continue
         fn = getattr(L, name)
         if fn.restype is ctypes.c_int:
             fn.restype = c_int32

@@ -617,7 +617,7 @@ extern "C" int arreau_sample_loop(arreau_model* m, float* d_frac, int32_t* d_typ
                                                     // which kernels a capture holds also depends on switches read per call
                                                     // (ARREAU_BASIS_MIN_RECEIVERS, ARREAU_FUSE_SMALL) and on the conv variant:
                                                     // a changed switch must not replay the stale graph
-                                                    (arreau_basis_form(m, N) ? 0x20000 : 0) | (arreau_basis_q16(m) ? 0x40000 : 0) | (arreau_cross_fp8(m) ? 0x400000 : 0) |
+                                                    (arreau_basis_form(m, N) ? 0x20000 : 0) | (arreau_basis_fp8(m) ? 0x40000 : 0) | (arreau_cross_fp8(m) ? 0x400000 : 0) |
                                                     (arreau_small_layer_fusable(m, N, NodeRange()) ? 0x80000 : 0) |
                                                     ((m->conv_variant & 3) << 20)) << 32) | (uint32_t)m->mlp_variant};
     hipGraphExec_t exec = (hipGraphExec_t)m->retired_graph;

@@ -65,21 +65,22 @@ __device__ __forceinline__ void cp_wait_but() {
 // PW = projection waves (4: two 16-channel tiles per wave, 8 waves per workgroup; 8: one tile per wave, 12 waves per
 // workgroup = two projection waves per SIMD, which cover each other's LDS latency -- a lone projection wave per SIMD
 // waits for its B fragments in the open: measured 149 us per layer at 256 x 20 with PW = 4)
-// BQ16 (round 5): the stashed basis is block-quantised (edge_f16.hip, f16x3.h): a slot block is 8.5 KiB -- eight 1 KiB fragments of
-// 16-bit mantissas, then 512 B of exponent codes -- and the loader waves decode it into the operand planes (see the kernel).
-// X8 (round 4, needs BQ16): the two CROSS products of the split scheme on the fp8 matrix instruction.  They sit 2^-11 below the
+// BFP8: the residual plane of the stashed basis is OCP fp8 e4m3 (edge_f16.hip): a slot block is 12 KiB -- eight 1 KiB hi
+// fragments, then eight 512 B lo fragments (8 bytes per lane), widened to fp16 in registers (exact) in front of their MFMAs.
+// X8 (round 4, needs BFP8): the two CROSS products of the split scheme on the fp8 matrix instruction.  They sit 2^-11 below the
 // main product, so four significand bits per operand are enough (profiles/r04_cross_precision_study.txt); both cross products
 // of a PAIR of k-blocks are one v_mfma_scale_f32_16x16x128_f8f6f4 with unit scales --
 //     A = [a1_8(kb) | a1_8(kb+1) | a2_8(kb) | a2_8(kb+1)]   (packed on the host: model.hip, pack_conv_cross_fp8; 64 registers)
-//     B = [b2_8(kb) | b2_8(kb+1) | b1_8(kb) | b1_8(kb+1)]   (b2_8 = e4m3 of the residual, b1_8 = e4m3(b1): both written by the loader
-//                                                            waves' decode -- the 8-byte LDS reads land in place)
+//     B = [b2_8(kb) | b2_8(kb+1) | b1_8(kb) | b1_8(kb+1)]   (b2_8 = the stash's residual planes as stored -- the two 8-byte LDS reads
+//                                                            land in place --, b1_8 = e4m3(b1), converted here)
 // -- 36 cycles for what took four fp16 instructions of 18 (tools/exp/fp8_mfma_check.hip); with the two main products a pair of
 // k-blocks costs 72 cycles of the matrix pipe instead of 108.  a1_8 = e4m3(64 a1), a2_8 = e4m3(64 a2): K = main + X / (64 * 2^11).
 // A timing-only build that dropped a third of the matrix work measured 140.6 -> 122.3 us per launch at 256 x 20
 // (profiles/r04a_conv_proj_sweep.txt); the real kernel, all products kept: 133.8 -> 125.1 us, step 1.414 -> 1.360 ms (same box).
 typedef int i32x8 __attribute__((ext_vector_type(8)));
 namespace {
-// four fp16 -> four e4m3 (round to nearest even, saturating) INTO `into`: each conversion writes one 16-bit word of its
+// four fp16 -> four e4m3 (round to nearest even; NOT saturating: beyond 464 the instruction returns NaN -- measured in round 5,
+// tools/exp/fp8_cvt_check.hip; such a basis value surfaces as NONFINITE and the host repeats the evaluation on fp16 planes) INTO `into`: each conversion writes one 16-bit word of its
 // destination and keeps the other, so the destination is an input too -- converting into the register that already is the MFMA
 // operand's slot (its old content is dead) costs no move
 __device__ __forceinline__ int cp_cvt4_fp8(int into, unsigned h01, unsigned h23) {
@@ -96,9 +97,9 @@ __device__ __forceinline__ int cp_cvt4_fp8(int into, unsigned h01, unsigned h23)
 #define CP_X8_SCALE_A 0x6e6e6e6e
 #define CP_X8_SCALE_B 0x7f7f7f7f
 
-template <int C, int D, int PW, bool BQ16, bool X8 = false>
+template <int C, int D, int PW, bool BFP8, bool X8 = false>
 __global__ __launch_bounds__(64 * (PW + 4), (PW + 4) / 4) void conv_proj_kernel(
-    const u32x4* __restrict__ basis,     // [N*8 slots][16 fragments = (k-block, plane)][64 lanes] x 16 bytes  (BQ16: 8.5 KiB blocks, see above)
+    const u32x4* __restrict__ basis,     // [N*8 slots][16 fragments = (k-block, plane)][64 lanes] x 16 bytes  (BFP8: see above)
     const u32x4* __restrict__ wchunks,   // this layer's projection chunks of the packed fp16x3 stream: [C/32][32][64]
     const u32x4* __restrict__ x8w,       // X8: this layer's fp8 cross operands [C/16 tiles][D/64 pairs][2][64 lanes] x 16 bytes
     const int32_t* __restrict__ deg, const int32_t* __restrict__ src,
@@ -106,32 +107,24 @@ __global__ __launch_bounds__(64 * (PW + 4), (PW + 4) / 4) void conv_proj_kernel(
     const float* __restrict__ fk,        // [16(o)][16(p)][C]
     const float* __restrict__ conv_bias, int n0, int N /* receivers n0 .. n0 + N - 1 (absolute indices into whole-batch arrays) */,
     float* __restrict__ x_conv,          // [N][16][C]
-    int32_t* __restrict__ status,        // sticky ARREAU_STATUS_* word of the model
     int reverse)  // walk the receivers from the last to the first (see the launcher: the Infinity Cache holds the END of the last pass)
 {
     static_assert(C == 128 && D == 256, "roles and register budgets assume C = 128, D = 256");
-    static_assert(!X8 || BQ16, "the fp8 cross products take the e4m3 planes the loader waves decode");
+    static_assert(!X8 || BFP8, "the fp8 cross products take the stash's e4m3 residual plane as it is stored");
     constexpr int K = 8, NKB = D / 32;
-    constexpr unsigned SLOT_BYTES = BQ16 ? 8704 : 16384;   // a slot block of the stash in HBM
-    // BQ16 (round 5): the stash holds block-quantised values (f16x3.h: 16-bit mantissas + one exponent code per lane block), so a
-    // slot takes TWO places in LDS.  (1) The landing ring of the copies: 8 KiB of mantissa fragments + FOUR copies of the 512 B
-    // exponent plane -- each loader wave fetches the plane for itself (lanes 0-31 of a 16-byte LDS-DMA), because a wave can only
-    // wait for its OWN copies: with private planes every wave issues the same three copies per slot and the counted waits are the
-    // ones round 4 ran with (the three extra 512 B requests per slot hit in L2).  (2) A ring of three DECODED slots in the layout
-    // the projection waves have read since round 4: 8 KiB of fp16 fragments b1 = f16(q), then 4 KiB b2_8 = e4m3((q - b1) 2^11),
-    // then 4 KiB b1_8 = e4m3(b1).  The loader wave that copied k-blocks 2 w, 2 w + 1 decodes them -- its own copies, behind its
-    // own counted wait, in front of the barrier that publishes the slot; ~5 vector instructions per value, 16 values per lane and
-    // slot step, on waves that otherwise wait.  Decoded slot q + 1 is written during step q into the buffer of slot q - 2, which
-    // the projection waves left before SYNC_(q-1).
-    constexpr unsigned ENC_LDS = BQ16 ? 8192 + 4 * 512 : 16384;  // a landing-ring entry
-    constexpr unsigned SLOT_LDS = 16384;                          // what the projection waves walk (decoded slot / two fp16 planes)
-    constexpr int NC = BQ16 ? 3 : 4;  // copies per loader wave and slot
-    // NINE landing buffers (slot q of the workgroup's sequence lives in buffer q mod 9): the stream's rate is bytes in flight over the
-    // loaded HBM latency, and an LDS-DMA byte in flight needs its landing place for the whole flight.
+    constexpr unsigned SLOT_BYTES = BFP8 ? 12288 : 16384;   // a slot block of the stash in HBM
+    // X8: in LDS a slot takes 16 KiB -- behind the two stashed planes a third one, b1_8 = e4m3(b1), 8 bytes per lane and k-block like
+    // the residual plane.  It is written by the MIX wave that copied the fp16 fragments it converts (its own copies, behind its own
+    // counted wait, before the barrier that publishes the slot): the projection wave, alone on its SIMD, pays ~7.5 cycles for every
+    // vector instruction it issues (a timing-only build without its 32 conversions per slot ran 120 -> 109 us per launch), the mix
+    // wave has the time.
+    constexpr unsigned SLOT_LDS = X8 ? 16384 : SLOT_BYTES;
+    constexpr int NC = SLOT_BYTES / 4096;  // 1 KiB copies per mix wave and slot
+    // NINE slot buffers (slot q of the workgroup's sequence lives in buffer q mod 9) + one tile = 152 KiB of the CU's 160:
+    // the stream's rate is bytes in flight over the loaded HBM latency (about 4.3 us: 80-96 KiB in flight per CU gave
+    // 4.7 TB/s with eight buffers), and an LDS-DMA byte in flight needs its landing place for the whole flight.
     constexpr int RING = 9;
-    constexpr int RINGP = BQ16 ? 3 : RING;  // buffers the projection waves cycle through
-    __shared__ u32x4 ring[RING][ENC_LDS / 16];
-    __shared__ u32x4 dec[BQ16 ? 3 : 1][BQ16 ? SLOT_LDS / 16 : 1];
+    __shared__ u32x4 ring[RING][SLOT_LDS / 16];
     __shared__ __attribute__((aligned(16))) float tile[16 * CP_STR];      // x1 of the receiver just finished
     const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
@@ -224,11 +217,11 @@ __global__ __launch_bounds__(64 * (PW + 4), (PW + 4) / 4) void conv_proj_kernel(
         constexpr int DIST = (PW == 4 || X8) ? 2 : 1, NBUF = (PW == 4 || X8) ? 4 : 2;
         typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
         u32x4 b1[NBUF], b2[NBUF];
-        u32x2_t b8[NBUF];  // BQ16 without X8: the e4m3 residual fragment (8 fp8 per lane), widened in front of its MFMAs
+        u32x2_t b8[NBUF];  // BFP8: the lo fragment as stored (8 fp8 per lane)
         // X8: the fp8 operand of a pair of k-blocks, [b2_8(kb) | b2_8(kb + 1) | b1_8(kb) | b1_8(kb + 1)]: two blocks alternate (the
         // residual fragments of the next pair arrive from LDS while this pair's block is the MFMA's operand)
         i32x8 B8[2] = {i32x8{0, 0, 0, 0, 0, 0, 0, 0}, i32x8{0, 0, 0, 0, 0, 0, 0, 0}};
-        const char* ring_b = BQ16 ? reinterpret_cast<const char*>(&dec[0][0]) : reinterpret_cast<const char*>(&ring[0][0]);
+        const char* ring_b = reinterpret_cast<const char*>(&ring[0][0]);
         const unsigned hi_off = 16u * lane, lo_off = 8192u + 8u * lane;
         auto frag = [&](unsigned base /* byte offset of the slot buffer: wave-uniform */, int kb, int sl_) {
             if constexpr (X8) {
@@ -239,7 +232,7 @@ __global__ __launch_bounds__(64 * (PW + 4), (PW + 4) / 4) void conv_proj_kernel(
                 B8[(kb >> 1) & 1][2 * (kb & 1) + 1] = (int)t[1];
                 B8[(kb >> 1) & 1][4 + 2 * (kb & 1)] = (int)t8[0];
                 B8[(kb >> 1) & 1][4 + 2 * (kb & 1) + 1] = (int)t8[1];
-            } else if constexpr (BQ16) {
+            } else if constexpr (BFP8) {
                 b1[sl_] = *reinterpret_cast<const u32x4*>(ring_b + base + hi_off + 1024 * kb);
                 b8[sl_] = *reinterpret_cast<const u32x2_t*>(ring_b + base + lo_off + 512 * kb);
             } else {
@@ -305,7 +298,7 @@ __global__ __launch_bounds__(64 * (PW + 4), (PW + 4) / 4) void conv_proj_kernel(
                 if (s + 2 < K) load_x(srow, s + 2, (s + 2) & 3);
                 else load_x(srow_next, s + 2 - K, (s + 2) & 3);  // (the last receiver re-reads its own rows: never used)
                 const unsigned f = (unsigned)rb * SLOT_LDS;
-                rb = rb == RINGP - 1 ? 0 : rb + 1;
+                rb = rb == RING - 1 ? 0 : rb + 1;
                 const unsigned f_next = (unsigned)rb * SLOT_LDS;
                 auto kstep = [&](int kb) {  // same product order per accumulator as MmaStream16 (edge_f16.hip)
                     if constexpr (X8) return;
@@ -314,8 +307,8 @@ __global__ __launch_bounds__(64 * (PW + 4), (PW + 4) / 4) void conv_proj_kernel(
                     else frag(f_next, kk - NKB, kk % NBUF);  // first k-blocks of the next slot (published by this slot's barrier;
                                                              // at the very end of the sequence: a buffer nobody writes any
                                                              // more, never used)
-                    const int s2 = BQ16 ? 0 : slot;  // (the widened fp8 fragment is made right in front of its MFMAs: one copy)
-                    if constexpr (BQ16) {
+                    const int s2 = BFP8 ? 0 : slot;  // (the widened fp8 fragment is made right in front of its MFMAs: one copy)
+                    if constexpr (BFP8) {
 #pragma unroll
                         for (int w2 = 0; w2 < 2; ++w2) {
                             b2[0][2 * w2] = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(b8[slot][w2], 1.0f, false));
@@ -466,68 +459,38 @@ __global__ __launch_bounds__(64 * (PW + 4), (PW + 4) / 4) void conv_proj_kernel(
     const unsigned ring_base = __builtin_amdgcn_readfirstlane((unsigned)(size_t)&ring[0][0]);
     const unsigned ring0 = ring_base + 1024u * NC * w4;
     int wb = 0;  // ring buffer the next copy goes to (copies are issued in slot order)
-    auto copy_slot = [&](int n, int s) {  // this wave's share of slot s of receiver n -> the next ring buffer
-        if constexpr (BQ16) {
-            // the mantissa fragments of k-blocks 2 w4, 2 w4 + 1 and a private copy of the 512 B exponent plane: the wave decodes
-            // exactly what it copied (three copies per wave and slot, like round 4's form)
+    auto copy_slot = [&](int n, int s) {  // this wave's quarter of slot s of receiver n -> the next ring buffer
+        if constexpr (X8) {
+            // the fp16 fragments of k-blocks 2 w4, 2 w4 + 1 and the KiB that holds their two residual fragments: the wave converts
+            // exactly what it copied
             const char* g = reinterpret_cast<const char*>(basis) + ((size_t)n * K + s) * SLOT_BYTES;
-            const unsigned l = ring_base + wb * ENC_LDS;
+            const unsigned l = ring_base + wb * SLOT_LDS;
             cp_glds16(lane16, g + 2048 * w4, l + 2048u * w4);
             cp_glds16(lane16, g + 2048 * w4 + 1024, l + 2048u * w4 + 1024u);
-            if (lane < 32) cp_glds16(lane16, g + 8192, l + 8192u + 512u * w4);
+            cp_glds16(lane16, g + 8192 + 1024 * w4, l + 8192u + 1024u * w4);
         } else {
             const char* g = reinterpret_cast<const char*>(basis) + ((size_t)n * K + s) * SLOT_BYTES + 1024u * NC * w4;
 #pragma unroll
-            for (int j = 0; j < NC; ++j) cp_glds16(lane16, g + 1024 * j, ring0 + wb * ENC_LDS + 1024u * j);
+            for (int j = 0; j < NC; ++j) cp_glds16(lane16, g + 1024 * j, ring0 + wb * SLOT_BYTES + 1024u * j);
         }
         wb = wb == RING - 1 ? 0 : wb + 1;
     };
-    // BQ16: decode the two k-blocks this wave copied of the slot in landing buffer `cb` into decoded buffer `db` (its copies have
-    // landed: called behind the counted wait that covers them, in front of the barrier that publishes the slot)
-    int cb = 0, db = 0;
-    unsigned big = 0;  // a decoded value beyond e4m3's range (448) was seen: its fp8 copies saturate (status flag at the end)
-    auto convert_slot = [&](bool live /* the slot holds an edge (wave-uniform): only then may its values raise the range flag */) {
-        if constexpr (BQ16) {
-            const char* src = reinterpret_cast<const char*>(&ring[0][0]) + (unsigned)cb * ENC_LDS;
-            char* dst = reinterpret_cast<char*>(&dec[0][0]) + (unsigned)db * SLOT_LDS;
-            const unsigned ecs = *reinterpret_cast<const unsigned short*>(src + 8192 + 512 * w4 + 8 * lane + 2 * w4);
+    // X8: b1_8 of the two k-blocks this wave copied, for the slot in ring buffer `cb` (its copies have landed: called behind the
+    // counted wait that covers them, in front of the barrier that publishes the slot)
+    int cb = 0;
+    auto convert_slot = [&]() {
+        if constexpr (X8) {
+            char* slot = reinterpret_cast<char*>(&ring[0][0]) + (unsigned)cb * SLOT_LDS;
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
-                const int kb = 2 * w4 + j;
-                const u32x4 mq = *reinterpret_cast<const u32x4*>(src + 1024 * kb + 16 * lane);
-                const unsigned ec = (ecs >> (8 * j)) & 0xffu;
-                const float sc = bq_scale(ec);
-                u32x4 hi4;
-                unsigned lo[4];
-#pragma unroll
-                for (int pp = 0; pp < 4; ++pp) {
-                    unsigned hi;
-                    split_pair2<false>(bq_decode_pair(mq[pp], sc), hi, lo[pp]);
-                    hi4[pp] = hi;
-                }
+                const u32x4 h = *reinterpret_cast<const u32x4*>(slot + 1024 * (2 * w4 + j) + 16 * lane);
                 typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
-                u32x2_t b2_8, b1_8;
-                b2_8[0] = (unsigned)cp_cvt4_fp8(0, lo[0], lo[1]);
-                b2_8[1] = (unsigned)cp_cvt4_fp8(0, lo[2], lo[3]);
-                b1_8[0] = (unsigned)cp_cvt4_fp8(0, hi4[0], hi4[1]);
-                b1_8[1] = (unsigned)cp_cvt4_fp8(0, hi4[2], hi4[3]);
-                *reinterpret_cast<u32x4*>(dst + 1024 * kb + 16 * lane) = hi4;
-                *reinterpret_cast<u32x2_t*>(dst + 8192 + 512 * kb + 8 * lane) = b2_8;
-                *reinterpret_cast<u32x2_t*>(dst + 12288 + 512 * kb + 8 * lane) = b1_8;
-                {
-                    // |q| < 2^E: only blocks with E >= 9 (code >= 41) can hold a value above 448 -- look at them (rare).  Beyond 448 the
-                    // e4m3 planes saturate: b1_8 (fp8 cross products) and, from 1024 on, the residual b2_8 itself
-                    if (live && ec >= 41u && ec != BQ_CODE_NAN) {
-#pragma unroll
-                        for (int pp = 0; pp < 4; ++pp) {
-                            const f32x2 q = bq_decode_pair(mq[pp], sc);
-                            big |= (fabsf(q.x) > 448.0f || fabsf(q.y) > 448.0f) ? 1u : 0u;
-                        }
-                    }
-                }
+                u32x2_t o;
+                o[0] = (unsigned)cp_cvt4_fp8(0, h[0], h[1]);
+                o[1] = (unsigned)cp_cvt4_fp8(0, h[2], h[3]);
+                *reinterpret_cast<u32x2_t*>(slot + 12288 + 512 * (2 * w4 + j) + 8 * lane) = o;
             }
             cb = cb == RING - 1 ? 0 : cb + 1;
-            db = db == 2 ? 0 : db + 1;
         }
     };
     const unsigned st_off = 4u * ((8 * ph) * C + c);
@@ -542,15 +505,13 @@ __global__ __launch_bounds__(64 * (PW + 4), (PW + 4) / 4) void conv_proj_kernel(
         cp_store4<24 * C>(xb, st_off, out[6] + bias);
         cp_store4<28 * C>(xb, st_off, out[7] + bias);
     };
-    // the receiver's degree by a SCALAR load (wave-uniform address; SMEM counts in lgkmcnt, not in the vmcnt queue of the copies)
-    auto deg_of = [&](int n) { return BQ16 ? min(deg[__builtin_amdgcn_readfirstlane(n)], K) : K; };
     // prologue: all eight slots of the first receiver are requested, slot 0 is waited for (the 7 NC younger copies stay in flight)
     {
         const int n = n0 + local_of(m);
 #pragma unroll
         for (int s = 0; s < K; ++s) copy_slot(n, s);
         cp_wait_but<7 * NC>();
-        convert_slot(0 < deg_of(n));   // slot 0
+        convert_slot();   // slot 0
         __syncthreads();  // SYNC_-1
     }
     int i = 0, n_prev = 0;
@@ -560,7 +521,6 @@ __global__ __launch_bounds__(64 * (PW + 4), (PW + 4) / 4) void conv_proj_kernel(
         const int n = n0 + local_of(m);
         const bool has_next = mn < n_iter;
         const int n_next = has_next ? n0 + local_of(mn) : n;
-        const int nd_cur = deg_of(n), nd_next = deg_of(n_next);
 #pragma unroll
         for (int s = 0; s < K; ++s) {
             // Before SYNC_q (q = 8 i + s) this wave's share of slot q + 1 must have landed.  Younger than that copy, in
@@ -570,10 +530,7 @@ __global__ __launch_bounds__(64 * (PW + 4), (PW + 4) / 4) void conv_proj_kernel(
             if (!has_next) cp_wait_but<0>();
             else if (s <= 6 && i >= 2) cp_wait_but<6 * NC + 8>();
             else cp_wait_but<6 * NC>();
-            // slot q + 1 (at the very end of the sequence: a buffer nobody reads any more).  Slots beyond the receiver's degree were
-            // never written by the edge kernel: they are streamed and decoded like the others (the projection waves drop them),
-            // but whatever bytes they hold must not raise the range flag
-            convert_slot(s + 1 < K ? s + 1 < nd_cur : (has_next && 0 < nd_next));
+            convert_slot();   // slot q + 1 (at the very end of the sequence: a buffer nobody reads any more)
             __syncthreads();  // SYNC_q: slot q - 1's buffer is free
             if (has_next) copy_slot(n_next, s);  // slot q + 8 = slot s of the next receiver
             if (i > 0) {  // orientation mix of the previous receiver, two input orientations per step (o ascending)
@@ -607,7 +564,6 @@ __global__ __launch_bounds__(64 * (PW + 4), (PW + 4) / 4) void conv_proj_kernel(
     // target a chunk nobody will read; the hardware's implicit wait at s_endpgm is not relied upon)
     cp_wait_but<0>();
     __syncthreads();  // the last receiver's tile is complete
-    if (big) atomicOr(status, ARREAU_STATUS_BASIS_RANGE);  // (behind the full wait: no counted wait follows)
 #pragma unroll
     for (int o = 0; o < 16; ++o) {
         const float xo = tile[o * CP_STR + c];
@@ -649,12 +605,12 @@ int arreau_launch_conv_proj(const arreau_model* m, int layer, const float* basis
     const u32x4* x8w = reinterpret_cast<const u32x4*>(m->conv_x8) + (size_t)layer * (m->C / 16) * (m->D / 64) * 2 * 64;
     auto launch = [&](auto kernel, int threads) {
         ARREAU_LAUNCH(kernel, dim3(blocks), dim3(threads), 0, s, reinterpret_cast<const u32x4*>(basis), wchunks, x8w, deg, src, x_in,
-                      m->fk + (size_t)layer * 16 * 16 * m->C, m->conv_bias + (size_t)layer * m->C, n0, Ng, x_conv, m->status, reverse);
+                      m->fk + (size_t)layer * 16 * 16 * m->C, m->conv_bias + (size_t)layer * m->C, n0, Ng, x_conv, reverse);
     };
-    const bool fp8 = arreau_basis_q16(m);  // (block-quantised stash; the name is round 4's)
+    const bool fp8 = arreau_basis_fp8(m);
     arreau_prof_conv(0, s);
     // (round 5: the twelve-wave geometry -- eight projection waves of one tile each, ARREAU_CONV_PROJ_WAVES=8 -- is gone: it never
-    // ran faster than this one and its loader waves have no registers for the decode)
+    // ran faster than this one)
     m->ran_x8 = fp8 && arreau_cross_fp8(m) ? 1 : 0;
     if (m->ran_x8) launch(conv_proj_kernel<128, 256, 4, true, true>, 512);
     else if (fp8) launch(conv_proj_kernel<128, 256, 4, true>, 512);

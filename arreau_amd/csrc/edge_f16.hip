@@ -83,15 +83,15 @@ extern "C" int arreau_debug_edge_ticks(unsigned long long* out8, int reset) {
 // storing their results: one 16 KiB block per edge slot ([k-block 0..7][plane][lane] x 16 bytes: whole 1 KiB, fully
 // coalesced store instructions), 1 KiB per (edge, orientation) row written ONCE, where the K stash writes L*C*3 = 1,920
 // bytes.  The projections move into the per-layer message kernel (conv_proj.hip), which streams those blocks through LDS.
-// BQ16 (round 5; replaces round 3's fp16 + e4m3 planes): the basis leaves BLOCK-QUANTISED (f16x3.h: bq_encode8) -- per edge slot
-// an 8.5 KiB block: [8 k-blocks] x 1 KiB of 16-bit mantissas in the fragment order (lane x 16 bytes = the lane's eight values of
-// the k-block), then 512 B of exponent codes (lane x 8 bytes, byte u = the code of k-block u).  2.125 bytes per basis value: the
-// only large stream of the step shrinks from 503 to 356 MB at 256 x 20 (the two-plane forms: 3 and 4 bytes per value).  The
-// message kernel's loader waves turn a block back into the operand planes (conv_proj.hip).
-// The kernels that project IN PLACE (PROJ = true: small launches, the round-2 pair) round their basis values to the same grid
-// (bq_round8) and their residual plane to e4m3 (round_lo_fp8: exact for all but tiny blocks) when BQ16 is set, so that every
-// path evaluates the same numbers -- a crystal alone (small-launch kernels) equals, bit for bit, the same crystal inside a
-// large batch (basis form).
+// BFP8 (basis form only): the residual plane leaves as OCP fp8 e4m3 instead of fp16 -- 3 bytes per basis value, a 12 KiB
+// block per slot ([8 k-blocks] x 1 KiB of hi fragments, then [8] x 512 B of lo fragments).  The basis then carries 11 + 4
+// significand bits; in the fp32 oracle that changes the network outputs by no more than the 4-byte form does (both at the
+// fp32 rounding floor: tools/exp/basis_precision_study.py, profiles/r03_basis_precision_study.txt), and it takes a quarter
+// off the only large stream of the step.
+// The residual plane of a basis value pair rounded to fp8 e4m3 and widened back (exact): what the basis form stores.  The
+// kernels that project IN PLACE (PROJ = true: small launches, the round-2 pair) apply the same rounding to their B operand
+// when BFP8 is set, so that every path evaluates the same numbers -- a crystal alone (small-launch kernels) equals, bit for
+// bit, the same crystal inside a large batch (basis form).
 __device__ __forceinline__ unsigned round_lo_fp8(unsigned lo_pair) {
     typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
     typedef short s2_t __attribute__((ext_vector_type(2)));
@@ -107,7 +107,7 @@ __device__ __forceinline__ unsigned round_lo_fp8(unsigned lo_pair) {
 // consecutive rows cover all eight groups for writers and readers alike.
 __device__ __forceinline__ int relayout_cell(int plane, int row, int slot) { return 128 * plane + 4 * row + (slot ^ ((row >> 1) & 3)); }
 
-template <int C, int D, int EH_WAVES, bool K3 /* K tiles as 3-byte floats (internal.h) */, bool PROJ = true, bool BQ16 = false>
+template <int C, int D, int EH_WAVES, bool K3 /* K tiles as 3-byte floats (internal.h) */, bool PROJ = true, bool BFP8 = false>
 __global__ __launch_bounds__(64 * EH_WAVES, 2) void edge_kernel_f16x3(
     const float* __restrict__ nbr_dir,   // [N][k][3]
     const float* __restrict__ nbr_dist,  // [N][k]
@@ -153,7 +153,6 @@ __global__ __launch_bounds__(64 * EH_WAVES, 2) void edge_kernel_f16x3(
         if constexpr (PROJ) dma_wait();
         else {
             if (pend == 0) dma_wait();
-            else if (pend == 1) dma_wait_but<1>();
             else if (pend == 2) dma_wait_but<2>();
             else dma_wait_but<4>();
         }
@@ -324,7 +323,6 @@ __global__ __launch_bounds__(64 * EH_WAVES, 2) void edge_kernel_f16x3(
         EDGE_TICK(1);
         // ---- layer 2: basis = GELU(W2 . h + b2) * window ------------------------------------------------------
         u32x4 b16[2][TD][2];  // [column block][k-block = 32 basis functions][plane]
-        unsigned ecode[2][2] = {{0u, 0u}, {0u, 0u}};  // BQ16 basis form: the exponent codes of the wave's two slots, byte u = k-block u
 #pragma unroll
         for (int u = 0; u < TD; ++u) {
             Acc16 acc;
@@ -352,60 +350,53 @@ __global__ __launch_bounds__(64 * EH_WAVES, 2) void edge_kernel_f16x3(
                 ms.template run<TC, 2 * TC>(acc, h16);
 #pragma unroll
                 for (int nb = 0; nb < 2; ++nb) {
-                    float bv[8];  // the lane's eight basis values of (k-block u, column block nb): index 4 mt + r
 #pragma unroll
                     for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
                         for (int pr = 0; pr < 2; ++pr) {
                             const f32x2 pre = fma2(f32x2{acc.x[mt][nb][2 * pr], acc.x[mt][nb][2 * pr + 1]}, splat2(F16X3_INV_SCALE),
                                                    f32x2{acc.m[mt][nb][2 * pr], acc.m[mt][nb][2 * pr + 1]});
-                            const f32x2 gw = gelu_fast2(pre) * splat2(win16[nb]);  // |window| <= 1
-                            bv[4 * mt + 2 * pr] = gw.x;
-                            bv[4 * mt + 2 * pr + 1] = gw.y;
+                            unsigned hi, lo;
+                            split_pair2<false>(gelu_fast2(pre) * splat2(win16[nb]), hi, lo);  // |window| <= 1
+                            if constexpr (PROJ && BFP8) lo = round_lo_fp8(lo);
+                            b16[nb][u][0][2 * mt + pr] = hi;
+                            b16[nb][u][1][2 * mt + pr] = lo;
                         }
-                    if constexpr (BQ16 && !PROJ) {
-                        // basis form: the block leaves as mantissas + exponent code, no planes are formed here
-                        unsigned mq[4], ec;
-                        bq_encode8(bv, mq, ec);
-                        b16[nb][u][0] = u32x4{mq[0], mq[1], mq[2], mq[3]};
-                        ecode[nb][u >> 2] |= ec << (8 * (u & 3));
-                    } else {
-                        if constexpr (BQ16) bq_round8(bv);  // the values the basis form would read back
-#pragma unroll
-                        for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-                            for (int pr = 0; pr < 2; ++pr) {
-                                unsigned hi, lo;
-                                split_pair2<false>(f32x2{bv[4 * mt + 2 * pr], bv[4 * mt + 2 * pr + 1]}, hi, lo);
-                                if constexpr (BQ16) lo = round_lo_fp8(lo);
-                                b16[nb][u][0][2 * mt + pr] = hi;
-                                b16[nb][u][1][2 * mt + pr] = lo;
-                            }
-                    }
                 }
                 if constexpr (!PROJ) {
-                    // the finished k-block of the basis leaves: fragment u of slot 2 wn + nb, 1 KiB per instruction
-                    // (asm stores: a KNOWN count per chunk, which wait_copies() relies on; wait states behind each: the
+                    // the finished k-block of the basis leaves: fragment (u, plane) of slot 2 wn + nb, 1 KiB per instruction
+                    // (asm stores: a FIXED count per chunk, which wait_copies() relies on; wait states behind each: the
                     // data registers of a VMEM store of more than 64 bits must not be rewritten at once)
                     const bool full_b = 2 * wn + 1 < k;  // wave-uniform: the wave's second slot exists
-                    constexpr unsigned SLOT = BQ16 ? 8704u : 16384u;
+                    constexpr unsigned SLOT = BFP8 ? 12288u : 16384u;
                     const char* blk = reinterpret_cast<const char*>(kbuf) + ((size_t)node * k + 2 * wn) * SLOT;
 #pragma unroll
                     for (int nb = 0; nb < 2; ++nb) {
                         if (nb == 1 && !full_b) continue;
-                        if constexpr (BQ16) {
+                        if constexpr (BFP8) {
                             asm volatile("global_store_dwordx4 %0, %1, %2" ARREAU_K_STORE_TAIL
                                          :
                                          : "v"(lane16), "v"(b16[nb][u][0]), "s"(blk + SLOT * nb + 1024 * u)
                                          : "memory");
-                            if (u == TD - 1) {  // the slot's exponent codes: byte u of the lane's eight = k-block u
-                                typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
-                                const u32x2_t ecs = {ecode[nb][0], ecode[nb][1]};
-                                asm volatile("global_store_dwordx2 %0, %1, %2"
-                                             :
-                                             : "v"(lane16 >> 1), "v"(ecs), "s"(blk + SLOT * nb + 8192)
-                                             : "memory");
+                            typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
+                            typedef short s2_t __attribute__((ext_vector_type(2)));
+                            unsigned lo8[2];
+#pragma unroll
+                            for (int w2 = 0; w2 < 2; ++w2) {  // halves 4 w2 .. 4 w2 + 3 of the lane's eight -> one dword of fp8
+                                // (element copies first: __builtin_bit_cast applied to a vector-element lvalue reads element
+                                // 0 whatever the index -- hipcc 7.2)
+                                const unsigned p0 = b16[nb][u][1][2 * w2], p1 = b16[nb][u][1][2 * w2 + 1];
+                                s2_t r = {0, 0};
+                                r = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(r, __builtin_bit_cast(h2_t, p0), 1.0f, false);
+                                r = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(r, __builtin_bit_cast(h2_t, p1), 1.0f, true);
+                                lo8[w2] = __builtin_bit_cast(unsigned, r);
                             }
+                            typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+                            const u32x2_t lo = {lo8[0], lo8[1]};
+                            asm volatile("global_store_dwordx2 %0, %1, %2"
+                                         :
+                                         : "v"(lane16 >> 1), "v"(lo), "s"(blk + SLOT * nb + 8192 + 512 * u)
+                                         : "memory");
                         } else {
 #pragma unroll
                             for (int plane = 0; plane < 2; ++plane)
@@ -415,8 +406,7 @@ __global__ __launch_bounds__(64 * EH_WAVES, 2) void edge_kernel_f16x3(
                                              : "memory");
                         }
                     }
-                    if constexpr (BQ16) pend += (full_b ? 2 : 1) * (u == TD - 1 ? 2 : 1);
-                    else pend += full_b ? 4 : 2;
+                    pend += full_b ? 4 : 2;
                 }
             }
             sl = slot_after(sl, 1);
@@ -530,7 +520,7 @@ __global__ __launch_bounds__(64 * EH_WAVES, 2) void edge_kernel_f16x3(
 // measured on MI355X (tools/gpu_edge_split_sweep.sh): 60 / 120 / 200 / 260 / 380 receivers: 19.8 / 31.8 / 56.9 / 71.0 / 88.1 us
 // against 65.9 / 67.0 / 69.0 / 71.8 / 74.0 us of the persistent form
 #define ARREAU_EDGE_SPLIT_MAX_NODES 240
-template <int C, int D, bool K3, bool BQ16>
+template <int C, int D, bool K3, bool BFP8>
 __global__ __launch_bounds__(512) void edge_kernel_f16x3_split(
     const float* __restrict__ nbr_dir, const float* __restrict__ nbr_dist, const int32_t* __restrict__ deg,
     const int32_t* __restrict__ batch, const float* __restrict__ lattice, const float* __restrict__ ori,
@@ -662,25 +652,15 @@ __global__ __launch_bounds__(512) void edge_kernel_f16x3_split(
 #pragma unroll
         for (int nb = 0; nb < 2; ++nb) {
             u32x4 hi4, lo4;
-            float bv[8];
 #pragma unroll
             for (int mt = 0; mt < 2; ++mt)
 #pragma unroll
                 for (int pr = 0; pr < 2; ++pr) {
                     const f32x2 pre = fma2(f32x2{acc.x[mt][nb][2 * pr], acc.x[mt][nb][2 * pr + 1]}, splat2(F16X3_INV_SCALE),
                                            f32x2{acc.m[mt][nb][2 * pr], acc.m[mt][nb][2 * pr + 1]});
-                    const f32x2 gw = gelu_fast2(pre) * splat2(win16[nb]);  // |window| <= 1
-                    bv[4 * mt + 2 * pr] = gw.x;
-                    bv[4 * mt + 2 * pr + 1] = gw.y;
-                }
-            if constexpr (BQ16) bq_round8(bv);  // the values the basis form would read back from its stash (f16x3.h)
-#pragma unroll
-            for (int mt = 0; mt < 2; ++mt)
-#pragma unroll
-                for (int pr = 0; pr < 2; ++pr) {
                     unsigned hi, lo;
-                    split_pair2<false>(f32x2{bv[4 * mt + 2 * pr], bv[4 * mt + 2 * pr + 1]}, hi, lo);
-                    if constexpr (BQ16) lo = round_lo_fp8(lo);
+                    split_pair2<false>(gelu_fast2(pre) * splat2(win16[nb]), hi, lo);  // |window| <= 1
+                    if constexpr (BFP8) lo = round_lo_fp8(lo);
                     hi4[2 * mt + pr] = hi;
                     lo4[2 * mt + pr] = lo;
                 }
@@ -812,7 +792,7 @@ int arreau_launch_edge_f16x3(const arreau_model* m, const float* dir, const floa
             ARREAU_LAUNCH(kernel, dim3((unsigned)(n1 - n0) * 4), dim3(512), 0, s, dir, dist, deg, batch, lattice, m->ori,
                                reinterpret_cast<const u32x4*>(m->edge_f16), m->b1, m->b2, m->cfg.radius, N, m->k, m->L, kbuf, n0);
         };
-        const bool bq = arreau_basis_q16(m);
+        const bool bq = arreau_basis_fp8(m);
         if (k3 && bq) launch(edge_kernel_f16x3_split<128, 256, true, true>);
         else if (k3) launch(edge_kernel_f16x3_split<128, 256, true, false>);
         else if (bq) launch(edge_kernel_f16x3_split<128, 256, false, true>);
@@ -826,7 +806,7 @@ int arreau_launch_edge_f16x3(const arreau_model* m, const float* dir, const floa
     // (decided from the WHOLE batch, not from this launch's range: the two forms lay the shared kbuf region out differently,
     // so slices of one batch on either side of the threshold must not mix them -- ADVICE round 3)
     if (arreau_basis_form(m, N)) {  // stop after layer 2, store the basis planes (the node-layer launcher projects them)
-        if (arreau_basis_q16(m))
+        if (arreau_basis_fp8(m))
             ARREAU_LAUNCH((edge_kernel_f16x3<128, 256, 8, false, false, true>), dim3(wgs), dim3(512), 0, s, dir, dist, deg, batch, lattice, m->ori,
                           reinterpret_cast<const u32x4*>(m->edge_f16), m->b1, m->b2, m->cfg.radius, N, m->k, m->L, kbuf, n0, n1);
         else
@@ -839,7 +819,7 @@ int arreau_launch_edge_f16x3(const arreau_model* m, const float* dir, const floa
         ARREAU_LAUNCH(kernel, dim3(wgs), dim3(512), 0, s, dir, dist, deg, batch, lattice, m->ori,
                            reinterpret_cast<const u32x4*>(m->edge_f16), m->b1, m->b2, m->cfg.radius, N, m->k, m->L, kbuf, n0, n1);
     };
-    const bool bq = arreau_basis_q16(m);
+    const bool bq = arreau_basis_fp8(m);
     if (k3 && bq) launch(edge_kernel_f16x3<128, 256, 8, true, true, true>);
     else if (k3) launch(edge_kernel_f16x3<128, 256, 8, true, true, false>);
     else if (bq) launch(edge_kernel_f16x3<128, 256, 8, false, true, true>);

@@ -95,62 +95,6 @@ __device__ __forceinline__ void split_pair2(f32x2 v, unsigned& hi, unsigned& lo)
     asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(lo) : "v"(hi), "s"(neg_scale), "v"(sc.x));
     asm("v_fma_mixhi_f16 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(lo) : "v"(hi), "s"(neg_scale), "v"(sc.y));
 }
-// ---- block-quantised basis values (round 5: the stash format of the basis form, "Q16") ----------------------------------
-// The eight basis values one lane holds of a k-block (one (edge, orientation) row, eight consecutive reduction indices in the
-// fragment order) share ONE power-of-two exponent E and are kept as signed 16-bit mantissas:
-//     q_i = m_i * 2^(E - 15),   m_i = rne(b_i * 2^(15 - E)),   max_i |b_i| * (1 + 2^-15) < 2^E   (so |m_i| <= 32767, no clamp)
-// -- 2.125 bytes per value in HBM (16 bytes of mantissas + 1 exponent byte per block) where the two planes of the split scheme
-// took 3 (fp16 + e4m3 residual) or 4 (fp16 + fp16).  In the fp32 oracle the network outputs move by no more than with those
-// planes (logits: 8.7e-7 from fp64 against 6.4e-7; profiles/r05_basis_q16_study.txt).  q_i is what EVERY fp16x3 path evaluates:
-// the kernels that project in place (small launches, the K pair) round their basis values the same way before they split them,
-// so a crystal alone equals, bit for bit, the same crystal inside a large batch (edge_f16.hip).  The planes of q_i:
-// hi = f16(q_i); the residual (q_i - hi) * 2^11 is a multiple of 2^(E - 4) below 2^(E - 1), i.e. four significant bits -- exact in
-// e4m3 while 2^(E - 4) >= 2^-9 (blocks whose largest value is at least 2^-6).
-// Exponent code (one byte): E + 32, E clamped to >= -32 (smaller blocks keep fewer bits: their values are below 2^-32);
-// 255 = "not representable": a non-finite value in the block, or one beyond the fp16 range (>= 65520, which the fp16 plane of
-// the previous format turned into inf) -- the block decodes to NaN, so an overflow stays as loud as it was (f16x3.h, top).
-// (A non-finite value never sits alone in a block: it comes from a non-finite hidden unit or attribute of its row, which
-// reaches every basis function of the row through the dense layer -- so the float maximum below, which drops NaNs next to
-// numbers, still sees one.)
-#define BQ_MAGIC 12582912.0f  // 1.5 * 2^23: fma(b, 2^s, magic) holds rne(b 2^s) in its low mantissa bits (two's complement)
-#define BQ_CODE_NAN 255u
-__device__ __forceinline__ void bq_encode8(const float (&v)[8], unsigned (&m)[4], unsigned& ec) {
-    float amax = fmaxf(fmaxf(fabsf(v[0]), fabsf(v[1])), fabsf(v[2]));
-    amax = fmaxf(fmaxf(amax, fabsf(v[3])), fabsf(v[4]));
-    amax = fmaxf(fmaxf(amax, fabsf(v[5])), fabsf(v[6]));
-    amax = fmaxf(amax, fabsf(v[7]));
-    const float am = fmaf(amax, 0x1p-15f, amax);
-    const int E = max(__builtin_amdgcn_frexp_expf(am), -32);  // am = f 2^E with f in [0.5, 1)  (0 -> 0)
-    const float scale = __builtin_amdgcn_ldexpf(1.0f, 15 - E);
-    float t[8];
-#pragma unroll
-    for (int i = 0; i < 8; ++i) t[i] = fmaf(v[i], scale, BQ_MAGIC);
-#pragma unroll
-    for (int p = 0; p < 4; ++p)  // low halves of t[2p], t[2p + 1]
-        m[p] = __builtin_amdgcn_perm(__float_as_uint(t[2 * p + 1]), __float_as_uint(t[2 * p]), 0x05040100u);
-    ec = am < 65520.0f ? (unsigned)(E + 32) : BQ_CODE_NAN;
-}
-// 2^(E - 15) of an exponent code (NaN for the "not representable" code)
-__device__ __forceinline__ float bq_scale(unsigned ec) {
-    return ec == BQ_CODE_NAN ? __builtin_nanf("") : __builtin_amdgcn_ldexpf(1.0f, (int)ec - 47);
-}
-// the two values of one mantissa dword
-__device__ __forceinline__ f32x2 bq_decode_pair(unsigned m, float scale) {
-    return f32x2{(float)(int)(short)(m & 0xffffu) * scale, (float)((int)m >> 16) * scale};
-}
-// the eight values as the stash would return them (the in-place form of encode + decode)
-__device__ __forceinline__ void bq_round8(float (&v)[8]) {
-    unsigned m[4], ec;
-    bq_encode8(v, m, ec);
-    const float sc = bq_scale(ec);
-#pragma unroll
-    for (int p = 0; p < 4; ++p) {
-        const f32x2 q = bq_decode_pair(m[p], sc);
-        v[2 * p] = q.x;
-        v[2 * p + 1] = q.y;
-    }
-}
-
 __device__ __forceinline__ Planes2 split_tile2(const f32x16& x) {
     Planes2 r;
 #pragma unroll

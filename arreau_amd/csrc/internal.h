@@ -55,9 +55,10 @@ struct arreau_model {
     int f16_ok;              // 1 when every packed weight fits fp16 (|w| < 6e4): the fp16x3 kernels may be used
     const float* conv_x8;    // [L] fp8 e4m3 cross-product operands of conv.kernel.weight (conv_proj.hip, round 4; uint8 data)
     int x8_ok;               // 1 when 64 |w| <= 448 for every kernel weight AND the calibration allows it: the fp8 cross products may be used
-    int q16_ok;              // 1 when the block-quantised basis stash passed the end-to-end calibration (model.hip: calibrate_message_formats)
-    float calib_q16, calib_x8;  // share of the parity bounds the formats used up on the calibration batch (Q16 stash; Q16 + fp8 cross products); -1: not measured
-    int calibrating;         // 1 while that calibration runs: basis form at any launch size, formats from q16_ok / x8_ok alone
+    int x8_weights_ok;       // 64 |w| <= 448 for every kernel weight (what x8_ok may be switched back to)
+    int fp8_ok;              // 1 when the fp8 (e4m3) residual plane of the basis stash passed the end-to-end calibration (model.hip: calibrate_message_formats)
+    float calib_fp8, calib_x8;  // share of the parity bounds the formats used up on the calibration batch (fp8 residual plane; that + fp8 cross products); -1: not measured
+    int calibrating;         // 1 while that calibration runs: basis form at any launch size, formats from fp8_ok / x8_ok alone
     float edge_act_bound, node_act_bound;  // weight-derived bounds of the fp16 operands of the edge / ConvNext chains (model.hip)
     // Arithmetic / geometry variants requested for this model (defaults from ARREAU_*_VARIANT at create,
     // arreau_model_set_variant overrides) and what the last arreau_predict_scores actually launched.
@@ -315,11 +316,12 @@ bool arreau_k3(const arreau_model* m);
 // planes instead of the L projected kernels, and each layer's message kernel projects them itself (conv_proj.hip) -- no K
 // stash.  The edge launcher and the node-layer launcher take the decision from the same fields and the same receiver count.
 bool arreau_basis_form(const arreau_model* m, int receivers);
-// Numerics switch of the split-precision edge path (round 5): the windowed basis is BLOCK-QUANTISED -- the eight values a lane
-// holds of a k-block share one power-of-two exponent and keep 16-bit mantissas (f16x3.h: bq_encode8; default) -- which is what the
-// basis form stores (2.125 bytes per value), applied by every fp16x3 edge kernel so that all launch sizes evaluate the same
-// numbers.  ARREAU_BASIS_Q16=0: two fp16 planes everywhere (the round-2 arithmetic, 4 bytes per value in the stash).
-bool arreau_basis_q16(const arreau_model* m);
+// Numerics switch of the split-precision edge path: the residual plane of the windowed basis is rounded to fp8 e4m3 (11 + 4
+// significand bits; default) -- what the basis form stores (3 bytes per value), applied by every fp16x3 edge kernel so that all
+// launch sizes evaluate the same numbers.  Round 5: per MODEL -- arreau_model_create keeps it only if its calibration batch says the
+// outputs hardly move (model.hip: calibrate_message_formats); ARREAU_BASIS_FP8=0 / 1 in the environment overrides either way
+// (0: both planes fp16 everywhere, the round-2 arithmetic).
+bool arreau_basis_fp8(const arreau_model* m);
 // Round 4: the two cross products of the per-layer kernel projection (conv_proj.hip) on the fp8 matrix instruction (twice the fp16
 // rate; operands e4m3: model.hip, pack_conv_cross_fp8).  Applies to the basis form with the fp8 residual plane; ARREAU_CROSS_FP8=0
 // keeps three fp16 products (bit-identical to the K pair of the small launches).  Read per call (tests toggle it).

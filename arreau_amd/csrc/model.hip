@@ -175,7 +175,8 @@ static float pack_linear_f16x3_m16(const float* W, int out_dim, int in_dim, int 
     return wmax;
 }
 
-// OCP fp8 e4m3fn, round to nearest even, saturating at +-448 (what v_cvt_scalef32_pk_fp8_f16 produces: tools/exp/fp8_cvt_check.hip)
+// OCP fp8 e4m3fn, round to nearest even, saturating at +-448.  (v_cvt_scalef32_pk_fp8_f16 rounds the same way up to 464 and returns
+// NaN beyond -- tools/exp/fp8_cvt_check.hip, measured on MI355X in round 5; the weights packed here are checked against 448 first.)
 static inline uint8_t f32_to_e4m3_rne_sat(float x) {
     const uint8_t sign = signbit(x) ? 0x80 : 0;
     const float a = fabsf(x);
@@ -296,19 +297,21 @@ struct BlobBuilder {
 
 // ---------------------------------------------------------------------------------------------------------------------------
 // Precision safety of the cheap operand formats of the message path (round 5), measured on the model itself like the range
-// bounds above are derived from it.  The per-layer kernel projection may read a block-quantised basis stash (f16x3.h: 16-bit
-// mantissas, one exponent per eight values -- 2.125 bytes per value instead of 4) and run its two cross products on fp8 (e4m3)
-// operands.  With weights like the initialisers produce, both leave the outputs at the fp32 rounding floor; with HEAVY-TAILED
-// weights (Student-t kernel / basis weights, a few rows fifty times the rest: profiles/r05_basis_q16_study.txt, second half) the
-// same formats cost up to 5.7e-6 on the logits -- ten times the exact fp32 kernels' distance to fp64, over half of the 1e-5
+// bounds above are derived from it.  The per-layer kernel projection may read a basis stash whose residual plane is fp8
+// (e4m3: 3 bytes per value instead of 4) and run its two cross products on fp8 (e4m3) operands.  With weights like the
+// initialisers produce, both leave the outputs at the fp32 rounding floor; with HEAVY-TAILED weights (Student-t kernel / basis
+// weights, a few rows fifty times the rest: profiles/r05_basis_q16_study.txt, second half; tests/helpers.py: make_heavy_tailed)
+// the fp8 cross products cost 3.3e-6 on the logits -- eight times the exact fp32 kernels' distance to fp64, a third of the 1e-5
 // parity target -- although the error of the projected kernels themselves is the same (a host-side calibration of K was written
 // first and could not tell the two models apart: what differs is how far the network carries the error).  So the check runs END
 // TO END, once, at arreau_model_create: one synthetic batch (16 crystals x 20 atoms, physical cells, t = T / 2, fixed seed)
 // through the score network with two fp16 planes + three fp16 products (the round-2 arithmetic, operand error 2^-22), with the
-// Q16 stash, and with the Q16 stash + fp8 cross products.  A format stays selected for this model only if it moves eps and the
-// logits by at most ARREAU_CALIB_SHARE (a tenth) of their parity bounds (1e-5 max(1, |eps|), 1e-5 max(1, |logits| / 8)); the measured shares
-// are reported (arreau_status.basis_q16_share / cross_fp8_share; -1 = not measured).  ARREAU_BASIS_Q16 / ARREAU_CROSS_FP8 in the
-// environment still override, ARREAU_CALIBRATE=0 skips the check (both formats on, the weights' range permitting).
+// fp8 residual plane, and with the fp8 residual plane + fp8 cross products.  A format stays selected for this model only if it
+// moves eps and the logits by at most ARREAU_CALIB_SHARE (a tenth) of their parity bounds (1e-5 max(1, |eps|), 1e-5 max(1,
+// |logits| / 8)); a format that makes the batch non-finite (the hardware's fp8 conversion returns NaN beyond 464) is dropped too.
+// The measured shares are reported (arreau_status.basis_fp8_share / cross_fp8_share; -1 = not measured).  ARREAU_BASIS_FP8 /
+// ARREAU_CROSS_FP8 in the environment still override, ARREAU_CALIBRATE=0 skips the check (both formats on, the weights' range
+// permitting), arreau_model_set_formats changes the selection afterwards.
 // ---------------------------------------------------------------------------------------------------------------------------
 #define ARREAU_CALIB_SHARE 0.1f
 static int calibrate_message_formats(arreau_model* m, hipStream_t s) {
@@ -348,16 +351,16 @@ static int calibrate_message_formats(arreau_model* m, hipStream_t s) {
     int rc = e == hipSuccess ? ARREAU_OK : ARREAU_EHIP;
     const int x8_weights = m->x8_ok;
     m->calibrating = 1;  // the basis form whatever the launch size; the formats below, whatever the environment says
-    const int modes[3][2] = {{0, 0}, {1, 0}, {1, 1}};  // {Q16 stash, fp8 cross products}
+    const int modes[3][2] = {{0, 0}, {1, 0}, {1, 1}};  // {fp8 residual plane in the stash, fp8 cross products}
     for (int v = 0; v < 3 && rc == ARREAU_OK; ++v) {
         if (modes[v][1] && !x8_weights) break;
-        m->q16_ok = modes[v][0]; m->x8_ok = modes[v][1];
+        m->fp8_ok = modes[v][0]; m->x8_ok = modes[v][1];
         float* o = d_out + (size_t)v * out1;
         rc = arreau_predict_scores(m, d_frac, d_types, d_len, d_ang, d_t, d_off, B, N, 0, nullptr, nullptr, nullptr, nullptr, o,
                                    o + (size_t)N * 3, o + (size_t)N * 3 + (size_t)N * S, d_ws, ws_bytes, (void*)s);
     }
     m->calibrating = 0;
-    m->q16_ok = 1; m->x8_ok = x8_weights;
+    m->fp8_ok = 1; m->x8_ok = x8_weights;
     std::vector<float> h(3 * out1);
     int32_t flags = 0;
     if (rc == ARREAU_OK) {
@@ -372,25 +375,32 @@ static int calibrate_message_formats(arreau_model* m, hipStream_t s) {
     m->ran_edge = m->ran_mlp = m->ran_conv = -1;
     m->ran_x8 = 0;
     if (rc != ARREAU_OK) { arreau_set_error(std::string("format calibration: ") + arreau_last_error()); return rc; }
-    if (flags & ~ARREAU_STATUS_BASIS_RANGE) return ARREAU_OK;  // a non-finite output: nothing to measure (the range safety of sample() handles it)
+    (void)flags;
+    auto finite = [&](int v) {
+        const float* q = h.data() + (size_t)v * out1;
+        for (size_t i = 0; i < (size_t)N * 3 + (size_t)N * S; ++i)
+            if (!(fabsf(q[i]) < INFINITY)) return false;
+        return true;
+    };
+    if (!finite(0)) return ARREAU_OK;  // the reference arithmetic itself is non-finite on this batch: nothing to measure here
     auto share = [&](int v) {  // how much of the parity bounds variant v uses up, against the two-plane reference
+        if (!finite(v)) return 1e9;
         const float* r = h.data();
         const float* q = h.data() + (size_t)v * out1;
         double me = 0.0, ml = 0.0, de = 0.0, dl = 0.0;
         for (size_t i = 0; i < (size_t)N * 3; ++i) { me = fmax(me, fabs((double)r[i])); de = fmax(de, fabs((double)q[i] - r[i])); }
         for (size_t i = (size_t)N * 3; i < (size_t)N * 3 + (size_t)N * S; ++i) { ml = fmax(ml, fabs((double)r[i])); dl = fmax(dl, fabs((double)q[i] - r[i])); }
-        if (!(de == de) || !(dl == dl)) return 1e9;
         return fmax(de / (1e-5 * fmax(1.0, me)), dl / (1e-5 * fmax(1.0, ml / 8.0)));
     };
-    m->calib_q16 = (float)share(1);
-    m->q16_ok = !(flags & ARREAU_STATUS_BASIS_RANGE) && m->calib_q16 <= ARREAU_CALIB_SHARE ? 1 : 0;  // (BASIS_RANGE: e4m3 planes saturated)
+    m->calib_fp8 = (float)fmin(share(1), 1e9);
+    m->fp8_ok = m->calib_fp8 <= ARREAU_CALIB_SHARE ? 1 : 0;
     if (x8_weights) {
-        m->calib_x8 = (float)share(2);
-        m->x8_ok = m->q16_ok && m->calib_x8 <= ARREAU_CALIB_SHARE ? 1 : 0;
+        m->calib_x8 = (float)fmin(share(2), 1e9);
+        m->x8_ok = m->fp8_ok && m->calib_x8 <= ARREAU_CALIB_SHARE ? 1 : 0;
     }
     if (getenv("ARREAU_VERBOSE_CALIBRATION"))
-        fprintf(stderr, "[arreau_hip] message-path formats: share of the parity bounds used up on the calibration batch -- Q16 stash %.3f, "
-                "Q16 + fp8 cross products %.3f (limit %.2f): q16 %d, fp8 cross %d\n", m->calib_q16, m->calib_x8, ARREAU_CALIB_SHARE, m->q16_ok, m->x8_ok);
+        fprintf(stderr, "[arreau_hip] message-path formats: share of the parity bounds used up on the calibration batch -- fp8 residual plane %.3f, "
+                "+ fp8 cross products %.3f (limit %.2f): basis fp8 %d, fp8 cross %d\n", m->calib_fp8, m->calib_x8, ARREAU_CALIB_SHARE, m->fp8_ok, m->x8_ok);
     return ARREAU_OK;
 }
 
@@ -647,7 +657,7 @@ extern "C" int arreau_model_create(const arreau_config* cfg, const arreau_state_
     }
     float* b = m->blob;
     m->ori = b + off_ori; m->w1p = b + off_w1p; m->b1 = b + off_b1; m->w2p = b + off_w2p; m->b2 = b + off_b2;
-    m->wkp = b + off_wkp; m->edge_bf16 = b + off_es16; m->edge_f16 = b + off_ef16; m->f16_ok = fused && wmax16 < 60000.0f ? 1 : 0; m->conv_x8 = b + off_x8; m->x8_ok = fused && x8_amax <= 448.0f ? 1 : 0; m->q16_ok = fused ? 1 : 0; m->calib_q16 = m->calib_x8 = -1.0f; m->fk = b + off_fk; m->conv_bias = b + off_conv_bias; m->ln_w = b + off_ln_w;
+    m->wkp = b + off_wkp; m->edge_bf16 = b + off_es16; m->edge_f16 = b + off_ef16; m->f16_ok = fused && wmax16 < 60000.0f ? 1 : 0; m->conv_x8 = b + off_x8; m->x8_ok = m->x8_weights_ok = fused && x8_amax <= 448.0f ? 1 : 0; m->fp8_ok = fused ? 1 : 0; m->calib_fp8 = m->calib_x8 = -1.0f; m->fk = b + off_fk; m->conv_bias = b + off_conv_bias; m->ln_w = b + off_ln_w;
     m->ln_b = b + off_ln_b; m->mlp = b + off_mlp; m->mlp_bf16 = b + off_mlp16; m->mlp_f16 = b + off_mlpf16; m->mlp_f16m = b + off_mlpf16m; m->mb1 = b + off_mb1; m->mb2 = b + off_mb2;
     m->ls = b + off_ls; m->embT = b + off_embT; m->ro_wT = b + off_ro_wT; m->ro_b = b + off_ro_b; m->ro_pack = b + off_ro_pack; m->ro_wv = b + off_ro_wv;
     for (int l = 0; l < L; ++l) m->ro_bv_host[l] = sd->readout_b[(size_t)l * RO + S];
@@ -748,6 +758,14 @@ extern "C" int arreau_model_set_variant(arreau_model* model, int32_t edge_varian
     return ARREAU_OK;
 }
 
+extern "C" int arreau_model_set_formats(arreau_model* model, int32_t basis_fp8, int32_t cross_fp8) {
+    ARREAU_REQUIRE(model, "arreau_model_set_formats: null model");
+    if (basis_fp8 >= 0) model->fp8_ok = basis_fp8 != 0 && model->fused ? 1 : 0;
+    if (cross_fp8 >= 0) model->x8_ok = cross_fp8 != 0 && model->x8_weights_ok ? 1 : 0;
+    if (!model->fp8_ok) model->x8_ok = 0;  // the fp8 cross products read the stash's e4m3 residual plane as stored
+    return ARREAU_OK;
+}
+
 extern "C" int arreau_model_status(const arreau_model* model, arreau_status* out, int32_t reset, void* stream) {
     ARREAU_REQUIRE(model && out, "arreau_model_status: null argument");
     hipStream_t s = (hipStream_t)stream;
@@ -756,20 +774,14 @@ extern "C" int arreau_model_status(const arreau_model* model, arreau_status* out
     if (reset) ARREAU_CHECK_HIP(hipMemsetAsync(model->status, 0, sizeof(int32_t), s));
     ARREAU_CHECK_HIP(hipStreamSynchronize(s));
     out->flags = flags;
-    // a basis value beyond e4m3's range reached the decode of the block-quantised stash (whose residual and fp8 planes are e4m3):
-    // this model keeps two fp16 planes and three fp16 products from now on
-    if (flags & ARREAU_STATUS_BASIS_RANGE) {
-        const_cast<arreau_model*>(model)->x8_ok = 0;
-        const_cast<arreau_model*>(model)->q16_ok = 0;
-    }
     out->edge_kernel = model->ran_edge;
     out->mlp_kernel = model->ran_mlp;
     out->conv_kernel = model->ran_conv;
-    out->basis_row_bytes = model->ran_conv == 2 ? (arreau_basis_q16(model) ? 544 : 1024) : 0;
+    out->basis_row_bytes = model->ran_conv == 2 ? (arreau_basis_fp8(model) ? 768 : 1024) : 0;
     out->conv_cross_fp8 = model->ran_conv == 2 ? model->ran_x8 : 0;
     out->edge_activation_bound = model->edge_act_bound;
     out->node_activation_bound = model->node_act_bound;
-    out->basis_q16_share = model->calib_q16;
+    out->basis_fp8_share = model->calib_fp8;
     out->cross_fp8_share = model->calib_x8;
     return ARREAU_OK;
 }

@@ -917,15 +917,15 @@ bool arreau_basis_form(const arreau_model* m, int receivers) {
            receivers > (min_receivers > 240 && !m->calibrating ? min_receivers : 240);
 }
 
-bool arreau_basis_q16(const arreau_model* m) {
-    static const int env = [] { const char* e = getenv("ARREAU_BASIS_Q16"); return e ? atoi(e) : -1; }();
+bool arreau_basis_fp8(const arreau_model* m) {
+    static const int env = [] { const char* e = getenv("ARREAU_BASIS_FP8"); return e ? atoi(e) : -1; }();
     // (the environment overrides the model's calibration either way -- A/B, tests -- except while that calibration runs)
-    return env >= 0 && !m->calibrating ? env != 0 : m->q16_ok != 0;
+    return env >= 0 && !m->calibrating ? env != 0 : m->fp8_ok != 0;
 }
 
 bool arreau_cross_fp8(const arreau_model* m) {
     const char* e = getenv("ARREAU_CROSS_FP8");
-    return (e == nullptr || atoi(e) != 0 || m->calibrating) && m->x8_ok && arreau_basis_q16(m);
+    return (e == nullptr || atoi(e) != 0 || m->calibrating) && m->x8_ok && arreau_basis_fp8(m);
 }
 
 bool arreau_range_launches_supported(const arreau_model* m) {

@@ -213,7 +213,7 @@ class DiffusionLoss(nn.Module):
         nz = eng.diffusion_noise(frac_d, types0, cell_d, t_d, off, z_frac_d, u_types_d, z_len_d)
         evaluate = eng.train_forward if training else eng.predict_scores
         run = lambda: evaluate(nz["noisy_frac"], nz["noisy_types"], nz["noisy_lengths"], nz["angles"], t_d, off)
-        # (validation: sticky device flags -> raise, a BASIS_RANGE flag -> repeated on three fp16 products: HipEngine.checked.
+        # (validation: sticky device flags -> raise; non-finite outputs with fp8 operand planes in use -> repeated on fp16 planes: HipEngine.checked.
         # Reading the flags synchronises the stream, so the training step -- whose host work overlaps the device's, and whose
         # forward runs no fp8 product -- leaves that to PONITA_DIFFUSION.training_step, every STATUS_CHECK_EVERY steps.)
         eps, logits, len0 = run() if training else eng.checked(run)
@@ -382,39 +382,42 @@ class DiffusionLoss(nn.Module):
         # outputs as NaN and sets the sticky NONFINITE flag.  When that happens on the default kernels the batch is re-run HERE,
         # from its saved initial state and with the same draws (same Philox seed / same host and device generator states), on
         # the full-range bf16x6 kernels; the engine stays on them if that run came out finite, and the result says so
-        # (SampleResult.info).  The same for BASIS_RANGE (a basis value beyond e4m3's range met the fp8 cross products of the
-        # layer projections): reading the flag has switched the library to three fp16 products, the batch is re-run with them.
+        # (SampleResult.info).  Before that, when fp8 operand planes were in use (basis stash residual, cross products of the layer
+        # projections): a basis value beyond e4m3's range turns into NaN there (the hardware conversion does not saturate), so the
+        # batch is first re-run with two fp16 planes and three fp16 products, which the engine then keeps.
         info = None
-        st = eng.status(reset=False)
         from .. import _hip as _h
-        overflow = (st["flags"] & _h.STATUS_NONFINITE) and not (st["flags"] & ~(_h.STATUS_NONFINITE | _h.STATUS_BASIS_RANGE)) \
-            and eng.fused_shape and (st["edge_kernel"] == "fp16x3" or st["mlp_kernel"].startswith("fp16x3"))
-        basis_range = st["flags"] == _h.STATUS_BASIS_RANGE
-        if overflow or basis_range:
-            import warnings
-            if overflow:
-                warnings.warn("arreau_amd: an activation left the fp16 range of the split-precision kernels (weights with activation "
-                              f"bounds edge {st['edge_activation_bound']:.3g} / node {st['node_activation_bound']:.3g}); re-running the "
-                              "batch on the full-range bf16x6 kernels, which this engine keeps if they come out finite")
-            else:
-                warnings.warn("arreau_amd: a basis value above 448 reached the e4m3 planes of the block-quantised basis stash; "
-                              "re-running the batch with two fp16 planes and three fp16 products, which this engine keeps from now on")
+        import warnings
+
+        def rerun():
             eng.status(reset=True)
-            previous = (st["edge_variant"], st["mlp_variant"])
-            if overflow:
-                eng.set_variant(3, 1)
             frac_d.copy_(init_state[0]); types_d.copy_(init_state[1]); len_d.copy_(init_state[2])
             torch.random.set_rng_state(rng_state)
             if cuda_rng_state is not None:
                 torch.cuda.set_rng_state(cuda_rng_state, dev)
             run_loop(False)
-            if overflow:
-                if eng.status(reset=False)["flags"] & _h.STATUS_NONFINITE:
-                    eng.set_variant(*previous)  # not a range problem (e.g. a degenerate cell): keep the faster kernels, raise below
-                info = {"full_range_rerun": True, "kernels": "bf16x6", "edge_activation_bound": st["edge_activation_bound"],
-                        "node_activation_bound": st["node_activation_bound"]}
-            else:
-                info = {"fp16_planes_rerun": True}
+
+        st = eng.status(reset=False)
+        if st["flags"] == _h.STATUS_NONFINITE and eng.fp8_formats_in_use(st):
+            warnings.warn("arreau_amd: non-finite outputs with fp8 operand planes in use (a basis value beyond e4m3's range?); "
+                          "re-running the batch with two fp16 planes and three fp16 products, which this engine keeps from now on")
+            eng.set_formats(0, 0)
+            rerun()
+            info = {"fp16_planes_rerun": True}
+            st = eng.status(reset=False)
+        overflow = (st["flags"] == _h.STATUS_NONFINITE) and eng.fused_shape \
+            and (st["edge_kernel"] == "fp16x3" or st["mlp_kernel"].startswith("fp16x3"))
+        if overflow:
+            warnings.warn("arreau_amd: an activation left the fp16 range of the split-precision kernels (weights with activation "
+                          f"bounds edge {st['edge_activation_bound']:.3g} / node {st['node_activation_bound']:.3g}); re-running the "
+                          "batch on the full-range bf16x6 kernels, which this engine keeps if they come out finite")
+            previous = (st["edge_variant"], st["mlp_variant"])
+            eng.set_variant(3, 1)
+            rerun()
+            if eng.status(reset=False)["flags"] & _h.STATUS_NONFINITE:
+                eng.set_variant(*previous)  # not a range problem (e.g. a degenerate cell): keep the faster kernels, raise below
+            info = dict(info or {}, full_range_rerun=True, kernels="bf16x6", edge_activation_bound=st["edge_activation_bound"],
+                        node_activation_bound=st["node_activation_bound"])
         eng.check_status()  # sticky device flags (non-finite outputs, clamped indices): raise instead of returning them
         if frames:
             vis_crystal_during_sampling(z_table, types_d.cpu().numpy(), lattice_d.cpu().numpy(), frac_d.cpu().numpy(),

@@ -110,7 +110,7 @@ class HipEngine:
                 "mlp_variant": int(st.mlp_kernel), "conv_variant": int(st.conv_kernel),
                 "basis_row_bytes": int(st.basis_row_bytes), "conv_cross_fp8": int(st.conv_cross_fp8), "edge_activation_bound": float(st.edge_activation_bound),
                 "node_activation_bound": float(st.node_activation_bound),
-                "basis_q16_share": float(st.basis_q16_share), "cross_fp8_share": float(st.cross_fp8_share)}
+                "basis_fp8_share": float(st.basis_fp8_share), "cross_fp8_share": float(st.cross_fp8_share)}
 
     def check_status(self, reset=True):
         """Raise if a kernel flagged a condition under which its results must not be trusted."""
@@ -126,23 +126,30 @@ class HipEngine:
                 why.append("a timestep index was outside the schedule")
             if f & _hip.STATUS_BAD_TYPE:
                 why.append("an atom-type index was outside [0, num_atomic_states)")
-            if f & _hip.STATUS_BASIS_RANGE:
-                why.append("a basis value above 448 reached the e4m3 planes of the block-quantised basis stash (they saturate); "
-                           "the library has switched this model to two fp16 planes and three fp16 products -- evaluate again")
             raise _hip.ArreauHipError("arreau_hip status flags %d: %s" % (f, "; ".join(why)))
         return st
 
+    def set_formats(self, basis_fp8=-1, cross_fp8=-1):
+        """Operand formats of the message path for this model (arreau_model_set_formats; -1 keeps the current choice)."""
+        _hip.check(_hip.lib().arreau_model_set_formats(self._handle, int(basis_fp8), int(cross_fp8)), "arreau_model_set_formats")
+
+    def fp8_formats_in_use(self, st=None):
+        """Did the last evaluation read an fp8 residual plane / run fp8 cross products?  (arreau_model_status)"""
+        st = self.status(reset=False) if st is None else st
+        return st["conv_variant"] == 2 and (st["basis_row_bytes"] == 768 or st["conv_cross_fp8"] == 1)
+
     def checked(self, fn):
-        """Run `fn()` (one evaluation through this engine), then read the sticky flags.  If the only flag is BASIS_RANGE -- a
-        basis value beyond e4m3's range met the block-quantised stash's e4m3 planes, whose result is then less accurate than
-        the parity target -- the library has already switched the model to two fp16 planes and three fp16 products: `fn()` runs once more and its result
-        is the one returned.  Any other flag raises (check_status)."""
+        """Run `fn()` (one evaluation through this engine), then read the sticky flags.  A NONFINITE flag while fp8 operand
+        formats were in use is first taken for what it usually is -- a basis value beyond e4m3's range (the hardware's fp8
+        conversion returns NaN above 464; tools/exp/fp8_cvt_check.hip): the model is switched to two fp16 planes and three fp16
+        products for good and `fn()` runs once more; its result is the one returned.  Any flag that survives raises."""
         out = fn()
         st = self.status(reset=False)
-        if st["flags"] == _hip.STATUS_BASIS_RANGE:
+        if st["flags"] == _hip.STATUS_NONFINITE and self.fp8_formats_in_use(st):
             import warnings
-            warnings.warn("arreau_amd: a basis value above 448 reached the e4m3 planes of the block-quantised basis stash; this "
+            warnings.warn("arreau_amd: non-finite outputs with fp8 operand planes in use (a basis value beyond e4m3's range?); this "
                           "engine keeps two fp16 planes and three fp16 products from now on and the evaluation is repeated with them")
+            self.set_formats(0, 0)
             self.status(reset=True)
             out = fn()
         self.check_status()

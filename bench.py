@@ -167,6 +167,8 @@ def parse_args(argv=None):
                     "statistics and PMC counters of whole-batch launches only); implies --eager-value")
     ap.add_argument("--eager-value", action="store_true", help="report the eager loop as `value` even where the product "
                     "defaults to graph replay")
+    ap.add_argument("--no-other-configs", action="store_true", help="default run only: skip the short legs of the other BASELINE "
+                    "configurations (c1, c4, c5) that the one-GPU default run appends as `other_configs`")
     ap.add_argument("--groups", type=int, default=0, help="experiment, needs ARREAU_ALLOW_MULTISTREAM=1: slices of the batch on separate streams "
                     "(0 = the product: one stream; 2 was 3 %% faster at 256 x 20 but is not run-to-run reproducible)")
     args = ap.parse_args(argv)
@@ -326,6 +328,33 @@ def gather_json(dist, where, world, obj, cap=2048):
         g = g.cpu()
         n = int.from_bytes(bytes(g[:4].tolist()), "little")
         out.append(json.loads(bytes(g[4:4 + n].tolist()).decode()))
+    return out
+
+
+def other_config_legs():
+    """Short legs of the other BASELINE configurations, each in a child process of its own (a fresh library state, the same
+    `python bench.py --config ...` a user would run; the parent has finished its GPU work), so that ONE default run -- the
+    command the driver times -- carries a measured figure for every configuration: c1 (configs[0]: 99 eager steps = one whole
+    sampler), c4 (configs[3]: graph replay at 1024 x 64), c5 (configs[4]: training steps).  No CPU baseline in the legs;
+    `steps` / `warmup` of the headline are untouched.  Each record: ms_per_step, value, unit, loop_mode, the leg's own
+    `roofline` block and config.workload."""
+    legs = (("c1", ["--steps", "99", "--warmup", "20"]), ("c4", ["--steps", "5", "--warmup", "2"]), ("c5", ["--steps", "10", "--warmup", "3"]))
+    out = {}
+    for name, extra in legs:
+        cmd = [sys.executable, os.path.abspath(__file__), "--config", name, "--no-cpu-baseline", "--no-fp32-variant",
+               "--no-full-sampler", "--no-other-configs"] + extra
+        t0 = time.perf_counter()
+        try:
+            env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "ARREAU_BENCH_CHILD")}
+            r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, env=env, timeout=240, text=True)
+            d = json.loads(r.stdout.strip().splitlines()[-1])
+            out[name] = {k: d.get(k) for k in ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "loop_mode", "forward_backward_ms",
+                                               "crystals_per_min", "roofline")}
+            out[name]["config"] = {"workload": d.get("config", {}).get("workload")}
+            out[name]["leg_wall_s"] = time.perf_counter() - t0
+        except Exception as exc:  # a failed leg must not cost the headline
+            out[name] = {"error": f"{type(exc).__name__}: {exc}"[:300]}
+        log(f"other_configs {name}: {out[name].get('ms_per_step')} ms per step ({time.perf_counter() - t0:.1f} s)")
     return out
 
 
@@ -576,7 +605,7 @@ def run_rank(args, rank, local_rank, world):
             # its ALGORITHMIC bytes are those of 8(d)'s conv pass (read x, write x_1).  The basis stash it streams is traffic the
             # design adds: reported beside the PMC figure, never as achieved work.
             rows = e_mean * 16 / launches_per_step
-            row_bytes = int(status.get("basis_row_bytes") or 544)
+            row_bytes = int(status.get("basis_row_bytes") or 768)
             # the roof of the arithmetic this kernel runs: three fp16 products per fp32 product (2500 / 3), or -- round 4 default --
             # one fp16 product + the two cross products as ONE fp8 product at twice the fp16 rate = two fp16-equivalents (2500 / 2)
             x8 = bool(status.get("conv_cross_fp8"))
@@ -645,11 +674,12 @@ def run_rank(args, rank, local_rank, world):
                           f"arreau_model_status): edge={status['edge_kernel']}, mlp={status['mlp_kernel']}.  fp16x3 = each "
                           "fp32 product of the dense layers as 3 fp16 MFMA products (two 11-bit operand planes, f16x3.h); "
                           f"message path (conv kernel variant {status.get('conv_variant')}): 2 = no K stash -- the edge kernel "
-                          "stores the windowed basis once (block-quantised: 16-bit mantissas + one exponent per 8 values, 2.125 bytes "
-                          f"per value, basis_row_bytes={status.get('basis_row_bytes')}; ARREAU_BASIS_Q16=0: two fp16 planes) and every layer's message kernel "
+                          "stores the windowed basis once (fp16 plane + residual plane rounded to fp8 e4m3: 3 bytes per value, 11 + 4 "
+                          f"significand bits, basis_row_bytes={status.get('basis_row_bytes')}; ARREAU_BASIS_FP8=0 or a model whose calibration "
+                          "dropped the fp8 plane: both planes fp16) and every layer's message kernel "
                           f"projects it, its two cross products as one fp8 (e4m3) MFMA product: conv_cross_fp8={status.get('conv_cross_fp8')} "
                           "(round 4; ARREAU_CROSS_FP8=0: three fp16 products); 1 = the round-2 pair with a K stash of 3-byte floats; environment: "
-                          f"ARREAU_BASIS_Q16={os.environ.get('ARREAU_BASIS_Q16', '1')} ARREAU_CONV_VARIANT={os.environ.get('ARREAU_CONV_VARIANT', '2')}; "
+                          f"ARREAU_BASIS_FP8={os.environ.get('ARREAU_BASIS_FP8', 'calibrated')} ARREAU_CONV_VARIANT={os.environ.get('ARREAU_CONV_VARIANT', '2')}; "
                           "measured deviations from the fp32 / fp64 CPU oracle: profiles/parity_r05.json; "
                           "roofline.fp32_mfma_variant = the same step on the plain fp32-MFMA kernels",
             "data": "synthetic",
@@ -676,6 +706,10 @@ def run_rank(args, rank, local_rank, world):
             out["INVALID_timing_only_experiment"] = True
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline(model, B, n, T, args.cpu_steps)
+        if args.config is None and world == 1 and not args.no_other_configs and not args.no_graph_loop and (B, n) == CONFIGS["c2"][:2]:
+            del eng, model
+            torch.cuda.empty_cache()
+            out["other_configs"] = other_config_legs()
         emit(out)
     if dist is not None:
         dist.barrier()
@@ -792,7 +826,7 @@ def run_rank_c5(args, rank, local_rank, world):
             "last_loss": float(loss),
             "ranks": ranks_info,
             "forward_backward_ms": fb_ms,
-            "roofline": training_roofline(flops, fb_ms, args.hidden_dim, B),
+            "roofline": training_roofline(flops, fb_ms, args.hidden_dim, B, alg_bytes=3.0 * step_bytes(n_atoms, 8 * n_atoms, B, C=args.hidden_dim)),
         }
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = cpu_baseline_training(model, batches[0], args.cpu_steps)
@@ -802,7 +836,7 @@ def run_rank_c5(args, rank, local_rank, world):
         dist.destroy_process_group()
 
 
-def training_roofline(flops, fb_ms, hidden_dim=128, crystals=64):
+def training_roofline(flops, fb_ms, hidden_dim=128, crystals=64, alg_bytes=None):
     """The training step's matrix work against the roof of the arithmetic it runs in.  ARREAU_TRAIN_GEMM (train_net.hip) selects it:
     default `split` = forward products as fp16x3 (3 fp16 MFMA products per fp32 product: 2500 / 3 TFLOP/s), products with a gradient
     operand as bf16x6 (2500 / 6); one third of the algorithmic FLOPs are forward, two thirds backward, so the step's roof is the
@@ -823,9 +857,13 @@ def training_roofline(flops, fb_ms, hidden_dim=128, crystals=64):
     out = {"kernel": "training step, forward + backward (sgemm_split_kernel products + element-wise / gather kernels of train_net.hip)",
            "bound": "mfma", "achieved": ach, "peak": peak, "unit": "TFLOP/s", "frac": ach / peak, "traffic": traffic, "peak_note": note,
            "frac_of_fp32_mfma_peak": ach / MFMA_F32_PEAK_TFLOPS, "gemm_mode": mode}
-    if traffic:
-        out["hbm"] = {"achieved": traffic / (fb_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": traffic / (fb_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                      "note": "PMC bytes per step (every intermediate of the step is materialised) over the forward + backward time"}
+    if alg_bytes:
+        # the same rule as the sampling line: `achieved` from ALGORITHMIC bytes -- forward + backward ~ three passes
+        # over the tensors of SURVEY 8(d)'s step --, the PMC bytes (every intermediate of the step is materialised) beside it as traffic
+        out["hbm"] = {"achieved": alg_bytes / (fb_ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                      "frac": alg_bytes / (fb_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, "algorithmic_bytes_per_step": alg_bytes,
+                      "note": "3 x SURVEY 8(d)'s algorithmic bytes of one forward step over the forward + backward time",
+                      "traffic": traffic, "traffic_over_algorithmic_bytes": (traffic / alg_bytes) if traffic else None}
     return out
 
 

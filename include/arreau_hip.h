@@ -117,13 +117,7 @@ int arreau_model_config(const arreau_model* model, arreau_config* out_cfg);
  *                fp16 range of the split-precision kernels (|v| >= 65520) surfaces: the planes overflow to inf and the
  *                value propagates as NaN instead of being clamped silently;
  *   BAD_TIMESTEP a timestep outside [0, T] (predict_scores) / [1, T] (reverse_step) was clamped;
- *   BAD_TYPE     an atom-type index outside [0, S) was clamped;
- *   BASIS_RANGE  (round 5) a value of the windowed basis above 448 was decoded from the block-quantised stash (basis_row_bytes ==
- *                544), whose operand planes for the layer projections hold e4m3 numbers: the fp8 copy of the value saturates
- *                (conv_cross_fp8 == 1: the a2 * b1 correction is truncated, up to ~2^-12 relative per product -- above the 1e-5
- *                parity target), and from 1024 on so does its residual.  Reading the flag (arreau_model_status) switches this
- *                model to two fp16 planes and three fp16 products for good; re-run the evaluation (DiffusionLoss.sample and
- *                PONITA_DIFFUSION.forward do, from their saved inputs).
+ *   BAD_TYPE     an atom-type index outside [0, S) was clamped.
  * edge_kernel / mlp_kernel / conv_kernel name the kernel family the last arreau_predict_scores really launched
  * (edge: 0-2 fp32 MFMA, 3 bf16x6, 4 fp16x3; mlp: 0 fp32 MFMA, 1 bf16x6, 2 fp16x3 32x32x16, 3 fp16x3 16x16x32;
  * conv: 0 register form, 1 streamed form, 2 fused into the MLP kernel) -- e.g. 3/1 instead of 4/3 when a weight does not
@@ -131,28 +125,33 @@ int arreau_model_config(const arreau_model* model, arreau_config* out_cfg);
 #define ARREAU_STATUS_NONFINITE 1
 #define ARREAU_STATUS_BAD_TIMESTEP 2
 #define ARREAU_STATUS_BAD_TYPE 4
-#define ARREAU_STATUS_BASIS_RANGE 8
 typedef struct arreau_status {
     int32_t flags;
     int32_t edge_kernel;
     int32_t mlp_kernel;
     int32_t conv_kernel;
     int32_t basis_row_bytes; /* conv_kernel == 2: bytes of the stashed basis per (edge, orientation) row the kernels really used
-                              * (544: block-quantised, 16-bit mantissas + one exponent byte per 8 values, round 5 default;
-                              * 1024: two fp16 planes, ARREAU_BASIS_Q16=0); 0 otherwise */
+                              * (768: fp16 plane + fp8 e4m3 residual plane; 1024: two fp16 planes -- ARREAU_BASIS_FP8=0, or a model whose
+                              * calibration dropped the fp8 plane); 0 otherwise */
     int32_t conv_cross_fp8;  /* conv_kernel == 2: 1 when the layer projections ran their two cross products on the fp8 matrix instruction
                               * (round 4 default; e4m3 operands, twice the fp16 rate), 0 for three fp16 products (ARREAU_CROSS_FP8=0) */
     float edge_activation_bound; /* bounds, from the weights alone, of every fp16 operand of the split-precision edge chain */
     float node_activation_bound; /* (monomials, hidden units, basis) resp. ConvNext chain (LayerNorm output, hidden units): at most
                                   * 65504 = the fp16x3 kernels provably cannot overflow; up to 64 x that the library keeps them
                                   * and relies on NONFINITE (the host re-runs on bf16x6); beyond, the model starts on bf16x6 */
-    float basis_q16_share;   /* round 5: what arreau_model_create measured on its calibration batch -- the share of the parity bounds
-                              * (1e-5 max(1, |eps|), 1e-5 max(1, |logits| / 8)) the block-quantised stash, resp. that stash + the fp8 */
-    float cross_fp8_share;   /* cross products used up against two fp16 planes + three fp16 products; a format above 0.1 is not used
-                              * for this model (basis_row_bytes 1024 / conv_cross_fp8 0 then); -1: not measured */
+    float basis_fp8_share;   /* round 5: what arreau_model_create measured on its calibration batch -- the share of the parity bounds
+                              * (1e-5 max(1, |eps|), 1e-5 max(1, |logits| / 8)) the fp8 residual plane of the stash, resp. that plane + */
+    float cross_fp8_share;   /* the fp8 cross products used up against two fp16 planes + three fp16 products; a format above 0.1 is not
+                              * used for this model (basis_row_bytes 1024 / conv_cross_fp8 0 then); -1: not measured */
 } arreau_status;
 /* Reads (and with reset != 0 clears) the status word; synchronises `stream`. */
 int arreau_model_status(const arreau_model* model, arreau_status* out, int32_t reset, void* stream);
+/* Round 5: selects the operand formats of the message path for this model (-1 keeps the current choice; 0 / 1): the fp8 (e4m3)
+ * residual plane of the basis stash and the fp8 cross products of the layer projections (which need that plane and kernel
+ * weights inside e4m3's range).  arreau_model_create chooses them from its calibration batch; the host clears both when an
+ * evaluation came out non-finite with them on -- the hardware's fp8 conversion returns NaN for a basis value beyond 464 -- and
+ * repeats it (HipEngine.checked, DiffusionLoss.sample).  No reference counterpart. */
+int arreau_model_set_formats(arreau_model* model, int32_t basis_fp8, int32_t cross_fp8);
 /* Selects the arithmetic of the dense kernels for this model (-1 keeps the current choice); the defaults come from
  * the environment (ARREAU_EDGE_VARIANT, ARREAU_MLP_VARIANT) at arreau_model_create.  Used by the parity report and
  * bench.py to time/compare the exact fp32-MFMA kernels against the default fp16x3 ones in one process.

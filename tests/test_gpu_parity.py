@@ -409,13 +409,13 @@ def test_full_size_architecture_parity(dev, full_model):
 @pytest.mark.parametrize("weights", ["default checkpoint", "heavy-tailed kernel and basis weights"])
 def test_the_benchmark_path_against_the_oracle_at_its_own_size(dev, weights):
     """the exact path bench.py times -- 256 crystals x 20 atoms, S = 90, the basis form on its
-    block-quantised stash with the fp8 cross products (asserted from arreau_model_status, not assumed) -- DIRECTLY against the
+    fp16 + e4m3 stash with the fp8 cross products (asserted from arreau_model_status, not assumed) -- DIRECTLY against the
     fp32 oracle at that size, teacher-forced edges, physical cells, first and last timesteps.  Second weight set: Student-t
     (3 degrees of freedom) kernel and basis weights with a few kernel rows x 50 (tests/helpers.py: make_heavy_tailed) -- the
     regime where a 4-significand-bit cross operand or a shared block exponent hurts first, which Gaussian initialisers never
-    visit (oracle study: profiles/r05_basis_q16_study.txt, second half: logits 5.7e-6 with the cheap formats).  The library
-    must notice by itself (arreau_model_create's calibration batch; arreau_status.basis_q16_share / cross_fp8_share), fall back
-    to two fp16 planes / three fp16 products, and with them stay within twice the exact fp32-MFMA kernels' distance to fp64."""
+    visit (oracle study: profiles/r05_basis_q16_study.txt, second half: logits 3.3e-6 with the fp8 cross products).  The library
+    must notice by itself (arreau_model_create's calibration batch; arreau_status.basis_fp8_share / cross_fp8_share), drop the
+    format that costs too much, and with what it keeps stay within twice the exact fp32-MFMA kernels' distance to fp64."""
     from arreau_amd.checkpoint import make_synthetic_model
     from tests.helpers import make_heavy_tailed
     heavy = weights.startswith("heavy")
@@ -437,14 +437,14 @@ def test_the_benchmark_path_against_the_oracle_at_its_own_size(dev, weights):
         st = eng.check_status()
         assert st["edge_kernel"] == "fp16x3" and st["mlp_kernel"] == "fp16x3-16x16x32" and st["conv_variant"] == 2, st
         if not heavy:  # what bench.py times
-            assert st["conv_cross_fp8"] == 1 and st["basis_row_bytes"] == 544, st
-            assert 0.0 <= st["basis_q16_share"] <= 0.1 and 0.0 <= st["cross_fp8_share"] <= 0.1, st
+            assert st["conv_cross_fp8"] == 1 and st["basis_row_bytes"] == 768, st
+            assert 0.0 <= st["basis_fp8_share"] <= 0.1 and 0.0 <= st["cross_fp8_share"] <= 0.1, st
         else:
-            # arreau_model_create measured, on its calibration batch, that the cheap formats would use up more than a tenth of
-            # the parity bounds with THESE weights, and keeps two fp16 planes + three fp16 products for this model
-            assert max(st["basis_q16_share"], st["cross_fp8_share"]) > 0.1, st
-            assert (st["basis_row_bytes"] == 544) == (st["basis_q16_share"] <= 0.1), st
-            assert st["conv_cross_fp8"] == int(st["basis_q16_share"] <= 0.1 and st["cross_fp8_share"] <= 0.1), st
+            # arreau_model_create measured, on its calibration batch, that a cheap format would use up more than a tenth of the
+            # parity bounds with THESE weights, and does not use it for this model
+            assert max(st["basis_fp8_share"], st["cross_fp8_share"]) > 0.1, st
+            assert (st["basis_row_bytes"] == 768) == (st["basis_fp8_share"] <= 0.1), st
+            assert st["conv_cross_fp8"] == int(st["basis_fp8_share"] <= 0.1 and st["cross_fp8_share"] <= 0.1), st
             assert st["conv_cross_fp8"] == 0
         e, l, g = assert_scores_close(got, (eps_o, logits_o, len0_o), f"{weights}, t = {t}")
         print(f"[bench path vs fp32 oracle, {weights}, t = {t}] eps {e:.2e} logits {l:.2e} (|logits| {float(logits_o.abs().max()):.1f}) "
@@ -540,7 +540,7 @@ def test_loop_at_the_benchmark_size_is_bitwise_across_eager_graph_and_per_step(d
         eps, logits, len0 = eng.predict_scores(f, ty, le, an, t_c, off)
         if t == T - 1:
             st = eng.check_status()
-            assert st["conv_variant"] == 2 and st["edge_kernel"] == "fp16x3" and st["basis_row_bytes"] == 544, st
+            assert st["conv_variant"] == 2 and st["edge_kernel"] == "fp16x3" and st["basis_row_bytes"] == 768, st
         eng.reverse_step(f, ty, le, an, t_c, off, eps, logits, len0, eng.philox_fill(seed, t, 0, 3 * B).view(B, 3),
                          eng.philox_fill(seed, t, 1, 3 * N).view(N, 3), eng.philox_fill(seed, t, 2, N * S).view(N, S), lat)
     ref = (f, ty, le, lat)
@@ -1074,7 +1074,7 @@ def test_launch_geometry_switches_and_counted_waits_are_bitwise_neutral(dev):
     outs = {}
     with tempfile.TemporaryDirectory() as d:
         for tag, env in (("default", {}), ("k3off", {"ARREAU_CONV_VARIANT": "1", "ARREAU_K3": "0"}), ("conv0", {"ARREAU_CONV_VARIANT": "0"}),
-                         ("pair", {"ARREAU_CONV_VARIANT": "1"}), ("basis16", {"ARREAU_BASIS_Q16": "0"}), ("x16", {"ARREAU_CROSS_FP8": "0"}),
+                         ("pair", {"ARREAU_CONV_VARIANT": "1"}), ("basis16", {"ARREAU_BASIS_FP8": "0"}), ("x16", {"ARREAU_CROSS_FP8": "0"}),
                          ("wgs", {"ARREAU_EDGE_WGS": "100000"}),
                          ("dbgwait", {"ARREAU_HIP_LIB": LIB_DEBUG_WAIT}), ("nb1", {"ARREAU_MLP_NB": "1"}),
                          ("nb2", {"ARREAU_MLP_NB": "2"}), ("slots4", {"ARREAU_MLP_SLOTS": "4"}),
@@ -1098,8 +1098,8 @@ def test_launch_geometry_switches_and_counted_waits_are_bitwise_neutral(dev):
     # round-2 default, the same pair with K as 3-byte floats, agrees to the parity tolerance (K rounded to 16 significand
     # bits: tools/exp/k_precision_study.py).
     # Same products in the same order: the basis form (default) is bit-identical to the round-2 pair on an fp32 K stash and
-    # to the register form of the conv kernel -- every fp16x3 edge kernel rounds its basis values to the grid the stash holds
-    # (round 5: 16-bit mantissas, one exponent per lane block of eight; 2.125 bytes per value).
+    # to the register form of the conv kernel -- every fp16x3 edge kernel rounds the basis' residual plane to fp8 e4m3, the
+    # form the stash holds (3 bytes per value).
     # (Round 4: with three fp16 products -- ARREAU_CROSS_FP8=0, "x16"; the default now runs the two cross products of the
     # projection on the fp8 matrix instruction, bounded below.)
     for tag in ("k3off", "conv0"):
@@ -1114,14 +1114,14 @@ def test_launch_geometry_switches_and_counted_waits_are_bitwise_neutral(dev):
           f"  len0 {x_len0:.2e} (|len0| {float(outs['x16'][2].abs().max()):.1f})")
     assert x_eps <= 3e-7 and x_logits <= 4e-7 * max(1.0, float(outs["x16"][1].abs().max()))
     assert x_len0 <= 6 * ulp32(float(outs["x16"][2].abs().max()))
-    # What the block-quantised stash costs (ARREAU_BASIS_Q16=0 keeps two fp16 planes = the round-2 arithmetic).  In the fp32
-    # oracle (tools/exp/basis_q16_study.py, profiles/r05_basis_q16_study.txt, three fp16 products, stash (16, 8) "to two fp16
-    # planes") the outputs move by eps 1.3e-7 / logits 7e-7 at |logits| = 2 (3.5e-7 of the largest logit) / len0 two ulps;
-    # bounded here at about twice that, so that a coarser format cannot eat the parity margin silently.
+    # What that rounding costs (11 + 4 significand bits of the basis; ARREAU_BASIS_FP8=0 keeps both planes in fp16 = the
+    # round-2 arithmetic).  In the fp32 oracle it is invisible (tools/exp/basis_precision_study.py: both forms at the
+    # rounding floor, eps 7e-8 / logits 3.6e-7 at |logits| = 2); measured here: eps 1.3e-7, logits 1.9e-6 at |logits| = 6.8
+    # (2.8e-7 relative), len0 4 ulps.  Bounded so that a coarser format cannot eat the parity margin silently.
     b_eps, b_logits, b_len0 = (float((a - b).abs().max()) for a, b in zip(outs["x16"], outs["basis16"]))
-    print(f"[basis stash] |Q16 - fp16 + fp16| : eps {b_eps:.2e}  logits {b_logits:.2e} (|logits| {float(outs['basis16'][1].abs().max()):.1f})"
+    print(f"[basis stash] |fp16 + fp8 - fp16 + fp16| : eps {b_eps:.2e}  logits {b_logits:.2e} (|logits| {float(outs['basis16'][1].abs().max()):.1f})"
           f"  len0 {b_len0:.2e} (|len0| {float(outs['basis16'][2].abs().max()):.1f})")
-    assert b_eps <= 3e-7 and b_logits <= 7e-7 * max(1.0, float(outs["basis16"][1].abs().max()))
+    assert b_eps <= 3e-7 and b_logits <= 4e-7 * max(1.0, float(outs["basis16"][1].abs().max()))
     assert b_len0 <= 6 * ulp32(float(outs["basis16"][2].abs().max()))
     # What the 3-byte stash costs, bounded by what tools/exp/k_precision_study.py measured for 16 significand bits in the
     # oracle (profiles/r02g_k_precision_study.txt: eps 7e-8, logits 3.6e-7 at |logits| <= 2, i.e. about 2e-7 of the
@@ -1161,56 +1161,67 @@ def test_fp8_cross_products_fall_back_when_a_weight_would_saturate(dev, monkeypa
         eng.close()
 
 
-def test_fp8_cross_products_fall_back_when_a_basis_value_would_saturate(dev, monkeypatch):
-    """the OTHER operand of the fp8 cross products, b1_8 = e4m3(b1), saturates at 448 -- well inside the fp16
-    range, so nothing else fires.  The loader waves of conv_proj.hip look at every decoded block whose exponent allows such a
-    value and raise the sticky BASIS_RANGE flag; reading it switches the model to two fp16 planes and three fp16 products (the
-    stash's residual plane is e4m3 too), and HipEngine.checked repeats the evaluation with them.  Model: the basis layer scaled x 1000 (basis values up to a few thousand), the kernel
-    weights scaled down by the same factor -- the same function in exact arithmetic."""
+def test_fp8_operand_planes_fall_back_when_a_basis_value_leaves_their_range(dev, monkeypatch):
+    """the OTHER operand of the fp8 cross products, b1_8 = e4m3(b1), leaves e4m3's range at 448 -- well inside the
+    fp16 range -- and so does the stash's e4m3 residual plane from |b| ~ 512 on.  Measured this round (tools/exp/fp8_cvt_check.hip
+    on the box): v_cvt_scalef32_pk_fp8_f16 does NOT saturate, a value above 464 becomes NaN -- the overflow was never silent, it
+    surfaces as NONFINITE.  The host now takes a NONFINITE flag with fp8 operand planes in use for that first: the model is
+    switched to two fp16 planes + three fp16 products (arreau_model_set_formats) and the evaluation repeated
+    (HipEngine.checked); only what survives goes on to the bf16x6 kernels.  Model: the basis layer scaled x 256 (basis values up
+    to about two thousand, all inside the fp16 range), the kernel weights scaled down by the same factor; the oracle evaluates the
+    same scaled model.  With its calibration batch arreau_model_create notices by itself and never selects the fp8 planes."""
     import warnings
     from arreau_amd import _hip
     from arreau_amd.checkpoint import make_synthetic_model
     monkeypatch.setenv("ARREAU_BASIS_MIN_RECEIVERS", "240")
-    # (without the calibration batch of arreau_model_create, which would meet such values itself and never select the fp8 form
-    # for this model: the flag exists for values that only a particular geometry produces)
-    monkeypatch.setenv("ARREAU_CALIBRATE", "0")
     state = random_state(12, [20] * 16, 23, cell=(4.0, 8.0))
     f, ty, le, an, off = _to_dev(dev, *state)
     t_c = torch.full((16,), 40, device=dev, dtype=torch.int32)
-    m = make_synthetic_model(S=12, seed=1234, num_timesteps=100)
-    with torch.no_grad():
-        m.model.basis_fn[3].weight *= 1000.0
-        m.model.basis_fn[3].bias *= 1000.0
-        for layer in m.model.interaction_layers:
-            layer.conv.kernel.weight /= 1000.0
-    m = m.to(dev)
+
+    def scaled_model():
+        m = make_synthetic_model(S=12, seed=1234, num_timesteps=100)
+        with torch.no_grad():
+            m.model.basis_fn[3].weight *= 256.0
+            m.model.basis_fn[3].bias *= 256.0
+            for layer in m.model.interaction_layers:
+                layer.conv.kernel.weight /= 256.0
+        return m.to(dev)
+
+    m = scaled_model()
     om32 = oracle_from_module(m, torch.float32)
     eps_o, logits_o, len0_o, (ei, dists, direction, _c, _l) = _oracle_scores(om32, *state, 40)
     deg, src, sdir, sdist = slots_from_edges(ei, dists, direction, 320, 8)
-    eng = m.engine()
     edges = tuple(x.to(dev).contiguous() for x in (deg, src, sdir, sdist))
+    # (1) the calibration batch of arreau_model_create meets such values itself: the fp8 planes are never selected
+    eng = m.engine()
+    got = eng.predict_scores(f, ty, le, an, t_c, off, edges=edges)
+    st = eng.check_status()
+    assert st["conv_variant"] == 2 and st["conv_cross_fp8"] == 0 and st["basis_row_bytes"] == 1024 and st["basis_fp8_share"] > 0.1, st
+    assert_scores_close(got, (eps_o, logits_o, len0_o), "scaled basis, formats chosen by the calibration")
+    eng.close()
+    # (2) without the calibration (values that only a particular geometry produces): loud, and repaired by the host
+    monkeypatch.setenv("ARREAU_CALIBRATE", "0")
+    m = scaled_model()
+    eng = m.engine()
     eng.predict_scores(f, ty, le, an, t_c, off, edges=edges)
     st = eng.status(reset=False)
-    assert st["conv_variant"] == 2 and st["conv_cross_fp8"] == 1 and st["flags"] == _hip.STATUS_BASIS_RANGE, st
-    with pytest.raises(_hip.ArreauHipError, match="448"):
-        eng.check_status(reset=False)
+    assert st["conv_variant"] == 2 and st["conv_cross_fp8"] == 1 and st["basis_row_bytes"] == 768 and st["flags"] == _hip.STATUS_NONFINITE, st
     with warnings.catch_warnings(record=True) as w:
         warnings.simplefilter("always")
         got = eng.checked(lambda: eng.predict_scores(f, ty, le, an, t_c, off, edges=edges))
-    assert any("448" in str(x.message) for x in w)
+    assert any("fp8 operand planes" in str(x.message) for x in w)
     st = eng.check_status()
     assert st["conv_variant"] == 2 and st["conv_cross_fp8"] == 0 and st["basis_row_bytes"] == 1024 and st["flags"] == 0, st
-    assert_scores_close(got, (eps_o, logits_o, len0_o), "basis scaled past e4m3's range: two fp16 planes, three fp16 products")
+    assert_scores_close(got, (eps_o, logits_o, len0_o), "scaled basis: two fp16 planes, three fp16 products")
     eng.close()
 
 
-def test_basis_stash_holds_block_quantised_values(dev, full_model):
-    """The stash the edge kernel writes in the basis form, read back from the workspace: per edge slot an 8.5 KiB block of
-    eight 1 KiB fragments of 16-bit mantissas ([k-block][lane][8]) and 512 B of exponent codes ([lane][k-block]) --
-    arreau_amd/csrc/f16x3.h: bq_encode8.  Against the 4-byte form (ARREAU_BASIS_Q16=0, two fp16 planes: the value to 22 bits) of
-    the same evaluation, run in a second process: every block's exponent is the smallest that holds its largest value (or the
-    clamp), every decoded value lies within half a mantissa step of the plane value, and the mantissas are the nearest
-    integers.  (Round 3 found a __builtin_bit_cast that read element 0 for every index with the comparison this replaces.)"""
+def test_basis_stash_holds_fp16_and_e4m3_planes(dev, full_model):
+    """The stash the edge kernel writes in the basis form, read back from the workspace: per edge slot a 12 KiB block of
+    eight 1 KiB hi fragments (fp16, [k-block][lane][8 halves]) and eight 512 B lo fragments (OCP fp8 e4m3).  Against the
+    4-byte form (ARREAU_BASIS_FP8=0, both planes fp16) of the same evaluation, run in a second process: the hi planes are
+    identical and every fp8 byte is torch's float8_e4m3fn rounding (nearest even) of the fp16 residual.  (Found with this
+    comparison in round 3: a __builtin_bit_cast on a vector-element lvalue that read element 0 for every index.)"""
     import subprocess
     import sys
     import tempfile
@@ -1232,33 +1243,20 @@ def test_basis_stash_holds_block_quantised_values(dev, full_model):
         off += nbytes
     ws = {}
     with tempfile.TemporaryDirectory() as d:
-        for tag, env in (("q16", {}), ("f16", {"ARREAU_BASIS_Q16": "0"})):
+        for tag, env in (("fp8", {}), ("f16", {"ARREAU_BASIS_FP8": "0"})):
             path = os.path.join(d, tag + ".pt")
             subprocess.run([sys.executable, "-c", code, path], check=True,
                            env={**os.environ, "ARREAU_BASIS_MIN_RECEIVERS": "240", **env}, timeout=300)
             ws[tag] = torch.load(path)
     slots = N * k
-    a = ws["q16"][k0:k0 + slots * 8704].view(slots, 8704)
+    a = ws["fp8"][k0:k0 + slots * 12288].view(slots, 12288)
     b16 = ws["f16"][k0:k0 + slots * 16384].contiguous().view(torch.float16).view(slots, 8, 2, 64, 8)  # [slot][k-block][plane][lane][8]
+    hi = a[:, :8192].contiguous().view(torch.float16).view(slots, 8, 64, 8)
+    lo = a[:, 8192:].contiguous().view(torch.uint8).view(slots, 8, 64, 8)
     assert torch.isfinite(b16.float()).all() and float(b16[:, :, 0].float().abs().max()) > 0.1  # every slot was written (k = 8 everywhere)
-    ref = b16[:, :, 0].double() + b16[:, :, 1].double() / 2048.0                 # [slot][k-block][lane][8]: the basis to ~22 bits
-    mant = a[:, :8192].contiguous().view(torch.int16).view(slots, 8, 64, 8).double()
-    code_b = a[:, 8192:].contiguous().view(torch.uint8).view(slots, 64, 8).permute(0, 2, 1).double()  # -> [slot][k-block][lane]
-    assert float(code_b.max()) < 255  # no block was flagged "not representable"
-    E = code_b - 32.0
-    step = torch.exp2(E - 15.0).unsqueeze(-1)
-    q = mant * step
-    amax = ref.abs().amax(-1)
-    # the exponent: amax (1 + 2^-15) < 2^E, and not a binade too large (up to the 2^-22 the reference planes lost); -32 = clamp
-    assert bool((amax * (1 + 2.0 ** -15) * (1 - 2.0 ** -20) < torch.exp2(E)).all())
-    tight = (amax * (1 + 2.0 ** -15) * (1 + 2.0 ** -20) >= torch.exp2(E - 1)) | (E == -32)
-    assert bool(tight.all()), int((~tight).sum())
-    assert float(mant.abs().max()) <= 32767
-    # the values: within half a step (+ what the 22-bit reference cannot resolve), mantissas = nearest integers almost everywhere
-    err = (q - ref).abs()
-    assert bool((err <= 0.5 * step * (1 + 1e-6) + ref.abs() * 2.0 ** -21).all()), float((err / step).max())
-    nearest = torch.round(ref / step)
-    assert float((nearest != mant).double().mean()) < 1e-3 and float((nearest - mant).abs().max()) <= 1
+    assert torch.equal(hi.view(torch.int16), b16[:, :, 0].contiguous().view(torch.int16))
+    want = b16[:, :, 1].float().to(torch.float8_e4m3fn).view(torch.uint8)
+    assert int((want != lo).sum()) == 0
 
 
 def _philox_ref(ctr, key):

@@ -52,18 +52,22 @@ def _worker(rank, world, port, total, n_atoms, batch, outfile):
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("total,batch", [(10, 4), (7, 16)])
-def test_two_rank_gloo_generate(total, batch):
+@pytest.mark.parametrize("total,batch,world", [(10, 4, 2), (7, 16, 2), (11, 3, 2), (13, 2, 3)])
+def test_two_rank_gloo_generate(total, batch, world):
+    """main_diffusion_generate.py:67-92 sharded over ranks: even and ODD crystal counts, sub-batches
+    that do not divide a rank's share, two and three ranks -- every crystal comes back exactly once, in crystal order."""
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     n_atoms = 3
     with tempfile.TemporaryDirectory() as d:
         out = os.path.join(d, "crystals.npz")
-        mp.spawn(_worker, args=(2, port, total, n_atoms, batch, out), nprocs=2, join=True)
+        mp.spawn(_worker, args=(world, port, total, n_atoms, batch, out), nprocs=world, join=True)
         z = np.load(out)
         assert z["lattice"].shape == (total, 3, 3)
-        assert np.allclose(z["lattice"][:, 0, 0], np.arange(total))  # crystal order preserved across ranks
+        ids = np.rint(z["lattice"][:, 0, 0]).astype(int)
+        assert sorted(ids.tolist()) == list(range(total))           # every crystal exactly once ...
+        assert np.allclose(z["lattice"][:, 0, 0], np.arange(total))  # ... and crystal order preserved across ranks
         assert z["num_atoms"].tolist() == [n_atoms] * total
         assert z["idx_start"].tolist() == list(range(0, total * n_atoms, n_atoms))
         assert z["atomic_numbers"].tolist() == np.repeat(1 + np.arange(total) % 5, n_atoms).tolist()

@@ -25,11 +25,11 @@ from tests.helpers import oracle_from_module, random_state  # noqa: E402
 
 
 def q_block(b, bits=16, grp=8):
-    """bq_encode8 + decode: signed `bits`-bit mantissas, one exponent per `grp` consecutive values; amax (1 + 2^-(bits-1)) < 2^E"""
+    """bq_encode8 + decode: signed `bits`-bit mantissas, one exponent per `grp` consecutive values; amax (1 + 2^-10) < 2^E, E >= -17"""
     R = b.shape[0]
     v = b.reshape(R, -1, grp).double()
-    am = v.abs().amax(-1, keepdim=True) * (1 + 2.0 ** -(bits - 1))
-    E = (torch.floor(torch.log2(am.clamp_min(2.0 ** -80))) + 1).clamp(min=-32)
+    am = v.abs().amax(-1, keepdim=True) * (1 + 2.0 ** -10)
+    E = (torch.floor(torch.log2(am.clamp_min(2.0 ** -80))) + 1).clamp(min=-17)
     s = torch.exp2((bits - 1) - E)
     return (torch.round(v * s) / s).float().reshape(b.shape)
 

@@ -1,3 +1,4 @@
+"""What arreau_model_create's calibration batch measures for several weight sets (GPU box): ARREAU_VERBOSE_CALIBRATION=1 python3 tools/exp/calib_probe.py"""
 import sys, torch
 sys.path.insert(0, "/root/repo")
 from arreau_amd.checkpoint import make_synthetic_model

@@ -1,9 +1,9 @@
 #!/bin/bash
-# usage (GPU box): tools/gpu_round.sh <tag> [prev-lib tag]  -- the whole GPU suite, then (optionally) an A/B at 256 x 20 of the in-tree library
-# against tools/exp/ab/lib_<prev>.so (alternating on this box: graph replay ms per step + the message kernel's launch time)
-tag=$1; prev=$2
+# usage (GPU box): tools/gpu_tests_from.sh <tag> "<pytest -k expression>" [prev-lib tag]  -- selected GPU tests, then (optionally) the A/B of
+# tools/gpu_round.sh
+tag=$1; kexpr=$2; prev=$3
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-timeout -k 10 1000 python3 -m pytest tests -m gpu -x -q -s > gpurun_out/${tag}_pytest.log 2>&1; rc=$?
+timeout -k 10 1000 python3 -m pytest tests -m gpu -x -q -s -k "$kexpr" > gpurun_out/${tag}_pytest.log 2>&1; rc=$?
 grep -n "passed\|failed" gpurun_out/${tag}_pytest.log | tail -n 2
 [ $rc -eq 0 ] || { grep -n "Error\|assert \|FAILED" gpurun_out/${tag}_pytest.log | tail -n 20; exit $rc; }
 [ -n "$prev" ] || exit 0

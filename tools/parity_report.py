@@ -59,7 +59,7 @@ def main():
     # Round 4: "basis_form_*" = the message path of launches above 2,000 receivers (what bench.py's `value` runs: stashed basis,
     # per-layer projection in conv_proj.hip), forced at these oracle-sized batches with ARREAU_BASIS_MIN_RECEIVERS=240 (read per
     # launch) -- with the two cross products on the fp8 matrix instruction (the default), with three fp16 products
-    # (ARREAU_CROSS_FP8=0); ARREAU_BASIS_Q16=0 in the environment of the whole run gives the same rows on two fp16 planes in the stash instead of
+    # (ARREAU_CROSS_FP8=0); ARREAU_BASIS_FP8=0 in the environment of the whole run gives the same rows on two fp16 planes in the stash instead of
     # the block-quantised values (that switch is read once per process).  Batches of at most 240 atoms
     # cannot take the basis form at all: their "basis_form_*" rows are SKIPPED (round 4 recorded them under a name they did not
     # run).
