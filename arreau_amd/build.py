@@ -13,7 +13,7 @@ import time
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
 SOURCES = ["model.hip", "graph.hip", "edge.hip", "edge_bf16.hip", "edge_f16.hip", "node.hip", "node_bf16.hip", "node_f16.hip", "node_f16m.hip", "conv_proj.hip", "update.hip", "train.hip", "train_net.hip", "api.hip"]
-HEADERS = ["internal.h", "bf16x6.h", "f16x3.h", os.path.join("..", "..", "include", "arreau_hip.h"), "sgemm.h", "philox.h", "embed_dev.h", "prep_dev.h"]
+HEADERS = ["internal.h", "bf16x6.h", "f16x3.h", os.path.join("..", "..", "include", "arreau_hip.h"), "sgemm.h", "philox.h", "embed_dev.h", "prep_dev.h", "graph_dev.h", "update_dev.h", "readout_dev.h"]
 LIB = os.path.join(CSRC, "libarreau_hip.so")
 # Debug twin: the same sources with -DARREAU_DEBUG_WAIT_ALL (every hand-counted `s_waitcnt vmcnt(N)` becomes vmcnt(0)).
 # Its outputs must be bit-identical to the product library's (test_counted_waits_match_full_waits); only the sources
