@@ -197,8 +197,12 @@ __global__ __launch_bounds__(64 * (PW + 4), (PW + 4) / 4) void conv_proj_kernel(
         // role issues no asm memory operation), consumed slot by slot
         f32x4v xv[4][MT];
         const unsigned x_off = (unsigned)c16 * C + cb;
+        // (round 5: a slot beyond the receiver's degree needs no select per value any more -- its stash block is all zeros (the edge
+        // kernel writes zero blocks for the slots it does not compute, and a computed slot beyond the degree has window 0), so its K
+        // tile is exactly zero and K * x adds nothing, whichever valid row x comes from: eight vector instructions fewer per slot on
+        // a wave that has its SIMD to itself)
         auto load_x = [&](const int32_t* srow, int s_, int buf) {
-            const int sn = max(srow[s_], 0);  // unused slots: any valid row, dropped by the select below
+            const int sn = max(srow[s_], 0);  // unused slots: any valid row
             const float* xr = x_in + (size_t)sn * 16 * C;  // wave-uniform base + one 32-bit lane offset
 #pragma unroll
             for (int mt = 0; mt < MT; ++mt) xv[buf][mt] = *reinterpret_cast<const f32x4v*>(xr + (x_off + 16 * mt));
@@ -255,7 +259,8 @@ __global__ __launch_bounds__(64 * (PW + 4), (PW + 4) / 4) void conv_proj_kernel(
                 for (int r = 0; r < 4; ++r) {
                     float kv = am[set][mt][r];
                     if constexpr (!X8) kv = fmaf(ax[set][mt][r], F16X3_INV_SCALE, kv);
-                    sum[mt][r] = on ? __fadd_rn(sum[mt][r], __fmul_rn(kv, xv[xbuf][mt][r])) : sum[mt][r];
+                    sum[mt][r] = __fadd_rn(sum[mt][r], __fmul_rn(kv, xv[xbuf][mt][r]));  // (a slot beyond the degree: 0 * x)
+                    asm volatile("" : "+v"(sum[mt][r]));  // (keeps each add where the select used to pin it: without it hipcc spills)
                 }
         };
         auto epilogue_piece = [&](int set, int xbuf, bool on, int v) {  // value v = 4 mt + r of the same arithmetic
@@ -263,7 +268,8 @@ __global__ __launch_bounds__(64 * (PW + 4), (PW + 4) / 4) void conv_proj_kernel(
             if (mt < MT) {
                 float kv = am[set][mt][r];
                 if constexpr (!X8) kv = fmaf(ax[set][mt][r], F16X3_INV_SCALE, kv);
-                sum[mt][r] = on ? __fadd_rn(sum[mt][r], __fmul_rn(kv, xv[xbuf][mt][r])) : sum[mt][r];
+                sum[mt][r] = __fadd_rn(sum[mt][r], __fmul_rn(kv, xv[xbuf][mt][r]));
+                asm volatile("" : "+v"(sum[mt][r]));
             }
         };
         auto write_tile = [&]() {

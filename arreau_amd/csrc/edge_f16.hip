@@ -208,7 +208,20 @@ __global__ __launch_bounds__(64 * EH_WAVES, 2) void edge_kernel_f16x3(
         };
 
         if (!active) {
-            // no slots: keep the ring turning
+            // no slots: keep the ring turning.  Basis form (round 5): the stash blocks of this wave's two slots are ZEROED -- the message
+            // kernel streams and projects all eight slots of a receiver and no longer selects per value: a slot beyond the degree must
+            // project to an exactly zero K tile (conv_proj.hip), as the computed slots beyond the degree do through their window 0.  (Rare: receivers with fewer
+            // than seven neighbours.  The stores are drained by the full waits below.)
+            if constexpr (!PROJ) {
+                if (node_raw < n1) {
+                    constexpr unsigned SLOT = BFP8 ? 12288u : 16384u;
+                    const char* blk = reinterpret_cast<const char*>(kbuf) + ((size_t)node * k + 2 * wn) * SLOT;
+                    const u32x4 zero4 = {0u, 0u, 0u, 0u};
+                    const int nblk = 2 * wn + 1 < k ? 2 : 1;
+                    for (unsigned o = 0; o < (unsigned)nblk * SLOT; o += 1024u)
+                        asm volatile("global_store_dwordx4 %0, %1, %2" ARREAU_K_STORE_TAIL : : "v"(lane16 + o), "v"(zero4), "s"(blk) : "memory");
+                }
+            }
             [&]<int... Q>(std::integer_sequence<int, Q...>) {
                 ((dma_wait(), __syncthreads(), copy12(std::integral_constant<int, Q>{}), sl = slot_after(sl, 1)), ...);
             }(std::make_integer_sequence<int, TC + TD>{});
