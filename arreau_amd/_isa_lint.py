@@ -561,7 +561,7 @@ def lds_protocol_summary(path):
 # what the rules above know how to reason about when it appears INSIDE an asm string
 _ASM_MODELLED = re.compile(r"^(s_mov_b32|s_add_u32|s_nop|s_waitcnt|landed|global_load_lds_dwordx4|global_load_dwordx4|"
                            r"global_store_dword|global_store_dwordx2|global_store_dwordx3|global_store_dwordx4|"
-                           r"v_fma_mixlo_f16|v_fma_mixhi_f16|v_mov_b32)$")
+                           r"v_fma_mixlo_f16|v_fma_mixhi_f16|v_fma_mix_f32|v_mov_b32)$")
 
 
 def check_modelled(name, code):

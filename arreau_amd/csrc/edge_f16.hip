@@ -361,6 +361,7 @@ __global__ __launch_bounds__(64 * EH_WAVES, 2) void edge_kernel_f16x3(
             for (int nb = 0; nb < 2; ++nb) { b16[nb][u][0] = u32x4{0, 0, 0, 0}; b16[nb][u][1] = u32x4{0, 0, 0, 0}; }
             if (go) {
                 ms.template run<TC, 2 * TC>(acc, h16);
+                unsigned lo8x[2][2] = {{0u, 0u}, {0u, 0u}};  // BFP8: the e4m3 residuals of this k-block, [column block][tile mt] x 4 bytes
 #pragma unroll
                 for (int nb = 0; nb < 2; ++nb) {
 #pragma unroll
@@ -369,11 +370,19 @@ __global__ __launch_bounds__(64 * EH_WAVES, 2) void edge_kernel_f16x3(
                         for (int pr = 0; pr < 2; ++pr) {
                             const f32x2 pre = fma2(f32x2{acc.x[mt][nb][2 * pr], acc.x[mt][nb][2 * pr + 1]}, splat2(F16X3_INV_SCALE),
                                                    f32x2{acc.m[mt][nb][2 * pr], acc.m[mt][nb][2 * pr + 1]});
+                            const f32x2 gw = gelu_fast2(pre) * splat2(win16[nb]);  // |window| <= 1
                             unsigned hi, lo;
-                            split_pair2<false>(gelu_fast2(pre) * splat2(win16[nb]), hi, lo);  // |window| <= 1
-                            if constexpr (PROJ && BFP8) lo = round_lo_fp8(lo);
+                            if constexpr (BFP8) {
+                                // residual straight to e4m3 (f16x3.h: split_pair_fp8); basis form: the bytes are what is stored
+                                // (lo8x[nb][mt] = the four bytes of tile mt), in place: widened back for the fp16 products
+                                if (pr == 0) split_pair_fp8<false>(gw, hi, lo8x[nb][mt]);
+                                else split_pair_fp8<true>(gw, hi, lo8x[nb][mt]);
+                                lo = pr == 0 ? widen_lo8<false>(lo8x[nb][mt]) : widen_lo8<true>(lo8x[nb][mt]);
+                            } else {
+                                split_pair2<false>(gw, hi, lo);
+                            }
                             b16[nb][u][0][2 * mt + pr] = hi;
-                            b16[nb][u][1][2 * mt + pr] = lo;
+                            if constexpr (PROJ || !BFP8) b16[nb][u][1][2 * mt + pr] = lo;
                         }
                 }
                 if constexpr (!PROJ) {
@@ -391,21 +400,8 @@ __global__ __launch_bounds__(64 * EH_WAVES, 2) void edge_kernel_f16x3(
                                          :
                                          : "v"(lane16), "v"(b16[nb][u][0]), "s"(blk + SLOT * nb + 1024 * u)
                                          : "memory");
-                            typedef _Float16 h2_t __attribute__((ext_vector_type(2)));
-                            typedef short s2_t __attribute__((ext_vector_type(2)));
-                            unsigned lo8[2];
-#pragma unroll
-                            for (int w2 = 0; w2 < 2; ++w2) {  // halves 4 w2 .. 4 w2 + 3 of the lane's eight -> one dword of fp8
-                                // (element copies first: __builtin_bit_cast applied to a vector-element lvalue reads element
-                                // 0 whatever the index -- hipcc 7.2)
-                                const unsigned p0 = b16[nb][u][1][2 * w2], p1 = b16[nb][u][1][2 * w2 + 1];
-                                s2_t r = {0, 0};
-                                r = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(r, __builtin_bit_cast(h2_t, p0), 1.0f, false);
-                                r = __builtin_amdgcn_cvt_scalef32_pk_fp8_f16(r, __builtin_bit_cast(h2_t, p1), 1.0f, true);
-                                lo8[w2] = __builtin_bit_cast(unsigned, r);
-                            }
                             typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
-                            const u32x2_t lo = {lo8[0], lo8[1]};
+                            const u32x2_t lo = {lo8x[nb][0], lo8x[nb][1]};  // (tile mt = halves 4 mt .. 4 mt + 3 of the lane's eight)
                             asm volatile("global_store_dwordx2 %0, %1, %2"
                                          :
                                          : "v"(lane16 >> 1), "v"(lo), "s"(blk + SLOT * nb + 8192 + 512 * u)
@@ -671,9 +667,15 @@ __global__ __launch_bounds__(512) void edge_kernel_f16x3_split(
                 for (int pr = 0; pr < 2; ++pr) {
                     const f32x2 pre = fma2(f32x2{acc.x[mt][nb][2 * pr], acc.x[mt][nb][2 * pr + 1]}, splat2(F16X3_INV_SCALE),
                                            f32x2{acc.m[mt][nb][2 * pr], acc.m[mt][nb][2 * pr + 1]});
+                    const f32x2 gw = gelu_fast2(pre) * splat2(win16[nb]);  // |window| <= 1
                     unsigned hi, lo;
-                    split_pair2<false>(gelu_fast2(pre) * splat2(win16[nb]), hi, lo);  // |window| <= 1
-                    if constexpr (BFP8) lo = round_lo_fp8(lo);
+                    if constexpr (BFP8) {  // (the residual as the basis form stores it: f16x3.h, split_pair_fp8)
+                        unsigned l8 = 0u;
+                        split_pair_fp8<false>(gw, hi, l8);
+                        lo = widen_lo8<false>(l8);
+                    } else {
+                        split_pair2<false>(gw, hi, lo);
+                    }
                     hi4[2 * mt + pr] = hi;
                     lo4[2 * mt + pr] = lo;
                 }

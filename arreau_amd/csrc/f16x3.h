@@ -95,6 +95,29 @@ __device__ __forceinline__ void split_pair2(f32x2 v, unsigned& hi, unsigned& lo)
     asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(lo) : "v"(hi), "s"(neg_scale), "v"(sc.x));
     asm("v_fma_mixhi_f16 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(lo) : "v"(hi), "s"(neg_scale), "v"(sc.y));
 }
+// The planes of a BASIS value pair (round 5): hi as above; the residual goes straight from fp32 to e4m3 --
+//     r = v - f32(hi)   (v_fma_mix_f32: reads the fp16 half in place; exact),   lo8 = e4m3(r * 2^11)   (v_cvt_scalef32_pk_fp8_f32,
+//     whose scale operand DIVIDES by its power of two: tools/exp/fp8_scale_check.hip)
+// -- 1.5 vector instructions per value where multiply + v_fma_mix*_f16 + v_cvt_scalef32_pk_fp8_f16 took 2.5 (the stash encoder
+// of the edge kernel: 168 M basis values per step at 256 x 20).  One rounding instead of two (fp32 -> fp16 -> e4m3): every fp16x3
+// path forms the basis residual with THIS function, so they still agree bit for bit.  WORD selects the half of `lo8` that
+// receives the two bytes.
+template <bool WORD>
+__device__ __forceinline__ void split_pair_fp8(f32x2 v, unsigned& hi, unsigned& lo8) {
+    typedef short s16x2 __attribute__((ext_vector_type(2)));
+    hi = __builtin_bit_cast(unsigned, cvt_f16x2(v));
+    float r0, r1;
+    const float neg_one = -1.0f;
+    asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(r0) : "v"(hi), "s"(neg_one), "v"(v.x));
+    asm("v_fma_mix_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "=v"(r1) : "v"(hi), "s"(neg_one), "v"(v.y));
+    lo8 = __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_scalef32_pk_fp8_f32(__builtin_bit_cast(s16x2, lo8), r0, r1, F16X3_INV_SCALE, WORD));
+}
+// the two e4m3 residuals of word WORD widened to fp16 (exact): the residual plane as the three-fp16-product kernels take it
+template <bool WORD>
+__device__ __forceinline__ unsigned widen_lo8(unsigned lo8) {
+    return __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(lo8, 1.0f, WORD));
+}
+
 __device__ __forceinline__ Planes2 split_tile2(const f32x16& x) {
     Planes2 r;
 #pragma unroll

@@ -1220,8 +1220,8 @@ def test_basis_stash_holds_fp16_and_e4m3_planes(dev, full_model):
     """The stash the edge kernel writes in the basis form, read back from the workspace: per edge slot a 12 KiB block of
     eight 1 KiB hi fragments (fp16, [k-block][lane][8 halves]) and eight 512 B lo fragments (OCP fp8 e4m3).  Against the
     4-byte form (ARREAU_BASIS_FP8=0, both planes fp16) of the same evaluation, run in a second process: the hi planes are
-    identical and every fp8 byte is torch's float8_e4m3fn rounding (nearest even) of the fp16 residual.  (Found with this
-    comparison in round 3: a __builtin_bit_cast on a vector-element lvalue that read element 0 for every index.)"""
+    identical and every fp8 byte is the e4m3 rounding (nearest even) of the residual.  (Found with this comparison in round 3:
+    a __builtin_bit_cast on a vector-element lvalue that read element 0 for every index.)"""
     import subprocess
     import sys
     import tempfile
@@ -1255,8 +1255,15 @@ def test_basis_stash_holds_fp16_and_e4m3_planes(dev, full_model):
     lo = a[:, 8192:].contiguous().view(torch.uint8).view(slots, 8, 64, 8)
     assert torch.isfinite(b16.float()).all() and float(b16[:, :, 0].float().abs().max()) > 0.1  # every slot was written (k = 8 everywhere)
     assert torch.equal(hi.view(torch.int16), b16[:, :, 0].contiguous().view(torch.int16))
-    want = b16[:, :, 1].float().to(torch.float8_e4m3fn).view(torch.uint8)
-    assert int((want != lo).sum()) == 0
+    # Round 5: the bytes come straight from the fp32 residual (one rounding: f16x3.h, split_pair_fp8), the fp16 plane of the other
+    # run from fp32 -> fp16: rounding that once more to e4m3 reproduces the stored byte except where the fp16 rounding moved the
+    # value onto or across an e4m3 tie -- rare, and then the two codes are neighbours.
+    want = b16[:, :, 1].float().to(torch.float8_e4m3fn)
+    got = lo.view(torch.float8_e4m3fn)
+    differ = want.view(torch.uint8) != lo
+    assert float(differ.double().mean()) < 2e-3, float(differ.double().mean())
+    gap = (got.float() - want.float()).abs()
+    assert bool((gap <= torch.clamp(want.float().abs() * 0.125, min=2.0 ** -9) * 1.001).all()), float(gap.max())
 
 
 def _philox_ref(ctr, key):
