@@ -12,7 +12,7 @@ import sys
 import time
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
-SOURCES = ["model.hip", "graph.hip", "edge.hip", "edge_bf16.hip", "edge_f16.hip", "node.hip", "node_bf16.hip", "node_f16.hip", "node_f16m.hip", "conv_proj.hip", "update.hip", "train.hip", "train_net.hip", "api.hip"]
+SOURCES = ["model.hip", "graph.hip", "edge.hip", "edge_bf16.hip", "edge_f16.hip", "node.hip", "node_bf16.hip", "node_f16m.hip", "conv_proj.hip", "update.hip", "train.hip", "train_net.hip", "api.hip"]
 HEADERS = ["internal.h", "bf16x6.h", "f16x3.h", os.path.join("..", "..", "include", "arreau_hip.h"), "sgemm.h", "philox.h", "embed_dev.h", "prep_dev.h", "graph_dev.h", "update_dev.h", "readout_dev.h"]
 LIB = os.path.join(CSRC, "libarreau_hip.so")
 # Debug twin: the same sources with -DARREAU_DEBUG_WAIT_ALL (every hand-counted `s_waitcnt vmcnt(N)` becomes vmcnt(0)).
@@ -26,18 +26,18 @@ STAMP = os.path.join(CSRC, ".build_stamp")
 # the compiler reports scratch for them.  source -> substrings of the (mangled) kernel names to check (None = all).
 # (conv_proj.hip is covered by the ISA lint instead: its projection role may spill -- it issues no asm memory operation
 # and hipcc counts its own scratch traffic --, its mix role, which hand-counts, must not share a path with a spill)
-NO_SCRATCH = {"edge_f16.hip": None, "node.hip": ["conv_kernel_streamed"], "node_f16.hip": None, "node_f16m.hip": None}
+NO_SCRATCH = {"edge_f16.hip": None, "node.hip": ["conv_kernel_streamed"], "node_f16m.hip": None}
 # Sources with inline asm: their device ISA is kept (-save-temps) and run through arreau_amd/_isa_lint.py -- software wait
 # states around every asm instruction (store-data, VALU-written SGPR -> VMEM, M0 -> LDS-DMA, ...), asm loads' destination
 # registers untouched until their wait, no compiler use of M0, no unmodelled instruction kind inside asm.  hipcc pads and
 # counts none of that for inline asm; a violation fails the build.
-ASM_LINT = ("edge_f16.hip", "node.hip", "node_f16.hip", "node_f16m.hip", "graph.hip", "api.hip", "conv_proj.hip", "train_net.hip")
+ASM_LINT = ("edge_f16.hip", "node.hip", "node_f16m.hip", "graph.hip", "api.hip", "conv_proj.hip", "train_net.hip")
 # -Wno-inline-asm: the lean LDS-DMA asm lists "m0" as clobbered (it overwrites M0 and does not restore it); clang warns
 # that reserved registers in a clobber list are not preserved for us -- which is what is declared, not asked for.  The
 # ISA check below verifies that the compiler itself never uses M0 in those kernels.
 # Extra flags per source.  The split-precision kernels keep their epilogue arithmetic as independent fp32 instructions
 # (f16x3.h): the SLP vectoriser would fuse adjacent ones back into v_pk_*_f32.
-PER_SOURCE_FLAGS = {src: ["-fno-slp-vectorize"] for src in ("edge_f16.hip", "node_f16.hip", "node_f16m.hip")}
+PER_SOURCE_FLAGS = {src: ["-fno-slp-vectorize"] for src in ("edge_f16.hip", "node_f16m.hip")}
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++20", "-fPIC", "-Wall", "-Wno-unused-function", "-Wno-inline-asm",
          "-Wno-unused-but-set-variable", "-Wno-misleading-indentation", "-ffp-contract=on"] + os.environ.get("ARREAU_EXTRA_HIPCC_FLAGS", "").split()
 

@@ -222,8 +222,7 @@ int arreau_launch_edge(const arreau_model* m, const float* dir, const float* dis
         return ARREAU_EINVAL;
     }
     // variant switch (default 4; the fp32-MFMA kernels stay for A/B runs and as the numerical cross-check):
-    // 0 = 32 rows/wave, 2 waves/SIMD; 1 = 64 rows/wave, 1 wave/SIMD;
-    // 2 = 32 rows/wave, 1 wave/SIMD; 3 = bf16x6 split-precision kernel (edge_bf16.hip);
+    // 0 (also 1, 2) = fp32 MFMA, 32 rows/wave, 2 waves/SIMD; 3 = bf16x6 split-precision kernel (edge_bf16.hip);
     // 4 = fp16x3 split-precision kernel (edge_f16.hip; falls back to 3 when a weight does not fit fp16)
     const int variant = m->edge_variant;
     if (variant == 4 && m->f16_ok) {
@@ -238,10 +237,8 @@ int arreau_launch_edge(const arreau_model* m, const float* dir, const float* dis
         m->ran_edge = 3;
         return arreau_launch_edge_bf16x6(m, dir, dist, deg, batch, lattice, N, kbuf, s);
     }
-    m->ran_edge = variant == 1 ? 1 : (variant == 2 ? 2 : 0);
-    if (variant == 1) launch_variant<2, 1>(m, dir, dist, deg, batch, lattice, N, kbuf, s);
-    else if (variant == 2) launch_variant<1, 1>(m, dir, dist, deg, batch, lattice, N, kbuf, s);
-    else launch_variant<1, 2>(m, dir, dist, deg, batch, lattice, N, kbuf, s);
+    m->ran_edge = 0;  // (variants 1 and 2, other wave geometries of the same fp32-MFMA kernel, were removed in round 5)
+    launch_variant<1, 2>(m, dir, dist, deg, batch, lattice, N, kbuf, s);
     ARREAU_CHECK_HIP(hipGetLastError());
     return ARREAU_OK;
 }

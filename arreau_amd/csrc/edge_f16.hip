@@ -801,16 +801,12 @@ int arreau_launch_edge_f16x3(const arreau_model* m, const float* dir, const floa
     const bool whole_batch = n0 == 0 && n1 == N && r.wg_cap == 0;
     const bool use_split = split_ok && !arreau_basis_form(m, N) &&
                            (split_env >= 0 ? split_env != 0 : (whole_batch && (n1 - n0) <= ARREAU_EDGE_SPLIT_MAX_NODES));
-    const bool k3 = arreau_k3(m);  // K tiles as 3-byte floats (the node-layer launcher reads the same decision)
     if (use_split) {
         auto launch = [&](auto kernel) {
             ARREAU_LAUNCH(kernel, dim3((unsigned)(n1 - n0) * 4), dim3(512), 0, s, dir, dist, deg, batch, lattice, m->ori,
                                reinterpret_cast<const u32x4*>(m->edge_f16), m->b1, m->b2, m->cfg.radius, N, m->k, m->L, kbuf, n0);
         };
-        const bool bq = arreau_basis_fp8(m);
-        if (k3 && bq) launch(edge_kernel_f16x3_split<128, 256, true, true>);
-        else if (k3) launch(edge_kernel_f16x3_split<128, 256, true, false>);
-        else if (bq) launch(edge_kernel_f16x3_split<128, 256, false, true>);
+        if (arreau_basis_fp8(m)) launch(edge_kernel_f16x3_split<128, 256, false, true>);
         else launch(edge_kernel_f16x3_split<128, 256, false, false>);
         ARREAU_CHECK_HIP(hipGetLastError());
         return ARREAU_OK;
@@ -834,10 +830,7 @@ int arreau_launch_edge_f16x3(const arreau_model* m, const float* dir, const floa
         ARREAU_LAUNCH(kernel, dim3(wgs), dim3(512), 0, s, dir, dist, deg, batch, lattice, m->ori,
                            reinterpret_cast<const u32x4*>(m->edge_f16), m->b1, m->b2, m->cfg.radius, N, m->k, m->L, kbuf, n0, n1);
     };
-    const bool bq = arreau_basis_fp8(m);
-    if (k3 && bq) launch(edge_kernel_f16x3<128, 256, 8, true, true, true>);
-    else if (k3) launch(edge_kernel_f16x3<128, 256, 8, true, true, false>);
-    else if (bq) launch(edge_kernel_f16x3<128, 256, 8, false, true, true>);
+    if (arreau_basis_fp8(m)) launch(edge_kernel_f16x3<128, 256, 8, false, true, true>);
     else launch(edge_kernel_f16x3<128, 256, 8, false, true, false>);
     ARREAU_CHECK_HIP(hipGetLastError());
     return ARREAU_OK;

@@ -340,8 +340,6 @@ int arreau_launch_small_layer(const arreau_model* m, int layer, const float* kbu
                               const float* x_in, float* x_out, float* xbar, float* vsum, int Ntot, hipStream_t s);
 int arreau_launch_mlp_f16x3_m16_split(const arreau_model* m, int layer, const float* x_conv, const float* x_in, float* x_out,
                                       float* xbar, float* vsum, int N, hipStream_t s, NodeRange r = NodeRange());
-int arreau_launch_mlp_f16x3(const arreau_model* m, int layer, const float* x_conv, const float* x_in, float* x_out,
-                            float* xbar, float* vsum, int N, hipStream_t s);
 int arreau_launch_readout(const arreau_model* m, const float* xbar, const float* vsum, const int32_t* offsets,
                           int B, int N, float* gs, float* eps, float* logits, float* len0, hipStream_t s, NodeRange r = NodeRange());
 bool arreau_range_launches_supported(const arreau_model* m);  // the default kernel set (fp16x3 edge + MLP, streamed conv, MFMA read-out)

@@ -646,12 +646,7 @@ int arreau_launch_node_layer(const arreau_model* m, int layer, const float* kbuf
     } else if (conv_variant == 1 && m->k == 8) {
         int blocks = Ng < 256 ? Ng : 256;
         if (r.wg_cap > 0 && blocks > r.wg_cap) blocks = r.wg_cap;
-        if (arreau_k3(m))  // (the edge launcher took the same decision: a row of K is 3 C bytes)
-            ARREAU_LAUNCH((conv_kernel_streamed<128, true>), dim3(blocks), dim3(512), 0, s,
-                               reinterpret_cast<const float*>(reinterpret_cast<const char*>(kbuf) + (size_t)layer * layer_stride * 3), deg,
-                               src, x_in, m->fk + (size_t)layer * 16 * 16 * C, m->conv_bias + (size_t)layer * C, n0, Ng, x_conv);
-        else
-            ARREAU_LAUNCH((conv_kernel_streamed<128, false>), dim3(blocks), dim3(512), 0, s, kbuf + (size_t)layer * layer_stride, deg,
+        ARREAU_LAUNCH((conv_kernel_streamed<128, false>), dim3(blocks), dim3(512), 0, s, kbuf + (size_t)layer * layer_stride, deg,
                                src, x_in, m->fk + (size_t)layer * 16 * 16 * C, m->conv_bias + (size_t)layer * C, n0, Ng, x_conv);
     } else {
         int blocks = Ng < 512 ? Ng : 512;
@@ -660,8 +655,8 @@ int arreau_launch_node_layer(const arreau_model* m, int layer, const float* kbuf
                            deg, src, x_in, m->fk + (size_t)layer * 16 * 16 * C, m->conv_bias + (size_t)layer * C, n0, Ng, m->k, x_conv);
     }
     ARREAU_CHECK_HIP(hipGetLastError());
-    // variant switch: 3 (default) = fp16x3 on 16x16x32 MFMAs (node_f16m.hip); 2 = fp16x3 on 32x32x16 MFMAs (node_f16.hip) -- both
-    // need weights that fit fp16; 1 = bf16x6 split-precision MLP kernel (node_bf16.hip); 0 = fp32-MFMA kernel below
+    // variant switch: 3 (default) = fp16x3 on 16x16x32 MFMAs (node_f16m.hip; needs weights that fit fp16); 1 = bf16x6 split-precision
+    // MLP kernel (node_bf16.hip); 0 = fp32-MFMA kernel below  (2, the same arithmetic on 32x32x16 MFMAs, was removed in round 5)
     // 4 = always the small-launch form of 3 (one node per workgroup, node_f16m.hip: bit-identical; 3 picks it by size)
     const int mlp_variant = m->mlp_variant;
     if (mlp_variant == 4 && m->f16_ok) {
@@ -675,10 +670,6 @@ int arreau_launch_node_layer(const arreau_model* m, int layer, const float* kbuf
     if (!whole) {
         arreau_set_error("mlp kernel: range launches are implemented for the fp16x3 16x16x32 kernel only");
         return ARREAU_EINVAL;
-    }
-    if (mlp_variant >= 2 && m->f16_ok) {
-        m->ran_mlp = 2;
-        return arreau_launch_mlp_f16x3(m, layer, x_conv, x_in, x_out, xbar, vsum, N, s);
     }
     if (mlp_variant >= 1) {
         m->ran_mlp = 1;
@@ -816,15 +807,9 @@ __global__ void readout_crystals_kernel(const float* __restrict__ gs, const int3
     len0[idx] = acc;
 }
 
-// K tiles as 3-byte floats (internal.h, "K stash format"): only for the producer / consumer pair that implements it -- the
-// split-precision edge kernels (both forms) and the streamed conv kernel.  ARREAU_K3=0 keeps fp32 (A/B, tests).
-bool arreau_k3(const arreau_model* m) {
-    static const int env = [] { const char* e = getenv("ARREAU_K3"); return e ? atoi(e) : 1; }();
-    // (conv_variant 2, the default, keeps K in fp32 wherever a launch is too small for the basis form: those launches are
-    // latency-bound, and an fp32 K makes them bit-identical to the basis form -- a crystal evaluated alone equals the same
-    // crystal inside a large batch)
-    return env != 0 && m->edge_variant == 4 && m->f16_ok && m->conv_variant == 1 && m->k == 8 && m->C == 128 && m->D == 256;
-}
+// (Round 5: the 3-byte K stash of round 2 -- ARREAU_K3, the K pair's format when it ran at every size -- is gone with that mode:
+// the K pair now only serves launches too small for the basis form, on an fp32 K buffer, bit-identical to the basis form.)
+bool arreau_k3(const arreau_model*) { return false; }
 
 // conv_variant 2 (default): basis form wherever it applies -- the fused shape, k = 8, fp16-representable weights, the
 // split-precision edge kernel -- and a launch large enough for it to pay: measured at n = 20 (graph replay, one box), the

@@ -1016,7 +1016,7 @@ def test_rotation_equivariance_through_the_kernels(dev, rot):
     assert (vec_a - vec_b).abs().max() > 1e-3 * float(vec_a.abs().max())  # and the vector output did rotate
 
 
-@pytest.mark.parametrize("edge_variant,mlp_variant", [("0", "0"), ("3", "1"), ("4", "2")])
+@pytest.mark.parametrize("edge_variant,mlp_variant", [("0", "0"), ("3", "1")])
 def test_alternative_arithmetic_variants_agree(dev, small_model, edge_variant, mlp_variant):
     """The exact fp32-MFMA kernels, the bf16x6 kernels and the 32x32x16 form of the fp16x3 MLP kernel stay in the
     library as cross-checks of the default kernels (fp16x3 on 16x16x32 MFMAs); the variant is read once per process,
@@ -1073,7 +1073,7 @@ def test_launch_geometry_switches_and_counted_waits_are_bitwise_neutral(dev):
     assert os.path.exists(LIB_DEBUG_WAIT)
     outs = {}
     with tempfile.TemporaryDirectory() as d:
-        for tag, env in (("default", {}), ("k3off", {"ARREAU_CONV_VARIANT": "1", "ARREAU_K3": "0"}), ("conv0", {"ARREAU_CONV_VARIANT": "0"}),
+        for tag, env in (("default", {}), ("conv0", {"ARREAU_CONV_VARIANT": "0"}),
                          ("pair", {"ARREAU_CONV_VARIANT": "1"}), ("basis16", {"ARREAU_BASIS_FP8": "0"}), ("x16", {"ARREAU_CROSS_FP8": "0"}),
                          ("wgs", {"ARREAU_EDGE_WGS": "100000"}),
                          ("dbgwait", {"ARREAU_HIP_LIB": LIB_DEBUG_WAIT}), ("nb1", {"ARREAU_MLP_NB": "1"}),
@@ -1093,16 +1093,15 @@ def test_launch_geometry_switches_and_counted_waits_are_bitwise_neutral(dev):
             assert torch.equal(x, y), tag
     # Round 3, the default: NO K stash -- the edge kernel stores the basis planes and every layer's message kernel projects
     # them itself (conv_proj.hip).  Same products in the same order as the kernels it replaces, so it is bit-identical to
-    # the round-2 pair (edge kernel with projections + streamed conv kernel, ARREAU_CONV_VARIANT=1) on an fp32 K stash
-    # (ARREAU_K3=0), which in turn is bit-identical to the register form of the conv kernel (ARREAU_CONV_VARIANT=0).  The
-    # round-2 default, the same pair with K as 3-byte floats, agrees to the parity tolerance (K rounded to 16 significand
-    # bits: tools/exp/k_precision_study.py).
+    # the round-2 pair (edge kernel with projections + streamed conv kernel, ARREAU_CONV_VARIANT=1) on its fp32 K stash, which
+    # in turn is bit-identical to the register form of the conv kernel (ARREAU_CONV_VARIANT=0).  (The 3-byte K stash that pair
+    # once ran on was removed in round 5.)
     # Same products in the same order: the basis form (default) is bit-identical to the round-2 pair on an fp32 K stash and
     # to the register form of the conv kernel -- every fp16x3 edge kernel rounds the basis' residual plane to fp8 e4m3, the
     # form the stash holds (3 bytes per value).
     # (Round 4: with three fp16 products -- ARREAU_CROSS_FP8=0, "x16"; the default now runs the two cross products of the
     # projection on the fp8 matrix instruction, bounded below.)
-    for tag in ("k3off", "conv0"):
+    for tag in ("pair", "conv0"):
         for x, y in zip(outs["x16"], outs[tag]):
             assert torch.equal(x, y), tag
     # What the fp8 cross products cost.  The cross products sit 2^-11 below the main product; with e4m3 operands (four
@@ -1123,16 +1122,6 @@ def test_launch_geometry_switches_and_counted_waits_are_bitwise_neutral(dev):
           f"  len0 {b_len0:.2e} (|len0| {float(outs['basis16'][2].abs().max()):.1f})")
     assert b_eps <= 3e-7 and b_logits <= 4e-7 * max(1.0, float(outs["basis16"][1].abs().max()))
     assert b_len0 <= 6 * ulp32(float(outs["basis16"][2].abs().max()))
-    # What the 3-byte stash costs, bounded by what tools/exp/k_precision_study.py measured for 16 significand bits in the
-    # oracle (profiles/r02g_k_precision_study.txt: eps 7e-8, logits 3.6e-7 at |logits| <= 2, i.e. about 2e-7 of the
-    # largest logit -- the fp32 rounding floor) and what this comparison measures on the GPU (eps 1.3e-7, logits 1.9e-6 at
-    # |logits| = 6.8 = 2.8e-7 relative = 4 ulps, len0 2 ulps): a narrower stash format cannot eat the remaining parity
-    # margin silently.
-    d_eps, d_logits, d_len0 = (float((a - b).abs().max()) for a, b in zip(outs["pair"], outs["k3off"]))
-    print(f"[K stash] |3-byte - fp32| : eps {d_eps:.2e}  logits {d_logits:.2e} (|logits| {float(outs['k3off'][1].abs().max()):.1f})"
-          f"  len0 {d_len0:.2e} (|len0| {float(outs['k3off'][2].abs().max()):.1f})")
-    assert d_eps <= 3e-7 and d_logits <= 4e-7 * max(1.0, float(outs["k3off"][1].abs().max()))
-    assert d_len0 <= 3 * ulp32(float(outs["k3off"][2].abs().max()))
 
 
 def test_fp8_cross_products_fall_back_when_a_weight_would_saturate(dev, monkeypatch):
