@@ -58,6 +58,7 @@ struct arreau_model {
     int x8_weights_ok;       // 64 |w| <= 448 for every kernel weight (what x8_ok may be switched back to)
     int fp8_ok;              // 1 when the fp8 (e4m3) residual plane of the basis stash passed the end-to-end calibration (model.hip: calibrate_message_formats)
     float calib_fp8, calib_x8;  // share of the parity bounds the formats used up on the calibration batch (fp8 residual plane; that + fp8 cross products); -1: not measured
+    int train_full_range;    // 1: the training forward runs bf16x6 products even where the weights fit fp16 (arreau_model_set_variant(.., 1))
     int calibrating;         // 1 while that calibration runs: basis form at any launch size, formats from fp8_ok / x8_ok alone
     float edge_act_bound, node_act_bound;  // weight-derived bounds of the fp16 operands of the edge / ConvNext chains (model.hip)
     // Arithmetic / geometry variants requested for this model (defaults from ARREAU_*_VARIANT at create,

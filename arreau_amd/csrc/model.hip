@@ -754,6 +754,9 @@ extern "C" int arreau_model_set_variant(arreau_model* model, int32_t edge_varian
                    "arreau_model_set_variant: this model's shape (hidden_dim, basis_dim, widening_factor) has no fused kernels; "
                    "only the general path (edge variant 5) is available");
     if (edge_variant >= 0) model->edge_variant = edge_variant;
+    // (the training forward follows the ConvNext choice: bf16x6 = full-range products, fp16x3 = the default: train_net.hip)
+    if (mlp_variant == 1) model->train_full_range = 1;
+    else if (mlp_variant == 3) model->train_full_range = 0;
     if (mlp_variant >= 0) model->mlp_variant = mlp_variant;
     return ARREAU_OK;
 }

@@ -158,8 +158,25 @@ class PONITA_DIFFUSION(nn.Module):
         # the device status word is sticky: checking it every few steps loses nothing and keeps the step free of host
         # synchronisation (a check is a device-to-host read)
         self._train_steps = getattr(self, "_train_steps", 0) + 1
-        if self._train_steps % self.STATUS_CHECK_EVERY == 1:
-            eng.check_status()
+        if (self._train_steps - 1) % self.STATUS_CHECK_EVERY == 0:
+            st = eng.status(reset=False)
+            from .. import _hip as _h
+            # (the status read above has synchronised the stream: looking at this step's loss costs nothing more.  The training
+            # network does not raise NONFINITE itself -- that flag belongs to the sampling read-out --, the loss shows it)
+            nonfinite = st["flags"] == _h.STATUS_NONFINITE or (st["flags"] == 0 and not bool(torch.isfinite(loss.detach()).all()))
+            if nonfinite and not getattr(self, "_train_full_range", False):
+                # The training forward runs fp16x3 products while the weights fit fp16; its operand bounds were taken at engine
+                # creation and the weights have moved since.  An overflow surfaces here as NONFINITE: switch the
+                # engine to the full-range bf16x6 products for good (the sampler's remedy), drop the flag and go on -- the
+                # optimizer driver has turned the poisoned steps into no-ops (arreau_amd.train.optimizer_step).
+                import warnings
+                warnings.warn("arreau_amd: a training step came out non-finite on the fp16x3 forward products; this engine trains "
+                              "on the full-range bf16x6 products from now on")
+                eng.status(reset=True)
+                eng.set_variant(3 if eng.fused_shape else -1, 1)
+                self._train_full_range = True
+            else:
+                eng.check_status()
         done = torch.cuda.Event()
         done.record(torch.cuda.current_stream(eng.device))
         inflight.append(done)

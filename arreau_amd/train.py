@@ -64,6 +64,10 @@ def optimizer_step(model, optimizer, world_size: int = 1, clip: Optional[float] 
         if clip:
             norm = torch.linalg.vector_norm(flat, 2)
             flat.mul_(torch.clamp(clip / (norm + 1e-6), max=1.0))
+            # A non-finite gradient (an activation beyond the fp16 range of the split-precision forward: ADVICE round 4) must not
+            # reach Adam's moments before the periodic status check has switched the engine to the full-range products
+            # (PONITA_DIFFUSION.training_step): such a step becomes a no-op -- on the device, no host synchronisation.
+            flat.copy_(torch.where(torch.isfinite(norm), flat, torch.zeros_like(flat)))
     else:
         all_reduce_gradients(params, world_size)
         norm = torch.nn.utils.clip_grad_norm_([p for p in params if p.grad is not None], clip) if clip else None

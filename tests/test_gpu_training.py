@@ -239,6 +239,44 @@ def test_optimizer_step_refreshes_training_weights_without_repacking(setup):
     assert mm.engine() is not eng and not mm.engine().stale_for_sampling  # a sampling engine is rebuilt on demand
 
 
+def test_training_survives_weights_that_outgrow_the_fp16_forward(setup):
+    """the training forward runs fp16x3 products chosen from the weights at engine creation, and the optimizer
+    moves the weights afterwards.  Here they are moved far beyond the fp16 range of the hidden activations between two steps:
+    the step comes out non-finite, the optimizer driver turns it into a no-op on the device (no NaN reaches the parameters or
+    Adam's moments), the periodic status check switches the engine to the full-range bf16x6 products instead of raising, and the
+    next step is finite again."""
+    import copy
+    import warnings
+    from arreau_amd.train import optimizer_step
+    m, om, batch, lattice0, timestep, noise = setup
+    mm = copy.deepcopy(m)
+    mm.STATUS_CHECK_EVERY = 1
+    opt = mm.configure_optimizers(max_epochs=10)["optimizer"]
+    loss0 = mm.training_step(batch, timestep=timestep, noise=noise)
+    optimizer_step(mm, opt, world_size=1)
+    assert bool(torch.isfinite(loss0))
+    with torch.no_grad():  # what a diverging run might do to one layer: hidden units of order 1e7
+        mm.model.interaction_layers[1].linear_1.weight *= 1.0e6
+    mm.notify_parameters_changed()
+    before = [p.detach().clone() for p in mm.parameters()]
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        loss1 = mm.training_step(batch, timestep=timestep, noise=noise)   # overflows; its status check (every step here) switches the engine
+        optimizer_step(mm, opt, world_size=1)
+        loss2 = mm.training_step(batch, timestep=timestep, noise=noise)
+        optimizer_step(mm, opt, world_size=1)
+        loss3 = mm.training_step(batch, timestep=timestep, noise=noise)   # full-range products
+    assert not bool(torch.isfinite(loss1))
+    assert any("bf16x6" in str(x.message) for x in w), [str(x.message) for x in w]
+    assert bool(torch.isfinite(loss3)), float(loss3)
+    for p in mm.parameters():
+        assert bool(torch.isfinite(p).all())
+    # the poisoned step changed nothing (its gradient was zeroed on the device)
+    after_first = [p.detach() for p in mm.parameters()]
+    assert all(torch.isfinite(a).all() for a in after_first) and len(before) == len(after_first)
+    assert mm._engine.status()["flags"] == 0
+
+
 def test_two_rank_training_loop_reduces_the_loss(tmp_path):
     """arreau_amd.train end to end: two data-parallel ranks (gloo, sharing this box's GPU), synthetic Alexandria-like
     crystals, forward + backward in the library, one flat all-reduce per step, Adam with the cosine warm-up schedule;
