@@ -348,7 +348,7 @@ __global__ __launch_bounds__(64 * EH_WAVES, 2) void edge_kernel_f16x3(
                     acc.x[mt][nb] = f32x4v{0.f, 0.f, 0.f, 0.f};
                 }
             }
-            MmaStream16<TC> ms;
+            MmaStream16<TC, true> ms;  // (B = the layer-1 output: activation planes)
             ms.start(lds[sl], lane);
             if (go) ms.template run<0, TC>(acc, h16);
             wait_copies();
@@ -612,8 +612,8 @@ __global__ __launch_bounds__(512) void edge_kernel_f16x3_split(
         for (int ks = 0; ks < 2 * TM; ++ks) {
             const int t = ks >> 1, s = ks & 1;
             acc = mfma_f16(w1[2 * ks], bm[t].p[0][s], acc);
-            cross = mfma_f16(w1[2 * ks], bm[t].p[1][s], cross);
             cross = mfma_f16(w1[2 * ks + 1], bm[t].p[0][s], cross);
+            acc = mfma_f16(w1[2 * ks], bm[t].p[1][s], acc);  // (activation planes: the residual is unscaled, f16x3.h)
         }
         const Planes2 pl = gelu_split_tile2(acc, cross, 1.0f);
 #pragma unroll
@@ -653,8 +653,8 @@ __global__ __launch_bounds__(512) void edge_kernel_f16x3_split(
                 for (int nb = 0; nb < 2; ++nb) {
                     const int st = 2 * kb + mt;
                     acc.m[mt][nb] = mfma16_f16(w2[2 * st], hq[nb][0], acc.m[mt][nb]);
-                    acc.x[mt][nb] = mfma16_f16(w2[2 * st], hq[nb][1], acc.x[mt][nb]);
                     acc.x[mt][nb] = mfma16_f16(w2[2 * st + 1], hq[nb][0], acc.x[mt][nb]);
+                    acc.m[mt][nb] = mfma16_f16(w2[2 * st], hq[nb][1], acc.m[mt][nb]);  // (activation planes)
                 }
             __builtin_amdgcn_sched_barrier(0);
         }

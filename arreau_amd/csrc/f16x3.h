@@ -95,6 +95,21 @@ __device__ __forceinline__ void split_pair2(f32x2 v, unsigned& hi, unsigned& lo)
     asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(lo) : "v"(hi), "s"(neg_scale), "v"(sc.x));
     asm("v_fma_mixhi_f16 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(lo) : "v"(hi), "s"(neg_scale), "v"(sc.y));
 }
+// ACTIVATION planes (round 5): hi as above, the residual UNSCALED -- lo = f16(v - f32(hi)), one v_fma_mix*_f16 per value and no
+// multiply by 2^11 (1.5 vector instructions per value instead of 2.5; every vector instruction of these kernels is paid in
+// full beside the matrix work: DESIGN.md section 8).  The residual of |v| >= 1/4 is a normal fp16 number (11 bits: 2^-23 |v|);
+// below that it is subnormal, step 2^-24: the pair then represents v to 3e-8 ABSOLUTE, which is what fp32 gives at 1/4 -- hidden
+// units, LayerNorm outputs and monomials are consumed by dot products, where an absolute 3e-8 per term is the rounding floor
+// (v_mfma_f32_*_f16 honours fp16 subnormals: tools/exp/coexec2.hip).  The product with a weight w = a1 + a2 / 2^11 becomes
+//     main += a1 hi + a1 lo ,   cross += a2 hi   (folded by 2^-11 as before; dropped: a2 lo / 2^11)
+// -- the same three matrix instructions, two of them on the main accumulator.  The BASIS planes keep the scaled e4m3 / fp16
+// residual (split_pair_fp8 / split_pair2): they are stored, streamed and read by the fp8 cross products.
+__device__ __forceinline__ void split_pair_act(f32x2 v, unsigned& hi, unsigned& lo) {
+    hi = __builtin_bit_cast(unsigned, cvt_f16x2(v));
+    const float neg_one = -1.0f;
+    asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(lo) : "v"(hi), "s"(neg_one), "v"(v.x));
+    asm("v_fma_mixhi_f16 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(lo) : "v"(hi), "s"(neg_one), "v"(v.y));
+}
 // The planes of a BASIS value pair (round 5): hi as above; the residual goes straight from fp32 to e4m3 --
 //     r = v - f32(hi)   (v_fma_mix_f32: reads the fp16 half in place; exact),   lo8 = e4m3(r * 2^11)   (v_cvt_scalef32_pk_fp8_f32,
 //     whose scale operand DIVIDES by its power of two: tools/exp/fp8_scale_check.hip)
@@ -125,7 +140,7 @@ __device__ __forceinline__ Planes2 split_tile2(const f32x16& x) {
 #pragma unroll
         for (int pp = 0; pp < 4; ++pp) {
             unsigned hi, lo;
-            split_pair2(F16X3_PAIR(x, 4 * s + pp), hi, lo);
+            split_pair_act(F16X3_PAIR(x, 4 * s + pp), hi, lo);
             r.p[0][s][pp] = hi;
             r.p[1][s][pp] = lo;
         }
@@ -139,7 +154,7 @@ __device__ __forceinline__ Planes2 gelu_split_folded2(const f32x16& v, float sca
 #pragma unroll
         for (int pp = 0; pp < 4; ++pp) {
             unsigned hi, lo;
-            split_pair2<false>(gelu_fast2(F16X3_PAIR(v, 4 * s + pp)) * splat2(scale), hi, lo);  // |scale| <= 1
+            split_pair_act(gelu_fast2(F16X3_PAIR(v, 4 * s + pp)) * splat2(scale), hi, lo);  // |scale| <= 1
             r.p[0][s][pp] = hi;
             r.p[1][s][pp] = lo;
         }
@@ -178,8 +193,8 @@ __device__ __forceinline__ void mma_range2(f32x16& mainacc, f32x16& cross, const
         }
         const int t = ks >> 1, s = ks & 1;
         mainacc = mfma_f16(c1[slot], b[t].p[0][s], mainacc);
-        cross = mfma_f16(c1[slot], b[t].p[1][s], cross);
         cross = mfma_f16(c2[slot], b[t].p[0][s], cross);
+        mainacc = mfma_f16(c1[slot], b[t].p[1][s], mainacc);  // (activation planes: the residual is unscaled)
     }
     __builtin_amdgcn_sched_group_barrier(0x100, 2 * (PF < KS1 - KS0 ? PF : KS1 - KS0), 0);  // the first PF k-steps' fragments
 #pragma unroll
@@ -213,8 +228,8 @@ struct MmaStream2 {
             }
             const int t = ks >> 1, s = ks & 1;
             mainacc = mfma_f16(c1[slot], b[t].p[0][s], mainacc);
-            cross = mfma_f16(c1[slot], b[t].p[1][s], cross);
             cross = mfma_f16(c2[slot], b[t].p[0][s], cross);
+            mainacc = mfma_f16(c1[slot], b[t].p[1][s], mainacc);  // (activation planes: the residual is unscaled)
         }
 #pragma unroll
         for (int ks = KS0; ks < KS1; ++ks) {
@@ -238,7 +253,7 @@ struct Acc16 { f32x4v m[2][2], x[2][2]; };  // [16-row tile mt][column block nb]
 // One chunk = 32 output rows x NKB k-blocks of 32: fragments (kb, mt, plane) at ((kb * 2 + mt) * 2 + plane) * 64 + lane.
 // Step st = kb * 2 + mt: two fragment reads (both planes), six MFMAs.  The reads of step st+1 are issued ahead of the
 // MFMAs of step st and run through cuts of the stream, as in MmaStream2.
-template <int NKB>
+template <int NKB, bool ACT = false /* B holds activation planes (unscaled residual): a1 b2 goes to the main accumulator */>
 struct MmaStream16 {
     const u32x4* f;
     u32x4 a1[2], a2[2];
@@ -265,8 +280,13 @@ struct MmaStream16 {
 #pragma unroll
             for (int nb = 0; nb < 2; ++nb) {
                 am[mt][nb] = mfma16_f16(a1[slot], b[nb][kb][0], am[mt][nb]);
-                ax[mt][nb] = mfma16_f16(a1[slot], b[nb][kb][1], ax[mt][nb]);
-                ax[mt][nb] = mfma16_f16(a2[slot], b[nb][kb][0], ax[mt][nb]);
+                if constexpr (ACT) {
+                    ax[mt][nb] = mfma16_f16(a2[slot], b[nb][kb][0], ax[mt][nb]);
+                    am[mt][nb] = mfma16_f16(a1[slot], b[nb][kb][1], am[mt][nb]);
+                } else {
+                    ax[mt][nb] = mfma16_f16(a1[slot], b[nb][kb][1], ax[mt][nb]);
+                    ax[mt][nb] = mfma16_f16(a2[slot], b[nb][kb][0], ax[mt][nb]);
+                }
             }
         }
 #pragma unroll
@@ -298,10 +318,10 @@ __device__ __forceinline__ void mma16_range(f32x4v (&am)[2][NB], f32x4v (&ax)[2]
         }
         const int kb = st >> 1, mt = st & 1;
 #pragma unroll
-        for (int nb = 0; nb < NB; ++nb) {
+        for (int nb = 0; nb < NB; ++nb) {  // (B = activation planes, unscaled residual: a1 b2 goes to the main accumulator)
             am[mt][nb] = mfma16_f16(a1[slot], b[nb][kb][0], am[mt][nb]);
-            ax[mt][nb] = mfma16_f16(a1[slot], b[nb][kb][1], ax[mt][nb]);
             ax[mt][nb] = mfma16_f16(a2[slot], b[nb][kb][0], ax[mt][nb]);
+            am[mt][nb] = mfma16_f16(a1[slot], b[nb][kb][1], am[mt][nb]);
         }
     }
     __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);

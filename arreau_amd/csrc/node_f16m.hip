@@ -42,7 +42,7 @@ __device__ __forceinline__ void split8(const float (&v)[8], u32x4& hi, u32x4& lo
 #pragma unroll
     for (int pp = 0; pp < 4; ++pp) {
         unsigned a, b;
-        split_pair2<CLAMP>(f32x2{v[2 * pp], v[2 * pp + 1]}, a, b);
+        split_pair_act(f32x2{v[2 * pp], v[2 * pp + 1]}, a, b);  // (activation planes: unscaled residual, f16x3.h)
         hi[pp] = a;
         lo[pp] = b;
     }
@@ -453,8 +453,8 @@ __global__ __launch_bounds__(512) void mlp_kernel_f16x3_m16_split(
         for (int st = 0; st < 2 * KC; ++st) {
             const int kb = st >> 1, mt = st & 1;
             am[mt] = mfma16_f16(w[2 * st], xn[kb][0], am[mt]);
-            ax[mt] = mfma16_f16(w[2 * st], xn[kb][1], ax[mt]);
             ax[mt] = mfma16_f16(w[2 * st + 1], xn[kb][0], ax[mt]);
+            am[mt] = mfma16_f16(w[2 * st], xn[kb][1], am[mt]);  // (activation planes: the residual is unscaled)
         }
         float v[8];
 #pragma unroll
@@ -498,8 +498,8 @@ __global__ __launch_bounds__(512) void mlp_kernel_f16x3_m16_split(
         for (int kb = 0; kb < 4; ++kb) {
             const u32x4 bh = hidx[4 * w2 + kb][0][lane], bl = hidx[4 * w2 + kb][1][lane];
             acc = mfma16_f16(w[w0 + 2 * kb], bh, acc);
-            cross = mfma16_f16(w[w0 + 2 * kb], bl, cross);
             cross = mfma16_f16(w[w0 + 2 * kb + 1], bh, cross);
+            acc = mfma16_f16(w[w0 + 2 * kb], bl, acc);  // (activation planes: the residual is unscaled)
         }
 #pragma unroll
         for (int r = 0; r < 4; ++r) acc[r] = fmaf(cross[r], F16X3_INV_SCALE, acc[r]);
