@@ -4,6 +4,9 @@
 # dispatches of one forward + backward step and of one step with its optimizer part cut out by their `prep_kernel` launches
 # -> gpurun_out/hbm_traffic_pmc_c5.json
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+# (per-kernel means and counters of the WORKLOAD: without the three small evaluations of arreau_model_create's calibration batch, which
+# launch the same kernels on 320 atoms; the synthetic checkpoint keeps both fp8 formats either way)
+export ARREAU_CALIBRATE=0
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf gpurun_out/pmc_traffic_c5_$c
   timeout -k 10 400 rocprofv3 --kernel-trace --pmc $c --output-format csv -d gpurun_out/pmc_traffic_c5_$c -- python3 bench.py --config c5 --steps 4 --warmup 2 --no-cpu-baseline > gpurun_out/pmc_traffic_c5_$c.json 2> gpurun_out/pmc_traffic_c5_$c.err || { tail -n 5 gpurun_out/pmc_traffic_c5_$c.err; exit 1; }
