@@ -238,11 +238,17 @@ __global__ __launch_bounds__(64 * EH_WAVES, 2) void edge_kernel_f16x3(
 
         const int slot = 2 * wn + (j >> 4);
         const int o = j & 15;
-        const int slot_c = min(slot, k - 1);
+        // A slot past the degree (the odd slot of this wave's pair when nd is odd; nd > 2 wn here) computes with the attributes
+        // of the receiver's last edge and a zero window: whatever the caller left in the unused slots, NaN included, its stash
+        // block is zeros, which conv_proj.hip's unconditional sum counts on.  (Not `slot < nd ? load : 0`: hipcc turns that into
+        // four exec-masked loads in a row, +8 us per launch at 256 x 20; a mask on the loaded words measured +3 us.)
+        const int slot_c = min(slot, nd - 1);
         // ---- per-row attributes (transforms/invariants.py:82-88) ------------------------------------------
         float a[6], window;
         {
             const size_t e = (size_t)node * k + slot_c;
+            // slots past the degree read as zeros whatever the caller left there: their window is zero below, and a
+            // non-finite attribute would turn the stash block into NaN instead of the zeros conv_proj.hip counts on
             const float dx = nbr_dir[3 * e + 0], dy = nbr_dir[3 * e + 1], dz = nbr_dir[3 * e + 2];
             const float dist = nbr_dist[e];
             const float ox = ori[3 * o + 0], oy = ori[3 * o + 1], oz = ori[3 * o + 2];
@@ -570,7 +576,7 @@ __global__ __launch_bounds__(512) void edge_kernel_f16x3_split(
     // ---- per-row attributes (transforms/invariants.py:82-88), as in the kernel above ------------------------------
     const int slot = 2 * wn + (j >> 4);
     const int o = j & 15;
-    const int slot_c = min(slot, k - 1);
+    const int slot_c = min(slot, nd - 1);  // (as above: an unused slot computes on its receiver's last edge, window zero)
     float a[6], window;
     {
         const size_t e = (size_t)node * k + slot_c;

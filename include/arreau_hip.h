@@ -233,7 +233,8 @@ int arreau_edges_to_slots(const int64_t* d_edge_index /*[2,E]*/, const float* d_
  * Outputs: d_eps[N,3] (pred_frac_eps_x), d_logits[N,S], d_len0[B,3] (pred_lengths_0).
  * When use_given_edges != 0 the slot arrays d_deg/d_src/d_dir/d_dist are inputs (teacher-forced
  * graph); otherwise they are outputs of the internal neighbour search and may be NULL to use
- * workspace storage. */
+ * workspace storage.  Of a given graph only slots [0, min(d_deg[i], k)) of receiver i are read as
+ * data: the rest may hold anything (NaN included) without changing an output bit. */
 int arreau_predict_scores(const arreau_model* model,
                           const float* d_frac, const int32_t* d_types, const float* d_lengths,
                           const float* d_angles, const int32_t* d_t,

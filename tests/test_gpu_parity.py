@@ -969,6 +969,18 @@ def test_many_ragged_crystals_persistent_edge_workgroups(dev, small_model, messa
     eps, logits, len0 = _engine_scores(m, dev, state, 60, edges=edges)
     assert_scores_close((eps, logits, len0), (eps_o, logits_o, len0_o))
     assert m.engine().check_status()["conv_variant"] == (2 if message_path == "basis form" else 1)
+    # slots past a receiver's degree are not inputs (include/arreau_hip.h, arreau_predict_scores): whatever a caller leaves
+    # there -- NaN, infinities, a stale index -- the outputs are the same bits (the basis form's projection adds every slot's
+    # block without a test, so the edge kernel must store exact zeros for those)
+    unused = torch.arange(8)[None, :] >= deg[:, None]
+    for fill in (float("nan"), float("inf"), -3.0e38):
+        sdir_f, sdist_f, src_f = sdir.clone(), sdist.clone(), src.clone()
+        sdir_f[unused] = fill
+        sdist_f[unused] = fill
+        src_f[unused] = 0
+        got = _engine_scores(m, dev, state, 60, edges=tuple(x.to(dev).contiguous() for x in (deg, src_f, sdir_f, sdist_f)))
+        for a, b in zip(got, (eps, logits, len0)):
+            assert torch.equal(a, b), fill
 
 
 def _rotation(axis, angle):
