@@ -21,7 +21,8 @@ EXPORTS = [
     "arreau_model_status", "arreau_model_set_variant", "arreau_ponita_forward",
     "arreau_diffusion_noise", "arreau_diffusion_losses", "arreau_sample_loop", "arreau_philox_fill",
     "arreau_train_forward", "arreau_train_backward", "arreau_train_conv_stats", "arreau_model_update_train_weights",
-    "arreau_debug_sgemm",
+    "arreau_debug_sgemm", "arreau_optimizer_create", "arreau_optimizer_step", "arreau_optimizer_destroy",
+    "arreau_model_train_weight_pointers", "arreau_model_refresh_derived_train_weights",
     "arreau_model_set_batch_layout", "arreau_model_set_formats", "arreau_debug_set_pollution", "arreau_debug_leftover_fraction",
 ]
 
@@ -34,6 +35,15 @@ VARIANT_GENERAL = 5  # edge variant selecting the shape-general fp32 network (an
 
 class ArreauHipError(RuntimeError):
     pass
+
+
+OPT_MAX_GROUPS = 4
+
+
+class AdamArgs(Structure):
+    """arreau_adam_args (include/arreau_hip.h)"""
+    _fields_ = [("step", c_int64), ("lr", c_double * OPT_MAX_GROUPS), ("weight_decay", c_double * OPT_MAX_GROUPS),
+                ("beta1", c_double), ("beta2", c_double), ("eps", c_double), ("max_norm", c_double)]
 
 
 class Config(Structure):
@@ -111,6 +121,14 @@ def lib():
     L.arreau_model_set_batch_layout.argtypes = [c_void_p, c_void_p, c_int32, c_int32]
     if hasattr(L, "arreau_model_set_formats") or not os.environ.get("ARREAU_HIP_LIB"):  # (an older build under test: tools/ab.sh)
         L.arreau_model_set_formats.argtypes = [c_void_p, c_int32, c_int32]
+    if hasattr(L, "arreau_optimizer_create") or not os.environ.get("ARREAU_HIP_LIB"):
+        L.arreau_optimizer_create.argtypes = [c_int32, POINTER(c_void_p), POINTER(c_void_p), POINTER(c_int64), POINTER(c_int64), POINTER(c_int32),
+                                              c_int32, c_int64, POINTER(c_void_p)]
+        L.arreau_model_train_weight_pointers.argtypes = [c_void_p, POINTER(StateDict)]
+        L.arreau_model_refresh_derived_train_weights.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p]
+        L.arreau_optimizer_step.argtypes = [c_void_p, c_void_p, c_void_p, c_void_p, POINTER(AdamArgs), c_void_p, c_void_p]
+        L.arreau_optimizer_destroy.argtypes = [c_void_p]
+        L.arreau_optimizer_destroy.restype = None
     L.arreau_debug_set_pollution.argtypes = [ctypes.c_uint32]
     L.arreau_debug_leftover_fraction.argtypes = [ctypes.c_uint32, POINTER(c_double), POINTER(c_double), c_void_p]
     L.arreau_profile_edge_kernel.argtypes = [c_int32]

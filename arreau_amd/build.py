@@ -12,7 +12,7 @@ import sys
 import time
 
 CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
-SOURCES = ["model.hip", "graph.hip", "edge.hip", "edge_bf16.hip", "edge_f16.hip", "node.hip", "node_bf16.hip", "node_f16m.hip", "conv_proj.hip", "update.hip", "train.hip", "train_net.hip", "api.hip"]
+SOURCES = ["model.hip", "graph.hip", "edge.hip", "edge_bf16.hip", "edge_f16.hip", "node.hip", "node_bf16.hip", "node_f16m.hip", "conv_proj.hip", "update.hip", "train.hip", "train_net.hip", "optim.hip", "api.hip"]
 HEADERS = ["internal.h", "bf16x6.h", "f16x3.h", os.path.join("..", "..", "include", "arreau_hip.h"), "sgemm.h", "philox.h", "embed_dev.h", "prep_dev.h", "graph_dev.h", "update_dev.h", "readout_dev.h"]
 LIB = os.path.join(CSRC, "libarreau_hip.so")
 # Debug twin: the same sources with -DARREAU_DEBUG_WAIT_ALL (every hand-counted `s_waitcnt vmcnt(N)` becomes vmcnt(0)).

@@ -1435,6 +1435,35 @@ extern "C" int arreau_model_update_train_weights(arreau_model* m, const arreau_s
     return ARREAU_OK;
 }
 
+// The optimizer's second destination (optim.hip): where arreau_model_update_train_weights would copy each tensor to.  Stacked [L, ...]
+// layout, the caller's own state_dict layout; NULL for the two tensors the training entry points read in a derived form.
+extern "C" int arreau_model_train_weight_pointers(arreau_model* m, arreau_state_dict* out) {
+    ARREAU_REQUIRE(m && out, "arreau_model_train_weight_pointers: null pointer");
+    *out = arreau_state_dict{};
+    out->basis_b1 = m->b1; out->basis_w2 = m->t_w2; out->basis_b2 = m->b2;
+    out->fiber_w1 = m->fiber_w1; out->fiber_b1 = m->fiber_b1; out->fiber_w2 = m->fiber_w2; out->fiber_b2 = m->fiber_b2;
+    out->conv_kernel_w = m->t_wk; out->conv_fiber_w = m->fiber_wk; out->conv_bias = m->conv_bias;
+    out->norm_w = m->ln_w; out->norm_b = m->ln_b;
+    out->linear1_w = m->t_lin1; out->linear1_b = m->mb1; out->linear2_w = m->t_lin2; out->linear2_b = m->mb2;
+    if (m->cfg.has_layer_scale) out->layer_scale = m->ls;
+    out->readout_w = m->t_ro_w; out->readout_b = m->ro_b;
+    return ARREAU_OK;
+}
+
+// ... and what is left of arreau_model_update_train_weights when the optimizer has written those itself: the folded polynomial weight
+// and the transposed embedder.
+extern "C" int arreau_model_refresh_derived_train_weights(arreau_model* m, const float* d_basis_w1, const float* d_x_embedder_w, void* stream) {
+    ARREAU_REQUIRE(m && d_basis_w1 && d_x_embedder_w, "arreau_model_refresh_derived_train_weights: null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    const size_t C = m->C, S = m->S;
+    auto W = [](const float* p) { return const_cast<float*>(p); };
+    m->packed_stale = 1;
+    if (!m->train) TRY(ensure_ctx(m, 1, 1, s));
+    LAUNCH(fold_poly_weight_kernel, dim3(blocks((long)C * ARREAU_MONO_PAD)), dim3(256), d_basis_w1, (int)C, m->train->mono_cols, W(m->t_w1f));
+    LAUNCH(transpose_kernel, dim3(blocks((long)C * (S + 78))), dim3(256), d_x_embedder_w, (int)C, (int)(S + 78), W(m->embT));
+    return ARREAU_OK;
+}
+
 extern "C" int arreau_debug_sgemm(int32_t mode, int32_t M, int32_t N, int32_t K, const float* d_A, int64_t as0, int64_t as1, const float* d_B,
                                   int64_t bs0, int64_t bs1, float* d_C, int32_t ldc, float alpha, float beta, void* stream) {
     ARREAU_REQUIRE(d_A && d_B && d_C, "arreau_debug_sgemm: null pointer");

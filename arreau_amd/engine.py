@@ -352,6 +352,38 @@ class HipEngine:
                    "arreau_model_update_train_weights")
         self.stale_for_sampling = not self._general
 
+    def train_weight_mirrors(self, module):
+        """{parameter: device address of the engine's own fp32 copy of it} for the optimizer's second destination
+        (arreau_model_train_weight_pointers; arreau_amd/optim.py) -- every trainable tensor of the score network except the two the
+        training entry points read in a derived form."""
+        cached = getattr(self, "_mirror_cache", None)
+        params = getattr(module, "_named_parameter_cache", None)
+        if params is None:
+            params = dict(module.named_parameters())
+        if cached is not None and cached[0] is module and all(p.data_ptr() == q for p, q in cached[2]):
+            return cached[1]
+        csd = _hip.StateDict()
+        _hip.check(_hip.lib().arreau_model_train_weight_pointers(self._handle, ctypes.byref(csd)), "arreau_model_train_weight_pointers")
+        mirrors = {}
+        for name, field, l in self._state_names():
+            base = getattr(csd, field)
+            p = params[name]
+            if base:
+                mirrors[p] = int(base) + 4 * p.numel() * (l or 0)
+        self._mirror_cache = (module, mirrors, [(p, p.data_ptr()) for p in mirrors])
+        return mirrors
+
+    def refresh_derived_train_weights(self, module):
+        """After an optimizer step that wrote the engine's copies itself (ClipAdam.step_flat with `mirrors`): rebuild the folded
+        polynomial weight and the transposed embedder from the module's updated tensors (two small launches)."""
+        params = getattr(module, "_named_parameter_cache", None)
+        if params is None:
+            params = dict(module.named_parameters())
+        _hip.check(_hip.lib().arreau_model_refresh_derived_train_weights(
+            self._handle, _hip.ptr(params["model.basis_fn.1.weight"].detach()), _hip.ptr(params["model.x_embedder.weight"].detach()),
+            _hip.stream_ptr(self.device)), "arreau_model_refresh_derived_train_weights")
+        self.stale_for_sampling = not self._general
+
     def conv_stats(self):
         """[L,3] unbiased std of (x, x_1, x_2) per layer from the last train_forward (FiberBundleConv.callibrate)."""
         st = torch.empty((self.cfg.num_layers, 3), device=self.device, dtype=torch.float32)

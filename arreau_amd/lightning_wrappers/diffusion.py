@@ -261,13 +261,15 @@ class PONITA_DIFFUSION(nn.Module):
         assert not (decay & no_decay) and not (param_dict.keys() - (decay | no_decay)), "parameter grouping is not a partition"
         groups = [{"params": [param_dict[pn] for pn in sorted(decay)], "weight_decay": self.weight_decay},
                   {"params": [param_dict[pn] for pn in sorted(no_decay)], "weight_decay": 0.0}]
-        # the reference's torch.optim.Adam(groups, lr); on the GPU its fused implementation (one launch per group instead of the
-        # multi-tensor form's 17, 0.17 ms of device time and 0.3 ms of host time per step; same update rule)
+        # the reference's torch.optim.Adam(groups, lr); on the GPU the subclass whose step on the training step's flat gradient buffer
+        # is two launches of the library (arreau_amd/optim.py: clip + update, 0.19 ms of device time per step through torch's norm,
+        # scalar arithmetic and fused multi-tensor Adam; same update rule, same state_dict)
         on_gpu = all(p.is_cuda for g in groups for p in g["params"])
-        try:
+        if on_gpu and os.environ.get("ARREAU_TORCH_ADAM", "0") != "1":   # (ARREAU_TORCH_ADAM=1: torch's fused Adam, for A/B runs)
+            from ..optim import ClipAdam
+            optimizer = ClipAdam(groups, lr=self.lr)
+        else:
             optimizer = torch.optim.Adam(groups, lr=self.lr, fused=True) if on_gpu else torch.optim.Adam(groups, lr=self.lr)
-        except (RuntimeError, TypeError):
-            optimizer = torch.optim.Adam(groups, lr=self.lr)
         scheduler = CosineWarmupScheduler(optimizer, self.warmup, max_epochs if max_epochs is not None else self.epochs)
         return {"optimizer": optimizer, "lr_scheduler": scheduler, "monitor": "val_loss"}
 

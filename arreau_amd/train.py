@@ -61,6 +61,21 @@ def optimizer_step(model, optimizer, world_size: int = 1, clip: Optional[float] 
             dist.all_reduce(flat, op=dist.ReduceOp.SUM)
             flat /= world_size
         norm = None
+        if hasattr(optimizer, "step_flat"):
+            # arreau_amd.optim.ClipAdam: norm, clip coefficient, non-finite guard and the update of every tensor in two launches
+            # ... and, where the module's engine keeps its own fp32 copy of a tensor, the update lands there in the same pass (then
+            # only the two weights the engine reads in a derived form are rebuilt, instead of copying all 70 tensors twice)
+            eng = getattr(model, "_engine", None)
+            mirrors = eng.train_weight_mirrors(model) if eng is not None and hasattr(eng, "train_weight_mirrors") else None
+            norm = optimizer.step_flat(flat, clip, mirrors)
+            if norm is not None:
+                optimizer.zero_grad(set_to_none=True)
+                model._grad_flat = None
+                if mirrors:
+                    eng.refresh_derived_train_weights(model)
+                else:
+                    model.notify_parameters_changed()
+                return norm
         if clip:
             norm = torch.linalg.vector_norm(flat, 2)
             flat.mul_(torch.clamp(clip / (norm + 1e-6), max=1.0))

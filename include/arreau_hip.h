@@ -354,6 +354,43 @@ int arreau_model_update_train_weights(arreau_model* model, const arreau_state_di
  * d_stats[L][3] = unbiased std of x (layer input), x_1 (after the spatial conv), x_2 (after the spherical conv). */
 int arreau_train_conv_stats(arreau_model* model, float* d_stats, void* stream);
 
+/* Gradient clipping + Adam of the training step as two launches on the step's flat gradient buffer (no counterpart as a
+ * function in the reference: `gradient_clip_val=0.5` of pl.Trainer, main_diffusion.py:297 = torch.nn.utils.clip_grad_norm_,
+ * then torch.optim.Adam over the two parameter groups of configure_optimizers, lightning_wrappers/diffusion.py:152-218).
+ * create: a table of `n_tensors` parameter tensors -- d_params[i] (device pointer, contiguous fp32, numel[i] elements), its
+ * position flat_offset[i] in the flat gradient buffer of arreau_train_backward's caller (all the d_grads arrays are views of
+ * one allocation of flat_len floats) and its parameter group; host arrays, copied.
+ * step (t = args->step, counted from 1): norm = |flat gradient|_2 -> *d_norm_out (may be NULL); coefficient
+ * min(max_norm / (norm + 1e-6), 1) (max_norm <= 0: none); per element torch's single-tensor Adam: g = grad * coef
+ * (+ weight_decay * p), m += (1 - beta1)(g - m), v = beta2 v + (1 - beta2) g g,
+ * p -= lr / (1 - beta1^t) * m / (sqrt(v) / sqrt(1 - beta2^t) + eps).  A non-finite norm makes g = 0 for the whole step.
+ * d_exp_avg / d_exp_avg_sq: the moments, flat_len floats each, laid out like the gradient buffer (caller-owned: they are the
+ * optimizer's state).  Reproducible bit for bit: the norm is a two-stage sum in a fixed order, no atomics.
+ * d_mirrors (may be NULL, entries may be NULL): a second destination per tensor for the updated values -- the model's own fp32
+ * copy of that tensor (arreau_model_train_weight_pointers), which makes arreau_model_update_train_weights' copies unnecessary;
+ * arreau_model_refresh_derived_train_weights then rebuilds the two weights the training entry points read in a derived form
+ * (the folded polynomial weight of basis_fn.1, the transposed embedder) from the caller's updated tensors. */
+#define ARREAU_OPT_MAX_GROUPS 4
+typedef struct arreau_optimizer arreau_optimizer;
+typedef struct {   /* doubles: torch forms 1 - beta, 1 - beta^t and lr / (1 - beta1^t) from Python floats before anything is rounded to fp32 */
+    int64_t step;
+    double lr[ARREAU_OPT_MAX_GROUPS];
+    double weight_decay[ARREAU_OPT_MAX_GROUPS];
+    double beta1, beta2, eps;
+    double max_norm;
+} arreau_adam_args;
+int arreau_optimizer_create(int32_t n_tensors, void* const* d_params, void* const* d_mirrors, const int64_t* numel,
+                            const int64_t* flat_offset, const int32_t* group, int32_t n_groups, int64_t flat_len,
+                            arreau_optimizer** out);
+int arreau_optimizer_step(arreau_optimizer* opt, const float* d_flat_grad, float* d_exp_avg, float* d_exp_avg_sq,
+                          const arreau_adam_args* args, float* d_norm_out, void* stream);
+void arreau_optimizer_destroy(arreau_optimizer* opt);
+/* DEVICE pointers of the model's own fp32 training weights, stacked [L, ...] in the state_dict layout (NULL: basis_w1,
+ * x_embedder_w and every buffer entry). */
+int arreau_model_train_weight_pointers(arreau_model* model, arreau_state_dict* out);
+int arreau_model_refresh_derived_train_weights(arreau_model* model, const float* d_basis_w1, const float* d_x_embedder_w,
+                                               void* stream);
+
 /* The dense product every Linear of the training step runs through (no counterpart in the reference: torch.nn.functional.linear and
  * autograd's matmuls, ponita.py:65-66, conv.py:110-116, convnext.py:24-30), exposed so that the parity tests can call it directly:
  *   C[m][n] = alpha * sum_k A(m, k) B(k, n) + beta * C[m][n],   A(m, k) = d_A[m * as0 + k * as1],  B(k, n) = d_B[k * bs0 + n * bs1]

@@ -239,6 +239,79 @@ def test_optimizer_step_refreshes_training_weights_without_repacking(setup):
     assert mm.engine() is not eng and not mm.engine().stale_for_sampling  # a sampling engine is rebuilt on demand
 
 
+def test_clip_adam_on_the_flat_gradient_buffer_is_torch_adam_after_clip_grad_norm():
+    """arreau_optimizer_step (arreau_amd/optim.py: ClipAdam.step_flat) against what it replaces -- torch.nn.utils.clip_grad_norm_(0.5)
+    (main_diffusion.py:297) followed by torch.optim.Adam over a decayed and an undecayed group (lightning_wrappers/diffusion.py:
+    152-218) -- over six steps with a changing learning rate: parameters, both moments and the reported norm.  Tensor sizes straddle the
+    kernel's 1,024-element chunks; one step has a non-finite gradient (no-op on the device: zero gradient into the update, as
+    arreau_amd.train.optimizer_step does through torch); the state_dict round-trips through a plain torch.optim.Adam."""
+    from arreau_amd.optim import ClipAdam
+    dev = torch.device("cuda", 0)
+    g = torch.Generator().manual_seed(11)
+    shapes = [(37, 29), (1024,), (5,), (3, 700), (1,)]
+    decayed = [True, False, False, True, False]
+    init = [torch.randn(s, generator=g) for s in shapes]
+    def make(cls):
+        ps = [torch.nn.Parameter(t.clone().to(dev)) for t in init]
+        groups = [{"params": [p for p, d in zip(ps, decayed) if d], "weight_decay": 1e-2},
+                  {"params": [p for p, d in zip(ps, decayed) if not d], "weight_decay": 0.0}]
+        return ps, cls(groups, lr=3e-3)
+    ps_a, opt_a = make(ClipAdam)
+    ps_b, opt_b = make(torch.optim.Adam)
+    sizes = [-(-p.numel() // 4) * 4 for p in ps_a]  # 16-byte aligned views, as HipEngine.train_backward lays them out
+    for step in range(6):
+        flat = torch.zeros(sum(sizes) + 8, device=dev)
+        off = 0
+        for p, q, n in zip(ps_a, ps_b, sizes):
+            grad = torch.randn(p.shape, generator=g) * (10.0 if step % 2 else 0.01)  # clipped and unclipped steps
+            if step == 3:
+                grad.view(-1)[0] = float("inf")
+            p.grad = flat[off:off + p.numel()].view(p.shape)
+            p.grad.copy_(grad)
+            q.grad = grad.to(dev)
+            off += n
+        for o in (opt_a, opt_b):
+            for grp in o.param_groups:
+                grp["lr"] = 3e-3 * (1 + step)
+        norm_a = opt_a.step_flat(flat, 0.5)
+        assert norm_a is not None
+        norm_b = torch.nn.utils.clip_grad_norm_(ps_b, 0.5)
+        if not bool(torch.isfinite(norm_b)):
+            for q in ps_b:
+                q.grad.zero_()
+        opt_b.step()
+        assert (torch.isfinite(norm_b) and abs(float(norm_a) - float(norm_b)) <= 1e-6 * float(norm_b)) or (not torch.isfinite(norm_b) and not torch.isfinite(norm_a))
+        for p, q in zip(ps_a, ps_b):
+            assert float((p - q).abs().max()) <= 2e-6 * max(1.0, float(q.abs().max())), step
+            sa, sb = opt_a.state[p], opt_b.state[q]
+            assert float(sa["step"]) == float(sb["step"]) == step + 1
+            for key in ("exp_avg", "exp_avg_sq"):
+                assert float((sa[key] - sb[key]).abs().max()) <= 1e-6 * max(1e-12, float(sb[key].abs().max())), (step, key)
+    # state_dict: same layout as torch's; loading it into a plain Adam and stepping both once more keeps them together
+    ps_c, opt_c = make(torch.optim.Adam)
+    with torch.no_grad():
+        for c, a in zip(ps_c, ps_a):
+            c.copy_(a)
+    import copy
+    opt_c.load_state_dict(copy.deepcopy(opt_a.state_dict()))  # (load_state_dict keeps same-device tensors as they are: without the copy the two optimizers would share moments)
+    flat = torch.zeros(sum(sizes) + 8, device=dev)
+    off = 0
+    for p, c, n in zip(ps_a, ps_c, sizes):
+        p.grad = flat[off:off + p.numel()].view(p.shape)
+        p.grad.copy_(torch.randn(p.shape, generator=g) * 0.01)
+        c.grad = p.grad.clone()
+        off += n
+    assert opt_a.step_flat(flat, None) is not None
+    opt_c.step()
+    for p, c in zip(ps_a, ps_c):
+        assert float((p - c).abs().max()) <= 2e-6 * max(1.0, float(c.abs().max()))
+    # gradients that are not views of one buffer: step_flat declines, step() is torch's
+    for p in ps_a:
+        p.grad = torch.zeros_like(p)
+    assert opt_a.step_flat(flat, 0.5) is None
+    opt_a.step()
+
+
 def test_training_survives_weights_that_outgrow_the_fp16_forward(setup):
     """the training forward runs fp16x3 products chosen from the weights at engine creation, and the optimizer
     moves the weights afterwards.  Here they are moved far beyond the fp16 range of the hidden activations between two steps:
