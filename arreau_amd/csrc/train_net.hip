@@ -848,6 +848,16 @@ struct arreau_train_ctx {
     float *dxn_all, *dx2_all;  // [L][M][C]: d(LayerNorm output) and d(spherical conv output), for the batched bias / norm gradients
     float *xn_all, *dout_all, *dfk_all;  // [L][...]: LayerNorm outputs (forward), d(out) and d(fiber kernel) (backward), for the batched weight gradients
     int32_t* colcount;  // colsum_kernel's arrival counters (one per 64-column group; zero between launches)
+    // The fiber branch (fiber basis MLP -> fiber kernels forward; their gradients backward) depends on the weights alone: a couple of
+    // dozen launches over 256 rows, 4-6 us each on a handful of CUs.  They run on a second stream beside the edge-level products
+    // (fork / join by events; ARREAU_TRAIN_SIDE_STREAM=0 keeps them in line) with their own split-K and column-sum scratch.
+    // Measured (64 crystals, alternating on one box, 3 x 60 steps): 2.130 -> 2.108 ms per step -- 1 %, not the 0.19 ms the branch takes
+    // in line: launches that share the chip slow each other (a 32-workgroup side launch beside a product of 1,024 workgroups, two per
+    // CU, cost that product a third of a round: 30 -> 39 us in the kernel trace).
+    hipStream_t side = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    float *partial2 = nullptr, *colpart2 = nullptr;
+    int32_t* colcount2 = nullptr;
     const int32_t *tstep, *offsets, *types;
     const float *frac, *lengths, *angles;
 };
@@ -892,6 +902,9 @@ size_t layout(arreau_train_ctx& t, const arreau_model* m, int N, int B, float* b
     t.dw1f = c.take<float>(C * ARREAU_MONO_PAD); t.partial = c.take<float>(PARTIAL_FLOATS); t.scratch_cols = c.take<float>(1024);
     t.colpart = c.take<float>((size_t)2 * COLSUM4_MAX_BATCH * COLSUM4_MAX_CHUNKS * 1024);  // (two results per pass, up to eight matrices per call)
     t.colcount = c.take<int32_t>(COLCOUNT_INTS);
+    t.partial2 = c.take<float>(PARTIAL_FLOATS);
+    t.colpart2 = c.take<float>((size_t)2 * COLSUM4_MAX_BATCH * COLSUM4_MAX_CHUNKS * 1024);
+    t.colcount2 = c.take<int32_t>(COLCOUNT_INTS);
     return c.off;
 }
 
@@ -1044,6 +1057,9 @@ int ordered_sum(hipStream_t s, const float* part, int Z, int M, int N, float* ou
 void arreau_train_ctx_destroy(arreau_train_ctx* t) {
     if (!t) return;
     if (t->buf) (void)hipFree(t->buf);
+    if (t->side) (void)hipStreamDestroy(t->side);
+    if (t->ev_fork) (void)hipEventDestroy(t->ev_fork);
+    if (t->ev_join) (void)hipEventDestroy(t->ev_join);
     delete t;
 }
 
@@ -1081,8 +1097,37 @@ static int ensure_ctx(arreau_model* m, int N, int B, hipStream_t s) {
     m->train = t;
     ARREAU_CHECK_HIP(hipMemsetAsync(t->scratch_cols, 0, 1024 * sizeof(float), s));
     ARREAU_CHECK_HIP(hipMemsetAsync(t->colcount, 0, COLCOUNT_INTS * sizeof(int32_t), s));
+    ARREAU_CHECK_HIP(hipMemsetAsync(t->colcount2, 0, COLCOUNT_INTS * sizeof(int32_t), s));
+    {
+        static const bool side_on = [] { const char* e = getenv("ARREAU_TRAIN_SIDE_STREAM"); return !e || atoi(e) != 0; }();
+        if (side_on) {
+            // (default priority: a lowest-priority side stream measured the same to slightly worse, tools/exp/ab_side_stream.sh)
+            ARREAU_CHECK_HIP(hipStreamCreateWithFlags(&t->side, hipStreamNonBlocking));
+            ARREAU_CHECK_HIP(hipEventCreateWithFlags(&t->ev_fork, hipEventDisableTiming));
+            ARREAU_CHECK_HIP(hipEventCreateWithFlags(&t->ev_join, hipEventDisableTiming));
+        }
+    }
     hipLaunchKernelGGL(mono_columns_kernel, dim3(1), dim3(128), 0, s, t->mono_cols);
     ARREAU_CHECK_HIP(hipGetLastError());
+    return ARREAU_OK;
+}
+
+// Side stream of the fiber branch.  fork: everything queued on `main_stream` so far happens before the side work; `ts` becomes a view
+// of the context with the side stream's own scratch, `s` the stream to launch on (the main stream itself when the side stream is
+// off: then this is a no-op and the work stays in line).  join: the main stream waits for the side work recorded in ev_join.
+static int fork_side(arreau_train_ctx& t, hipStream_t main_stream, arreau_train_ctx& ts, hipStream_t& s) {
+    ts = t;
+    s = main_stream;
+    if (!t.side) return ARREAU_OK;
+    ARREAU_CHECK_HIP(hipEventRecord(t.ev_fork, main_stream));
+    ARREAU_CHECK_HIP(hipStreamWaitEvent(t.side, t.ev_fork, 0));
+    ts.partial = t.partial2; ts.colpart = t.colpart2; ts.colcount = t.colcount2;
+    s = t.side;
+    return ARREAU_OK;
+}
+static int join_side(arreau_train_ctx& t, hipStream_t main_stream) {
+    if (!t.side) return ARREAU_OK;
+    ARREAU_CHECK_HIP(hipStreamWaitEvent(main_stream, t.ev_join, 0));
     return ARREAU_OK;
 }
 
@@ -1094,21 +1139,28 @@ int arreau_general_network(arreau_model* m, const arreau_graph_view& g, const in
     const int C = m->C, D = m->D, L = m->L, H = m->H, k = m->k, S = m->S, RO = S + 4;
     const long R = (long)N * k * 16, M = (long)N * 16;
     if (N == 0) return ARREAU_OK;
+    {   // fiber basis (ponita.py:66,95) and the fiber kernels of all layers, fk_l = fkb . Wfk_l^T (conv.py:113-116; one batched product):
+        // functions of the weights alone -- on the side stream, beside the edge basis
+        hipStream_t main_stream = s;
+        arreau_train_ctx ts = t;
+        hipStream_t s = main_stream;   // (LAUNCH and the helpers below take the stream by this name)
+        TRY(fork_side(t, main_stream, ts, s));
+        LAUNCH(fiber_poly_kernel, dim3(1), dim3(256), m->ori, ts.fpoly);
+        TRY(linear(s, ts, 256, 3, C, ts.fpoly, m->fiber_w1, ts.fh1pre));
+        TRY(launch_bias_gelu(s, ts.fh1pre, m->fiber_b1, (const float*)nullptr, 256L, C, ts.fh1));
+        TRY(linear_bias_gelu(s, ts, 256, C, D, ts.fh1, m->fiber_w2, m->fiber_b2, (const float*)nullptr, ts.fh2pre, ts.fkb));
+        TRY(arreau_sgemm(s, ts.partial, 256, C, D, ts.fkb, D, 1, m->fiber_wk, 1, D, ts.fk, C, 1.f, 0.f, L, 0, (long)C * D, 256L * C, ts.fwd_mode));
+        if (t.side) ARREAU_CHECK_HIP(hipEventRecord(t.ev_join, t.side));
+    }
     // edge basis: kb = gelu(W2 gelu(W1 poly + b1) + b2) * window   (ponita.py:65,94)
     LAUNCH(edge_rows_kernel, dim3(blocks(R)), dim3(256), g.dir, g.dist, g.deg, g.batch, g.lattice, m->ori, m->cfg.radius, N, k,
            t.mono, t.window);
     TRY(linear(s, t, R, ARREAU_MONO_PAD, C, t.mono, t.w1f, t.h1pre));
     TRY(launch_bias_gelu(s, t.h1pre, m->b1, (const float*)nullptr, R, C, t.h1));
     TRY(linear_bias_gelu(s, t, R, C, D, t.h1, t.w2, m->b2, (const float*)t.window, t.h2pre, t.kb));
-    // fiber basis (ponita.py:66,95)
-    LAUNCH(fiber_poly_kernel, dim3(1), dim3(256), m->ori, t.fpoly);
-    TRY(linear(s, t, 256, 3, C, t.fpoly, m->fiber_w1, t.fh1pre));
-    TRY(launch_bias_gelu(s, t.fh1pre, m->fiber_b1, (const float*)nullptr, 256L, C, t.fh1));
-    TRY(linear_bias_gelu(s, t, 256, C, D, t.fh1, m->fiber_w2, m->fiber_b2, (const float*)nullptr, t.fh2pre, t.fkb));
     // kernel_l = kb . Wk_l^T for all layers in one product (conv.py:110; conv.kernel.weight stacked [L*C][D])
     TRY(linear(s, t, R, D, L * C, t.kb, t.wk, t.kern));
-    // fiber kernels of all layers: fk_l = fkb . Wfk_l^T (conv.py:113-116), one batched product
-    TRY(arreau_sgemm(s, t.partial, 256, C, D, t.fkb, D, 1, m->fiber_wk, 1, D, t.fk, C, 1.f, 0.f, L, 0, (long)C * D, 256L * C, t.fwd_mode));
+    TRY(join_side(t, s));   // the fiber kernels: first used by the layer loop below
     for (int l = 0; l < L; ++l) {
         const float* xl = t.x + (size_t)l * M * C;
         float* xnext = t.x + (size_t)(l + 1) * M * C;
@@ -1272,8 +1324,14 @@ extern "C" int arreau_train_backward(arreau_model* m, const float* d_g_eps, cons
                                             hipMemcpyDeviceToDevice, s));
     }
     // d(fiber kernel) of every layer = sum over nodes of x1 (x) dx2 / 16: one batched pair of launches (both operands were kept
-    // per layer), then its two uses
+    // per layer), then its two uses -- and from there the whole fiber branch down to d(fiber_basis_fn): on the side stream, beside the
+    // edge-level weight gradients below (it reads x1 and d(x2) of the loop above and writes gradients nothing else touches)
     {
+        hipStream_t main_stream = s;
+        arreau_train_ctx ts = t;
+        hipStream_t s = main_stream;
+        TRY(fork_side(t, main_stream, ts, s));
+        arreau_train_ctx& t = ts;   // (the helpers take their scratch from the context they are handed)
         // partial sums live in the split-K scratch (free here): as many layers per pair of launches as fit it -- all L at the
         // bench's 64 crystals, one at the reference's `make train` preset (batch 270, hidden_dim 200: ~2,200 atoms) -- and
         // atom chunks that grow with the batch once a single layer's partial sums would not fit
@@ -1292,12 +1350,20 @@ extern "C" int arreau_train_backward(arreau_model* m, const float* d_g_eps, cons
         TRY(arreau_sgemm(s, t.partial, 256, D, C, t.dfk_all + (size_t)(L - 1) * 256 * C, C, 1, m->fiber_wk + (size_t)(L - 1) * C * D, D, 1, t.dfkb_all, D,
                          1.0f, 0.f, L, -256L * C, -(long)C * D, 256L * D, t.bwd_mode));
         TRY(ordered_sum(s, t.dfkb_all, L, 256, D, t.dfkb));
+        TRY(linear_dw_batched(s, t, L, 256, D, C, t.dfk_all, 256L * C, t.fkb, 0, W(g->conv_fiber_w)));
+        // fiber basis MLP
+        TRY(launch_gelu_backward(s, t.dfkb, t.fh2pre, (const float*)nullptr, 256L, D));
+        TRY(linear_dw(s, t, 256, C, D, t.dfkb, t.fh1, W(g->fiber_w2)));
+        TRY(colsum(s, t, t.dfkb, nullptr, 256, D, 1.0f, W(g->fiber_b2)));
+        TRY(linear_dx_gelu_backward(s, t, 256, C, D, t.dfkb, m->fiber_w2, t.fh1pre, (const float*)nullptr, t.dfh1));
+        TRY(linear_dw(s, t, 256, 3, C, t.dfh1, t.fpoly, W(g->fiber_w1)));
+        TRY(colsum(s, t, t.dfh1, nullptr, 256, C, 1.0f, W(g->fiber_b1)));
+        if (t.side) ARREAU_CHECK_HIP(hipEventRecord(t.ev_join, t.side));
     }
     // the layers' weight gradients, one batched product per kind (operands kept per layer above / by the forward pass)
     TRY(linear_dw_batched(s, t, L, M, C, RO, t.drbar, 0, t.x + (size_t)M * C, (long)M * C, W(g->readout_w), invL));         // x_{l+1}
     TRY(linear_dw_batched(s, t, L, M, H, C, t.dout_all, (long)M * C, t.h, (long)M * H, W(g->linear2_w)));
     TRY(linear_dw_batched(s, t, L, M, C, H, t.dh, (long)M * H, t.xn_all, (long)M * C, W(g->linear1_w)));
-    TRY(linear_dw_batched(s, t, L, 256, D, C, t.dfk_all, 256L * C, t.fkb, 0, W(g->conv_fiber_w)));
     // ... and the column sums: d(linear_1.bias) = sum_rows dhpre; d(norm.weight) = sum_rows dxn * xhat and d(norm.bias) = sum_rows dxn
     // in one pass over dxn; d(conv.bias) = sum_rows dx2
     TRY(colsum(s, t, t.dh, nullptr, M, H, 1.0f, W(g->linear1_b), 0, nullptr, nullptr, L, (long)M * H, 0, H, 0));
@@ -1315,13 +1381,7 @@ extern "C" int arreau_train_backward(arreau_model* m, const float* d_g_eps, cons
     TRY(linear_dw(s, t, R, ARREAU_MONO_PAD, C, t.dh1, t.mono, t.dw1f));
     LAUNCH(unfold_poly_grad_kernel, dim3(blocks((long)C * ARREAU_POLY_COLS)), dim3(256), t.dw1f, C, W(g->basis_w1));
     TRY(colsum(s, t, t.dh1, nullptr, R, C, 1.0f, W(g->basis_b1)));
-    // fiber basis MLP
-    TRY(launch_gelu_backward(s, t.dfkb, t.fh2pre, (const float*)nullptr, 256L, D));
-    TRY(linear_dw(s, t, 256, C, D, t.dfkb, t.fh1, W(g->fiber_w2)));
-    TRY(colsum(s, t, t.dfkb, nullptr, 256, D, 1.0f, W(g->fiber_b2)));
-    TRY(linear_dx_gelu_backward(s, t, 256, C, D, t.dfkb, m->fiber_w2, t.fh1pre, (const float*)nullptr, t.dfh1));
-    TRY(linear_dw(s, t, 256, 3, C, t.dfh1, t.fpoly, W(g->fiber_w1)));
-    TRY(colsum(s, t, t.dfh1, nullptr, 256, C, 1.0f, W(g->fiber_b1)));
+    TRY(join_side(t, s));   // the fiber branch's gradients are complete when this call's work is
     return ARREAU_OK;
 }
 
