@@ -183,9 +183,15 @@ struct SgemmEpilogue {
     const float* mat = nullptr;
     float* out = nullptr;
 };
-__device__ __forceinline__ float sg_gelu_exact(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+// GELU and its derivative, branch-free (round 5; the element-wise kernels of train_net.hip use the same two functions, so a fused
+// and an unfused product still agree to the bit).  Forward: the sampling kernels' own form (f16x3.h gelu_fast2: 2.8e-7 absolute).
+// Derivative Phi(x) + x phi(x): Phi from the branch-free erf of internal.h (< 1 ulp + the 2e-7 of v_exp_f32), phi from one
+// v_exp_f32.  libm's erff / expf -- branches on |x|, about fifty instructions per element -- made a GELU epilogue cost more than
+// the launch it replaced on the 128 x 128 tiles.
+__device__ __forceinline__ float sg_gelu_exact(float x) { return gelu_fast(x); }
 __device__ __forceinline__ float sg_gelu_grad(float x) {
-    return 0.5f * (1.0f + erff(x * 0.70710678118654752440f)) + x * 0.39894228040143267794f * expf(-0.5f * x * x);
+    return 0.5f * (1.0f + arreau_erf(x * 0.70710678118654752440f)) +
+           x * 0.39894228040143267794f * __builtin_amdgcn_exp2f(-0.72134752044448170368f * x * x);
 }
 // Split-precision form of the kernel above (round 4; BASELINE configs[4] asks for the training step on matrix-rate
 // arithmetic).  Same tiling, same operand addressing, same split-K protocol; what changes is the staging -- every fp32
@@ -588,6 +594,8 @@ inline int arreau_sgemm(hipStream_t s, float* partial, int M, int N, int K, cons
     // ... and only on the 64 x 64 tiles: at 128 x 128 (two workgroups per CU, 64 outputs per thread) the erf / exp arithmetic of the GELU
     // epilogues is not hidden behind anything and the fused product ran slower than product + element-wise launch (round 4: 133 + 31 us
     // -> 256 us for the kernel-projection gradient with the GELU derivative)
+    // (round 5: again with the branch-free GELU of this file, a quarter of libm's instructions -- 2.143 -> 2.180 ms per step with the
+    // three 128 x 128 epilogues fused, alternating runs: 64 outputs per thread behind a single tile leave the epilogue nothing to hide in)
     const bool fuse = epi && epi->kind != 0 && split && small && Z == 1 && beta == 0.f && batch == 1;
     if (fused) *fused = fuse;
     SgemmEpilogue ep = fuse ? *epi : SgemmEpilogue{};

@@ -199,10 +199,9 @@ __global__ __launch_bounds__(256) void colsum4_final_kernel(const f32x4* __restr
     }
 }
 
-__device__ __forceinline__ float gelu_exact(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
-__device__ __forceinline__ float gelu_grad(float x) {
-    return 0.5f * (1.0f + erff(x * 0.70710678118654752440f)) + x * 0.39894228040143267794f * expf(-0.5f * x * x);
-}
+// (the products' epilogues use the same two functions: sgemm.h)
+__device__ __forceinline__ float gelu_exact(float x) { return arreau_sgemm_detail::sg_gelu_exact(x); }
+__device__ __forceinline__ float gelu_grad(float x) { return arreau_sgemm_detail::sg_gelu_grad(x); }
 
 // pre[r][c] += bias[c]; act[r][c] = gelu(pre) * (rowscale ? rowscale[r] : 1)
 __global__ void bias_gelu_kernel(float* __restrict__ pre, const float* __restrict__ bias, const float* __restrict__ rowscale,
