@@ -333,6 +333,10 @@ int arreau_launch_conv_proj(const arreau_model* m, int layer, const float* basis
 
 int arreau_launch_mlp_bf16x6(const arreau_model* m, int layer, const float* x_conv, const float* x_in, float* x_out,
                              float* xbar, float* vsum, int N, hipStream_t s);
+bool arreau_mlp_train_forward_available(const arreau_model* m);
+int arreau_launch_mlp_train_forward(const arreau_model* m, int layer, const float* x_conv, const float* x_in, float* x_out, float* xhat,
+                                    float* rstd, float* xn, float* hpre, float* h, float* out, int N, hipStream_t s);
+int arreau_repack_mlp_f16x3_m16(arreau_model* m, hipStream_t s);
 int arreau_launch_mlp_f16x3_m16(const arreau_model* m, int layer, const float* x_conv, const float* x_in, float* x_out,
                                 float* xbar, float* vsum, int N, hipStream_t s, NodeRange r = NodeRange());
 // one launch per layer for small unsliced launches (node_f16m.hip): conv_kernel_streamed<128, false> + the split MLP form

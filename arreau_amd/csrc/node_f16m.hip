@@ -320,15 +320,25 @@ __device__ __forceinline__ void load_steps(u32x4 (&w)[2 * NST], const u32x4* __r
 // of conv_kernel / conv_kernel_streamed (node.hip) on an fp32 K block, same thread roles (512 threads), same order of the
 // rounded products and of the mix -- and keeps the 16 convolved rows in LDS instead of reading them back from x_conv: one
 // launch per layer instead of two where launches, not bytes, are what a step costs (1 x 8: 15 -> 10 launches per step).
-template <int C, int H, bool FUSE = false>
+// TRAIN (round 5): the training forward of the block (arreau_general_network, train_net.hip) through this kernel instead of a
+// LayerNorm launch and two products with epilogues: the same numbers as the sampling step, plus what the backward pass reads --
+// xhat, rstd, the LayerNorm output (wave 0: every wave normalises the 16 rows for its own B operand), every hidden unit before and
+// after the GELU (the wave that owns the chunk, 16-byte pieces of four consecutive units per row) and linear_2's output with its
+// bias (the wave that owns the tile).  No read-out partials (the training read-outs are one batched product over the kept x_l).
+struct MlpTrainSave {
+    float *xhat, *rstd, *xn, *hpre, *h, *out;  // [M][C], [M], [M][C], [M][H], [M][H], [M][C] of this layer (M = 16 N rows)
+};
+template <int C, int H, bool FUSE = false, bool TRAIN = false>
 __global__ __launch_bounds__(512) void mlp_kernel_f16x3_m16_split(
     const float* __restrict__ x_conv, const float* __restrict__ x_in, float* __restrict__ x_out,
     const float* __restrict__ ln_w, const float* __restrict__ ln_b, const u32x4* __restrict__ stream,
     const float* __restrict__ mb1, const float* __restrict__ mb2, const float* __restrict__ ls,
     const float* __restrict__ wv, float bv, int n0, int first_layer, float* __restrict__ xbar, float* __restrict__ vsum,
     const float* __restrict__ kl /* FUSE: this layer's kernels [N*8*16][C] fp32 */, const int32_t* __restrict__ deg,
-    const int32_t* __restrict__ src, const float* __restrict__ fk /* [16][16][C] */, const float* __restrict__ conv_bias) {
+    const int32_t* __restrict__ src, const float* __restrict__ fk /* [16][16][C] */, const float* __restrict__ conv_bias,
+    MlpTrainSave save) {
     static_assert(C == 128 && H == 512, "chunking below assumes C = 128, H = 512");
+    static_assert(!(FUSE && TRAIN), "the training forward keeps its own conv launches (x_1 is kept for the backward pass)");
     constexpr int KC = C / 32, HQ = H / 4;
     constexpr int TS = 132;             // row stride of the two conv tiles (node.hip: CONV_LDS_STRIDE)
     __shared__ u32x4 hidx[16][2][64];   // hidden chunk (quarter * 4 + u) as B operand: [chunk][plane][lane], 32 KiB
@@ -426,12 +436,28 @@ __global__ __launch_bounds__(512) void mlp_kernel_f16x3_m16_split(
                 sq += dlt * dlt;
             }
         const float rstd = 1.0f / sqrtf(group4_sum(sq) * (1.0f / C) + 1e-5f);
+        if constexpr (TRAIN) {
+            if (wave == 0 && gp == 0) save.rstd[(size_t)n * 16 + cp] = rstd;
+        }
 #pragma unroll
         for (int kb = 0; kb < KC; ++kb) {
 #pragma unroll
             for (int hf = 0; hf < 2; ++hf) {
                 const f32x4 gw = *reinterpret_cast<const f32x4*>(ln_w + 32 * kb + 16 * hf + 4 * gp);
                 const f32x4 gb = *reinterpret_cast<const f32x4*>(ln_b + 32 * kb + 16 * hf + 4 * gp);
+                if constexpr (TRAIN) {
+                    if (wave == 0) {
+                        const size_t o = ((size_t)n * 16 + cp) * C + 32 * kb + 16 * hf + 4 * gp;
+                        f32x4 xh, xo;
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) {
+                            xh[r] = x[kb][4 * hf + r] * rstd;
+                            xo[r] = x[kb][4 * hf + r] * rstd * gw[r] + gb[r];
+                        }
+                        *reinterpret_cast<f32x4*>(save.xhat + o) = xh;
+                        *reinterpret_cast<f32x4*>(save.xn + o) = xo;
+                    }
+                }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) x[kb][4 * hf + r] = x[kb][4 * hf + r] * rstd * gw[r] + gb[r];
             }
@@ -466,6 +492,12 @@ __global__ __launch_bounds__(512) void mlp_kernel_f16x3_m16_split(
                 const f32x2 act = gelu_fast2(pre);
                 v[4 * mt + 2 * pr] = act.x;
                 v[4 * mt + 2 * pr + 1] = act.y;
+                if constexpr (TRAIN) {  // row (n, cp), hidden units q HQ + 32 u + 16 mt + 4 gp + 2 pr, + 1
+                    const size_t o = ((size_t)n * 16 + cp) * H + q * HQ + 32 * u + 16 * mt + 4 * gp + 2 * pr;
+                    typedef float f2v __attribute__((ext_vector_type(2)));
+                    *reinterpret_cast<f2v*>(save.hpre + o) = f2v{pre.x, pre.y};
+                    *reinterpret_cast<f2v*>(save.h + o) = f2v{act.x, act.y};
+                }
             }
         u32x4 hi, lo;
         split8<false>(v, hi, lo);
@@ -515,6 +547,10 @@ __global__ __launch_bounds__(512) void mlp_kernel_f16x3_m16_split(
 #pragma unroll
         for (int r = 0; r < 4; ++r) xo[r] = (acc[r] + ep_b2[r]) * ep_ls[r] + ep_xi[r];
         *reinterpret_cast<f32x4*>(x_out + ep_off) = xo;
+        if constexpr (TRAIN) {
+            *reinterpret_cast<f32x4*>(save.out + ep_off) = f32x4{acc[0] + ep_b2[0], acc[1] + ep_b2[1], acc[2] + ep_b2[2], acc[3] + ep_b2[3]};
+            return;  // (no barrier follows on this path)
+        }
         f32x4 sum;
 #pragma unroll
         for (int r = 0; r < 4; ++r) sum[r] = row16_sum_m(xo[r]);
@@ -561,7 +597,7 @@ int arreau_launch_mlp_f16x3_m16_split(const arreau_model* m, int layer, const fl
                        m->ln_w + (size_t)layer * C, m->ln_b + (size_t)layer * C, stream, m->mb1 + (size_t)layer * H,
                        m->mb2 + (size_t)layer * C, m->ls + (size_t)layer * C, m->ro_wv + (size_t)layer * C, m->ro_bv_host[layer],
                        n0, layer == 0 ? 1 : 0, xbar + (size_t)layer * Ntot * C, vsum, (const float*)nullptr, (const int32_t*)nullptr,
-                       (const int32_t*)nullptr, (const float*)nullptr, (const float*)nullptr);
+                       (const int32_t*)nullptr, (const float*)nullptr, (const float*)nullptr, MlpTrainSave{});
     ARREAU_CHECK_HIP(hipGetLastError());
     return ARREAU_OK;
 }
@@ -588,7 +624,61 @@ int arreau_launch_small_layer(const arreau_model* m, int layer, const float* kbu
                        m->ln_w + (size_t)layer * C, m->ln_b + (size_t)layer * C, stream, m->mb1 + (size_t)layer * H,
                        m->mb2 + (size_t)layer * C, m->ls + (size_t)layer * C, m->ro_wv + (size_t)layer * C, m->ro_bv_host[layer],
                        0, layer == 0 ? 1 : 0, xbar + (size_t)layer * Ntot * C, vsum, kbuf + layer_stride * layer, deg, src,
-                       m->fk + (size_t)layer * 16 * 16 * C, m->conv_bias + (size_t)layer * C);
+                       m->fk + (size_t)layer * 16 * 16 * C, m->conv_bias + (size_t)layer * C, MlpTrainSave{});
+    ARREAU_CHECK_HIP(hipGetLastError());
+    return ARREAU_OK;
+}
+
+// The ConvNext block of the TRAINING forward (train_net.hip): x_conv = the layer's spherical-conv output with bias, x_in / x_out the
+// residual stream, everything the backward pass reads written beside (see MlpTrainSave).  The weights come from the packed plane
+// stream like in sampling: arreau_repack_mlp_f16x3_m16 below rebuilds it from the fp32 training weights after every optimizer step.
+bool arreau_mlp_train_forward_available(const arreau_model* m) {
+    const char* e = getenv("ARREAU_TRAIN_FUSED_MLP");  // 0: LayerNorm launch + two products (A/B, tests); read per call
+    return (!e || atoi(e) != 0) && m->C == 128 && m->H == 512 && m->mlp_f16m != nullptr;
+}
+int arreau_launch_mlp_train_forward(const arreau_model* m, int layer, const float* x_conv, const float* x_in, float* x_out, float* xhat,
+                                    float* rstd, float* xn, float* hpre, float* h, float* out, int N, hipStream_t s) {
+    if (N <= 0) return ARREAU_OK;
+    const int C = m->C, H = m->H;
+    const size_t layer_u32x4 = (size_t)2 * H * C * 2 * 2 / 16;
+    const u32x4* stream = reinterpret_cast<const u32x4*>(m->mlp_f16m) + (size_t)layer * layer_u32x4;
+    ARREAU_LAUNCH((mlp_kernel_f16x3_m16_split<128, 512, false, true>), dim3((unsigned)N), dim3(512), 0, s, x_conv, x_in, x_out,
+                  m->ln_w + (size_t)layer * C, m->ln_b + (size_t)layer * C, stream, m->mb1 + (size_t)layer * H, m->mb2 + (size_t)layer * C,
+                  m->ls + (size_t)layer * C, (const float*)nullptr, 0.0f, 0, 0, (float*)nullptr, (float*)nullptr, (const float*)nullptr,
+                  (const int32_t*)nullptr, (const int32_t*)nullptr, (const float*)nullptr, (const float*)nullptr,
+                  MlpTrainSave{xhat, rstd, xn, hpre, h, out});
+    ARREAU_CHECK_HIP(hipGetLastError());
+    return ARREAU_OK;
+}
+
+// Device form of model.hip's pack_linear_f16x3_m16(native) for the block's two Linears: per layer and hidden quarter w, the quarter's
+// rows of linear_1 [H][C] (32,768 halves: [u][kb][mt][plane][lane][e]) then its columns of linear_2 [C][H] (the same), both fp16
+// planes (hi, residual * 2^11; round to nearest even like the host packer: the streams agree bit for bit).
+namespace {
+__global__ __launch_bounds__(256) void repack_mlp_f16x3_m16_kernel(const float* __restrict__ lin1 /*[L][H][C]*/, const float* __restrict__ lin2 /*[L][C][H]*/,
+                                                                    int L, unsigned short* __restrict__ q) {
+    constexpr int C = 128, H = 512, HQ = 128;
+    const long i = (long)blockIdx.x * 256 + threadIdx.x;   // one (layer, quarter, matrix, u, kb, mt, lane, e)
+    const long per_mat = 4L * 4 * 2 * 64 * 8;                // 16,384 elements of a 128 x 128 quarter
+    if (i >= (long)L * 4 * 2 * per_mat) return;
+    const int e = (int)(i & 7), lane = (int)((i >> 3) & 63), mt = (int)((i >> 9) & 1), kb = (int)((i >> 10) & 3), u = (int)((i >> 12) & 3);
+    const int mat = (int)((i >> 14) & 1), w = (int)((i >> 15) & 3), l = (int)(i >> 17);
+    const int g = lane >> 4;
+    const int o = 32 * u + 16 * mt + (lane & 15);                     // output row of the quarter's matrix
+    const int k = 32 * kb + 16 * (e >> 2) + 4 * g + (e & 3);          // input column (native k order)
+    const float v = mat == 0 ? lin1[((size_t)l * H + (size_t)w * HQ + o) * C + k] : lin2[((size_t)l * C + o) * H + (size_t)w * HQ + k];
+    const _Float16 h1 = (_Float16)v;
+    const _Float16 h2 = (_Float16)((v - (float)h1) * 2048.0f);
+    const size_t base = (((size_t)l * 4 + w) * 2 + mat) * (size_t)(2 * per_mat) + (((size_t)u * 4 + kb) * 2 + mt) * 2 * 512 + (size_t)lane * 8 + e;
+    q[base] = __builtin_bit_cast(unsigned short, h1);
+    q[base + 512] = __builtin_bit_cast(unsigned short, h2);
+}
+}  // namespace
+int arreau_repack_mlp_f16x3_m16(arreau_model* m, hipStream_t s) {
+    if (!(m->C == 128 && m->H == 512 && m->mlp_f16m)) return ARREAU_OK;
+    const long n = (long)m->L * 4 * 2 * 16384;
+    ARREAU_LAUNCH(repack_mlp_f16x3_m16_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, m->t_lin1, m->t_lin2, m->L,
+                  reinterpret_cast<unsigned short*>(const_cast<float*>(m->mlp_f16m)));
     ARREAU_CHECK_HIP(hipGetLastError());
     return ARREAU_OK;
 }

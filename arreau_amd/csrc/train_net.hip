@@ -1173,11 +1173,18 @@ int arreau_general_network(arreau_model* m, const arreau_graph_view& g, const in
             LAUNCH(conv_forward_kernel, dim3(blocks(M * C)), dim3(256), t.kern + (size_t)l * C, L * C, xl, g.deg, g.src, N, k, C, x1);
             LAUNCH(mix_forward_kernel, dim3(blocks(M * C)), dim3(256), x1, fk, m->conv_bias + (size_t)l * C, N, C, t.dtmp);
         }
-        LAUNCH(ln_forward_kernel, dim3(blocks(M, 4)), dim3(256), t.dtmp, m->ln_w + (size_t)l * C, m->ln_b + (size_t)l * C, M, C,
-               t.xhat + (size_t)l * M * C, t.rstd + (size_t)l * M, t.xn_all + (size_t)l * M * C);
         float* hpre = t.hpre + (size_t)l * M * H;
         float* h = t.h + (size_t)l * M * H;
         float* out = t.out + (size_t)l * M * C;
+        if (t.fwd_mode == 1 && arreau_mlp_train_forward_available(m)) {
+            // LayerNorm + linear_1 + GELU + linear_2 + layer scale + residual as ONE launch of the sampling step's kernel, which also
+            // writes what the backward pass reads (node_f16m.hip, TRAIN): 3 launches per layer instead of 5
+            TRY(arreau_launch_mlp_train_forward(m, l, t.dtmp, xl, xnext, t.xhat + (size_t)l * M * C, t.rstd + (size_t)l * M,
+                                                t.xn_all + (size_t)l * M * C, hpre, h, out, N, s));
+            continue;
+        }
+        LAUNCH(ln_forward_kernel, dim3(blocks(M, 4)), dim3(256), t.dtmp, m->ln_w + (size_t)l * C, m->ln_b + (size_t)l * C, M, C,
+               t.xhat + (size_t)l * M * C, t.rstd + (size_t)l * M, t.xn_all + (size_t)l * M * C);
         TRY(linear_bias_gelu(s, t, M, C, H, t.xn_all + (size_t)l * M * C, t.lin1 + (size_t)l * H * C, m->mb1 + (size_t)l * H, (const float*)nullptr,
                              hpre, h));
         {   // out = h W2^T + b2;  x_{l+1} = out * layer_scale + x_l  (in the product's epilogue where the split kernel runs it)
@@ -1491,6 +1498,7 @@ extern "C" int arreau_model_update_train_weights(arreau_model* m, const arreau_s
     cp(m->t_ro_w, d->readout_w, L * RO * C);
     cp(m->ro_b, d->readout_b, L * RO);
     LAUNCH(copy_segments_kernel, dim3(64, nseg), dim3(256), seg);
+    TRY(arreau_repack_mlp_f16x3_m16(m, s));   // the plane stream the fused training forward of the ConvNext block reads
     return ARREAU_OK;
 }
 
@@ -1520,6 +1528,7 @@ extern "C" int arreau_model_refresh_derived_train_weights(arreau_model* m, const
     if (!m->train) TRY(ensure_ctx(m, 1, 1, s));
     LAUNCH(fold_poly_weight_kernel, dim3(blocks((long)C * ARREAU_MONO_PAD)), dim3(256), d_basis_w1, (int)C, m->train->mono_cols, W(m->t_w1f));
     LAUNCH(transpose_kernel, dim3(blocks((long)C * (S + 78))), dim3(256), d_x_embedder_w, (int)C, (int)(S + 78), W(m->embT));
+    TRY(arreau_repack_mlp_f16x3_m16(m, s));
     return ARREAU_OK;
 }
 

@@ -173,6 +173,35 @@ def test_training_step_gradients_match_oracle_autograd(setup):
     assert "t_emb.gaussian_fourier_proj_w" not in got  # requires_grad = False in the reference too
 
 
+def test_fused_convnext_training_forward_against_the_product_form(setup, monkeypatch):
+    """The training forward runs the ConvNext block through the sampling step's kernel (node_f16m.hip, TRAIN: one launch instead of a
+    LayerNorm launch and two products; ARREAU_TRAIN_FUSED_MLP=0 keeps those) and that kernel also writes what the backward pass
+    reads.  Both forms against each other: loss and every gradient -- the saved activations are only visible through them -- and
+    again after an optimizer step, when the kernel's weight planes have been rebuilt on the device from the updated fp32 weights."""
+    import copy
+    from arreau_amd.train import optimizer_step
+    m, om, batch, lattice0, timestep, noise = setup
+    results = {}
+    for fused in ("1", "0"):
+        monkeypatch.setenv("ARREAU_TRAIN_FUSED_MLP", fused)
+        mm = copy.deepcopy(m)
+        opt = mm.configure_optimizers(max_epochs=10)["optimizer"]
+        for g in opt.param_groups:
+            g["lr"] = 1e-3
+        out = []
+        for _ in range(2):
+            loss = mm.training_step(batch, timestep=timestep, noise=noise)
+            out.append((float(loss), {n: p.grad.detach().clone() for n, p in mm.named_parameters() if p.grad is not None}))
+            optimizer_step(mm, opt, world_size=1)
+        results[fused] = out
+    for (la, ga), (lb, gb) in zip(results["1"], results["0"]):
+        assert abs(la - lb) <= 1e-6 * max(1.0, abs(lb)), (la, lb)
+        assert ga.keys() == gb.keys() and len(ga) > 60
+        for n in ga:
+            scale = max(float(gb[n].abs().max()), 1e-30)
+            assert float((ga[n] - gb[n]).abs().max()) <= 2e-5 * scale, (n, float((ga[n] - gb[n]).abs().max()) / scale)
+
+
 def test_first_training_forward_callibrates_conv_weights(setup):
     """FiberBundleConv.callibrate (conv.py:121-123,140-146): after the first training forward kernel.weight is scaled by
     std(x) / std(x_1) and fiber_kernel.weight by std(x_1) / std(x_2) (per layer, unbiased std), once."""
