@@ -185,3 +185,43 @@ def test_host_inputs_are_packed_into_one_staging_buffer_on_the_calling_thread():
     ints = torch.full((12,), -1, dtype=torch.int32)
     _pack(ints, [(0, torch.arange(5, dtype=torch.int64)), (1, torch.tensor([7, 8, 9], dtype=torch.int16))], [0, 8])
     assert ints.tolist() == [0, 1, 2, 3, 4, -1, -1, -1, 7, 8, 9, -1]
+
+
+def test_clip_adam_without_a_gpu_is_torch_adam():
+    """arreau_amd.optim.ClipAdam is a torch.optim.Adam: on the CPU (or with gradients that are not views of one CUDA buffer) `step_flat`
+    declines and the driver (arreau_amd.train.optimizer_step) clips through torch and calls `step()` -- the same parameters as a plain
+    Adam after clip_grad_norm_, and a state_dict a plain Adam loads."""
+    from arreau_amd.optim import ClipAdam
+    from arreau_amd.train import optimizer_step
+
+    class Toy(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            g = torch.Generator().manual_seed(3)
+            self.a = torch.nn.Parameter(torch.randn(4, 3, generator=g))
+            self.b = torch.nn.Parameter(torch.randn(5, generator=g))
+            self.notified = 0
+
+        def notify_parameters_changed(self):
+            self.notified += 1
+
+    m1, m2 = Toy(), Toy()
+    groups = lambda m: [{"params": [m.a], "weight_decay": 1e-2}, {"params": [m.b], "weight_decay": 0.0}]
+    o1, o2 = ClipAdam(groups(m1), lr=1e-2), torch.optim.Adam(groups(m2), lr=1e-2)
+    assert isinstance(o1, torch.optim.Adam)
+    g = torch.Generator().manual_seed(4)
+    for step in range(3):
+        flat = torch.zeros(20)
+        m1.a.grad, m1.b.grad = flat[0:12].view(4, 3), flat[12:17]
+        flat[:17] = torch.randn(17, generator=g) * (5.0 if step == 1 else 0.05)
+        m2.a.grad, m2.b.grad = flat[0:12].view(4, 3).clone(), flat[12:17].clone()
+        m1._grad_flat = flat
+        assert o1.step_flat(flat, 0.5) is None   # not a CUDA buffer: declined, nothing touched
+        norm = optimizer_step(m1, o1, world_size=1, clip=0.5)
+        ref = torch.nn.utils.clip_grad_norm_([m2.a, m2.b], 0.5)
+        o2.step()
+        assert abs(float(norm) - float(ref)) < 1e-6 * max(1.0, float(ref)) and m1.notified == step + 1 and m1._grad_flat is None
+        assert torch.allclose(m1.a, m2.a, atol=1e-6) and torch.allclose(m1.b, m2.b, atol=1e-6)
+    o3 = torch.optim.Adam(groups(Toy()), lr=1e-2)
+    o3.load_state_dict(o1.state_dict())
+    assert float(o3.state[o3.param_groups[0]["params"][0]]["step"]) == 3.0
