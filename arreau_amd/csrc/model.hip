@@ -632,7 +632,10 @@ extern "C" int arreau_model_create(const arreau_config* cfg, const arreau_state_
     const size_t off_t_wk = bb.put(sd->conv_kernel_w, (size_t)L * C * D);
     const size_t off_t_lin1 = bb.put(sd->linear1_w, (size_t)L * H * C);
     const size_t off_t_lin2 = bb.put(sd->linear2_w, (size_t)L * C * H);
-    const size_t off_t_ro_w = bb.put(sd->readout_w, (size_t)L * RO * C);
+    // (+ four zero rows behind the last layer: the training step's d(x) product reads the read-out weights with the reduction padded to a
+    // multiple of four -- its d(rbar) operand carries zero pad columns -- so layer L - 1 reads up to three rows past its own)
+    const size_t off_t_ro_w = bb.reserve((size_t)L * RO * C + (size_t)4 * C);
+    memcpy(bb.data.data() + off_t_ro_w, sd->readout_w, (size_t)L * RO * C * sizeof(float));
     const size_t off_status = bb.reserve(64);  // zero-initialised sticky status word (+ pad)
 
     arreau_model* m = new arreau_model();

@@ -177,6 +177,9 @@ __global__ __launch_bounds__(256) void sgemm_kernel(int M, int N, int K, const f
 //   3  bias, scale, residual:  v += vec[n];  C = v;  out = v * vec2[n] + mat[m][n]               (convnext.py: x + layer_scale * linear_2(...))
 struct SgemmEpilogue {
     int kind = 0;
+    // round 5: a short reduction (K <= 256) whose output traffic dominates may ask for the 64 x 64 tiles just to get its epilogue inside the
+    // product (the 128 x 128 tiles take none: below) -- [64768, 128] x [256, 128]^T + bias + GELU: 30 + 30 us as product + pass
+    bool prefer_small = false;
     const float* vec = nullptr;
     const float* vec2 = nullptr;
     const float* row = nullptr;
@@ -530,7 +533,77 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
     const int m = (int)(i / N), n = (int)(i % N);
     C[(size_t)m * ldc + n] = alpha * s + (beta != 0.f ? beta * C[(size_t)m * ldc + n] : 0.f);
 }
+// Round 5: the k-slice sums of SEVERAL products in one launch -- the weight gradients of a backward pass, which nothing waits for: each
+// product keeps its partial tiles in its own piece of a scratch region and leaves a descriptor; one launch at the end adds them all
+// (same threads-per-element choice and the same association per product as splitk_reduce_kernel<ZP>: bit-identical results).
+struct SgemmReduceDesc {
+    const float* partial;
+    float* C;
+    int Z, M, N, ldc;
+    float alpha, beta;
+    int zp;               // threads per output element (1, 4 or 8)
+};
+constexpr int SGEMM_DEFER_MAX = 40;
+struct SgemmReduceList {
+    SgemmReduceDesc d[SGEMM_DEFER_MAX];
+    unsigned block0[SGEMM_DEFER_MAX];  // first workgroup of each product in the launch (ascending)
+    int n;
+};
+__global__ __launch_bounds__(256) void splitk_reduce_multi_kernel(SgemmReduceList list) {
+    __shared__ float sh[256];
+    // this workgroup's product = the number of products that start at or before it: the starts arrive as three wide scalar loads and
+    // the count is forty scalar compares (a search loop over the descriptors, one dependent scalar load per step, cost more than the
+    // sums themselves: 55 us for 125 MB in the first version)
+    int q = 0;
+#pragma unroll
+    for (int i = 1; i < SGEMM_DEFER_MAX; ++i) q += (i < list.n && blockIdx.x >= list.block0[i]) ? 1 : 0;
+    const SgemmReduceDesc d = list.d[q];
+    const unsigned first = list.block0[q];
+    const int ZP = d.zp, EPB = 256 / ZP;
+    const int el = threadIdx.x % EPB, zl = threadIdx.x / EPB;
+    const long i = (long)(blockIdx.x - first) * EPB + el;
+    const long MN = (long)d.M * d.N;
+    const float* __restrict__ partial = d.partial;
+    float s = 0.f;
+    if (i < MN) {
+        // (four independent loads in flight, added in slice order: with a run-time stride hipcc leaves a one-load loop, every step the
+        // full memory latency -- 32 us for 65 MB)
+        int z = zl;
+        for (; z + 3 * ZP < d.Z; z += 4 * ZP) {
+            const float v0 = partial[(size_t)z * MN + i], v1 = partial[(size_t)(z + ZP) * MN + i];
+            const float v2 = partial[(size_t)(z + 2 * ZP) * MN + i], v3 = partial[(size_t)(z + 3 * ZP) * MN + i];
+            s += v0; s += v1; s += v2; s += v3;
+        }
+        for (; z < d.Z; z += ZP) s += partial[(size_t)z * MN + i];
+    }
+    if (ZP > 1) {
+        sh[zl * EPB + el] = s;
+        __syncthreads();
+        if (zl != 0) return;
+        for (int w = 1; w < ZP; ++w) s += sh[w * EPB + el];
+    }
+    if (i >= MN) return;
+    const int m = (int)(i / d.N), n = (int)(i % d.N);
+    d.C[(size_t)m * d.ldc + n] = d.alpha * s + (d.beta != 0.f ? d.beta * d.C[(size_t)m * d.ldc + n] : 0.f);
+}
 }  // namespace arreau_sgemm_detail
+
+// Deferred k-slice sums (see splitk_reduce_multi_kernel): scratch region + descriptor list, owned by the caller.
+struct arreau_sgemm_defer {
+    float* scratch = nullptr;
+    size_t cap = 0, used = 0;   // floats
+    arreau_sgemm_detail::SgemmReduceList list{};
+    unsigned blocks = 0;
+};
+inline void arreau_sgemm_defer_reset(arreau_sgemm_defer& d) { d.used = 0; d.list.n = 0; d.blocks = 0; }
+inline int arreau_sgemm_flush(hipStream_t s, arreau_sgemm_defer& d) {
+    if (d.list.n > 0) {
+        hipLaunchKernelGGL(arreau_sgemm_detail::splitk_reduce_multi_kernel, dim3(d.blocks), dim3(256), 0, s, d.list);
+        ARREAU_CHECK_HIP(hipGetLastError());
+    }
+    arreau_sgemm_defer_reset(d);
+    return ARREAU_OK;
+}
 
 // batch > 1: `batch` products of the same shape in one launch (operands a_bs / b_bs / c_bs floats apart; a stride of 0 shares an
 // operand): the weight gradients of the L layers, which nothing in the backward pass waits for, leave the chip idle one by one
@@ -538,7 +611,8 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restr
 inline int arreau_sgemm(hipStream_t s, float* partial, int M, int N, int K, const float* A, long as0, long as1, const float* B,
                         long bs0, long bs1, float* C, int ldc, float alpha = 1.f, float beta = 0.f, int batch = 1, long a_bs = 0,
                         long b_bs = 0, long c_bs = 0, int mode = 0 /* 0: exact fp32; 1: fp16x3; 2: bf16x6 (sgemm_split_kernel) */,
-                        const arreau_sgemm_detail::SgemmEpilogue* epi = nullptr, bool* fused = nullptr /* out: the epilogue ran inside the product */) {
+                        const arreau_sgemm_detail::SgemmEpilogue* epi = nullptr, bool* fused = nullptr /* out: the epilogue ran inside the product */,
+                        arreau_sgemm_defer* defer = nullptr /* a split-K product leaves its slice sum to arreau_sgemm_flush (C is NOT complete before that) */) {
     using namespace arreau_sgemm_detail;
     if (M == 0 || N == 0 || batch <= 0) return ARREAU_OK;
     // Tile size.  The kernel is bound by the matrix pipe of the busiest CU, so what matters is how evenly the tiles divide
@@ -553,7 +627,7 @@ inline int arreau_sgemm(hipStream_t s, float* partial, int M, int N, int K, cons
     // are bound by their loads (round 4: [640, 68096] x [68096, 256] without its loads 244 -> 123 us).
     const int z128 = min(64, K / 256);
     const bool long_k = mode != 0 && tiles128 < 512 && K >= 2048 && (long)tiles128 * z128 >= 256;
-    const bool small = tiles128 < 512 && !long_k;
+    const bool small = (tiles128 < 512 && !long_k) || (epi && epi->kind != 0 && epi->prefer_small && mode != 0 && K <= 256 && K >= 64 && batch == 1 && beta == 0.f);
     const int T = small ? 64 : 128;
     const int gm = (M + T - 1) / T, gn = (N + T - 1) / T;
     int Z = 1;
@@ -586,6 +660,11 @@ inline int arreau_sgemm(hipStream_t s, float* partial, int M, int N, int K, cons
     const int BK = (small || split) ? 32 : 16;
     const int kchunk = ((K + Z - 1) / Z + BK - 1) / BK * BK;
     Z = (K + kchunk - 1) / kchunk;
+    bool deferred = false;
+    if (defer && Z > 1 && defer->scratch && defer->used + (size_t)batch * Z * M * N <= defer->cap && defer->list.n + batch <= SGEMM_DEFER_MAX) {
+        partial = defer->scratch + defer->used;
+        deferred = true;
+    }
     auto launch = [&](auto kernel) {
         hipLaunchKernelGGL(kernel, dim3(gn, gm, Z * batch), dim3(256), 0, s, M, N, K, A, as0, as1, B, bs0, bs1, C, ldc, alpha, beta, kchunk,
                            partial, Z, a_bs, b_bs, c_bs);
@@ -629,7 +708,20 @@ inline int arreau_sgemm(hipStream_t s, float* partial, int M, int N, int K, cons
         if (vec) launch(sgemm_kernel<1, 2, 2, 16>); else launch(sgemm_kernel<0, 2, 2, 16>);
     }
     ARREAU_CHECK_HIP(hipGetLastError());
-    if (Z > 1) {
+    if (Z > 1 && deferred) {
+        const long mn = (long)M * N;
+        const int zp = Z <= 8 ? 1 : Z <= 32 ? 4 : 8;
+        const unsigned nb = (unsigned)((mn + 256 / zp - 1) / (256 / zp));
+        for (int b = 0; b < batch; ++b) {
+            SgemmReduceDesc& d = defer->list.d[defer->list.n++];
+            d.partial = partial + (size_t)b * Z * mn;
+            d.C = C + (long)b * c_bs;
+            d.Z = Z; d.M = M; d.N = N; d.ldc = ldc; d.alpha = alpha; d.beta = beta; d.zp = zp;
+            defer->list.block0[defer->list.n - 1] = defer->blocks;
+            defer->blocks += nb;
+        }
+        defer->used += ((size_t)batch * Z * mn + 63) & ~(size_t)63;
+    } else if (Z > 1) {
         const long mn = (long)M * N;
         if (Z <= 8)
             hipLaunchKernelGGL(splitk_reduce_kernel<1>, dim3((unsigned)((mn + 255) / 256), batch), dim3(256), 0, s, partial, Z, M, N, C, ldc, alpha, beta, c_bs);

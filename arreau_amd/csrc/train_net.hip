@@ -95,17 +95,34 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ a
 // phases per column in a fixed order, then the phases in order.  Deterministic.
 constexpr int COLSUM4_MAX_CHUNKS = 1024;
 constexpr int COLSUM4_MAX_BATCH = 8;  // matrices per batched call (the layers of the network)
-__global__ __launch_bounds__(256) void colsum4_partial_kernel(const f32x4* __restrict__ a, const f32x4* __restrict__ b, long rows,
-                                                              int cols4, long rows_per_chunk,
+// GELU_BWD (round 5): `a` is a gradient that still has to pass through a GELU -- a *= gelu'(gpre) * rowscale[row], gelu_backward_kernel4's
+// expression, written back in place -- and the column sums are those of the result: the bias gradient of a layer whose d(pre-activation)
+// comes out of a 128 x 128 product costs no pass of its own.
+template <bool GELU_BWD>
+__global__ __launch_bounds__(256) void colsum4_partial_kernel(std::conditional_t<GELU_BWD, f32x4*, const f32x4*> __restrict__ a,
+                                                              const f32x4* __restrict__ b, long rows, int cols4, long rows_per_chunk,
                                                               f32x4* __restrict__ part,   // [batch][chunks][cols4]
                                                               f32x4* __restrict__ part2,  // plain sums of a (or null)
                                                               long a_bs4, long b_bs4,     // blockIdx.y = matrix of the batch (strides in float4)
                                                               f32x4* __restrict__ scaled_out = nullptr,      // also a * colscale (or null):
-                                                              const f32x4* __restrict__ colscale = nullptr)  // d(out) = d(x) * layer_scale in the same pass
+                                                              const f32x4* __restrict__ colscale = nullptr,  // d(out) = d(x) * layer_scale in the same pass
+                                                              const f32x4* __restrict__ gpre = nullptr, const float* __restrict__ rowscale = nullptr)
 {
     __shared__ f32x4 sh[256];
     a += (long)blockIdx.y * a_bs4;
     if (b) b += (long)blockIdx.y * b_bs4;
+    auto fetch = [&](size_t i, long row) {
+        f32x4 av = a[i];
+        if constexpr (GELU_BWD) {
+            const float rs = rowscale ? rowscale[row] : 1.0f;
+            const f32x4 pv = gpre[i];
+            using arreau_sgemm_detail::sg_gelu_grad;
+            av = f32x4{av[0] * sg_gelu_grad(pv[0]) * rs, av[1] * sg_gelu_grad(pv[1]) * rs, av[2] * sg_gelu_grad(pv[2]) * rs,
+                       av[3] * sg_gelu_grad(pv[3]) * rs};
+            a[i] = av;
+        }
+        return av;
+    };
     part += (size_t)blockIdx.y * gridDim.x * cols4;
     if (part2) part2 += (size_t)blockIdx.y * gridDim.x * cols4;
     const int P = 256 / cols4;
@@ -123,7 +140,7 @@ __global__ __launch_bounds__(256) void colsum4_partial_kernel(const f32x4* __res
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const size_t i = (size_t)(r + u * P) * cols4 + c4;
-                const f32x4 av = a[i];
+                const f32x4 av = fetch(i, r + u * P);
                 acc[u] += b ? av * b[i] : av;
                 if (dual) plain[u] += av;
                 if (scaled_out) scaled_out[i] = av * cs;
@@ -131,7 +148,7 @@ __global__ __launch_bounds__(256) void colsum4_partial_kernel(const f32x4* __res
         }
         for (; r < r1; r += P) {
             const size_t i = (size_t)r * cols4 + c4;
-            const f32x4 av = a[i];
+            const f32x4 av = fetch(i, r);
             acc[0] += b ? av * b[i] : av;
             if (dual) plain[0] += av;
             if (scaled_out) scaled_out[i] = av * cs;
@@ -195,6 +212,67 @@ __global__ __launch_bounds__(256) void colsum4_final_kernel(const f32x4* __restr
         if (ph == 0 && c4 < cols4) {
 #pragma unroll
             for (int q = 0; q < 4; ++q) out2[4 * c4 + q] = (colscale2 ? colscale2[4 * c4 + q] : 1.0f) * tot2[q];
+        }
+    }
+}
+
+// Round 5: the chunk sums of SEVERAL column-sum passes in one launch.  The bias / norm / layer-scale gradients are results nothing in
+// the backward pass waits for, so each pass leaves its chunk rows in its own piece of a scratch region plus a descriptor, and one
+// launch at the end of the pass adds them all: colsum4_final_kernel's sums per descriptor (blockIdx.y), bit-identical.
+struct ColsumFinalDesc {
+    const f32x4* part;
+    const f32x4* part2;
+    float* out;
+    float* out2;
+    const float* colscale2;
+    int chunks, cols4;
+    float scale;
+    int accumulate;
+};
+constexpr int COLSUM_DEFER_MAX = 48;
+struct ColsumFinalList {
+    ColsumFinalDesc d[COLSUM_DEFER_MAX];
+};
+__global__ __launch_bounds__(256) void colsum4_final_multi_kernel(ColsumFinalList list) {
+    __shared__ f32x4 sh[256];
+    const ColsumFinalDesc& d = list.d[blockIdx.y];
+    const int cols4 = d.cols4, chunks = d.chunks;
+    if ((int)blockIdx.x * 8 >= cols4) return;  // (uniform)
+    const f32x4* __restrict__ part = d.part;
+    const f32x4* __restrict__ part2 = d.part2;
+    const int cl = threadIdx.x & 7, ph = threadIdx.x >> 3;
+    const int c4 = blockIdx.x * 8 + cl;
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    auto column_sum = [&](const f32x4* src) {
+        f32x4 tot = zero;
+        if (c4 < cols4)
+            for (int i = ph; i < chunks; i += 32 * 8) {  // eight loads in flight, added in row order
+                f32x4 v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u] = i + 32 * u < chunks ? src[(size_t)(i + 32 * u) * cols4 + c4] : zero;
+#pragma unroll
+                for (int u = 0; u < 8; ++u) tot += v[u];
+            }
+        __syncthreads();
+        sh[threadIdx.x] = tot;
+        __syncthreads();
+        f32x4 r = zero;
+        if (ph == 0) {
+            r = sh[cl];
+            for (int p = 1; p < 32; ++p) r += sh[p * 8 + cl];
+        }
+        return r;
+    };
+    const f32x4 tot = column_sum(part);
+    if (ph == 0 && c4 < cols4) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) d.out[4 * c4 + q] = d.scale * tot[q] + (d.accumulate ? d.out[4 * c4 + q] : 0.f);
+    }
+    if (part2 != nullptr) {
+        const f32x4 tot2 = column_sum(part2);
+        if (ph == 0 && c4 < cols4) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) d.out2[4 * c4 + q] = (d.colscale2 ? d.colscale2[4 * c4 + q] : 1.0f) * tot2[q];
         }
     }
 }
@@ -472,9 +550,10 @@ __global__ void conv_forward_kernel4(const f32x4* __restrict__ kern, int ldk4, c
     }
     x1[i] = acc;
 }
-__global__ void conv_backward_kern_kernel4(const f32x4* __restrict__ x, const f32x4* __restrict__ dx1, const int32_t* __restrict__ deg,
-                                           const int32_t* __restrict__ src, int N, int k, int C4, int ldk4, f32x4* __restrict__ dkern) {
-    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+// (device bodies: shared by the two kernels and by the one-launch form below)
+__device__ __forceinline__ void conv_backward_kern_body4(long i, const f32x4* __restrict__ x, const f32x4* __restrict__ dx1,
+                                                         const int32_t* __restrict__ deg, const int32_t* __restrict__ src, int N, int k,
+                                                         int C4, int ldk4, f32x4* __restrict__ dkern) {
     if (i >= (long)N * k * 16 * C4) return;
     const int c = (int)(i % C4);
     const long row = i / C4;
@@ -487,11 +566,10 @@ __global__ void conv_backward_kern_kernel4(const f32x4* __restrict__ x, const f3
     const f32x4 a = dx1[((size_t)n * 16 + o) * C4 + c], b = x[((size_t)j * 16 + o) * C4 + c];
     dkern[ik] = f32x4{a[0] * b[0], a[1] * b[1], a[2] * b[2], a[3] * b[3]};
 }
-__global__ void conv_backward_dx_kernel4(const f32x4* __restrict__ kern, int ldk4, const f32x4* __restrict__ dx1,
-                                         const int32_t* __restrict__ rev_start, const int32_t* __restrict__ rev_cnt,
-                                         const int32_t* __restrict__ rev_idx, int N, int k, int C4, const f32x4* dx_in,
-                                         const f32x4* __restrict__ add2, f32x4* dx) {
-    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void conv_backward_dx_body4(long i, const f32x4* __restrict__ kern, int ldk4, const f32x4* __restrict__ dx1,
+                                                       const int32_t* __restrict__ rev_start, const int32_t* __restrict__ rev_cnt,
+                                                       const int32_t* __restrict__ rev_idx, int N, int k, int C4, const f32x4* dx_in,
+                                                       const f32x4* __restrict__ add2, f32x4* dx) {
     if (i >= (long)N * 16 * C4) return;
     const int c = (int)(i % C4);
     const long row = i / C4;
@@ -514,6 +592,67 @@ __global__ void conv_backward_dx_kernel4(const f32x4* __restrict__ kern, int ldk
         for (int r = 0; r < 4; ++r) d[r] += a2[r];
     }
     dx[i] = d;
+}
+__global__ void conv_backward_kern_kernel4(const f32x4* __restrict__ x, const f32x4* __restrict__ dx1, const int32_t* __restrict__ deg,
+                                           const int32_t* __restrict__ src, int N, int k, int C4, int ldk4, f32x4* __restrict__ dkern) {
+    conv_backward_kern_body4((long)blockIdx.x * blockDim.x + threadIdx.x, x, dx1, deg, src, N, k, C4, ldk4, dkern);
+}
+__global__ void conv_backward_dx_kernel4(const f32x4* __restrict__ kern, int ldk4, const f32x4* __restrict__ dx1,
+                                         const int32_t* __restrict__ rev_start, const int32_t* __restrict__ rev_cnt,
+                                         const int32_t* __restrict__ rev_idx, int N, int k, int C4, const f32x4* dx_in,
+                                         const f32x4* __restrict__ add2, f32x4* dx) {
+    conv_backward_dx_body4((long)blockIdx.x * blockDim.x + threadIdx.x, kern, ldk4, dx1, rev_start, rev_cnt, rev_idx, N, k, C4, dx_in, add2, dx);
+}
+// Round 5: both gradients of the spatial conv in ONE launch -- they read the same d(x1) and write disjoint arrays, so nothing orders
+// them: the first `dx_blocks` workgroups run the sender-side sum (the launch the layer loop waits for: gather chains, started
+// first), the rest the receiver-side products (a 35 MB store stream per layer at 64 crystals).  Same arithmetic per element.
+__global__ void conv_backward_both_kernel4(int dx_blocks, const f32x4* __restrict__ x, const f32x4* __restrict__ dx1,
+                                           const int32_t* __restrict__ deg, const int32_t* __restrict__ src, const f32x4* __restrict__ kern,
+                                           int ldk4, const int32_t* __restrict__ rev_start, const int32_t* __restrict__ rev_cnt,
+                                           const int32_t* __restrict__ rev_idx, int N, int k, int C4, const f32x4* dx_in,
+                                           const f32x4* __restrict__ add2, f32x4* dx, f32x4* __restrict__ dkern) {
+    if ((int)blockIdx.x < dx_blocks)
+        conv_backward_dx_body4((long)blockIdx.x * blockDim.x + threadIdx.x, kern, ldk4, dx1, rev_start, rev_cnt, rev_idx, N, k, C4, dx_in, add2, dx);
+    else
+        conv_backward_kern_body4((long)(blockIdx.x - dx_blocks) * blockDim.x + threadIdx.x, x, dx1, deg, src, N, k, C4, ldk4, dkern);
+}
+// Round 5: the spatial conv and the spherical mix behind it as ONE launch, a workgroup per node: x1 (kept: the backward pass reads it)
+// goes to memory and to LDS, the mix reads it from there.  The sums and their order per element are conv_forward_kernel4's and
+// mix_forward_kernel4's.  Dynamic LDS: 16 * C4 float4.
+__global__ __launch_bounds__(512) void conv_mix_forward_kernel4(const f32x4* __restrict__ kern, int ldk4, const f32x4* __restrict__ x,
+                                                                const int32_t* __restrict__ deg, const int32_t* __restrict__ src, int N,
+                                                                int k, int C4, const f32x4* __restrict__ fk, const f32x4* __restrict__ bias,
+                                                                f32x4* __restrict__ x1, f32x4* __restrict__ x2) {
+    extern __shared__ f32x4 s_node[];  // [16][C4]
+    const int n = blockIdx.x, E = 16 * C4;
+    const int nd = min(deg[n], k);
+    for (int e = threadIdx.x; e < E; e += blockDim.x) {
+        const int c = e % C4, o = e / C4;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+        for (int s = 0; s < nd; ++s) {
+            const int j = src[(size_t)n * k + s];
+            const f32x4 kv = kern[(((size_t)n * k + s) * 16 + o) * ldk4 + c], xv = x[((size_t)j * 16 + o) * C4 + c];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) acc[q] += kv[q] * xv[q];
+        }
+        x1[(size_t)n * E + e] = acc;
+        s_node[e] = acc;
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < E; e += blockDim.x) {
+        const int c = e % C4, p = e / C4;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int o = 0; o < 16; ++o) {
+            const f32x4 a = s_node[o * C4 + c], b = fk[((size_t)o * 16 + p) * C4 + c];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) acc[r] += a[r] * b[r];
+        }
+        const f32x4 bv = bias[c];
+        x2[(size_t)n * E + e] = f32x4{acc[0] * (1.0f / 16.0f) + bv[0], acc[1] * (1.0f / 16.0f) + bv[1], acc[2] * (1.0f / 16.0f) + bv[2],
+                                      acc[3] * (1.0f / 16.0f) + bv[3]};
+    }
 }
 __global__ void mix_forward_kernel4(const f32x4* __restrict__ x1, const f32x4* __restrict__ fk, const f32x4* __restrict__ bias,
                                     int N, int C4, f32x4* __restrict__ x2) {
@@ -669,6 +808,46 @@ __global__ __launch_bounds__(256) void ln_backward_kernel(const float* __restric
         dx[(size_t)row * C + c] = r * (dy - m1 - xhat[(size_t)row * C + c] * m2);
     }
 }
+// Round 5: LayerNorm backward and the spherical mix's backward in ONE launch, a workgroup of sixteen waves per node: wave p runs
+// ln_backward_kernel's row (n, p) -- same lane sums, same butterflies -- and leaves d(x2) in memory (kept per layer for the batched bias
+// and fiber-kernel gradients) and in LDS; after the barrier the workgroup forms d(x1) = mix^T d(x2) with mix_backward_x_kernel4's sums.
+// Dynamic LDS: 16 * C floats.
+__global__ __launch_bounds__(1024) void ln_mix_backward_kernel4(const float* __restrict__ dyn, const float* __restrict__ xhat,
+                                                                const float* __restrict__ rstd, const float* __restrict__ g,
+                                                                const f32x4* __restrict__ fk, int N, int C, float* __restrict__ dx2,
+                                                                f32x4* __restrict__ dx1) {
+    extern __shared__ f32x4 s_node[];  // [16][C / 4]
+    float* s_dx2 = reinterpret_cast<float*>(s_node);
+    const int n = blockIdx.x, p = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const long row = (long)n * 16 + p;
+    float s1 = 0.f, s2 = 0.f;
+    for (int c = lane; c < C; c += 64) {
+        const float dy = dyn[(size_t)row * C + c] * g[c];
+        s1 += dy;
+        s2 += dy * xhat[(size_t)row * C + c];
+    }
+    for (int off = 32; off >= 1; off >>= 1) { s1 += __shfl_xor(s1, off, 64); s2 += __shfl_xor(s2, off, 64); }
+    const float m1 = s1 / (float)C, m2 = s2 / (float)C, r = rstd[row];
+    for (int c = lane; c < C; c += 64) {
+        const float dy = dyn[(size_t)row * C + c] * g[c];
+        const float v = r * (dy - m1 - xhat[(size_t)row * C + c] * m2);
+        dx2[(size_t)row * C + c] = v;
+        s_dx2[p * C + c] = v;
+    }
+    __syncthreads();
+    const int C4 = C / 4, E = 16 * C4;
+    for (int e = threadIdx.x; e < E; e += blockDim.x) {
+        const int c = e % C4, o = e / C4;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const f32x4 a = s_node[q * C4 + c], b = fk[((size_t)o * 16 + q) * C4 + c];
+#pragma unroll
+            for (int w = 0; w < 4; ++w) acc[w] += a[w] * b[w];
+        }
+        dx1[(size_t)n * E + e] = f32x4{acc[0] * (1.0f / 16.0f), acc[1] * (1.0f / 16.0f), acc[2] * (1.0f / 16.0f), acc[3] * (1.0f / 16.0f)};
+    }
+}
 // x_next = out * ls + x   (convnext.py:30-32)
 __global__ void scale_residual_kernel(const float* __restrict__ out, const float* __restrict__ ls, const float* __restrict__ x,
                                       long rows, int C, float* __restrict__ xn) {
@@ -732,17 +911,19 @@ __global__ void pool_crystals_kernel(const float* __restrict__ gs, const int32_t
 // d rbar[(n,o)][j] from the gradient seeds
 __global__ void train_outputs_backward_kernel(const float* __restrict__ g_eps, const float* __restrict__ g_logits,
                                               const float* __restrict__ g_len0, const int32_t* __restrict__ batch,
-                                              const float* __restrict__ ori, int S, int N, float* __restrict__ drbar) {
+                                              const float* __restrict__ ori, int S, int N, float* __restrict__ drbar,
+                                              int ld /* row pitch of drbar: S + 4 rounded up to a multiple of four, pad columns zero */) {
     const int row = blockIdx.x, n = row >> 4, o = row & 15, RO = S + 4;
     const int b = batch[n];
-    for (int j = threadIdx.x; j < RO; j += blockDim.x) {
+    for (int j = threadIdx.x; j < ld; j += blockDim.x) {
         float v;
-        if (j < S) v = g_logits[(size_t)n * S + j] * (1.0f / 16.0f);
+        if (j >= RO) v = 0.f;
+        else if (j < S) v = g_logits[(size_t)n * S + j] * (1.0f / 16.0f);
         else if (j == S)
             v = ((g_eps[3 * (size_t)n] * ori[3 * o] + g_eps[3 * (size_t)n + 1] * ori[3 * o + 1]) +
                  g_eps[3 * (size_t)n + 2] * ori[3 * o + 2]) * (1.0f / 16.0f);
         else v = g_len0[3 * (size_t)b + (j - S - 1)] * (1.0f / 16.0f);
-        drbar[(size_t)row * RO + j] = v;
+        drbar[(size_t)row * ld + j] = v;
     }
 }
 // index, in the canonical monomial order of edge_rows_kernel, of the monomial that column `col` of
@@ -844,6 +1025,7 @@ struct arreau_train_ctx {
     float *x, *x1, *xhat, *rstd, *xn, *hpre, *h, *out, *fk, *rbar, *gs, *kern;
     // backward temporaries
     float *dx, *dxro, *rbar_all, *dfkb_all, *dtmp, *dh, *drbar, *dx1, *dkern, *dkb, *dh1, *dfk, *dfkb, *dfh1, *dw1f, *partial, *scratch_cols, *colpart;
+    float* robias;  // [ROP] the one column sum of d(rbar) (every layer's read-out bias gradient)
     float *dxn_all, *dx2_all;  // [L][M][C]: d(LayerNorm output) and d(spherical conv output), for the batched bias / norm gradients
     float *xn_all, *dout_all, *dfk_all;  // [L][...]: LayerNorm outputs (forward), d(out) and d(fiber kernel) (backward), for the batched weight gradients
     int32_t* colcount;  // colsum_kernel's arrival counters (one per 64-column group; zero between launches)
@@ -857,6 +1039,17 @@ struct arreau_train_ctx {
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     float *partial2 = nullptr, *colpart2 = nullptr;
     int32_t* colcount2 = nullptr;
+    // Round 5: deferred reductions of the backward pass (main stream only): the k-slice sums of the weight-gradient products and the
+    // chunk sums of the column-sum passes, each ONE launch at the end of arreau_train_backward (sgemm.h: arreau_sgemm_defer;
+    // colsum4_final_multi_kernel).  Shared by the side stream's copy of this struct (pointers), never used through it.
+    struct Deferred {
+        arreau_sgemm_defer gemm;
+        ColsumFinalList cols{};
+        int ncols = 0, max_colblocks = 0;
+        float* colscratch = nullptr;
+        size_t colcap = 0, colused = 0;  // floats
+    };
+    Deferred* defer = nullptr;
     const int32_t *tstep, *offsets, *types;
     const float *frac, *lengths, *angles;
 };
@@ -893,20 +1086,37 @@ size_t layout(arreau_train_ctx& t, const arreau_model* m, int N, int B, float* b
     t.rstd = c.take<float>(L * M); t.xn = c.take<float>(M * C); t.hpre = c.take<float>(L * M * H); t.h = c.take<float>(L * M * H);
     t.out = c.take<float>(L * M * C); t.fk = c.take<float>(L * 256 * C); t.rbar = c.take<float>(M * RO); t.rbar_all = c.take<float>(L * M * RO); t.gs = c.take<float>(N * 3);
     t.kern = c.take<float>(R * L * C);   // all layers' spatial kernels, [R][L*C] (one GEMM: the basis is layer-independent)
-    t.dx = c.take<float>(M * C); t.dxro = c.take<float>(L * M * C); t.dtmp = c.take<float>(M * C); t.dh = c.take<float>(L * M * H); t.drbar = c.take<float>(M * RO);
+    t.dx = c.take<float>(M * C); t.dxro = c.take<float>(L * M * C); t.dtmp = c.take<float>(M * C); t.dh = c.take<float>(L * M * H); t.drbar = c.take<float>(M * ((RO + 3) & ~(size_t)3));
     t.xn_all = c.take<float>(L * M * C); t.dout_all = c.take<float>(L * M * C); t.dfk_all = c.take<float>(L * 256 * C);
     t.dxn_all = c.take<float>(L * M * C); t.dx2_all = c.take<float>(L * M * C);  // kept per layer for the batched weight gradients
     t.dx1 = c.take<float>(M * C); t.dkern = c.take<float>(R * L * C); t.dkb = c.take<float>(R * D); t.dh1 = c.take<float>(R * C);
     t.dfk = c.take<float>(256 * C); t.dfkb = c.take<float>(256 * D); t.dfkb_all = c.take<float>(L * 256 * D); t.dfh1 = c.take<float>(256 * C);
-    t.dw1f = c.take<float>(C * ARREAU_MONO_PAD); t.partial = c.take<float>(PARTIAL_FLOATS); t.scratch_cols = c.take<float>(1024);
+    t.dw1f = c.take<float>(C * ARREAU_MONO_PAD); t.partial = c.take<float>(PARTIAL_FLOATS); t.scratch_cols = c.take<float>(1024); t.robias = c.take<float>(1024);
     t.colpart = c.take<float>((size_t)2 * COLSUM4_MAX_BATCH * COLSUM4_MAX_CHUNKS * 1024);  // (two results per pass, up to eight matrices per call)
     t.colcount = c.take<int32_t>(COLCOUNT_INTS);
     t.partial2 = c.take<float>(PARTIAL_FLOATS);
     t.colpart2 = c.take<float>((size_t)2 * COLSUM4_MAX_BATCH * COLSUM4_MAX_CHUNKS * 1024);
     t.colcount2 = c.take<int32_t>(COLCOUNT_INTS);
+    {   // deferred reductions: room for every weight gradient's k-slices at once (each product is capped at PARTIAL_FLOATS) and for
+        // the chunk rows of every column-sum pass of a backward pass; a request that does not fit runs its reduction at once
+        float* gs = c.take<float>(3 * PARTIAL_FLOATS);
+        const size_t colcap = (size_t)2 * COLSUM4_MAX_BATCH * COLSUM4_MAX_CHUNKS * 1024;
+        float* cs = c.take<float>(colcap);
+        if (t.defer) {
+            t.defer->gemm.scratch = gs; t.defer->gemm.cap = 3 * PARTIAL_FLOATS;
+            t.defer->colscratch = cs; t.defer->colcap = colcap;
+        }
+    }
     return c.off;
 }
 
+// Round 5: launch merges of the training step (conv + mix forward, LayerNorm + mix backward, both conv gradients in one launch,
+// column-sum and split-K reductions deferred to one launch each at the end of the backward pass).  ARREAU_TRAIN_FUSE=0 restores the
+// one-kernel-per-operation sequence (same arithmetic per element: tests compare the two bit for bit).
+inline bool train_fuse_on() {
+    const char* e = getenv("ARREAU_TRAIN_FUSE");  // read per call (A/B runs, tests): a few dozen getenv per step
+    return !e || atoi(e) != 0;
+}
 typedef arreau_sgemm_detail::SgemmEpilogue Epi;
 int gemm(hipStream_t s, arreau_train_ctx& t, int mode, int M, int N, int K, const float* A, long as0, long as1, const float* B, long bs0,
          long bs1, float* C, int ldc, float alpha = 1.f, float beta = 0.f, const Epi* epi = nullptr, bool* fused = nullptr) {
@@ -924,26 +1134,35 @@ int linear_dx(hipStream_t s, arreau_train_ctx& t, long rows, int in, int out, co
 }
 // the same for `batch` layers in one launch (dY / X / dW of consecutive layers dy_bs / x_bs / out * in floats apart; 0 = shared)
 int linear_dw_batched(hipStream_t s, arreau_train_ctx& t, int batch, long rows, int in, int out, const float* dY, long dy_bs,
-                      const float* X, long x_bs, float* dW, float alpha = 1.f) {
-    return arreau_sgemm(s, t.partial, out, in, (int)rows, dY, 1, out, X, in, 1, dW, in, alpha, 0.f, batch, dy_bs, x_bs, (long)out * in, t.bwd_mode);
+                      const float* X, long x_bs, float* dW, float alpha = 1.f, bool defer = false, int dy_ld = 0 /* row pitch of dY (0: out) */) {
+    return arreau_sgemm(s, t.partial, out, in, (int)rows, dY, 1, dy_ld ? dy_ld : out, X, in, 1, dW, in, alpha, 0.f, batch, dy_bs, x_bs, (long)out * in, t.bwd_mode,
+                        nullptr, nullptr, defer && train_fuse_on() && t.defer ? &t.defer->gemm : nullptr);
 }
 // dW[out][in] = alpha * dY[rows][out]^T . X[rows][in]
 int linear_dw(hipStream_t s, arreau_train_ctx& t, long rows, int in, int out, const float* dY, const float* X, float* dW,
-              float alpha = 1.f) {
-    return gemm(s, t, t.bwd_mode, out, in, (int)rows, dY, 1, out, X, in, 1, dW, in, alpha, 0.f);
+              float alpha = 1.f, bool defer = false) {
+    return linear_dw_batched(s, t, 1, rows, in, out, dY, 0, X, 0, dW, alpha, defer);
 }
 // `batch` > 1: the same sums for `batch` matrices (a / b a_bs / b_bs floats apart, results out_bs / out2_bs apart) in the two
 // launches of one -- the bias gradients of the L layers (16-byte columns only).
 int colsum(hipStream_t s, arreau_train_ctx& t, const float* a, const float* b, long rows, int cols, float scale, float* out,
            int accumulate = 0, float* out2 = nullptr, const float* colscale2 = nullptr, int batch = 1, long a_bs = 0, long b_bs = 0,
            long out_bs = 0, long out2_bs = 0, float* scaled_out = nullptr /* also a * colscale_out (16-byte path, one matrix) */,
-           const float* colscale_out = nullptr, bool* wrote_scaled = nullptr) {
+           const float* colscale_out = nullptr, bool* wrote_scaled = nullptr,
+           bool defer = false /* the sums may wait for flush_deferred (main stream of the backward pass only) */, long colscale2_bs = 0,
+           const float* gelu_pre = nullptr /* 16-byte path, one matrix: a *= gelu'(gelu_pre) * gelu_rowscale[row] in place first */,
+           const float* gelu_rowscale = nullptr) {
     if (wrote_scaled) *wrote_scaled = false;
     if (cols > 1024) {
         arreau_set_error("colsum: more than 1024 columns");
         return ARREAU_EINVAL;
     }
-    if (cols % 4 == 0 && (size_t)a % 16 == 0 && (b == nullptr || (size_t)b % 16 == 0) && a_bs % 4 == 0 && b_bs % 4 == 0) {
+    const bool path16 = cols % 4 == 0 && (size_t)a % 16 == 0 && (b == nullptr || (size_t)b % 16 == 0) && a_bs % 4 == 0 && b_bs % 4 == 0;
+    if (gelu_pre && !(path16 && batch == 1 && (size_t)gelu_pre % 16 == 0)) {
+        arreau_set_error("colsum: the GELU-backward form needs 16-byte columns");
+        return ARREAU_EINVAL;
+    }
+    if (path16) {
         const int chunks = (int)std::min<long>(COLSUM4_MAX_CHUNKS, std::max<long>(1, rows / 16));
         const long rpc = (rows + chunks - 1) / chunks;
         if (batch > COLSUM4_MAX_BATCH) {
@@ -952,11 +1171,37 @@ int colsum(hipStream_t s, arreau_train_ctx& t, const float* a, const float* b, l
         }
         f32x4* part = reinterpret_cast<f32x4*>(t.colpart);
         f32x4* part2 = b && out2 ? part + (size_t)COLSUM4_MAX_BATCH * COLSUM4_MAX_CHUNKS * 256 : nullptr;
-        hipLaunchKernelGGL(colsum4_partial_kernel, dim3(chunks, batch), dim3(256), 0, s, reinterpret_cast<const f32x4*>(a),
+        const bool dual = b && out2;
+        const size_t need = (size_t)batch * chunks * cols * (dual ? 2 : 1);  // floats
+        arreau_train_ctx::Deferred* df = defer && train_fuse_on() ? t.defer : nullptr;
+        const bool deferred = df && df->colscratch && df->colused + need <= df->colcap && df->ncols + batch <= COLSUM_DEFER_MAX && (!out2 || b);
+        if (deferred) {
+            part = reinterpret_cast<f32x4*>(df->colscratch + df->colused);
+            part2 = dual ? part + (size_t)batch * chunks * (cols / 4) : nullptr;
+            df->colused += (need + 63) & ~(size_t)63;
+            for (int i = 0; i < batch; ++i) {
+                ColsumFinalDesc& d = df->cols.d[df->ncols++];
+                d.part = part + (size_t)i * chunks * (cols / 4);
+                d.part2 = dual ? part2 + (size_t)i * chunks * (cols / 4) : nullptr;
+                d.out = out + (long)i * out_bs;
+                d.out2 = dual ? out2 + (long)i * out2_bs : nullptr;
+                d.colscale2 = colscale2 ? colscale2 + (long)i * colscale2_bs : nullptr;
+                d.chunks = chunks; d.cols4 = cols / 4; d.scale = scale; d.accumulate = accumulate;
+            }
+            df->max_colblocks = std::max(df->max_colblocks, (cols / 4 + 7) / 8);
+        }
+        if (gelu_pre)
+            hipLaunchKernelGGL(colsum4_partial_kernel<true>, dim3(chunks, batch), dim3(256), 0, s, reinterpret_cast<f32x4*>(const_cast<float*>(a)),
+                               reinterpret_cast<const f32x4*>(b), rows, cols / 4, rpc, part, part2, a_bs / 4, b_bs / 4, (f32x4*)nullptr,
+                               (const f32x4*)nullptr, reinterpret_cast<const f32x4*>(gelu_pre), gelu_rowscale);
+        else
+        hipLaunchKernelGGL(colsum4_partial_kernel<false>, dim3(chunks, batch), dim3(256), 0, s, reinterpret_cast<const f32x4*>(a),
                            reinterpret_cast<const f32x4*>(b), rows, cols / 4, rpc, part, part2, a_bs / 4, b_bs / 4,
-                           batch == 1 ? reinterpret_cast<f32x4*>(scaled_out) : (f32x4*)nullptr, reinterpret_cast<const f32x4*>(colscale_out));
+                           batch == 1 ? reinterpret_cast<f32x4*>(scaled_out) : (f32x4*)nullptr, reinterpret_cast<const f32x4*>(colscale_out),
+                           (const f32x4*)nullptr, (const float*)nullptr);
         if (wrote_scaled) *wrote_scaled = batch == 1 && scaled_out != nullptr;
         ARREAU_CHECK_HIP(hipGetLastError());
+        if (deferred) return ARREAU_OK;
         hipLaunchKernelGGL(colsum4_final_kernel, dim3((cols / 4 + 7) / 8, batch), dim3(256), 0, s, part, part2, chunks, cols / 4, scale,
                            accumulate, out, part2 ? out2 : nullptr, colscale2, out_bs, out2_bs);
         ARREAU_CHECK_HIP(hipGetLastError());
@@ -1021,6 +1266,7 @@ int linear_bias_gelu(hipStream_t s, arreau_train_ctx& t, long rows, int in, int 
                      const float* rowscale, float* pre, float* act) {
     Epi e;
     e.kind = 1; e.vec = bias; e.row = rowscale; e.out = act;
+    e.prefer_small = train_fuse_on();
     bool fused = false;
     int rc = linear(s, t, rows, in, out, X, W, pre, 1.f, 0.f, &e, &fused);
     if (rc || fused) return rc;
@@ -1043,6 +1289,24 @@ int ordered_sum(hipStream_t s, const float* part, int Z, int M, int N, float* ou
     ARREAU_CHECK_HIP(hipGetLastError());
     return ARREAU_OK;
 }
+// the deferred reductions of a backward pass (arreau_train_ctx::Deferred): one launch for the column sums, one for the k-slice sums
+void reset_deferred(arreau_train_ctx& t) {
+    if (!t.defer) return;
+    arreau_sgemm_defer_reset(t.defer->gemm);
+    t.defer->ncols = 0; t.defer->max_colblocks = 0; t.defer->colused = 0;
+}
+int flush_deferred_colsums(hipStream_t s, arreau_train_ctx& t) {
+    arreau_train_ctx::Deferred* df = t.defer;
+    if (df && df->ncols > 0) {
+        hipLaunchKernelGGL(colsum4_final_multi_kernel, dim3(df->max_colblocks, df->ncols), dim3(256), 0, s, df->cols);
+        ARREAU_CHECK_HIP(hipGetLastError());
+    }
+    if (df) { df->ncols = 0; df->max_colblocks = 0; df->colused = 0; }
+    return ARREAU_OK;
+}
+int flush_deferred_gemms(hipStream_t s, arreau_train_ctx& t) {
+    return t.defer ? arreau_sgemm_flush(s, t.defer->gemm) : ARREAU_OK;
+}
 #define V4(p) reinterpret_cast<const f32x4*>(p)
 #define V4W(p) reinterpret_cast<f32x4*>(p)
 #define TRY(expr) do { int rc_ = (expr); if (rc_) return rc_; } while (0)
@@ -1059,6 +1323,7 @@ void arreau_train_ctx_destroy(arreau_train_ctx* t) {
     if (t->side) (void)hipStreamDestroy(t->side);
     if (t->ev_fork) (void)hipEventDestroy(t->ev_fork);
     if (t->ev_join) (void)hipEventDestroy(t->ev_join);
+    delete t->defer;
     delete t;
 }
 
@@ -1082,11 +1347,13 @@ static int ensure_ctx(arreau_model* m, int N, int B, hipStream_t s) {
         memset(m->graph_key, 0, sizeof(m->graph_key));
     }
     t = new arreau_train_ctx();
+    t->defer = new arreau_train_ctx::Deferred();
     t->capN = capN; t->capB = capB;
     arreau_train_ctx probe;
     t->buf_floats = layout(probe, m, capN, capB, nullptr);
     hipError_t e = hipMalloc((void**)&t->buf, t->buf_floats * sizeof(float));
     if (e != hipSuccess) {
+        delete t->defer;
         delete t;
         arreau_set_error(std::string("hipMalloc(training buffers): ") + hipGetErrorString(e));
         return ARREAU_EHIP;
@@ -1138,12 +1405,30 @@ int arreau_general_network(arreau_model* m, const arreau_graph_view& g, const in
     const int C = m->C, D = m->D, L = m->L, H = m->H, k = m->k, S = m->S, RO = S + 4;
     const long R = (long)N * k * 16, M = (long)N * 16;
     if (N == 0) return ARREAU_OK;
+    // edge basis: kb = gelu(W2 gelu(W1 poly + b1) + b2) * window   (ponita.py:65,94)
+    auto edge_basis = [&]() -> int {
+        LAUNCH(edge_rows_kernel, dim3(blocks(R)), dim3(256), g.dir, g.dist, g.deg, g.batch, g.lattice, m->ori, m->cfg.radius, N, k,
+               t.mono, t.window);
+        if (train_fuse_on()) {   // (round 5: bias + GELU inside the product on its 64 x 64 tiles, as layer 2 and the ConvNext block had them)
+            TRY(linear_bias_gelu(s, t, R, ARREAU_MONO_PAD, C, t.mono, t.w1f, m->b1, (const float*)nullptr, t.h1pre, t.h1));
+        } else {
+            TRY(linear(s, t, R, ARREAU_MONO_PAD, C, t.mono, t.w1f, t.h1pre));
+            TRY(launch_bias_gelu(s, t.h1pre, m->b1, (const float*)nullptr, R, C, t.h1));
+        }
+        TRY(linear_bias_gelu(s, t, R, C, D, t.h1, t.w2, m->b2, (const float*)t.window, t.h2pre, t.kb));
+        // kernel_l = kb . Wk_l^T for all layers in one product (conv.py:110; conv.kernel.weight stacked [L*C][D])
+        TRY(linear(s, t, R, D, L * C, t.kb, t.wk, t.kern));
+        return ARREAU_OK;
+    };
     {   // fiber basis (ponita.py:66,95) and the fiber kernels of all layers, fk_l = fkb . Wfk_l^T (conv.py:113-116; one batched product):
         // functions of the weights alone -- on the side stream, beside the edge basis
         hipStream_t main_stream = s;
         arreau_train_ctx ts = t;
         hipStream_t s = main_stream;   // (LAUNCH and the helpers below take the stream by this name)
         TRY(fork_side(t, main_stream, ts, s));
+        // (the main stream's products are handed to the driver before the side branch's small launches: no difference in a free-running
+        // loop -- the host is far ahead -- but under a tracer, whose launches cost more, the main stream no longer sits idle here)
+        TRY(edge_basis());
         LAUNCH(fiber_poly_kernel, dim3(1), dim3(256), m->ori, ts.fpoly);
         TRY(linear(s, ts, 256, 3, C, ts.fpoly, m->fiber_w1, ts.fh1pre));
         TRY(launch_bias_gelu(s, ts.fh1pre, m->fiber_b1, (const float*)nullptr, 256L, C, ts.fh1));
@@ -1151,21 +1436,17 @@ int arreau_general_network(arreau_model* m, const arreau_graph_view& g, const in
         TRY(arreau_sgemm(s, ts.partial, 256, C, D, ts.fkb, D, 1, m->fiber_wk, 1, D, ts.fk, C, 1.f, 0.f, L, 0, (long)C * D, 256L * C, ts.fwd_mode));
         if (t.side) ARREAU_CHECK_HIP(hipEventRecord(t.ev_join, t.side));
     }
-    // edge basis: kb = gelu(W2 gelu(W1 poly + b1) + b2) * window   (ponita.py:65,94)
-    LAUNCH(edge_rows_kernel, dim3(blocks(R)), dim3(256), g.dir, g.dist, g.deg, g.batch, g.lattice, m->ori, m->cfg.radius, N, k,
-           t.mono, t.window);
-    TRY(linear(s, t, R, ARREAU_MONO_PAD, C, t.mono, t.w1f, t.h1pre));
-    TRY(launch_bias_gelu(s, t.h1pre, m->b1, (const float*)nullptr, R, C, t.h1));
-    TRY(linear_bias_gelu(s, t, R, C, D, t.h1, t.w2, m->b2, (const float*)t.window, t.h2pre, t.kb));
-    // kernel_l = kb . Wk_l^T for all layers in one product (conv.py:110; conv.kernel.weight stacked [L*C][D])
-    TRY(linear(s, t, R, D, L * C, t.kb, t.wk, t.kern));
     TRY(join_side(t, s));   // the fiber kernels: first used by the layer loop below
     for (int l = 0; l < L; ++l) {
         const float* xl = t.x + (size_t)l * M * C;
         float* xnext = t.x + (size_t)(l + 1) * M * C;
         float* x1 = t.x1 + (size_t)l * M * C;
         float* fk = t.fk + (size_t)l * 256 * C;
-        if (C % 4 == 0) {
+        if (C % 4 == 0 && train_fuse_on() && C <= 2048) {
+            hipLaunchKernelGGL(conv_mix_forward_kernel4, dim3((unsigned)N), dim3(512), (size_t)16 * C * sizeof(float), s, V4(t.kern + (size_t)l * C),
+                               L * C / 4, V4(xl), g.deg, g.src, N, k, C / 4, V4(fk), V4(m->conv_bias + (size_t)l * C), V4W(x1), V4W(t.dtmp));
+            ARREAU_CHECK_HIP(hipGetLastError());
+        } else if (C % 4 == 0) {
             LAUNCH(conv_forward_kernel4, dim3(blocks(M * C / 4)), dim3(256), V4(t.kern + (size_t)l * C), L * C / 4, V4(xl), g.deg, g.src, N, k,
                    C / 4, V4W(x1));
             LAUNCH(mix_forward_kernel4, dim3(blocks(M * C / 4)), dim3(256), V4(x1), V4(fk), V4(m->conv_bias + (size_t)l * C), N, C / 4, V4W(t.dtmp));
@@ -1265,11 +1546,16 @@ extern "C" int arreau_train_backward(arreau_model* m, const float* d_g_eps, cons
     const int N = t.N, C = m->C, D = m->D, L = m->L, H = m->H, k = m->k, S = m->S, RO = S + 4;
     const long R = (long)N * k * 16, M = (long)N * 16;
     auto W = [](const float* p) { return const_cast<float*>(p); };  // the gradient struct reuses the const state_dict type
-    LAUNCH(train_outputs_backward_kernel, dim3((unsigned)M), dim3(128), d_g_eps, d_g_logits, d_g_len0, t.batch, m->ori, S, N, t.drbar);
+    reset_deferred(t);
+    // d(rbar) [M][ROP], ROP = RO rounded up to a multiple of four with zero pad columns (round 5): its products and its column sum run on
+    // 16-byte fetches -- 94 columns sent the d(x) product to the exact fp32 kernel (24.6 us) and the bias gradient to the element-wise
+    // column sum (15.1 us); the weight operand's pad rows are the next layer's first rows resp. zeros behind the last layer (model.hip)
+    const int ROP = (RO + 3) & ~3;
+    LAUNCH(train_outputs_backward_kernel, dim3((unsigned)M), dim3(128), d_g_eps, d_g_logits, d_g_len0, t.batch, m->ori, S, N, t.drbar, ROP);
     // The read-outs' contributions to d x_{l+1} = d(rbar) . W_ro,l / L depend on nothing inside the layer loop: ONE batched product for all
     // layers up front (they were L launches of the element-wise-fetch kernel -- 94 read-out columns are no multiple of four -- 13.6 us
     // each inside the chain); layer L - 1 starts from its slice, the others are added by the launch that completes d x_{l+1}.
-    TRY(arreau_sgemm(s, t.partial, (int)M, C, RO, t.drbar, RO, 1, t.ro_w, C, 1, t.dxro, C, 1.0f / (float)L, 0.f, L, 0, (long)RO * C, (long)M * C,
+    TRY(arreau_sgemm(s, t.partial, (int)M, C, ROP, t.drbar, ROP, 1, t.ro_w, C, 1, t.dxro, C, 1.0f / (float)L, 0.f, L, 0, (long)RO * C, (long)M * C,
                      t.bwd_mode));
     const float invL = 1.0f / (float)L;
     for (int l = L - 1; l >= 0; --l) {
@@ -1283,7 +1569,8 @@ extern "C" int arreau_train_backward(arreau_model* m, const float* d_g_eps, cons
         const float* out = t.out + (size_t)l * M * C;
         // read-out (ponita.py:105,108); its weight gradient: one batched product over the layers, below the loop
         // (every layer's read-out sees the same d(rbar): the bias gradients are equal -- copied to the other layers in one launch below)
-        if (l == L - 1) TRY(colsum(s, t, t.drbar, nullptr, M, RO, invL, W(g->readout_b) + (size_t)l * RO));
+        // (ROP sums into the scratch row -- the pad columns sum to zero --, copied to every layer's slice at the end of the pass)
+        if (l == L - 1) TRY(colsum(s, t, t.drbar, nullptr, M, ROP, invL, t.robias, 0, nullptr, nullptr, 1, 0, 0, 0, 0, nullptr, nullptr, nullptr, true));
         const float* dxl = l == L - 1 ? t.dxro + (size_t)l * M * C : t.dx;   // d x_{l+1}
         const float* dx_add = l > 0 ? t.dxro + (size_t)(l - 1) * M * C : nullptr;
         // ConvNext tail: x_{l+1} = out * ls + x_l
@@ -1292,7 +1579,7 @@ extern "C" int arreau_train_backward(arreau_model* m, const float* d_g_eps, cons
         bool have_dout = false;  // (d(out) = d(x) * layer_scale rides in the column-sum pass over d(x) where that pass takes 16-byte columns)
         if (m->cfg.has_layer_scale)
             TRY(colsum(s, t, dxl, out, M, C, 1.0f, W(g->layer_scale) + (size_t)l * C, 0, W(g->linear2_b) + (size_t)l * C, m->ls + (size_t)l * C, 1, 0, 0,
-                       0, 0, dout, m->ls + (size_t)l * C, &have_dout));
+                       0, 0, dout, m->ls + (size_t)l * C, &have_dout, true));
         // (the weight gradients of linear_2, linear_1, the read-out and the fiber kernel are products nothing below waits for:
         // their operands are kept per layer and each kind runs as ONE batched product after the loop)
         float* dh = t.dh + (size_t)l * M * H;
@@ -1302,10 +1589,20 @@ extern "C" int arreau_train_backward(arreau_model* m, const float* d_g_eps, cons
         float* dxn = t.dxn_all + (size_t)l * M * C;
         float* dx2 = t.dx2_all + (size_t)l * M * C;
         TRY(linear_dx(s, t, M, C, H, dh, t.lin1 + (size_t)l * H * C, dxn));                                          // dxn
-        LAUNCH(ln_backward_kernel, dim3(blocks(M, 4)), dim3(256), dxn, xhat, t.rstd + (size_t)l * M, m->ln_w + (size_t)l * C, M, C, dx2);
+        const bool fuse = C % 4 == 0 && train_fuse_on() && C <= 2048;
+        if (!fuse)
+            LAUNCH(ln_backward_kernel, dim3(blocks(M, 4)), dim3(256), dxn, xhat, t.rstd + (size_t)l * M, m->ln_w + (size_t)l * C, M, C, dx2);
         // spherical conv: x2 = mix(x1, fk) / 16 + bias
         // spatial conv: x1 = sum_s kern * x_l[src]; the residual path already sits in dx (= d x_l so far)
-        if (C % 4 == 0) {
+        if (fuse) {
+            hipLaunchKernelGGL(ln_mix_backward_kernel4, dim3((unsigned)N), dim3(1024), (size_t)16 * C * sizeof(float), s, dxn, xhat,
+                               t.rstd + (size_t)l * M, m->ln_w + (size_t)l * C, V4(fk), N, C, dx2, V4W(t.dx1));
+            ARREAU_CHECK_HIP(hipGetLastError());
+            const unsigned dx_blocks = blocks(M * C / 4), kern_blocks = blocks(R * C / 4);
+            LAUNCH(conv_backward_both_kernel4, dim3(dx_blocks + kern_blocks), dim3(256), (int)dx_blocks, V4(xl), V4(t.dx1), t.deg, t.src,
+                   V4(t.kern + (size_t)l * C), L * C / 4, t.rev_start, t.rev_cnt, t.rev_idx, N, k, C / 4, V4(dxl),
+                   dx_add ? V4(dx_add) : (const f32x4*)nullptr, V4W(t.dx), V4W(t.dkern + (size_t)l * C));
+        } else if (C % 4 == 0) {
             LAUNCH(mix_backward_x_kernel4, dim3(blocks(M * C / 4)), dim3(256), V4(dx2), V4(fk), N, C / 4, V4W(t.dx1));
             LAUNCH(conv_backward_kern_kernel4, dim3(blocks(R * C / 4)), dim3(256), V4(xl), V4(t.dx1), t.deg, t.src, N, k, C / 4, L * C / 4,
                    V4W(t.dkern + (size_t)l * C));
@@ -1318,25 +1615,35 @@ extern "C" int arreau_train_backward(arreau_model* m, const float* d_g_eps, cons
                    t.rev_idx, N, k, C, dxl, dx_add, t.dx);
         }
     }
-    if (L > 1) {
-        CopySegments seg;
-        const int nseg = std::min(L - 1, 24);
-        for (int l = 0; l < nseg; ++l) {
-            seg.dst[l] = W(g->readout_b) + (size_t)l * RO; seg.src[l] = g->readout_b + (size_t)(L - 1) * RO; seg.n[l] = (unsigned)RO;
-        }
-        LAUNCH(copy_segments_kernel, dim3(1, nseg), dim3(128), seg);
-        for (int l = nseg; l < L - 1; ++l)  // (more than 25 layers: the rest one by one)
-            ARREAU_CHECK_HIP(hipMemcpyAsync(W(g->readout_b) + (size_t)l * RO, g->readout_b + (size_t)(L - 1) * RO, RO * sizeof(float),
-                                            hipMemcpyDeviceToDevice, s));
-    }
     // d(fiber kernel) of every layer = sum over nodes of x1 (x) dx2 / 16: one batched pair of launches (both operands were kept
     // per layer), then its two uses -- and from there the whole fiber branch down to d(fiber_basis_fn): on the side stream, beside the
     // edge-level weight gradients below (it reads x1 and d(x2) of the loop above and writes gradients nothing else touches)
+    // the layers' weight gradients, one batched product per kind (operands kept per layer above / by the forward pass), and the batched
+    // column sums: main-stream work that depends on nothing of the side branch
+    auto main_batched = [&]() -> int {
+        // (round 5: the k-slice sums of these products and the chunk sums of the column-sum passes below wait for the two launches at the
+        // end of this function)
+        TRY(linear_dw_batched(s, t, L, M, C, RO, t.drbar, 0, t.x + (size_t)M * C, (long)M * C, W(g->readout_w), invL, true, ROP));         // x_{l+1}
+        TRY(linear_dw_batched(s, t, L, M, H, C, t.dout_all, (long)M * C, t.h, (long)M * H, W(g->linear2_w), 1.f, true));
+        TRY(linear_dw_batched(s, t, L, M, C, H, t.dh, (long)M * H, t.xn_all, (long)M * C, W(g->linear1_w), 1.f, true));
+        // the k-slice sums of the three products in one launch, while their 65 MB of partial tiles are still in the Infinity Cache
+        // (ONE such launch at the very end of the pass read 125 MB of long-evicted tiles from HBM in plane-strided pieces: 60 us
+        // against 49 us for the seven separate sums; per cluster of products it is three launches fewer and faster than both)
+        TRY(flush_deferred_gemms(s, t));
+        // ... and the column sums: d(linear_1.bias) = sum_rows dhpre; d(norm.weight) = sum_rows dxn * xhat and d(norm.bias) = sum_rows dxn
+        // in one pass over dxn; d(conv.bias) = sum_rows dx2
+        TRY(colsum(s, t, t.dh, nullptr, M, H, 1.0f, W(g->linear1_b), 0, nullptr, nullptr, L, (long)M * H, 0, H, 0, nullptr, nullptr, nullptr, true));
+        TRY(colsum(s, t, t.dxn_all, t.xhat, M, C, 1.0f, W(g->norm_w), 0, W(g->norm_b), nullptr, L, (long)M * C, (long)M * C, C, C, nullptr, nullptr,
+                   nullptr, true));
+        TRY(colsum(s, t, t.dx2_all, nullptr, M, C, 1.0f, W(g->conv_bias), 0, nullptr, nullptr, L, (long)M * C, 0, C, 0, nullptr, nullptr, nullptr, true));
+        return ARREAU_OK;
+    };
     {
         hipStream_t main_stream = s;
         arreau_train_ctx ts = t;
         hipStream_t s = main_stream;
         TRY(fork_side(t, main_stream, ts, s));
+        TRY(main_batched());   // (before the side branch's two dozen small launches: see the forward pass)
         arreau_train_ctx& t = ts;   // (the helpers take their scratch from the context they are handed)
         // partial sums live in the split-K scratch (free here): as many layers per pair of launches as fit it -- all L at the
         // bench's 64 crystals, one at the reference's `make train` preset (batch 270, hidden_dim 200: ~2,200 atoms) -- and
@@ -1366,27 +1673,43 @@ extern "C" int arreau_train_backward(arreau_model* m, const float* d_g_eps, cons
         TRY(colsum(s, t, t.dfh1, nullptr, 256, C, 1.0f, W(g->fiber_b1)));
         if (t.side) ARREAU_CHECK_HIP(hipEventRecord(t.ev_join, t.side));
     }
-    // the layers' weight gradients, one batched product per kind (operands kept per layer above / by the forward pass)
-    TRY(linear_dw_batched(s, t, L, M, C, RO, t.drbar, 0, t.x + (size_t)M * C, (long)M * C, W(g->readout_w), invL));         // x_{l+1}
-    TRY(linear_dw_batched(s, t, L, M, H, C, t.dout_all, (long)M * C, t.h, (long)M * H, W(g->linear2_w)));
-    TRY(linear_dw_batched(s, t, L, M, C, H, t.dh, (long)M * H, t.xn_all, (long)M * C, W(g->linear1_w)));
-    // ... and the column sums: d(linear_1.bias) = sum_rows dhpre; d(norm.weight) = sum_rows dxn * xhat and d(norm.bias) = sum_rows dxn
-    // in one pass over dxn; d(conv.bias) = sum_rows dx2
-    TRY(colsum(s, t, t.dh, nullptr, M, H, 1.0f, W(g->linear1_b), 0, nullptr, nullptr, L, (long)M * H, 0, H, 0));
-    TRY(colsum(s, t, t.dxn_all, t.xhat, M, C, 1.0f, W(g->norm_w), 0, W(g->norm_b), nullptr, L, (long)M * C, (long)M * C, C, C));
-    TRY(colsum(s, t, t.dx2_all, nullptr, M, C, 1.0f, W(g->conv_bias), 0, nullptr, nullptr, L, (long)M * C, 0, C, 0));
     // kernel projections of all layers at once: dWk [L*C][D] = dkern^T . kb,  dkb = dkern . Wk
     TRY(linear_dw(s, t, R, D, L * C, t.dkern, t.kb, W(g->conv_kernel_w)));
+    const bool dkb_colsum_fused = train_fuse_on() && D % 4 == 0;
+    if (dkb_colsum_fused) {
+        // (round 5: a 128 x 128 product takes no GELU epilogue -- sgemm.h -- so d(h2pre) = (dkern . Wk) * gelu'(h2pre) * window is finished by
+        // the column-sum pass of d(basis_fn.2.bias), which had to read it anyway: one pass over 66 MB instead of two)
+        bool fused = false;
+        Epi e;
+        e.kind = 2; e.mat = t.h2pre; e.row = t.window;
+        TRY(linear_dx(s, t, R, D, L * C, t.dkern, t.wk, t.dkb, 1.f, 0.f, &e, &fused));
+        TRY(colsum(s, t, t.dkb, nullptr, R, D, 1.0f, W(g->basis_b2), 0, nullptr, nullptr, 1, 0, 0, 0, 0, nullptr, nullptr, nullptr, true, 0,
+                   fused ? nullptr : t.h2pre, fused ? nullptr : t.window));
+    } else
     TRY(linear_dx_gelu_backward(s, t, R, D, L * C, t.dkern, t.wk, t.h2pre, (const float*)t.window, t.dkb));   // dh2pre
     // embedding: x_0 = F . W_emb^T  -> dW_emb[c][i] = sum_rows dx[row][c] F[row][i]
-    TRY(linear_dw(s, t, M, S + 78, C, t.dx, t.F, W(g->x_embedder_w)));
+    TRY(linear_dw(s, t, M, S + 78, C, t.dx, t.F, W(g->x_embedder_w), 1.f, true));
     // edge basis MLP
-    TRY(linear_dw(s, t, R, C, D, t.dkb, t.h1, W(g->basis_w2)));
-    TRY(colsum(s, t, t.dkb, nullptr, R, D, 1.0f, W(g->basis_b2)));
+    TRY(linear_dw(s, t, R, C, D, t.dkb, t.h1, W(g->basis_w2), 1.f, true));
+    TRY(flush_deferred_gemms(s, t));     // (x_embedder and basis_fn.2 weight gradients: one launch)
+    if (!dkb_colsum_fused) TRY(colsum(s, t, t.dkb, nullptr, R, D, 1.0f, W(g->basis_b2), 0, nullptr, nullptr, 1, 0, 0, 0, 0, nullptr, nullptr, nullptr, true));
     TRY(linear_dx_gelu_backward(s, t, R, C, D, t.dkb, t.w2, t.h1pre, (const float*)nullptr, t.dh1));   // dh1pre
     TRY(linear_dw(s, t, R, ARREAU_MONO_PAD, C, t.dh1, t.mono, t.dw1f));
+    TRY(colsum(s, t, t.dh1, nullptr, R, C, 1.0f, W(g->basis_b1), 0, nullptr, nullptr, 1, 0, 0, 0, 0, nullptr, nullptr, nullptr, true));
+    TRY(flush_deferred_gemms(s, t));     // (nothing pending on the default path: a product that did not fit its cluster's scratch)
+    TRY(flush_deferred_colsums(s, t));   // every bias / norm / layer-scale gradient's chunk sum: one launch
+    {   // d(readout bias): every layer's read-out sees the same d(rbar), so the one column sum (scratch row, complete behind the launch
+        // above) is copied to all L slices
+        CopySegments seg;
+        const int nseg = std::min(L, 24);
+        for (int l = 0; l < nseg; ++l) {
+            seg.dst[l] = W(g->readout_b) + (size_t)l * RO; seg.src[l] = t.robias; seg.n[l] = (unsigned)RO;
+        }
+        LAUNCH(copy_segments_kernel, dim3(1, nseg), dim3(128), seg);
+        for (int l = nseg; l < L; ++l)  // (more than 24 layers: the rest one by one)
+            ARREAU_CHECK_HIP(hipMemcpyAsync(W(g->readout_b) + (size_t)l * RO, t.robias, RO * sizeof(float), hipMemcpyDeviceToDevice, s));
+    }
     LAUNCH(unfold_poly_grad_kernel, dim3(blocks((long)C * ARREAU_POLY_COLS)), dim3(256), t.dw1f, C, W(g->basis_w1));
-    TRY(colsum(s, t, t.dh1, nullptr, R, C, 1.0f, W(g->basis_b1)));
     TRY(join_side(t, s));   // the fiber branch's gradients are complete when this call's work is
     return ARREAU_OK;
 }

@@ -202,6 +202,39 @@ def test_fused_convnext_training_forward_against_the_product_form(setup, monkeyp
             assert float((ga[n] - gb[n]).abs().max()) <= 2e-5 * scale, (n, float((ga[n] - gb[n]).abs().max()) / scale)
 
 
+def test_merged_launches_of_the_training_step_are_bitwise_the_one_kernel_per_operation_sequence(setup, monkeypatch):
+    """Round 5: the training step merges launches -- spatial conv + spherical mix forward as one kernel, LayerNorm backward + mix
+    backward as one, both gradients of the spatial conv in one launch, and the chunk sums of every column-sum pass / the k-slice
+    sums of every weight-gradient product deferred to ONE launch each at the end of the backward pass.  None of that changes a sum
+    or its order: against ARREAU_TRAIN_FUSE=0 (one kernel per operation) the loss and every gradient must be the same bits, at
+    the 17-atom fixture and at the benchmark's 64 crystals, over two steps with an optimizer step between them."""
+    import copy
+    from arreau_amd.train import optimizer_step
+    m, om, batch, lattice0, timestep, noise = setup
+    big = _alexandria_like_batch(64, 12, 21)
+    cases = [(batch, timestep, noise), (big[0], big[2], big[3])]
+    results = {}
+    for fuse in ("1", "0"):
+        monkeypatch.setenv("ARREAU_TRAIN_FUSE", fuse)
+        out = []
+        for b, ts, nz in cases:
+            mm = copy.deepcopy(m)
+            for layer in mm.model.interaction_layers:
+                layer.conv.callibrated.fill_(True)
+            opt = mm.configure_optimizers(max_epochs=10)["optimizer"]
+            for _ in range(2):
+                loss = mm.training_step(b, timestep=ts, noise=nz)
+                out.append((float(loss), {n: p.grad.detach().clone() for n, p in mm.named_parameters() if p.grad is not None}))
+                optimizer_step(mm, opt, world_size=1)
+        results[fuse] = out
+    assert len(results["1"]) == 4
+    for (la, ga), (lb, gb) in zip(results["1"], results["0"]):
+        assert la == lb, (la, lb)
+        assert ga.keys() == gb.keys() and len(ga) > 60
+        for n in ga:
+            assert torch.equal(ga[n], gb[n]), ("merged launches changed a gradient", n, float((ga[n] - gb[n]).abs().max()))
+
+
 def test_first_training_forward_callibrates_conv_weights(setup):
     """FiberBundleConv.callibrate (conv.py:121-123,140-146): after the first training forward kernel.weight is scaled by
     std(x) / std(x_1) and fiber_kernel.weight by std(x_1) / std(x_2) (per layer, unbiased std), once."""
