@@ -183,16 +183,20 @@ __device__ __forceinline__ Post posterior(float l0, float l1, bool v0, bool v1, 
         if (v0) f0 += p0 * d0;
         if (v1) f1 += p1 * d1;
         float fm = 0.f;
+        // (c is wave-uniform: the broadcasts are v_readlane, not LDS-crossbar permutes -- round 5, as update_dev.h since round 3: the
+        // 4 S permutes per atom of the two posteriors were most of loss_atoms_kernel's 26 us)
+        auto lane_value = [](float v, int l) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), l)); };
         for (int c = 0; c < S; ++c) {  // wave-uniform
-            const float pc = c < 64 ? __shfl(p0, c, 64) : __shfl(p1, c - 64, 64);
-            const float qc = c < 64 ? __shfl(c0, c, 64) : __shfl(c1, c - 64, 64);
+            const float pc = c < 64 ? lane_value(p0, c) : lane_value(p1, c - 64);
+            const float qc = c < 64 ? lane_value(c0, c) : lane_value(c1, c - 64);
             fm += pc * qc;
         }
         if (s0 == mask) f0 = fm;
         if (s1 == mask) f1 = fm;
     } else
     for (int c = 0; c < S; ++c) {  // fact2 = softmax . Qbar_{t-1}
-        const float sc = c < 64 ? __shfl(p0, c, 64) : __shfl(p1, c - 64, 64);
+        const float sc = c < 64 ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(p0), c))
+                                : __int_as_float(__builtin_amdgcn_readlane(__float_as_int(p1), c - 64));
         if (v0) f0 += sc * qm[(size_t)c * S + s0];
         if (v1) f1 += sc * qm[(size_t)c * S + s1];
     }
@@ -289,7 +293,8 @@ __global__ __launch_bounds__(256) void loss_atoms_kernel(
                 if (v1) { h1 += qm[(size_t)s1 * S + s1] * g1; if (s1 != mask) h1 += qm[(size_t)s1 * S + mask] * gm; }
             } else
             for (int s = 0; s < S; ++s) {
-                const float gs = s < 64 ? __shfl(g0, s, 64) : __shfl(g1, s - 64, 64);
+                const float gs = s < 64 ? __int_as_float(__builtin_amdgcn_readlane(__float_as_int(g0), s))
+                                        : __int_as_float(__builtin_amdgcn_readlane(__float_as_int(g1), s - 64));
                 if (v0) h0 += qm[(size_t)s0 * S + s] * gs;
                 if (v1) h1 += qm[(size_t)s1 * S + s] * gs;
             }

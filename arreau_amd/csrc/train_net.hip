@@ -98,19 +98,14 @@ constexpr int COLSUM4_MAX_BATCH = 8;  // matrices per batched call (the layers o
 // GELU_BWD (round 5): `a` is a gradient that still has to pass through a GELU -- a *= gelu'(gpre) * rowscale[row], gelu_backward_kernel4's
 // expression, written back in place -- and the column sums are those of the result: the bias gradient of a layer whose d(pre-activation)
 // comes out of a 128 x 128 product costs no pass of its own.
+// (device body: one matrix, workgroup blockIdx.x = row chunk; `part` / `part2` = this matrix's chunk rows)
 template <bool GELU_BWD>
-__global__ __launch_bounds__(256) void colsum4_partial_kernel(std::conditional_t<GELU_BWD, f32x4*, const f32x4*> __restrict__ a,
-                                                              const f32x4* __restrict__ b, long rows, int cols4, long rows_per_chunk,
-                                                              f32x4* __restrict__ part,   // [batch][chunks][cols4]
-                                                              f32x4* __restrict__ part2,  // plain sums of a (or null)
-                                                              long a_bs4, long b_bs4,     // blockIdx.y = matrix of the batch (strides in float4)
-                                                              f32x4* __restrict__ scaled_out = nullptr,      // also a * colscale (or null):
-                                                              const f32x4* __restrict__ colscale = nullptr,  // d(out) = d(x) * layer_scale in the same pass
-                                                              const f32x4* __restrict__ gpre = nullptr, const float* __restrict__ rowscale = nullptr)
-{
+__device__ __forceinline__ void colsum4_partial_body(std::conditional_t<GELU_BWD, f32x4*, const f32x4*> __restrict__ a,
+                                                     const f32x4* __restrict__ b, long rows, int cols4, long rows_per_chunk,
+                                                     f32x4* __restrict__ part, f32x4* __restrict__ part2, f32x4* __restrict__ scaled_out,
+                                                     const f32x4* __restrict__ colscale, const f32x4* __restrict__ gpre,
+                                                     const float* __restrict__ rowscale) {
     __shared__ f32x4 sh[256];
-    a += (long)blockIdx.y * a_bs4;
-    if (b) b += (long)blockIdx.y * b_bs4;
     auto fetch = [&](size_t i, long row) {
         f32x4 av = a[i];
         if constexpr (GELU_BWD) {
@@ -123,8 +118,6 @@ __global__ __launch_bounds__(256) void colsum4_partial_kernel(std::conditional_t
         }
         return av;
     };
-    part += (size_t)blockIdx.y * gridDim.x * cols4;
-    if (part2) part2 += (size_t)blockIdx.y * gridDim.x * cols4;
     const int P = 256 / cols4;
     const int c4 = threadIdx.x % cols4, ph = threadIdx.x / cols4;
     const bool act = ph < P;
@@ -166,6 +159,42 @@ __global__ __launch_bounds__(256) void colsum4_partial_kernel(std::conditional_t
     };
     block_sum((acc[0] + acc[1]) + (acc[2] + acc[3]), part);
     if (dual) block_sum((plain[0] + plain[1]) + (plain[2] + plain[3]), part2);
+}
+template <bool GELU_BWD>
+__global__ __launch_bounds__(256) void colsum4_partial_kernel(std::conditional_t<GELU_BWD, f32x4*, const f32x4*> __restrict__ a,
+                                                              const f32x4* __restrict__ b, long rows, int cols4, long rows_per_chunk,
+                                                              f32x4* __restrict__ part,   // [batch][chunks][cols4]
+                                                              f32x4* __restrict__ part2,  // plain sums of a (or null)
+                                                              long a_bs4, long b_bs4,     // blockIdx.y = matrix of the batch (strides in float4)
+                                                              f32x4* __restrict__ scaled_out = nullptr,      // also a * colscale (or null):
+                                                              const f32x4* __restrict__ colscale = nullptr,  // d(out) = d(x) * layer_scale in the same pass
+                                                              const f32x4* __restrict__ gpre = nullptr, const float* __restrict__ rowscale = nullptr)
+{
+    colsum4_partial_body<GELU_BWD>(a + (long)blockIdx.y * a_bs4, b ? b + (long)blockIdx.y * b_bs4 : nullptr, rows, cols4, rows_per_chunk,
+                                   part + (size_t)blockIdx.y * gridDim.x * cols4, part2 ? part2 + (size_t)blockIdx.y * gridDim.x * cols4 : nullptr,
+                                   scaled_out, colscale, gpre, rowscale);
+}
+// Round 5: the chunk sums of SEVERAL matrices of different widths in one launch (blockIdx.y = descriptor; all share the row count and the
+// chunking): the three batched passes of a backward pass (L x linear_1.bias, L x norm weight + bias, L x conv bias) as one.
+struct ColsumPartialDesc {
+    const f32x4* a;
+    const f32x4* b;
+    f32x4* part;
+    f32x4* part2;
+    int cols4;
+};
+constexpr int COLSUM_PARTIAL_MULTI_MAX = 24;
+struct ColsumPartialList {
+    ColsumPartialDesc d[COLSUM_PARTIAL_MULTI_MAX];
+};
+struct ColsumGather {   // host side: passes collected for one launch
+    ColsumPartialList list{};
+    int n = 0, chunks = 0;
+    long rows = 0, rpc = 0;
+};
+__global__ __launch_bounds__(256) void colsum4_partial_multi_kernel(ColsumPartialList list, long rows, long rows_per_chunk) {
+    const ColsumPartialDesc d = list.d[blockIdx.y];
+    colsum4_partial_body<false>(d.a, d.b, rows, d.cols4, rows_per_chunk, d.part, d.part2, nullptr, nullptr, nullptr, nullptr);
 }
 // out[c] = scale * sum_chunks part[chunk][c] (+ out[c]); out2[c] = colscale2[c] * sum_chunks part2[chunk][c].
 // Workgroup = 8 float4 columns x 32 row phases.
@@ -1151,7 +1180,8 @@ int colsum(hipStream_t s, arreau_train_ctx& t, const float* a, const float* b, l
            const float* colscale_out = nullptr, bool* wrote_scaled = nullptr,
            bool defer = false /* the sums may wait for flush_deferred (main stream of the backward pass only) */, long colscale2_bs = 0,
            const float* gelu_pre = nullptr /* 16-byte path, one matrix: a *= gelu'(gelu_pre) * gelu_rowscale[row] in place first */,
-           const float* gelu_rowscale = nullptr) {
+           const float* gelu_rowscale = nullptr,
+           ColsumGather* gather = nullptr /* deferred passes over the same rows: collected here, launched together by launch_gathered */) {
     if (wrote_scaled) *wrote_scaled = false;
     if (cols > 1024) {
         arreau_set_error("colsum: more than 1024 columns");
@@ -1189,6 +1219,19 @@ int colsum(hipStream_t s, arreau_train_ctx& t, const float* a, const float* b, l
                 d.chunks = chunks; d.cols4 = cols / 4; d.scale = scale; d.accumulate = accumulate;
             }
             df->max_colblocks = std::max(df->max_colblocks, (cols / 4 + 7) / 8);
+        }
+        if (deferred && gather && !gelu_pre && !scaled_out && gather->n + batch <= COLSUM_PARTIAL_MULTI_MAX &&
+            (gather->n == 0 || (gather->rows == rows && gather->chunks == chunks))) {
+            gather->rows = rows; gather->chunks = chunks; gather->rpc = rpc;
+            for (int i = 0; i < batch; ++i) {
+                ColsumPartialDesc& d = gather->list.d[gather->n++];
+                d.a = reinterpret_cast<const f32x4*>(a) + (long)i * (a_bs / 4);
+                d.b = b ? reinterpret_cast<const f32x4*>(b) + (long)i * (b_bs / 4) : nullptr;
+                d.part = part + (size_t)i * chunks * (cols / 4);
+                d.part2 = part2 ? part2 + (size_t)i * chunks * (cols / 4) : nullptr;
+                d.cols4 = cols / 4;
+            }
+            return ARREAU_OK;
         }
         if (gelu_pre)
             hipLaunchKernelGGL(colsum4_partial_kernel<true>, dim3(chunks, batch), dim3(256), 0, s, reinterpret_cast<f32x4*>(const_cast<float*>(a)),
@@ -1302,6 +1345,14 @@ int flush_deferred_colsums(hipStream_t s, arreau_train_ctx& t) {
         ARREAU_CHECK_HIP(hipGetLastError());
     }
     if (df) { df->ncols = 0; df->max_colblocks = 0; df->colused = 0; }
+    return ARREAU_OK;
+}
+int launch_gathered(hipStream_t s, ColsumGather& g) {
+    if (g.n > 0) {
+        hipLaunchKernelGGL(colsum4_partial_multi_kernel, dim3(g.chunks, g.n), dim3(256), 0, s, g.list, g.rows, g.rpc);
+        ARREAU_CHECK_HIP(hipGetLastError());
+    }
+    g.n = 0;
     return ARREAU_OK;
 }
 int flush_deferred_gemms(hipStream_t s, arreau_train_ctx& t) {
@@ -1632,10 +1683,15 @@ extern "C" int arreau_train_backward(arreau_model* m, const float* d_g_eps, cons
         TRY(flush_deferred_gemms(s, t));
         // ... and the column sums: d(linear_1.bias) = sum_rows dhpre; d(norm.weight) = sum_rows dxn * xhat and d(norm.bias) = sum_rows dxn
         // in one pass over dxn; d(conv.bias) = sum_rows dx2
-        TRY(colsum(s, t, t.dh, nullptr, M, H, 1.0f, W(g->linear1_b), 0, nullptr, nullptr, L, (long)M * H, 0, H, 0, nullptr, nullptr, nullptr, true));
+        // (round 5: the three passes as ONE launch where their chunk sums are deferred -- 15 matrices of the same row count)
+        ColsumGather cg;
+        TRY(colsum(s, t, t.dh, nullptr, M, H, 1.0f, W(g->linear1_b), 0, nullptr, nullptr, L, (long)M * H, 0, H, 0, nullptr, nullptr, nullptr, true, 0,
+                   nullptr, nullptr, &cg));
         TRY(colsum(s, t, t.dxn_all, t.xhat, M, C, 1.0f, W(g->norm_w), 0, W(g->norm_b), nullptr, L, (long)M * C, (long)M * C, C, C, nullptr, nullptr,
-                   nullptr, true));
-        TRY(colsum(s, t, t.dx2_all, nullptr, M, C, 1.0f, W(g->conv_bias), 0, nullptr, nullptr, L, (long)M * C, 0, C, 0, nullptr, nullptr, nullptr, true));
+                   nullptr, true, 0, nullptr, nullptr, &cg));
+        TRY(colsum(s, t, t.dx2_all, nullptr, M, C, 1.0f, W(g->conv_bias), 0, nullptr, nullptr, L, (long)M * C, 0, C, 0, nullptr, nullptr, nullptr, true, 0,
+                   nullptr, nullptr, &cg));
+        TRY(launch_gathered(s, cg));
         return ARREAU_OK;
     };
     {
