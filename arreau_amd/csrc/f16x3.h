@@ -104,9 +104,19 @@ __device__ __forceinline__ void split_pair2(f32x2 v, unsigned& hi, unsigned& lo)
 //     main += a1 hi + a1 lo ,   cross += a2 hi   (folded by 2^-11 as before; dropped: a2 lo / 2^11)
 // -- the same three matrix instructions, two of them on the main accumulator.  The BASIS planes keep the scaled e4m3 / fp16
 // residual (split_pair_fp8 / split_pair2): they are stored, streamed and read by the fp8 cross products.
+// OWNED: the asm's destination is first written by an instruction the compiler knows (a move), so that hipcc's own hazard handling
+// separates it from a matrix instruction that wrote the same register just before -- hipcc counts no wait states for inline asm, and
+// in one instantiation (the training forward with the conv inside, node_f16m.hip) its register allocator handed the asm the
+// accumulator of a matrix instruction issued five instructions earlier (found by arreau_amd/_isa_lint.py: mfma-result).  One move
+// per pair: only that instantiation pays it.
+template <bool OWNED = false>
 __device__ __forceinline__ void split_pair_act(f32x2 v, unsigned& hi, unsigned& lo) {
     hi = __builtin_bit_cast(unsigned, cvt_f16x2(v));
     const float neg_one = -1.0f;
+    if constexpr (OWNED) {
+        lo = hi;
+        asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "+v"(lo) : "v"(hi), "s"(neg_one), "v"(v.x));
+    } else
     asm("v_fma_mixlo_f16 %0, %1, %2, %3 op_sel_hi:[1,0,0]" : "=v"(lo) : "v"(hi), "s"(neg_one), "v"(v.x));
     asm("v_fma_mixhi_f16 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[1,0,0]" : "+v"(lo) : "v"(hi), "s"(neg_one), "v"(v.y));
 }

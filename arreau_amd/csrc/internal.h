@@ -335,7 +335,11 @@ int arreau_launch_mlp_bf16x6(const arreau_model* m, int layer, const float* x_co
                              float* xbar, float* vsum, int N, hipStream_t s);
 bool arreau_mlp_train_forward_available(const arreau_model* m);
 int arreau_launch_mlp_train_forward(const arreau_model* m, int layer, const float* x_conv, const float* x_in, float* x_out, float* xhat,
-                                    float* rstd, float* xn, float* hpre, float* h, float* out, int N, hipStream_t s);
+                                    float* rstd, float* xn, float* hpre, float* h, float* out, int N, hipStream_t s,
+                                    // round 5: the spatial conv + spherical mix of the layer inside the same launch (kl = the layer's kernels,
+                                    // rows kl_pitch floats apart; x1 receives the spatial conv's output; x_conv is not read) -- null: x_conv given
+                                    const float* kl = nullptr, int kl_pitch = 0, const int32_t* deg = nullptr, const int32_t* src = nullptr,
+                                    const float* fk = nullptr, float* x1 = nullptr);
 int arreau_repack_mlp_f16x3_m16(arreau_model* m, hipStream_t s);
 int arreau_launch_mlp_f16x3_m16(const arreau_model* m, int layer, const float* x_conv, const float* x_in, float* x_out,
                                 float* xbar, float* vsum, int N, hipStream_t s, NodeRange r = NodeRange());

@@ -37,12 +37,12 @@ __device__ __forceinline__ float group4_sum(float v) {
     return v;
 }
 // planes of 8 fp32 values (e = 0..7) -> two u32x4 (8 halves each)
-template <bool CLAMP>
+template <bool CLAMP, bool OWNED = false>
 __device__ __forceinline__ void split8(const float (&v)[8], u32x4& hi, u32x4& lo) {
 #pragma unroll
     for (int pp = 0; pp < 4; ++pp) {
         unsigned a, b;
-        split_pair_act(f32x2{v[2 * pp], v[2 * pp + 1]}, a, b);  // (activation planes: unscaled residual, f16x3.h)
+        split_pair_act<OWNED>(f32x2{v[2 * pp], v[2 * pp + 1]}, a, b);  // (activation planes: unscaled residual, f16x3.h)
         hi[pp] = a;
         lo[pp] = b;
     }
@@ -325,8 +325,14 @@ __device__ __forceinline__ void load_steps(u32x4 (&w)[2 * NST], const u32x4* __r
 // xhat, rstd, the LayerNorm output (wave 0: every wave normalises the 16 rows for its own B operand), every hidden unit before and
 // after the GELU (the wave that owns the chunk, 16-byte pieces of four consecutive units per row) and linear_2's output with its
 // bias (the wave that owns the tile).  No read-out partials (the training read-outs are one batched product over the kept x_l).
+// FUSE + TRAIN (round 5, second session): the training forward's spatial conv + spherical mix inside the same launch too -- one launch
+// per layer instead of two: the layer's kernels are a column block of the all-layer matrix [R][L C] (row pitch kl_pitch), the fiber
+// kernel carries no 1 / 16 (the training branch divides after the mix, as conv.py does), and x_1 -- which the backward pass reads --
+// leaves beside the other saved activations.
 struct MlpTrainSave {
     float *xhat, *rstd, *xn, *hpre, *h, *out;  // [M][C], [M], [M][C], [M][H], [M][H], [M][C] of this layer (M = 16 N rows)
+    float* x1 = nullptr;                        // FUSE: [M][C] the spatial conv's output
+    int kl_pitch = 0;                           // FUSE: floats between consecutive rows of `kl`
 };
 template <int C, int H, bool FUSE = false, bool TRAIN = false>
 __global__ __launch_bounds__(512) void mlp_kernel_f16x3_m16_split(
@@ -338,7 +344,6 @@ __global__ __launch_bounds__(512) void mlp_kernel_f16x3_m16_split(
     const int32_t* __restrict__ src, const float* __restrict__ fk /* [16][16][C] */, const float* __restrict__ conv_bias,
     MlpTrainSave save) {
     static_assert(C == 128 && H == 512, "chunking below assumes C = 128, H = 512");
-    static_assert(!(FUSE && TRAIN), "the training forward keeps its own conv launches (x_1 is kept for the backward pass)");
     constexpr int KC = C / 32, HQ = H / 4;
     constexpr int TS = 132;             // row stride of the two conv tiles (node.hip: CONV_LDS_STRIDE)
     __shared__ u32x4 hidx[16][2][64];   // hidden chunk (quarter * 4 + u) as B operand: [chunk][plane][lane], 32 KiB
@@ -373,12 +378,13 @@ __global__ __launch_bounds__(512) void mlp_kernel_f16x3_m16_split(
         constexpr int K = 8;
         const int nd = min(deg[n], K);
         const int32_t* srow = src + (size_t)n * K;
-        const size_t kbase = ((size_t)n * K * 16 + o_row) * C + 4 * c4;
+        const size_t kp = TRAIN ? (size_t)save.kl_pitch : (size_t)C;
+        const size_t kbase = ((size_t)n * K * 16 + o_row) * kp + 4 * c4;
         f32x4 kv[K], xv[K];
 #pragma unroll
         for (int s_ = 0; s_ < K; ++s_) {  // unused slots: any valid row, dropped by the select below (their K rows may be uninitialised)
             const int sn = max(srow[s_], 0);
-            kv[s_] = *reinterpret_cast<const f32x4*>(kl + kbase + (size_t)s_ * 16 * C);
+            kv[s_] = *reinterpret_cast<const f32x4*>(kl + kbase + (size_t)s_ * 16 * kp);
             xv[s_] = *reinterpret_cast<const f32x4*>(x_in + ((size_t)sn * 16 + o_row) * C + 4 * c4);
         }
         float fkr[16][4];
@@ -397,6 +403,7 @@ __global__ __launch_bounds__(512) void mlp_kernel_f16x3_m16_split(
             acc[3] = on ? __fadd_rn(acc[3], __fmul_rn(kv[s_][3], xv[s_][3])) : acc[3];
         }
         *reinterpret_cast<f32x4*>(&ctile[o_row * TS + 4 * c4]) = acc;
+        if constexpr (TRAIN) *reinterpret_cast<f32x4*>(save.x1 + ((size_t)n * 16 + o_row) * C + 4 * c4) = acc;
         __syncthreads();
         float out[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -406,7 +413,7 @@ __global__ __launch_bounds__(512) void mlp_kernel_f16x3_m16_split(
             for (int p = 0; p < 4; ++p) out[p] += xo * fkr[o][p];
         }
 #pragma unroll
-        for (int p = 0; p < 4; ++p) xc_s[(4 * pq + p) * TS + c] = out[p] + cbias;
+        for (int p = 0; p < 4; ++p) xc_s[(4 * pq + p) * TS + c] = TRAIN ? out[p] * (1.0f / 16.0f) + cbias : out[p] + cbias;
         __syncthreads();
     }
 
@@ -461,7 +468,7 @@ __global__ __launch_bounds__(512) void mlp_kernel_f16x3_m16_split(
 #pragma unroll
                 for (int r = 0; r < 4; ++r) x[kb][4 * hf + r] = x[kb][4 * hf + r] * rstd * gw[r] + gb[r];
             }
-            split8<true>(x[kb], xn[kb][0], xn[kb][1]);
+            split8<true, FUSE && TRAIN>(x[kb], xn[kb][0], xn[kb][1]);
         }
     }
 
@@ -500,7 +507,7 @@ __global__ __launch_bounds__(512) void mlp_kernel_f16x3_m16_split(
                 }
             }
         u32x4 hi, lo;
-        split8<false>(v, hi, lo);
+        split8<false, FUSE && TRAIN>(v, hi, lo);
         hidx[4 * q + u][0][lane] = hi;
         hidx[4 * q + u][1][lane] = lo;
     };
@@ -637,11 +644,23 @@ bool arreau_mlp_train_forward_available(const arreau_model* m) {
     return (!e || atoi(e) != 0) && m->C == 128 && m->H == 512 && m->mlp_f16m != nullptr;
 }
 int arreau_launch_mlp_train_forward(const arreau_model* m, int layer, const float* x_conv, const float* x_in, float* x_out, float* xhat,
-                                    float* rstd, float* xn, float* hpre, float* h, float* out, int N, hipStream_t s) {
+                                    float* rstd, float* xn, float* hpre, float* h, float* out, int N, hipStream_t s,
+                                    const float* kl, int kl_pitch, const int32_t* deg, const int32_t* src, const float* fk, float* x1) {
     if (N <= 0) return ARREAU_OK;
     const int C = m->C, H = m->H;
     const size_t layer_u32x4 = (size_t)2 * H * C * 2 * 2 / 16;
     const u32x4* stream = reinterpret_cast<const u32x4*>(m->mlp_f16m) + (size_t)layer * layer_u32x4;
+    if (kl != nullptr) {  // conv + mix + ConvNext block in one launch (k = 8; x_conv unused)
+        ARREAU_REQUIRE(m->k == 8 && kl_pitch % 4 == 0 && deg && src && fk && x1, "fused training conv: k = 8 and 16-byte kernel rows");
+        MlpTrainSave sv{xhat, rstd, xn, hpre, h, out};
+        sv.x1 = x1; sv.kl_pitch = kl_pitch;
+        ARREAU_LAUNCH((mlp_kernel_f16x3_m16_split<128, 512, true, true>), dim3((unsigned)N), dim3(512), 0, s, (const float*)nullptr, x_in, x_out,
+                      m->ln_w + (size_t)layer * C, m->ln_b + (size_t)layer * C, stream, m->mb1 + (size_t)layer * H, m->mb2 + (size_t)layer * C,
+                      m->ls + (size_t)layer * C, (const float*)nullptr, 0.0f, 0, 0, (float*)nullptr, (float*)nullptr, kl, deg, src, fk,
+                      m->conv_bias + (size_t)layer * C, sv);
+        ARREAU_CHECK_HIP(hipGetLastError());
+        return ARREAU_OK;
+    }
     ARREAU_LAUNCH((mlp_kernel_f16x3_m16_split<128, 512, false, true>), dim3((unsigned)N), dim3(512), 0, s, x_conv, x_in, x_out,
                   m->ln_w + (size_t)layer * C, m->ln_b + (size_t)layer * C, stream, m->mb1 + (size_t)layer * H, m->mb2 + (size_t)layer * C,
                   m->ls + (size_t)layer * C, (const float*)nullptr, 0.0f, 0, 0, (float*)nullptr, (float*)nullptr, (const float*)nullptr,

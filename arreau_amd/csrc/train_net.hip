@@ -451,7 +451,8 @@ __global__ void conv_forward_kernel(const float* __restrict__ kern, int ldk, con
     float acc = 0.f;
     for (int s = 0; s < nd; ++s) {
         const int j = src[(size_t)n * k + s];
-        acc += kern[(((size_t)n * k + s) * 16 + o) * ldk + c] * x[((size_t)j * 16 + o) * C + c];
+        // (product rounded, then added in edge order: messages = kernel * x, then index_add_ -- conv.py:131-133; the fused kernels' form)
+        acc = __fadd_rn(acc, __fmul_rn(kern[(((size_t)n * k + s) * 16 + o) * ldk + c], x[((size_t)j * 16 + o) * C + c]));
     }
     x1[i] = acc;
 }
@@ -575,7 +576,7 @@ __global__ void conv_forward_kernel4(const f32x4* __restrict__ kern, int ldk4, c
         const int j = src[(size_t)n * k + s];
         const f32x4 kv = kern[(((size_t)n * k + s) * 16 + o) * ldk4 + c], xv = x[((size_t)j * 16 + o) * C4 + c];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) acc[q] += kv[q] * xv[q];
+        for (int q = 0; q < 4; ++q) acc[q] = __fadd_rn(acc[q], __fmul_rn(kv[q], xv[q]));
     }
     x1[i] = acc;
 }
@@ -663,7 +664,7 @@ __global__ __launch_bounds__(512) void conv_mix_forward_kernel4(const f32x4* __r
             const int j = src[(size_t)n * k + s];
             const f32x4 kv = kern[(((size_t)n * k + s) * 16 + o) * ldk4 + c], xv = x[((size_t)j * 16 + o) * C4 + c];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) acc[q] += kv[q] * xv[q];
+            for (int q = 0; q < 4; ++q) acc[q] = __fadd_rn(acc[q], __fmul_rn(kv[q], xv[q]));
         }
         x1[(size_t)n * E + e] = acc;
         s_node[e] = acc;
@@ -1493,6 +1494,14 @@ int arreau_general_network(arreau_model* m, const arreau_graph_view& g, const in
         float* xnext = t.x + (size_t)(l + 1) * M * C;
         float* x1 = t.x1 + (size_t)l * M * C;
         float* fk = t.fk + (size_t)l * 256 * C;
+        if (t.fwd_mode == 1 && arreau_mlp_train_forward_available(m) && train_fuse_on() && k == 8) {
+            // round 5: spatial conv + spherical mix + LayerNorm + linear_1 + GELU + linear_2 + layer scale + residual as ONE launch of the
+            // sampling step's one-node-per-workgroup kernel (node_f16m.hip, FUSE + TRAIN), which writes everything the backward pass reads
+            TRY(arreau_launch_mlp_train_forward(m, l, nullptr, xl, xnext, t.xhat + (size_t)l * M * C, t.rstd + (size_t)l * M,
+                                                t.xn_all + (size_t)l * M * C, t.hpre + (size_t)l * M * H, t.h + (size_t)l * M * H,
+                                                t.out + (size_t)l * M * C, N, s, t.kern + (size_t)l * C, L * C, g.deg, g.src, fk, x1));
+            continue;
+        }
         if (C % 4 == 0 && train_fuse_on() && C <= 2048) {
             hipLaunchKernelGGL(conv_mix_forward_kernel4, dim3((unsigned)N), dim3(512), (size_t)16 * C * sizeof(float), s, V4(t.kern + (size_t)l * C),
                                L * C / 4, V4(xl), g.deg, g.src, N, k, C / 4, V4(fk), V4(m->conv_bias + (size_t)l * C), V4W(x1), V4W(t.dtmp));
