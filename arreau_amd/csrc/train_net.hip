@@ -905,16 +905,26 @@ __global__ void affine_cols_kernel(const float* __restrict__ a, const float* __r
 }
 // read-outs from rbar[(n,o)][S+4] = mean over layers (bias added here): logits = mean_o, eps = sum_o vec * ori / 16,
 // gs = mean_o (ponita.py:108-117,126-155); len0 by readout_crystals-style ordered sums
+// Round 5: `layers` > 0 -- rbar holds the L per-layer products [L][M][RO] and the sum over the layers is formed here, a running sum from
+// zero in layer order per element: what the ordered-sum launch in front of this kernel wrote, bit for bit, without that launch.
 __global__ void train_outputs_kernel(const float* __restrict__ rbar, const float* __restrict__ ro_b, const float* __restrict__ ori,
                                      int S, int L, int N, float* __restrict__ eps, float* __restrict__ logits,
-                                     float* __restrict__ gs) {
+                                     float* __restrict__ gs, int layers = 0) {
     const int n = blockIdx.x, RO = S + 4;
+    const size_t layer_stride = (size_t)N * 16 * RO;
+    auto rb = [&](int o, int j) {
+        const size_t i = ((size_t)n * 16 + o) * RO + j;
+        if (layers == 0) return rbar[i];
+        float s = 0.f;
+        for (int l = 0; l < layers; ++l) s += rbar[(size_t)l * layer_stride + i];
+        return 1.0f * s + 0.0f;
+    };
     for (int j = threadIdx.x; j < RO + 2; j += blockDim.x) {
         if (j < S || (j > S && j < RO)) {
             float bsum = 0.f;
             for (int l = 0; l < L; ++l) bsum += ro_b[l * RO + j];
             float acc = 0.f;
-            for (int o = 0; o < 16; ++o) acc += rbar[((size_t)n * 16 + o) * RO + j];
+            for (int o = 0; o < 16; ++o) acc += rb(o, j);
             const float v = acc * (1.0f / 16.0f) + bsum / (float)L;
             if (j < S) logits[(size_t)n * S + j] = v;
             else gs[(size_t)n * 3 + (j - S - 1)] = v;
@@ -924,7 +934,7 @@ __global__ void train_outputs_kernel(const float* __restrict__ rbar, const float
             for (int l = 0; l < L; ++l) bsum += ro_b[l * RO + S];
             bsum /= (float)L;
             float acc = 0.f;
-            for (int o = 0; o < 16; ++o) acc += (rbar[((size_t)n * 16 + o) * RO + S] + bsum) * ori[3 * o + d];
+            for (int o = 0; o < 16; ++o) acc += (rb(o, S) + bsum) * ori[3 * o + d];
             eps[(size_t)n * 3 + d] = acc * (1.0f / 16.0f);
         }
     }
@@ -1067,6 +1077,8 @@ struct arreau_train_ctx {
     // CU, cost that product a third of a round: 30 -> 39 us in the kernel trace).
     hipStream_t side = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipEvent_t ev_rev = nullptr;   // the reversed adjacency of the forward pass is complete (side stream; the backward pass waits for it)
+    bool rev_pending = false;
     float *partial2 = nullptr, *colpart2 = nullptr;
     int32_t* colcount2 = nullptr;
     // Round 5: deferred reductions of the backward pass (main stream only): the k-slice sums of the weight-gradient products and the
@@ -1375,6 +1387,7 @@ void arreau_train_ctx_destroy(arreau_train_ctx* t) {
     if (t->side) (void)hipStreamDestroy(t->side);
     if (t->ev_fork) (void)hipEventDestroy(t->ev_fork);
     if (t->ev_join) (void)hipEventDestroy(t->ev_join);
+    if (t->ev_rev) (void)hipEventDestroy(t->ev_rev);
     delete t->defer;
     delete t;
 }
@@ -1423,6 +1436,7 @@ static int ensure_ctx(arreau_model* m, int N, int B, hipStream_t s) {
             ARREAU_CHECK_HIP(hipStreamCreateWithFlags(&t->side, hipStreamNonBlocking));
             ARREAU_CHECK_HIP(hipEventCreateWithFlags(&t->ev_fork, hipEventDisableTiming));
             ARREAU_CHECK_HIP(hipEventCreateWithFlags(&t->ev_join, hipEventDisableTiming));
+            ARREAU_CHECK_HIP(hipEventCreateWithFlags(&t->ev_rev, hipEventDisableTiming));
         }
     }
     hipLaunchKernelGGL(mono_columns_kernel, dim3(1), dim3(128), 0, s, t->mono_cols);
@@ -1541,8 +1555,12 @@ int arreau_general_network(arreau_model* m, const arreau_graph_view& g, const in
     // x_1 .. x_L and a sum in layer order -- the same products and the same association as L accumulating launches inside the loop
     TRY(arreau_sgemm(s, t.partial, (int)M, RO, C, t.x + (size_t)M * C, C, 1, t.ro_w, 1, C, t.rbar_all, RO, 1.0f / (float)L, 0.f, L, (long)M * C,
                      (long)RO * C, (long)M * RO, t.fwd_mode));
-    TRY(ordered_sum(s, t.rbar_all, L, (int)M, RO, t.rbar));
-    LAUNCH(train_outputs_kernel, dim3(N), dim3(128), t.rbar, m->ro_b, m->ori, S, L, N, d_eps, d_logits, t.gs);
+    if (train_fuse_on()) {
+        LAUNCH(train_outputs_kernel, dim3(N), dim3(128), t.rbar_all, m->ro_b, m->ori, S, L, N, d_eps, d_logits, t.gs, L);
+    } else {
+        TRY(ordered_sum(s, t.rbar_all, L, (int)M, RO, t.rbar));
+        LAUNCH(train_outputs_kernel, dim3(N), dim3(128), t.rbar, m->ro_b, m->ori, S, L, N, d_eps, d_logits, t.gs, 0);
+    }
     LAUNCH(pool_crystals_kernel, dim3(blocks(3 * B, 128)), dim3(128), t.gs, d_off, B, d_len0);
     m->ran_edge = m->ran_mlp = ARREAU_VARIANT_GENERAL;
     m->ran_conv = ARREAU_VARIANT_GENERAL;
@@ -1578,18 +1596,39 @@ extern "C" int arreau_train_forward(arreau_model* m, const float* d_frac, const 
         t.fwd_mode = env == 0 ? 0 : (m->f16_ok && !m->train_full_range ? 1 : 2);
         t.bwd_mode = env == 0 ? 0 : (env == 2 && m->f16_ok ? 1 : 2);
     }
+    const bool side_setup = t.side != nullptr && train_fuse_on();
+    // (a previous forward's reversed adjacency may still be in flight on the side stream: the neighbour list below rewrites its input)
+    if (t.rev_pending) { ARREAU_CHECK_HIP(hipStreamWaitEvent(s, t.ev_rev, 0)); t.rev_pending = false; }
     // geometry and graph: the sampling path's own kernels (prep, neighbour list)
     TRY(arreau_launch_prep(m, d_frac, d_lengths, d_angles, d_t, d_off, B, N, t.lattice, t.cart, t.batch, t.cvec, s));
+    // embedding (ponita.py:98): x_0 = F . W_emb^T, embT = W_emb^T [S+78][C]  (F is kept for the embedder's gradient).  Round 5: on the
+    // side stream beside the neighbour list -- it needs prep's cell and atom -> crystal map only, and x_0 is first read by the layer
+    // loop, behind arreau_general_network's join
+    {
+        arreau_train_ctx ts = t;
+        hipStream_t ss = s;
+        if (side_setup) TRY(fork_side(t, s, ts, ss));
+        hipLaunchKernelGGL(features_kernel, dim3((unsigned)M), dim3(64), 0, ss, d_frac, d_types, d_lengths, d_angles, d_t, d_off, t.batch, t.lattice,
+                           m->vp_betas, m->t_emb_w, m->ori, S, m->T, N, t.F);
+        ARREAU_CHECK_HIP(hipGetLastError());
+        TRY(gemm(ss, ts, t.fwd_mode, (int)M, C, S + 78, t.F, S + 78, 1, m->embT, C, 1, t.x, C));
+    }
     TRY(arreau_launch_neighbor(t.cart, t.lattice, d_off, t.batch, B, N, m->cfg.radius, k, t.deg, t.src, t.cell, t.dir, t.dist, s));
     // sender-side adjacency of this step's graph, for the ordered, atomic-free d(x_l) of the spatial conv in the backward pass
-    // (built here, while the caller's offsets are certainly alive: the backward pass reads only the context's own arrays)
-    LAUNCH(reverse_adjacency_kernel, dim3((unsigned)B), dim3(1024), d_off, t.deg, t.src, k, t.rev_start, t.rev_cnt, t.rev_idx);
-    // embedding (ponita.py:98): x_0 = F . W_emb^T, embT = W_emb^T [S+78][C]  (F is kept for the embedder's gradient)
-    LAUNCH(features_kernel, dim3((unsigned)M), dim3(64), d_frac, d_types, d_lengths, d_angles, d_t, d_off, t.batch, t.lattice,
-           m->vp_betas, m->t_emb_w, m->ori, S, m->T, N, t.F);
-    TRY(gemm(s, t, t.fwd_mode, (int)M, C, S + 78, t.F, S + 78, 1, m->embT, C, 1, t.x, C));
-    return arreau_general_network(m, arreau_graph_view{t.batch, t.deg, t.src, t.lattice, t.dir, t.dist}, d_off, B, N, d_eps,
-                                  d_logits, d_len0, s);
+    // (built here, while the caller's offsets are certainly alive: the backward pass reads only the context's own arrays).  Round 5: only
+    // the backward pass reads it, so it runs on the side stream behind the network's fiber branch (which waits for the neighbour list:
+    // fork_side in arreau_general_network) and the backward pass waits for ev_rev
+    if (!side_setup) LAUNCH(reverse_adjacency_kernel, dim3((unsigned)B), dim3(1024), d_off, t.deg, t.src, k, t.rev_start, t.rev_cnt, t.rev_idx);
+    const int rc = arreau_general_network(m, arreau_graph_view{t.batch, t.deg, t.src, t.lattice, t.dir, t.dist}, d_off, B, N, d_eps,
+                                          d_logits, d_len0, s);
+    if (rc) return rc;
+    if (side_setup) {
+        hipLaunchKernelGGL(reverse_adjacency_kernel, dim3((unsigned)B), dim3(1024), 0, t.side, d_off, t.deg, t.src, k, t.rev_start, t.rev_cnt, t.rev_idx);
+        ARREAU_CHECK_HIP(hipGetLastError());
+        ARREAU_CHECK_HIP(hipEventRecord(t.ev_rev, t.side));
+        t.rev_pending = true;
+    }
+    return ARREAU_OK;
 }
 
 extern "C" int arreau_train_backward(arreau_model* m, const float* d_g_eps, const float* d_g_logits, const float* d_g_len0,
@@ -1607,6 +1646,7 @@ extern "C" int arreau_train_backward(arreau_model* m, const float* d_g_eps, cons
     const long R = (long)N * k * 16, M = (long)N * 16;
     auto W = [](const float* p) { return const_cast<float*>(p); };  // the gradient struct reuses the const state_dict type
     reset_deferred(t);
+    if (t.rev_pending) { ARREAU_CHECK_HIP(hipStreamWaitEvent(s, t.ev_rev, 0)); t.rev_pending = false; }
     // d(rbar) [M][ROP], ROP = RO rounded up to a multiple of four with zero pad columns (round 5): its products and its column sum run on
     // 16-byte fetches -- 94 columns sent the d(x) product to the exact fp32 kernel (24.6 us) and the bias gradient to the element-wise
     // column sum (15.1 us); the weight operand's pad rows are the next layer's first rows resp. zeros behind the last layer (model.hip)
