@@ -599,7 +599,10 @@ __device__ __forceinline__ void conv_backward_kern_body4(long i, const f32x4* __
 __device__ __forceinline__ void conv_backward_dx_body4(long i, const f32x4* __restrict__ kern, int ldk4, const f32x4* __restrict__ dx1,
                                                        const int32_t* __restrict__ rev_start, const int32_t* __restrict__ rev_cnt,
                                                        const int32_t* __restrict__ rev_idx, int N, int k, int C4, const f32x4* dx_in,
-                                                       const f32x4* __restrict__ add2, f32x4* dx) {
+                                                       const f32x4* __restrict__ add2, f32x4* dx,
+                                                       // round 5: also d(out) of the NEXT layer down = d(x_l) * its layer scale (what the
+                                                       // column-sum pass at the top of that iteration wrote: the same multiply), or null
+                                                       f32x4* __restrict__ dout_next = nullptr, const f32x4* __restrict__ ls_next = nullptr) {
     if (i >= (long)N * 16 * C4) return;
     const int c = (int)(i % C4);
     const long row = i / C4;
@@ -622,6 +625,7 @@ __device__ __forceinline__ void conv_backward_dx_body4(long i, const f32x4* __re
         for (int r = 0; r < 4; ++r) d[r] += a2[r];
     }
     dx[i] = d;
+    if (dout_next) dout_next[i] = d * ls_next[c];
 }
 __global__ void conv_backward_kern_kernel4(const f32x4* __restrict__ x, const f32x4* __restrict__ dx1, const int32_t* __restrict__ deg,
                                            const int32_t* __restrict__ src, int N, int k, int C4, int ldk4, f32x4* __restrict__ dkern) {
@@ -640,9 +644,11 @@ __global__ void conv_backward_both_kernel4(int dx_blocks, const f32x4* __restric
                                            const int32_t* __restrict__ deg, const int32_t* __restrict__ src, const f32x4* __restrict__ kern,
                                            int ldk4, const int32_t* __restrict__ rev_start, const int32_t* __restrict__ rev_cnt,
                                            const int32_t* __restrict__ rev_idx, int N, int k, int C4, const f32x4* dx_in,
-                                           const f32x4* __restrict__ add2, f32x4* dx, f32x4* __restrict__ dkern) {
+                                           const f32x4* __restrict__ add2, f32x4* dx, f32x4* __restrict__ dkern,
+                                           f32x4* __restrict__ dout_next, const f32x4* __restrict__ ls_next) {
     if ((int)blockIdx.x < dx_blocks)
-        conv_backward_dx_body4((long)blockIdx.x * blockDim.x + threadIdx.x, kern, ldk4, dx1, rev_start, rev_cnt, rev_idx, N, k, C4, dx_in, add2, dx);
+        conv_backward_dx_body4((long)blockIdx.x * blockDim.x + threadIdx.x, kern, ldk4, dx1, rev_start, rev_cnt, rev_idx, N, k, C4, dx_in, add2, dx,
+                               dout_next, ls_next);
     else
         conv_backward_kern_body4((long)(blockIdx.x - dx_blocks) * blockDim.x + threadIdx.x, x, dx1, deg, src, N, k, C4, ldk4, dkern);
 }
@@ -1128,7 +1134,8 @@ size_t layout(arreau_train_ctx& t, const arreau_model* m, int N, int B, float* b
     t.rstd = c.take<float>(L * M); t.xn = c.take<float>(M * C); t.hpre = c.take<float>(L * M * H); t.h = c.take<float>(L * M * H);
     t.out = c.take<float>(L * M * C); t.fk = c.take<float>(L * 256 * C); t.rbar = c.take<float>(M * RO); t.rbar_all = c.take<float>(L * M * RO); t.gs = c.take<float>(N * 3);
     t.kern = c.take<float>(R * L * C);   // all layers' spatial kernels, [R][L*C] (one GEMM: the basis is layer-independent)
-    t.dx = c.take<float>(M * C); t.dxro = c.take<float>(L * M * C); t.dtmp = c.take<float>(M * C); t.dh = c.take<float>(L * M * H); t.drbar = c.take<float>(M * ((RO + 3) & ~(size_t)3));
+    t.dx = c.take<float>(L * M * C);   // d x_l of every layer (round 5: kept per layer for the batched layer-scale / linear_2.bias column sums)
+    t.dxro = c.take<float>(L * M * C); t.dtmp = c.take<float>(M * C); t.dh = c.take<float>(L * M * H); t.drbar = c.take<float>(M * ((RO + 3) & ~(size_t)3));
     t.xn_all = c.take<float>(L * M * C); t.dout_all = c.take<float>(L * M * C); t.dfk_all = c.take<float>(L * 256 * C);
     t.dxn_all = c.take<float>(L * M * C); t.dx2_all = c.take<float>(L * M * C);  // kept per layer for the batched weight gradients
     t.dx1 = c.take<float>(M * C); t.dkern = c.take<float>(R * L * C); t.dkb = c.take<float>(R * D); t.dh1 = c.take<float>(R * C);
@@ -1671,13 +1678,19 @@ extern "C" int arreau_train_backward(arreau_model* m, const float* d_g_eps, cons
         // (every layer's read-out sees the same d(rbar): the bias gradients are equal -- copied to the other layers in one launch below)
         // (ROP sums into the scratch row -- the pad columns sum to zero --, copied to every layer's slice at the end of the pass)
         if (l == L - 1) TRY(colsum(s, t, t.drbar, nullptr, M, ROP, invL, t.robias, 0, nullptr, nullptr, 1, 0, 0, 0, 0, nullptr, nullptr, nullptr, true));
-        const float* dxl = l == L - 1 ? t.dxro + (size_t)l * M * C : t.dx;   // d x_{l+1}
+        const float* dxl = l == L - 1 ? t.dxro + (size_t)l * M * C : t.dx + (size_t)(l + 1) * M * C;   // d x_{l+1}
+        float* dxo = t.dx + (size_t)l * M * C;                                                        // d x_l
+        // round 5: below the top layer d(out) = d(x_{l+1}) * layer_scale was written by the previous iteration's conv-gradient launch, and
+        // the column sums over d(x_{l+1}) (d(layer_scale), d(linear_2.bias): results nothing waits for) leave the chain: one batched
+        // pass behind the loop.  The same multiplies and the same sums.
+        const bool dout_ahead = m->cfg.has_layer_scale && C % 4 == 0 && train_fuse_on() && C <= 2048;
         const float* dx_add = l > 0 ? t.dxro + (size_t)(l - 1) * M * C : nullptr;
         // ConvNext tail: x_{l+1} = out * ls + x_l
         // d(layer_scale) = sum_rows dx * out and d(linear_2.bias) = sum_rows dout = ls * sum_rows dx, in one pass over dx
         float* dout = t.dout_all + (size_t)l * M * C;
         bool have_dout = false;  // (d(out) = d(x) * layer_scale rides in the column-sum pass over d(x) where that pass takes 16-byte columns)
-        if (m->cfg.has_layer_scale)
+        if (dout_ahead && l < L - 1) have_dout = true;
+        else if (m->cfg.has_layer_scale)
             TRY(colsum(s, t, dxl, out, M, C, 1.0f, W(g->layer_scale) + (size_t)l * C, 0, W(g->linear2_b) + (size_t)l * C, m->ls + (size_t)l * C, 1, 0, 0,
                        0, 0, dout, m->ls + (size_t)l * C, &have_dout, true));
         // (the weight gradients of linear_2, linear_1, the read-out and the fiber kernel are products nothing below waits for:
@@ -1701,18 +1714,19 @@ extern "C" int arreau_train_backward(arreau_model* m, const float* d_g_eps, cons
             const unsigned dx_blocks = blocks(M * C / 4), kern_blocks = blocks(R * C / 4);
             LAUNCH(conv_backward_both_kernel4, dim3(dx_blocks + kern_blocks), dim3(256), (int)dx_blocks, V4(xl), V4(t.dx1), t.deg, t.src,
                    V4(t.kern + (size_t)l * C), L * C / 4, t.rev_start, t.rev_cnt, t.rev_idx, N, k, C / 4, V4(dxl),
-                   dx_add ? V4(dx_add) : (const f32x4*)nullptr, V4W(t.dx), V4W(t.dkern + (size_t)l * C));
+                   dx_add ? V4(dx_add) : (const f32x4*)nullptr, V4W(dxo), V4W(t.dkern + (size_t)l * C),
+                   dout_ahead && l > 0 ? V4W(t.dout_all + (size_t)(l - 1) * M * C) : (f32x4*)nullptr, V4(m->ls + (size_t)(l > 0 ? l - 1 : 0) * C));
         } else if (C % 4 == 0) {
             LAUNCH(mix_backward_x_kernel4, dim3(blocks(M * C / 4)), dim3(256), V4(dx2), V4(fk), N, C / 4, V4W(t.dx1));
             LAUNCH(conv_backward_kern_kernel4, dim3(blocks(R * C / 4)), dim3(256), V4(xl), V4(t.dx1), t.deg, t.src, N, k, C / 4, L * C / 4,
                    V4W(t.dkern + (size_t)l * C));
             LAUNCH(conv_backward_dx_kernel4, dim3(blocks(M * C / 4)), dim3(256), V4(t.kern + (size_t)l * C), L * C / 4, V4(t.dx1), t.rev_start,
-                   t.rev_cnt, t.rev_idx, N, k, C / 4, V4(dxl), dx_add ? V4(dx_add) : (const f32x4*)nullptr, V4W(t.dx));
+                   t.rev_cnt, t.rev_idx, N, k, C / 4, V4(dxl), dx_add ? V4(dx_add) : (const f32x4*)nullptr, V4W(dxo));
         } else {
             LAUNCH(mix_backward_x_kernel, dim3(blocks(M * C)), dim3(256), dx2, fk, N, C, t.dx1);
             LAUNCH(conv_backward_kern_kernel, dim3(blocks(R * C)), dim3(256), xl, t.dx1, t.deg, t.src, N, k, C, L * C, t.dkern + (size_t)l * C);
             LAUNCH(conv_backward_dx_kernel, dim3(blocks(M * C)), dim3(256), t.kern + (size_t)l * C, L * C, t.dx1, t.rev_start, t.rev_cnt,
-                   t.rev_idx, N, k, C, dxl, dx_add, t.dx);
+                   t.rev_idx, N, k, C, dxl, dx_add, dxo);
         }
     }
     // d(fiber kernel) of every layer = sum over nodes of x1 (x) dx2 / 16: one batched pair of launches (both operands were kept
@@ -1740,6 +1754,11 @@ extern "C" int arreau_train_backward(arreau_model* m, const float* d_g_eps, cons
                    nullptr, true, 0, nullptr, nullptr, &cg));
         TRY(colsum(s, t, t.dx2_all, nullptr, M, C, 1.0f, W(g->conv_bias), 0, nullptr, nullptr, L, (long)M * C, 0, C, 0, nullptr, nullptr, nullptr, true, 0,
                    nullptr, nullptr, &cg));
+        // d(layer_scale) = sum_rows d(x_{l+1}) * out_l and d(linear_2.bias) = layer_scale * sum_rows d(x_{l+1}) of the layers below the top one
+        // (the top layer's pass ran at the head of the loop; d(x_{l+1}) = slice l + 1 of the kept d(x))
+        if (m->cfg.has_layer_scale && C % 4 == 0 && train_fuse_on() && C <= 2048 && L > 1)
+            TRY(colsum(s, t, t.dx + (size_t)M * C, t.out, M, C, 1.0f, W(g->layer_scale), 0, W(g->linear2_b), m->ls, L - 1, (long)M * C, (long)M * C, C, C,
+                       nullptr, nullptr, nullptr, true, C, nullptr, nullptr, &cg));
         TRY(launch_gathered(s, cg));
         return ARREAU_OK;
     };
