@@ -1677,7 +1677,9 @@ extern "C" int arreau_train_backward(arreau_model* m, const float* d_g_eps, cons
         // read-out (ponita.py:105,108); its weight gradient: one batched product over the layers, below the loop
         // (every layer's read-out sees the same d(rbar): the bias gradients are equal -- copied to the other layers in one launch below)
         // (ROP sums into the scratch row -- the pad columns sum to zero --, copied to every layer's slice at the end of the pass)
-        if (l == L - 1) TRY(colsum(s, t, t.drbar, nullptr, M, ROP, invL, t.robias, 0, nullptr, nullptr, 1, 0, 0, 0, 0, nullptr, nullptr, nullptr, true));
+        // (with the batched column-sum pass behind the loop when the launches are merged: nothing waits for it)
+        if (l == L - 1 && !train_fuse_on())
+            TRY(colsum(s, t, t.drbar, nullptr, M, ROP, invL, t.robias, 0, nullptr, nullptr, 1, 0, 0, 0, 0, nullptr, nullptr, nullptr, true));
         const float* dxl = l == L - 1 ? t.dxro + (size_t)l * M * C : t.dx + (size_t)(l + 1) * M * C;   // d x_{l+1}
         float* dxo = t.dx + (size_t)l * M * C;                                                        // d x_l
         // round 5: below the top layer d(out) = d(x_{l+1}) * layer_scale was written by the previous iteration's conv-gradient launch, and
@@ -1748,6 +1750,9 @@ extern "C" int arreau_train_backward(arreau_model* m, const float* d_g_eps, cons
         // in one pass over dxn; d(conv.bias) = sum_rows dx2
         // (round 5: the three passes as ONE launch where their chunk sums are deferred -- 15 matrices of the same row count)
         ColsumGather cg;
+        if (train_fuse_on())   // d(readout bias): the one column sum of d(rbar) (scratch row, copied to every layer's slice at the end)
+            TRY(colsum(s, t, t.drbar, nullptr, M, ROP, invL, t.robias, 0, nullptr, nullptr, 1, 0, 0, 0, 0, nullptr, nullptr, nullptr, true, 0, nullptr,
+                       nullptr, &cg));
         TRY(colsum(s, t, t.dh, nullptr, M, H, 1.0f, W(g->linear1_b), 0, nullptr, nullptr, L, (long)M * H, 0, H, 0, nullptr, nullptr, nullptr, true, 0,
                    nullptr, nullptr, &cg));
         TRY(colsum(s, t, t.dxn_all, t.xhat, M, C, 1.0f, W(g->norm_w), 0, W(g->norm_b), nullptr, L, (long)M * C, (long)M * C, C, C, nullptr, nullptr,
