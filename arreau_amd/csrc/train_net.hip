@@ -1608,9 +1608,12 @@ extern "C" int arreau_train_forward(arreau_model* m, const float* d_frac, const 
     if (t.rev_pending) { ARREAU_CHECK_HIP(hipStreamWaitEvent(s, t.ev_rev, 0)); t.rev_pending = false; }
     // geometry and graph: the sampling path's own kernels (prep, neighbour list)
     TRY(arreau_launch_prep(m, d_frac, d_lengths, d_angles, d_t, d_off, B, N, t.lattice, t.cart, t.batch, t.cvec, s));
+    TRY(arreau_launch_neighbor(t.cart, t.lattice, d_off, t.batch, B, N, m->cfg.radius, k, t.deg, t.src, t.cell, t.dir, t.dist, s));
     // embedding (ponita.py:98): x_0 = F . W_emb^T, embT = W_emb^T [S+78][C]  (F is kept for the embedder's gradient).  Round 5: on the
-    // side stream beside the neighbour list -- it needs prep's cell and atom -> crystal map only, and x_0 is first read by the layer
-    // loop, behind arreau_general_network's join
+    // side stream, in front of the network's fiber branch and beside its edge-level products -- x_0 is first read by the layer loop,
+    // behind arreau_general_network's join.  (It needs prep's outputs only, but is NOT started beside the neighbour list: kernels of two
+    // streams sharing a CU is where round 2 saw a receiver's neighbour list lose a candidate -- DESIGN.md section 8, cause unknown --
+    // and a wrong edge is a different graph, not a rounding difference.)
     {
         arreau_train_ctx ts = t;
         hipStream_t ss = s;
@@ -1620,7 +1623,6 @@ extern "C" int arreau_train_forward(arreau_model* m, const float* d_frac, const 
         ARREAU_CHECK_HIP(hipGetLastError());
         TRY(gemm(ss, ts, t.fwd_mode, (int)M, C, S + 78, t.F, S + 78, 1, m->embT, C, 1, t.x, C));
     }
-    TRY(arreau_launch_neighbor(t.cart, t.lattice, d_off, t.batch, B, N, m->cfg.radius, k, t.deg, t.src, t.cell, t.dir, t.dist, s));
     // sender-side adjacency of this step's graph, for the ordered, atomic-free d(x_l) of the spatial conv in the backward pass
     // (built here, while the caller's offsets are certainly alive: the backward pass reads only the context's own arrays).  Round 5: only
     // the backward pass reads it, so it runs on the side stream behind the network's fiber branch (which waits for the neighbour list:
