@@ -1437,7 +1437,8 @@ static int ensure_ctx(arreau_model* m, int N, int B, hipStream_t s) {
     ARREAU_CHECK_HIP(hipMemsetAsync(t->colcount, 0, COLCOUNT_INTS * sizeof(int32_t), s));
     ARREAU_CHECK_HIP(hipMemsetAsync(t->colcount2, 0, COLCOUNT_INTS * sizeof(int32_t), s));
     {
-        static const bool side_on = [] { const char* e = getenv("ARREAU_TRAIN_SIDE_STREAM"); return !e || atoi(e) != 0; }();
+        // (read per context, i.e. per model: a test can build the one-stream form beside the default one in one process)
+        const bool side_on = [] { const char* e = getenv("ARREAU_TRAIN_SIDE_STREAM"); return !e || atoi(e) != 0; }();
         if (side_on) {
             // (default priority: a lowest-priority side stream measured the same to slightly worse, tools/exp/ab_side_stream.sh)
             ARREAU_CHECK_HIP(hipStreamCreateWithFlags(&t->side, hipStreamNonBlocking));

@@ -206,7 +206,8 @@ def test_merged_launches_of_the_training_step_are_bitwise_the_one_kernel_per_ope
     """Round 5: the training step merges launches -- spatial conv + spherical mix forward as one kernel, LayerNorm backward + mix
     backward as one, both gradients of the spatial conv in one launch, and the chunk sums of every column-sum pass / the k-slice
     sums of every weight-gradient product deferred to ONE launch each at the end of the backward pass.  None of that changes a sum
-    or its order: against ARREAU_TRAIN_FUSE=0 (one kernel per operation) the loss and every gradient must be the same bits, at
+    or its order: against ARREAU_TRAIN_FUSE=0 ARREAU_TRAIN_SIDE_STREAM=0 (one kernel per operation, one stream) the loss and every gradient
+    must be the same bits, at
     the 17-atom fixture and at the benchmark's 64 crystals, over two steps with an optimizer step between them."""
     import copy
     from arreau_amd.train import optimizer_step
@@ -215,7 +216,10 @@ def test_merged_launches_of_the_training_step_are_bitwise_the_one_kernel_per_ope
     cases = [(batch, timestep, noise), (big[0], big[2], big[3])]
     results = {}
     for fuse in ("1", "0"):
+        # "0": one kernel per operation AND everything on the caller's stream (the side stream is chosen when a model's training context
+        # is created, i.e. at the first training_step of each deep copy below)
         monkeypatch.setenv("ARREAU_TRAIN_FUSE", fuse)
+        monkeypatch.setenv("ARREAU_TRAIN_SIDE_STREAM", fuse)
         out = []
         for b, ts, nz in cases:
             mm = copy.deepcopy(m)
