@@ -338,7 +338,7 @@ def other_config_legs():
     sampler), c4 (configs[3]: graph replay at 1024 x 64), c5 (configs[4]: training steps).  No CPU baseline in the legs;
     `steps` / `warmup` of the headline are untouched.  Each record: ms_per_step, value, unit, loop_mode, the leg's own
     `roofline` block and config.workload."""
-    legs = (("c1", ["--steps", "99", "--warmup", "20"]), ("c4", ["--steps", "5", "--warmup", "2"]), ("c5", ["--steps", "10", "--warmup", "3"]))
+    legs = (("c1", ["--steps", "99", "--warmup", "20"]), ("c4", ["--steps", "5", "--warmup", "2"]), ("c5", ["--steps", "30", "--warmup", "8"]))
     out = {}
     for name, extra in legs:
         cmd = [sys.executable, os.path.abspath(__file__), "--config", name, "--no-cpu-baseline", "--no-fp32-variant",
